@@ -1,0 +1,184 @@
+/*
+ * rustcv_hip.h -- C ABI of librustcv_hip.so, the MI355X (gfx950) backend for the
+ * per-pixel hot path of rustcv::imgproc / rustcv::videoio.
+ *
+ * This is the drop-in boundary.  The reference has no plugin interface for
+ * imgproc (its ops are plain `pub fn`s on `&mut Mat`), so the ABI follows the
+ * one FFI precedent in the reference, rustcv-camera/src/backend/macos/bridge.h:16-65
+ * as consumed by rustcv-camera/src/backend/macos/mod.rs:42-80 :
+ *   - opaque handle with explicit create/free          (bridge.h:17,36-39,65)
+ *   - int return, 0 = OK, negative = error, no unwinding (bridge.h:20-24)
+ *   - caller owns every pixel buffer, capacity is explicit (bridge.h:47-62)
+ *   - one thread per handle, handles independent        (bridge.h:4-7)
+ * All citations are file:line under /root/reference.  Plain pointers and sizes
+ * only; nothing here depends on torch, C++ or HIP types.
+ *
+ * There is NO CPU fallback behind these symbols.  Every compute entry point
+ * returns RCV_ERR_DEVICE when no gfx950 device/context is available.
+ */
+#ifndef RUSTCV_HIP_H
+#define RUSTCV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCV_ABI_VERSION 1
+
+/* ---- status codes (Rust side maps them to its error enum, cf. macos/mod.rs:82-85) */
+#define RCV_OK               0
+#define RCV_NOOP             1   /* success; a reference length guard made the call a silent no-op */
+#define RCV_ERR_ARG         (-1) /* null pointer, bad enum, bad ksize/shift/block */
+#define RCV_ERR_UNSUPPORTED (-2) /* valid but not implemented (channels/depth combination) */
+#define RCV_ERR_SIZE        (-3) /* a buffer is smaller than rows*step or than the op needs */
+#define RCV_ERR_DEVICE      (-4) /* no device, HIP error, kernel launch failure */
+#define RCV_ERR_OOM         (-5) /* device or host allocation failed */
+
+/* ---- element depth of an rcv_mat */
+#define RCV_8U  0
+#define RCV_16S 1
+#define RCV_32F 2
+
+/* ---- where rcv_mat.data lives */
+#define RCV_HOST   0  /* pageable/pinned host memory: the op stages H2D, runs, stages D2H, and syncs */
+#define RCV_DEVICE 1  /* device memory from rcv_malloc (or any hipMalloc on the ctx's device): async on the ctx stream */
+
+/* ---- colour conversion codes for rcv_cvt_color.
+ * The first three reproduce the reference's FourCC dispatch
+ * (rustcv/src/videoio/mod.rs:201-258; rustcv-camera/src/decode.rs:36-86).      */
+#define RCV_YUYV2BGR       0  /* rustcv/src/videoio/mod.rs:344-371 guard: src only            */
+#define RCV_BGRA2BGR       1  /* rustcv/src/videoio/mod.rs:385-399 guard: src and dst          */
+#define RCV_RGB2BGR        2  /* rustcv-camera/src/decode.rs:213-219 (min whole pixels)        */
+#define RCV_YUYV2BGR_TWIN  3  /* rustcv-camera/src/decode.rs:160-191 guard: pairs*4 / pairs*6  */
+#define RCV_BGRA2BGR_TWIN  4  /* rustcv-camera/src/decode.rs:200-207 (min whole pixels)        */
+#define RCV_BGR2GRAY       5  /* build-defined; stride-aware                  */
+
+/* ---- synthetic frame families (replaces the empty rustcv-simulation crate) */
+#define RCV_SYNTH_NOISE 0
+#define RCV_SYNTH_SCENE 1
+#define RCV_SYNTH_YUYV  2
+
+/* Mirror of rustcv::core::mat::Mat (rustcv/src/core/mat.rs:6-15):
+ *   data: Vec<u8> -> (data, cap) ; rows, cols: i32 ; step: usize ; channels: u8.
+ * `cap` is Vec::len(): the reference's guards (`src.len() < ...`,
+ * `idx + 2 < data.len()`) are evaluated against it.  depth/device are additions. */
+typedef struct rcv_mat {
+    void*    data;
+    size_t   cap;      /* addressable bytes at data */
+    size_t   step;     /* bytes per row, >= cols*channels*elem_size */
+    int32_t  rows;
+    int32_t  cols;
+    uint8_t  channels;
+    uint8_t  depth;    /* RCV_8U / RCV_16S / RCV_32F */
+    uint8_t  device;   /* RCV_HOST / RCV_DEVICE */
+    uint8_t  reserved;
+} rcv_mat;
+
+/* A batch of n equally shaped frames, frame i at frame0.data + i*frame_stride.
+ * frame0.cap is the capacity of ONE frame.  Batches must be device-resident.   */
+typedef struct rcv_batch {
+    rcv_mat  frame0;
+    size_t   frame_stride;
+    int32_t  n;
+    int32_t  reserved;
+} rcv_batch;
+
+typedef struct rcv_ctx rcv_ctx; /* opaque: one device + one HIP stream + staging workspace */
+
+/* ---- library / context (replaces nothing; precedent bridge.h:36-39,65) ------- */
+int         rcv_abi_version(void);
+const char* rcv_strerror(int code);
+int         rcv_device_count(int* n);
+int         rcv_ctx_create(int device, rcv_ctx** out);
+void        rcv_ctx_destroy(rcv_ctx* ctx);
+int         rcv_sync(rcv_ctx* ctx);                       /* block until the ctx stream is idle */
+int         rcv_ctx_device(const rcv_ctx* ctx);
+void*       rcv_ctx_stream(const rcv_ctx* ctx);           /* the hipStream_t, for event timing by the harness */
+
+/* ---- device memory for resident batches ------------------------------------- */
+int rcv_malloc(rcv_ctx* ctx, size_t bytes, void** out);
+int rcv_free(rcv_ctx* ctx, void* p);
+int rcv_upload(rcv_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);   /* synchronous */
+int rcv_download(rcv_ctx* ctx, void* dst_host, const void* src_device, size_t bytes); /* synchronous */
+int rcv_memset(rcv_ctx* ctx, void* dst_device, int value, size_t bytes);
+
+/* ---- stream timing (hipEvent on the ctx stream; used by bench.py) ------------ */
+int rcv_timer_start(rcv_ctx* ctx);
+int rcv_timer_stop(rcv_ctx* ctx, float* elapsed_ms);      /* records, synchronises, returns ms */
+
+/* ---- host-side helpers (pure CPU, no device needed) -------------------------- */
+/* FourCC (little-endian ASCII, rustcv-core/src/pixel_format.rs:10-12) -> cvt code.
+ * 'YUYV' -> RCV_YUYV2BGR, 'BGRA' and 'BGR4' -> RCV_BGRA2BGR, 'RGB3' -> RCV_RGB2BGR;
+ * anything else RCV_ERR_UNSUPPORTED (twin: DecodeError, decode.rs:77-82).       */
+int rcv_fourcc_to_code(uint32_t fourcc, int* code);
+/* f32 taps of GaussianBlur(sigma>0): exp(-x^2/2s^2), normalised in f64, cast once */
+int rcv_gaussian_taps_f32(int ksize, double sigma, float* taps);
+
+/* ---- a1/a2/a4/a5: colour conversion ------------------------------------------ *
+ * replaces yuyv_to_bgr / bgra_to_bgr (rustcv/src/videoio/mod.rs:203,205 call
+ * sites) and rustcv_camera::decode::{yuyv_to_bgr,bgra32_to_bgr,rgb_to_bgr}.
+ * For codes 0-4 src is a FLAT byte buffer of src->cap bytes (row stride ignored,
+ * exactly like the reference) and width/height come from dst->cols/rows;
+ * dst is written packed from dst->data.  Returns RCV_NOOP where the reference
+ * returns silently.  RCV_BGR2GRAY honours step on both sides.                   */
+int rcv_cvt_color(rcv_ctx* ctx, int code, const rcv_mat* src, rcv_mat* dst);
+int rcv_cvt_color_batch(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst);
+
+/* ---- a3: rectangle ------------------------------------------------------------ *
+ * replaces rustcv::imgproc::rectangle (rustcv/src/imgproc/drawing.rs:67-106):
+ * in-place outline grown inward, clip to the Mat, 3 channels hard-coded,
+ * `idx+2 < data.len()` guard against mat->cap.                                  */
+int rcv_rectangle(rcv_ctx* ctx, rcv_mat* mat, int32_t x, int32_t y, int32_t w, int32_t h,
+                  uint8_t b, uint8_t g, uint8_t r, int32_t thickness);
+int rcv_rectangle_batch(rcv_ctx* ctx, rcv_batch* mats, int32_t x, int32_t y, int32_t w, int32_t h,
+                        uint8_t b, uint8_t g, uint8_t r, int32_t thickness);
+
+/* ---- build-defined ops (not in the reference; spec SURVEY.md 8-A) -------------- *
+ * u8, channels in {1,3} unless stated, BORDER_REFLECT_101, arbitrary step.        */
+int rcv_gaussian_blur(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, int ksize, double sigma);
+int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, int ksize, double sigma);
+
+/* k: ksize*ksize weights row-major (correlation).  ksize odd, 1..7.  0<=shift<=24 */
+int rcv_filter2d_i8(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const int8_t* k, int ksize, int shift);
+int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift);
+int rcv_filter2d_f32(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* k, int ksize, float delta);
+int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* k, int ksize, float delta);
+
+/* src u8 1-ch; dx, dy i16 1-ch */
+int rcv_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy);
+int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy);
+
+/* bilinear, output size = dst->rows x dst->cols */
+int rcv_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst);
+int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst);
+
+/* bilinear, M[6] row-major 2x3 maps dst->src, constant border 0 */
+int rcv_warp_affine(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M);
+int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M);
+
+/* gray u8 1-ch -> f32 response; aperture fixed at 3; block in 1..7 */
+int rcv_corner_harris(rcv_ctx* ctx, const rcv_mat* gray, rcv_mat* resp, int block, float k);
+int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_batch* resp, int block, float k);
+
+/* f32 response -> u8 mask (255 = local max above thr) */
+int rcv_nms3x3(rcv_ctx* ctx, const rcv_mat* resp, rcv_mat* mask, float thr);
+int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* mask, float thr);
+
+/* fused BGR -> gray -> Sobel -> Harris response -> 3x3 NMS in one launch.
+ * resp may be NULL (mask only).                                                 */
+int rcv_harris_pipeline(rcv_ctx* ctx, const rcv_mat* bgr, rcv_mat* mask, rcv_mat* resp,
+                        int block, float k, float thr);
+int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mask, rcv_batch* resp,
+                              int block, float k, float thr);
+
+/* ---- synthetic frames generated on device --------------------- *
+ * family NOISE/SCENE: u8, channels 1/3/4.  family YUYV: 2 B/px packed, the mat is
+ * described as channels=2.  Frame index of batch element i is frame_base+i.      */
+int rcv_synth_batch(rcv_ctx* ctx, rcv_batch* dst, int family, uint64_t seed, uint64_t frame_base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTCV_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of librustcv_hip.so (the C ABI declared in include/rustcv_hip.h).
+
+This is the Python twin of the Rust `extern "C"` block a maintainer would add to the
+reference.  There is no fallback of any kind: if the shared library is
+missing, or a compute call is made without a gfx950 device, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librustcv_hip.so")
+
+RCV_OK, RCV_NOOP = 0, 1
+RCV_ERR_ARG, RCV_ERR_UNSUPPORTED, RCV_ERR_SIZE, RCV_ERR_DEVICE, RCV_ERR_OOM = -1, -2, -3, -4, -5
+RCV_8U, RCV_16S, RCV_32F = 0, 1, 2
+RCV_HOST, RCV_DEVICE = 0, 1
+RCV_YUYV2BGR, RCV_BGRA2BGR, RCV_RGB2BGR, RCV_YUYV2BGR_TWIN, RCV_BGRA2BGR_TWIN, RCV_BGR2GRAY = range(6)
+RCV_SYNTH_NOISE, RCV_SYNTH_SCENE, RCV_SYNTH_YUYV = 0, 1, 2
+
+
+class RcvError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: rustcv_hip error {code} ({strerror(code)})")
+
+
+class rcv_mat(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("cap", C.c_size_t), ("step", C.c_size_t),
+                ("rows", C.c_int32), ("cols", C.c_int32),
+                ("channels", C.c_uint8), ("depth", C.c_uint8), ("device", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class rcv_batch(C.Structure):
+    _fields_ = [("frame0", rcv_mat), ("frame_stride", C.c_size_t), ("n", C.c_int32), ("reserved", C.c_int32)]
+
+
+_P = C.POINTER
+_ctx = C.c_void_p
+_mat, _bat = _P(rcv_mat), _P(rcv_batch)
+_i, _u8, _f, _d, _sz, _u64, _i32 = C.c_int, C.c_uint8, C.c_float, C.c_double, C.c_size_t, C.c_uint64, C.c_int32
+
+# name -> (restype, argtypes); the list every symbol in include/rustcv_hip.h must appear in
+SIGNATURES = {
+    "rcv_abi_version": (_i, []),
+    "rcv_strerror": (C.c_char_p, [_i]),
+    "rcv_device_count": (_i, [_P(_i)]),
+    "rcv_ctx_create": (_i, [_i, _P(_ctx)]),
+    "rcv_ctx_destroy": (None, [_ctx]),
+    "rcv_sync": (_i, [_ctx]),
+    "rcv_ctx_device": (_i, [_ctx]),
+    "rcv_ctx_stream": (C.c_void_p, [_ctx]),
+    "rcv_malloc": (_i, [_ctx, _sz, _P(C.c_void_p)]),
+    "rcv_free": (_i, [_ctx, C.c_void_p]),
+    "rcv_upload": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz]),
+    "rcv_download": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz]),
+    "rcv_memset": (_i, [_ctx, C.c_void_p, _i, _sz]),
+    "rcv_timer_start": (_i, [_ctx]),
+    "rcv_timer_stop": (_i, [_ctx, _P(_f)]),
+    "rcv_fourcc_to_code": (_i, [C.c_uint32, _P(_i)]),
+    "rcv_gaussian_taps_f32": (_i, [_i, _d, _P(_f)]),
+    "rcv_cvt_color": (_i, [_ctx, _i, _mat, _mat]),
+    "rcv_cvt_color_batch": (_i, [_ctx, _i, _bat, _bat]),
+    "rcv_rectangle": (_i, [_ctx, _mat, _i32, _i32, _i32, _i32, _u8, _u8, _u8, _i32]),
+    "rcv_rectangle_batch": (_i, [_ctx, _bat, _i32, _i32, _i32, _i32, _u8, _u8, _u8, _i32]),
+    "rcv_gaussian_blur": (_i, [_ctx, _mat, _mat, _i, _d]),
+    "rcv_gaussian_blur_batch": (_i, [_ctx, _bat, _bat, _i, _d]),
+    "rcv_filter2d_i8": (_i, [_ctx, _mat, _mat, _P(C.c_int8), _i, _i]),
+    "rcv_filter2d_i8_batch": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i]),
+    "rcv_filter2d_f32": (_i, [_ctx, _mat, _mat, _P(_f), _i, _f]),
+    "rcv_filter2d_f32_batch": (_i, [_ctx, _bat, _bat, _P(_f), _i, _f]),
+    "rcv_sobel": (_i, [_ctx, _mat, _mat, _mat]),
+    "rcv_sobel_batch": (_i, [_ctx, _bat, _bat, _bat]),
+    "rcv_resize": (_i, [_ctx, _mat, _mat]),
+    "rcv_resize_batch": (_i, [_ctx, _bat, _bat]),
+    "rcv_warp_affine": (_i, [_ctx, _mat, _mat, _P(_f)]),
+    "rcv_warp_affine_batch": (_i, [_ctx, _bat, _bat, _P(_f)]),
+    "rcv_corner_harris": (_i, [_ctx, _mat, _mat, _i, _f]),
+    "rcv_corner_harris_batch": (_i, [_ctx, _bat, _bat, _i, _f]),
+    "rcv_nms3x3": (_i, [_ctx, _mat, _mat, _f]),
+    "rcv_nms3x3_batch": (_i, [_ctx, _bat, _bat, _f]),
+    "rcv_harris_pipeline": (_i, [_ctx, _mat, _mat, _mat, _i, _f, _f]),
+    "rcv_harris_pipeline_batch": (_i, [_ctx, _bat, _bat, _bat, _i, _f, _f]),
+    "rcv_synth_batch": (_i, [_ctx, _bat, _i, _u64, _u64]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librustcv_hip.so (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C rustcv_amd/csrc`.  rustcv_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if l.rcv_abi_version() != 1:
+            raise ImportError("librustcv_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def strerror(code):
+    return lib().rcv_strerror(int(code)).decode()
+
+
+def check(code, what):
+    """Negative status -> RcvError.  Returns the (non-negative) status otherwise."""
+    if code < 0:
+        raise RcvError(code, what)
+    return code

@@ -1,0 +1,348 @@
+// rcv_ctx.hip -- context, device memory, staging and host-only helpers of the C ABI.
+// include/rustcv_hip.h documents every entry point; precedent for the conventions is
+// /root/reference rustcv-camera/src/backend/macos/bridge.h:16-65.
+#include "rcv_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+extern "C" int rcv_abi_version(void) { return RCV_ABI_VERSION; }
+
+extern "C" const char* rcv_strerror(int code)
+{
+    switch (code) {
+    case RCV_OK: return "ok";
+    case RCV_NOOP: return "ok (reference length guard: silent no-op)";
+    case RCV_ERR_ARG: return "invalid argument";
+    case RCV_ERR_UNSUPPORTED: return "unsupported format or parameter";
+    case RCV_ERR_SIZE: return "buffer too small for the described image";
+    case RCV_ERR_DEVICE: return "HIP device error (no gfx950 device, or a runtime/launch failure)";
+    case RCV_ERR_OOM: return "out of memory";
+    default: return "unknown rustcv_hip status";
+    }
+}
+
+extern "C" int rcv_device_count(int* n)
+{
+    if (!n) return RCV_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *n = 0;
+        return RCV_ERR_DEVICE;
+    }
+    *n = c;
+    return RCV_OK;
+}
+
+extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
+{
+    if (!out) return RCV_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    RCV_TRY(rcv_device_count(&count));
+    if (device < 0 || device >= count) return RCV_ERR_DEVICE;
+    RCV_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RCV_HIP(hipGetDeviceProperties(&prop, device));
+    // gfx950 only: the kernels use CDNA4 instructions and sizes; refuse anything else loudly.
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RCV_ERR_DEVICE;
+    rcv_ctx* c = new (std::nothrow) rcv_ctx();
+    if (!c) return RCV_ERR_OOM;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->kconst, 65536);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rcv_ctx_destroy(c);
+        return e == hipErrorOutOfMemory ? RCV_ERR_OOM : RCV_ERR_DEVICE;
+    }
+    *out = c;
+    return RCV_OK;
+}
+
+extern "C" void rcv_ctx_destroy(rcv_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    for (int i = 0; i < RCV_MAX_STAGE; ++i)
+        if (c->stage_buf[i]) (void)hipFree(c->stage_buf[i]);
+    if (c->kconst) (void)hipFree(c->kconst);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rcv_bind(rcv_ctx* ctx)
+{
+    if (!ctx) return RCV_ERR_ARG;
+    RCV_HIP(hipSetDevice(ctx->device));
+    return RCV_OK;
+}
+
+int rcv_launch_check(rcv_ctx*)
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? RCV_OK : RCV_ERR_DEVICE;
+}
+
+extern "C" int rcv_sync(rcv_ctx* ctx)
+{
+    RCV_TRY(rcv_bind(ctx));
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    return RCV_OK;
+}
+
+extern "C" int rcv_ctx_device(const rcv_ctx* ctx) { return ctx ? ctx->device : RCV_ERR_ARG; }
+extern "C" void* rcv_ctx_stream(const rcv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int rcv_malloc(rcv_ctx* ctx, size_t bytes, void** out)
+{
+    if (!out) return RCV_ERR_ARG;
+    *out = nullptr;
+    RCV_TRY(rcv_bind(ctx));
+    if (bytes == 0) bytes = 16;
+    RCV_HIP(hipMalloc(out, bytes));
+    return RCV_OK;
+}
+
+extern "C" int rcv_free(rcv_ctx* ctx, void* p)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!p) return RCV_OK;
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    RCV_HIP(hipFree(p));
+    return RCV_OK;
+}
+
+extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (bytes == 0) return RCV_OK;
+    if (!dst || !src) return RCV_ERR_ARG;
+    RCV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    return RCV_OK;
+}
+
+extern "C" int rcv_download(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (bytes == 0) return RCV_OK;
+    if (!dst || !src) return RCV_ERR_ARG;
+    RCV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    return RCV_OK;
+}
+
+extern "C" int rcv_memset(rcv_ctx* ctx, void* dst, int value, size_t bytes)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (bytes == 0) return RCV_OK;
+    if (!dst) return RCV_ERR_ARG;
+    RCV_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return RCV_OK;
+}
+
+extern "C" int rcv_timer_start(rcv_ctx* ctx)
+{
+    RCV_TRY(rcv_bind(ctx));
+    RCV_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return RCV_OK;
+}
+
+extern "C" int rcv_timer_stop(rcv_ctx* ctx, float* ms)
+{
+    if (!ms) return RCV_ERR_ARG;
+    RCV_TRY(rcv_bind(ctx));
+    RCV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RCV_HIP(hipEventSynchronize(ctx->ev1));
+    RCV_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RCV_OK;
+}
+
+// ---- host-only helpers --------------------------------------------------------------------
+
+static constexpr uint32_t fourcc(char a, char b, char c, char d)
+{
+    // rustcv-core/src/pixel_format.rs:10-12 : little-endian ASCII
+    return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24);
+}
+
+extern "C" int rcv_fourcc_to_code(uint32_t fcc, int* code)
+{
+    if (!code) return RCV_ERR_ARG;
+    // rustcv/src/videoio/mod.rs:201-206 (YUYV, BGRA) ; rustcv-camera/src/pixel_format.rs:84-92 (RGB3, BGR4)
+    if (fcc == fourcc('Y', 'U', 'Y', 'V')) { *code = RCV_YUYV2BGR; return RCV_OK; }
+    if (fcc == fourcc('B', 'G', 'R', 'A') || fcc == fourcc('B', 'G', 'R', '4')) { *code = RCV_BGRA2BGR; return RCV_OK; }
+    if (fcc == fourcc('R', 'G', 'B', '3')) { *code = RCV_RGB2BGR; return RCV_OK; }
+    return RCV_ERR_UNSUPPORTED;
+}
+
+extern "C" int rcv_gaussian_taps_f32(int ksize, double sigma, float* taps)
+{
+    if (!taps || !(ksize & 1) || ksize < 3 || ksize > 31 || !(sigma > 0.0)) return RCV_ERR_ARG;
+    double t[32], sum = 0.0;
+    int r = ksize / 2;
+    for (int i = 0; i < ksize; ++i) {
+        double x = (double)(i - r);
+        t[i] = exp(-(x * x) / (2.0 * sigma * sigma));
+        sum += t[i];
+    }
+    for (int i = 0; i < ksize; ++i) taps[i] = (float)(t[i] / sum);
+    return RCV_OK;
+}
+
+// ---- workspace ------------------------------------------------------------------------------
+// Kernel-internal temporaries (unfused intermediates).  rcv_ws_reserve(total) first, then carve.
+
+int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
+{
+    ctx->ws_off = 0;
+    if (total <= ctx->ws_cap) return RCV_OK;
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) RCV_HIP(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_cap = 0;
+    RCV_HIP(hipMalloc((void**)&ctx->ws, total));
+    ctx->ws_cap = total;
+    return RCV_OK;
+}
+
+int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out)
+{
+    size_t off = (ctx->ws_off + 255) & ~(size_t)255;
+    if (off + bytes > ctx->ws_cap) return RCV_ERR_OOM;
+    *out = ctx->ws + off;
+    ctx->ws_off = off + bytes;
+    return RCV_OK;
+}
+
+int rcv_upload_const(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset)
+{
+    if (offset + bytes > 65536) return RCV_ERR_ARG;
+    // pageable source: hipMemcpyAsync snapshots it before returning, and the copy is
+    // ordered on the ctx stream ahead of the kernel that reads it.
+    RCV_HIP(hipMemcpyAsync(ctx->kconst + offset, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RCV_OK;
+}
+
+// ---- views ----------------------------------------------------------------------------------
+
+int rcv_view_strided(const rcv_mat* m, int want_depth, View* v)
+{
+    if (!m || !v) return RCV_ERR_ARG;
+    if (m->rows < 0 || m->cols < 0) return RCV_ERR_ARG;
+    if (m->depth != want_depth) return RCV_ERR_UNSUPPORTED;
+    int esz = rcv_elem_size(m->depth);
+    if (esz == 0 || m->channels == 0) return RCV_ERR_ARG;
+    size_t rowb = (size_t)m->cols * m->channels * esz;
+    if (m->rows > 0 && m->cols > 0) {
+        if (!m->data) return RCV_ERR_ARG;
+        if (m->step < rowb) return RCV_ERR_SIZE;
+        if (m->step % esz) return RCV_ERR_ARG;
+        size_t need = (size_t)(m->rows - 1) * m->step + rowb;
+        if (m->cap < need) return RCV_ERR_SIZE;
+    }
+    v->p = (uint8_t*)m->data;
+    v->step = m->step;
+    v->fstride = 0;
+    v->cap = m->cap;
+    v->rows = m->rows;
+    v->cols = m->cols;
+    v->ch = m->channels;
+    v->esz = esz;
+    v->n = 1;
+    return RCV_OK;
+}
+
+int rcv_view_batch(const rcv_batch* b, int want_depth, View* v)
+{
+    if (!b) return RCV_ERR_ARG;
+    if (b->n < 0) return RCV_ERR_ARG;
+    if (b->frame0.device != RCV_DEVICE) return RCV_ERR_ARG;
+    RCV_TRY(rcv_view_strided(&b->frame0, want_depth, v));
+    v->n = b->n;
+    v->fstride = b->frame_stride;
+    if (b->n > 1 && v->rows > 0 && v->cols > 0) {
+        size_t need = (size_t)(v->rows - 1) * v->step + (size_t)v->cols * v->ch * v->esz;
+        if (b->frame_stride < need) return RCV_ERR_SIZE;
+    }
+    return RCV_OK;
+}
+
+// ---- host staging ---------------------------------------------------------------------------
+// A host Mat is mirrored whole (all `cap` bytes == Vec::len()) into a per-ctx, grow-only
+// staging buffer, so the reference's length guards see exactly the caller's capacity.
+
+int stage_begin(Stage* s, rcv_ctx* ctx)
+{
+    RCV_TRY(rcv_bind(ctx));
+    s->ctx = ctx;
+    s->count = 0;
+    s->any_host = false;
+    return RCV_OK;
+}
+
+int stage_in(Stage* s, const rcv_mat* m, bool upload, bool copy_back, rcv_mat** dev_out)
+{
+    if (!m || !dev_out) return RCV_ERR_ARG;
+    if (s->count >= RCV_MAX_STAGE) return RCV_ERR_ARG;
+    rcv_ctx* ctx = s->ctx;
+    StagedMat* sm = &s->m[s->count];
+    sm->host = m;
+    sm->dev = *m;
+    sm->copy_back = false;
+    if (m->device == RCV_DEVICE) {
+        if (s->any_host) return RCV_ERR_ARG; // all mats of one call live on the same side
+    } else if (m->device == RCV_HOST) {
+        if (s->count > 0 && !s->any_host) return RCV_ERR_ARG;
+        s->any_host = true;
+        size_t bytes = m->cap;
+        if (bytes > 0 && !m->data) return RCV_ERR_ARG;
+        int slot = s->count;
+        if (ctx->stage_cap[slot] < bytes + 64) {
+            RCV_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->stage_buf[slot]) RCV_HIP(hipFree(ctx->stage_buf[slot]));
+            ctx->stage_buf[slot] = nullptr;
+            ctx->stage_cap[slot] = 0;
+            size_t want = bytes + 64 + (bytes >> 3);
+            RCV_HIP(hipMalloc((void**)&ctx->stage_buf[slot], want));
+            ctx->stage_cap[slot] = want;
+        }
+        if (upload && bytes)
+            RCV_HIP(hipMemcpyAsync(ctx->stage_buf[slot], m->data, bytes, hipMemcpyHostToDevice, ctx->stream));
+        sm->dev.data = ctx->stage_buf[slot];
+        sm->dev.device = RCV_DEVICE;
+        sm->copy_back = copy_back;
+    } else {
+        return RCV_ERR_ARG;
+    }
+    *dev_out = &sm->dev;
+    s->count++;
+    return RCV_OK;
+}
+
+int stage_finish(Stage* s, int rc)
+{
+    if (!s->any_host) return rc;
+    rcv_ctx* ctx = s->ctx;
+    if (rc >= 0) {
+        for (int i = 0; i < s->count; ++i) {
+            StagedMat* sm = &s->m[i];
+            if (!sm->copy_back || sm->host->cap == 0) continue;
+            RCV_HIP(hipMemcpyAsync(sm->host->data, sm->dev.data, sm->host->cap, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    RCV_HIP(hipStreamSynchronize(ctx->stream));
+    return rc;
+}

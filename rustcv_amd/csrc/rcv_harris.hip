@@ -1,0 +1,234 @@
+// rcv_harris.hip -- cornerHarris response, 3x3 NMS and the BGR->mask pipeline: argument
+// checking, dispatch and the GENERIC (unfused, workspace-backed) kernels.  The fused
+// single-launch pipeline lives in rcv_harris_fused.hip.  Not in the reference;
+// semantics SURVEY.md 8-A == oracle/rcv_oracle.c.  Six separate IEEE f32 ops for the response,
+// no contraction (-ffp-contract=off).
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// ix/iy: packed i16 planes [n][rows][cols]
+__global__ __launch_bounds__(kBlock) void k_sobel_packed(View s, int16_t* ix, int16_t* iy)
+{
+    int y = blockIdx.y;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    const uint8_t* r0 = sf + (size_t)reflect101(y - 1, s.rows) * s.step;
+    const uint8_t* r1 = sf + (size_t)y * s.step;
+    const uint8_t* r2 = sf + (size_t)reflect101(y + 1, s.rows) * s.step;
+    size_t base = ((size_t)blockIdx.z * s.rows + y) * s.cols;
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < s.cols; x += gridDim.x * kBlock) {
+        int xl = reflect101(x - 1, s.cols), xr = reflect101(x + 1, s.cols);
+        ix[base + x] = (int16_t)(((int)r0[xr] - (int)r0[xl]) + 2 * ((int)r1[xr] - (int)r1[xl]) + ((int)r2[xr] - (int)r2[xl]));
+        iy[base + x] = (int16_t)(((int)r2[xl] - (int)r0[xl]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xr] - (int)r0[xr]));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_harris_resp(const int16_t* ix, const int16_t* iy, View r, int block, float s2, float k)
+{
+    int y = blockIdx.y, a = block / 2;
+    size_t fbase = (size_t)blockIdx.z * r.rows * r.cols;
+    float* out = (float*)(r.p + (size_t)blockIdx.z * r.fstride + (size_t)y * r.step);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < r.cols; x += gridDim.x * kBlock) {
+        int sxx = 0, sxy = 0, syy = 0;
+        for (int by = 0; by < block; ++by) {
+            size_t rb = fbase + (size_t)reflect101(y + by - a, r.rows) * r.cols;
+            for (int bx = 0; bx < block; ++bx) {
+                int xx = reflect101(x + bx - a, r.cols);
+                int gx = ix[rb + xx], gy = iy[rb + xx];
+                sxx += gx * gx;
+                sxy += gx * gy;
+                syy += gy * gy;
+            }
+        }
+        float fa = (float)sxx * s2, fb = (float)sxy * s2, fc = (float)syy * s2;
+        float t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+        float t4 = k * t3;
+        float t5 = t4 * t3;
+        out[x] = (t1 - t2) - t5;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_nms3x3(View r, View m, float thr)
+{
+    int y = blockIdx.y;
+    const uint8_t* rf = r.p + (size_t)blockIdx.z * r.fstride;
+    uint8_t* mrow = m.p + (size_t)blockIdx.z * m.fstride + (size_t)y * m.step;
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < r.cols; x += gridDim.x * kBlock) {
+        float v = *(const float*)(rf + (size_t)y * r.step + (size_t)x * 4);
+        bool keep = v > thr;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int yy = y + dy, xx = x + dx;
+                if ((dx == 0 && dy == 0) || yy < 0 || yy >= r.rows || xx < 0 || xx >= r.cols) continue;
+                float nb = *(const float*)(rf + (size_t)yy * r.step + (size_t)xx * 4);
+                if (!(v >= nb)) keep = false;
+            }
+        mrow[x] = keep ? 255 : 0;
+    }
+}
+
+inline dim3 px_grid(const View& d)
+{
+    unsigned gx = (unsigned)((d.cols + kBlock - 1) / kBlock);
+    if (gx > 1024) gx = 1024;
+    return dim3(gx, d.rows, d.n);
+}
+
+float harris_scale2(int block)
+{
+    double s = 1.0 / (4.0 * (double)block * 255.0); // 2^(aperture-1) * blockSize * 255, aperture = 3
+    return (float)(s * s);
+}
+
+// gray (device View) -> resp using two packed i16 planes carved from the workspace
+int harris_from_gray(rcv_ctx* ctx, const View& g, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
+{
+    hipLaunchKernelGGL(k_sobel_packed, px_grid(g), dim3(kBlock), 0, ctx->stream, g, (int16_t*)wix, (int16_t*)wiy);
+    hipLaunchKernelGGL(k_harris_resp, px_grid(r), dim3(kBlock), 0, ctx->stream, (const int16_t*)wix, (const int16_t*)wiy, r, block,
+                       harris_scale2(block), k);
+    return rcv_launch_check(ctx);
+}
+
+} // namespace
+
+extern "C" int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_batch* resp, int block, float k)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!gray || !resp) return RCV_ERR_ARG;
+    if (block < 1 || block > 7) return RCV_ERR_ARG;
+    View g, r;
+    RCV_TRY(rcv_view_batch(gray, RCV_8U, &g));
+    RCV_TRY(rcv_view_batch(resp, RCV_32F, &r));
+    if (g.ch != 1 || r.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (g.rows != r.rows || g.cols != r.cols || g.n != r.n) return RCV_ERR_ARG;
+    if (g.rows > 65535 || g.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (g.rows == 0 || g.cols == 0 || g.n == 0) return RCV_OK;
+    size_t plane = (size_t)g.n * g.rows * g.cols * 2;
+    RCV_TRY(rcv_ws_reserve(ctx, 2 * (plane + 256)));
+    uint8_t *wix, *wiy;
+    RCV_TRY(rcv_ws_alloc(ctx, plane, &wix));
+    RCV_TRY(rcv_ws_alloc(ctx, plane, &wiy));
+    return harris_from_gray(ctx, g, r, block, k, wix, wiy);
+}
+
+extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* mask, float thr)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!resp || !mask) return RCV_ERR_ARG;
+    View r, m;
+    RCV_TRY(rcv_view_batch(resp, RCV_32F, &r));
+    RCV_TRY(rcv_view_batch(mask, RCV_8U, &m));
+    if (r.ch != 1 || m.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (m.rows != r.rows || m.cols != r.cols || m.n != r.n) return RCV_ERR_ARG;
+    if (r.rows > 65535 || r.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (r.rows == 0 || r.cols == 0 || r.n == 0) return RCV_OK;
+    hipLaunchKernelGGL(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mask, rcv_batch* resp,
+                                         int block, float k, float thr)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!bgr || !mask) return RCV_ERR_ARG;
+    if (block < 1 || block > 7) return RCV_ERR_ARG;
+    View s, m, r;
+    RCV_TRY(rcv_view_batch(bgr, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(mask, RCV_8U, &m));
+    if (s.ch != 3 || m.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (s.rows != m.rows || s.cols != m.cols || s.n != m.n) return RCV_ERR_ARG;
+    if (resp) {
+        RCV_TRY(rcv_view_batch(resp, RCV_32F, &r));
+        if (r.ch != 1) return RCV_ERR_UNSUPPORTED;
+        if (r.rows != s.rows || r.cols != s.cols || r.n != s.n) return RCV_ERR_ARG;
+    }
+    if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int rc = rcv_harris_fused(ctx, s, m, resp ? &r : nullptr, block, k, thr);
+    if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    // generic: gray, Ix, Iy (and the response when the caller does not want it) live in the workspace
+    size_t npx = (size_t)s.n * s.rows * s.cols;
+    RCV_TRY(rcv_ws_reserve(ctx, npx * (1 + 2 + 2 + (resp ? 0 : 4)) + 4 * 256));
+    uint8_t *wg, *wix, *wiy, *wr = nullptr;
+    RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));
+    RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wix));
+    RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wiy));
+    if (!resp) RCV_TRY(rcv_ws_alloc(ctx, npx * 4, &wr));
+    rcv_batch gb;
+    gb.frame0.data = wg;
+    gb.frame0.cap = (size_t)s.rows * s.cols;
+    gb.frame0.step = (size_t)s.cols;
+    gb.frame0.rows = s.rows;
+    gb.frame0.cols = s.cols;
+    gb.frame0.channels = 1;
+    gb.frame0.depth = RCV_8U;
+    gb.frame0.device = RCV_DEVICE;
+    gb.frame0.reserved = 0;
+    gb.frame_stride = (size_t)s.rows * s.cols;
+    gb.n = s.n;
+    gb.reserved = 0;
+    RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
+    View g;
+    RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
+    if (!resp) {
+        r = g;
+        r.p = wr;
+        r.step = (size_t)s.cols * 4;
+        r.fstride = (size_t)s.rows * s.cols * 4;
+        r.esz = 4;
+    }
+    RCV_TRY(harris_from_gray(ctx, g, r, block, k, wix, wiy));
+    hipLaunchKernelGGL(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
+    return rcv_launch_check(ctx);
+}
+
+// ---- single-Mat forms -----------------------------------------------------------------------------
+
+extern "C" int rcv_corner_harris(rcv_ctx* ctx, const rcv_mat* gray, rcv_mat* resp, int block, float k)
+{
+    if (!gray || !resp) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dd;
+    RCV_TRY(stage_in(&st, gray, true, false, &ds));
+    RCV_TRY(stage_in(&st, resp, true, true, &dd));
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
+    return stage_finish(&st, rcv_corner_harris_batch(ctx, &bs, &bd, block, k));
+}
+
+extern "C" int rcv_nms3x3(rcv_ctx* ctx, const rcv_mat* resp, rcv_mat* mask, float thr)
+{
+    if (!resp || !mask) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dd;
+    RCV_TRY(stage_in(&st, resp, true, false, &ds));
+    RCV_TRY(stage_in(&st, mask, true, true, &dd));
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
+    return stage_finish(&st, rcv_nms3x3_batch(ctx, &bs, &bd, thr));
+}
+
+extern "C" int rcv_harris_pipeline(rcv_ctx* ctx, const rcv_mat* bgr, rcv_mat* mask, rcv_mat* resp, int block, float k, float thr)
+{
+    if (!bgr || !mask) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dm, *dr = nullptr;
+    RCV_TRY(stage_in(&st, bgr, true, false, &ds));
+    RCV_TRY(stage_in(&st, mask, true, true, &dm));
+    if (resp) RCV_TRY(stage_in(&st, resp, true, true, &dr));
+    rcv_batch bs = rcv_single(ds), bm = rcv_single(dm), br;
+    if (resp) br = rcv_single(dr);
+    return stage_finish(&st, rcv_harris_pipeline_batch(ctx, &bs, &bm, resp ? &br : nullptr, block, k, thr));
+}

@@ -1,0 +1,90 @@
+// rcv_internal.h -- shared host-side plumbing of librustcv_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/rustcv_hip.h"
+
+#define RCV_MAX_STAGE 6
+
+struct rcv_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    // grow-only staging mirrors for RCV_HOST mats, one per argument slot of a call
+    uint8_t* stage_buf[RCV_MAX_STAGE];
+    size_t stage_cap[RCV_MAX_STAGE];
+    // workspace for kernel-internal temporaries (reserve once per call, then carve)
+    uint8_t* ws;
+    size_t ws_cap, ws_off;
+    // small device scratch for per-call constants (filter taps, weight tables)
+    uint8_t* kconst;     // 64 KiB
+    int cu_count;
+};
+
+// Kernel-facing description of a (batch of) strided image(s).
+struct View {
+    uint8_t* p;      // frame 0
+    size_t step;     // bytes per row
+    size_t fstride;  // bytes between frames
+    size_t cap;      // capacity of one frame
+    int rows, cols, ch, esz, n;
+};
+
+#define RCV_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) {                         \
+            (void)hipGetLastError();                    \
+            return e_ == hipErrorOutOfMemory ? RCV_ERR_OOM : RCV_ERR_DEVICE; \
+        }                                               \
+    } while (0)
+
+#define RCV_TRY(expr)                \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ < 0) return rc_;     \
+    } while (0)
+
+static inline int rcv_elem_size(int depth) { return depth == RCV_8U ? 1 : (depth == RCV_16S ? 2 : (depth == RCV_32F ? 4 : 0)); }
+
+// ---- helpers implemented in rcv_ctx.hip -------------------------------------------------
+int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ctx->device)
+int rcv_launch_check(rcv_ctx* ctx);                           // hipGetLastError -> code
+int rcv_ws_reserve(rcv_ctx* ctx, size_t total);               // (re)size the workspace, reset the carve pointer
+int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out);  // 256-B aligned carve
+int rcv_upload_const(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset); // into ctx->kconst (async, stream ordered)
+
+// Validate a strided mat (step/cap vs rows/cols) and turn it into a View.
+int rcv_view_strided(const rcv_mat* m, int want_depth, View* v);
+// Batch -> View (device only).
+int rcv_view_batch(const rcv_batch* b, int want_depth, View* v);
+
+// Host staging: the single-Mat entry points accept RCV_HOST mats.  A Stage keeps the
+// device mirror of each argument; outputs are copied back by stage_finish().
+struct StagedMat {
+    const rcv_mat* host;  // original (may be device-resident: then dev == *host)
+    rcv_mat dev;          // device-resident description
+    bool copy_back;
+};
+struct Stage {
+    rcv_ctx* ctx;
+    StagedMat m[RCV_MAX_STAGE];
+    int count;
+    bool any_host;
+};
+int stage_begin(Stage* s, rcv_ctx* ctx);
+int stage_in(Stage* s, const rcv_mat* m, bool upload, bool copy_back, rcv_mat** dev_out);
+int stage_finish(Stage* s, int rc);
+
+static inline rcv_batch rcv_single(const rcv_mat* dev)
+{
+    rcv_batch b;
+    b.frame0 = *dev;
+    b.frame_stride = 0;
+    b.n = 1;
+    b.reserved = 0;
+    return b;
+}
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

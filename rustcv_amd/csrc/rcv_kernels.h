@@ -1,0 +1,10 @@
+// rcv_kernels.h -- internal dispatch hooks of the shape-specialised (tiled / MFMA) kernels.
+// Each returns RCV_ERR_UNSUPPORTED when it does not take the shape; the caller then falls
+// through to the generic HIP kernel for that op (never to a CPU path).
+#pragma once
+#include "rcv_internal.h"
+
+int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize);
+int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
+int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy);
+int rcv_harris_fused(rcv_ctx* ctx, const View& bgr, const View& mask, const View* resp, int block, float k, float thr);

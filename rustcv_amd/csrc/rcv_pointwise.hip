@@ -1,0 +1,464 @@
+// rcv_pointwise.hip -- colour conversion (a1, a2, a4, a5), rectangle (a3), bgr2gray and the
+// synthetic frame generator.  gfx950 only.
+//
+// Reference semantics followed (file:line under /root/reference):
+//   yuyv_to_bgr   rustcv/src/videoio/mod.rs:344-382 ; twin rustcv-camera/src/decode.rs:160-191
+//   bgra_to_bgr   rustcv/src/videoio/mod.rs:385-399 ; twin rustcv-camera/src/decode.rs:200-207
+//   rgb_to_bgr    rustcv-camera/src/decode.rs:213-219
+//   rectangle     rustcv/src/imgproc/drawing.rs:67-106
+// The three conversions treat the frame as a FLAT byte array (row stride ignored), exactly as
+// the reference does; the kernels are therefore 1-D streaming kernels: every lane moves whole
+// 16-byte vectors (HBM-bound, 5 / 7 / 6 algorithmic bytes per pixel).
+#include "rcv_internal.h"
+#include "rcv_device_utils.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// one macropixel [Y0 U Y1 V] (little-endian dword) -> the six pre-shift sums b0 g0 r0 b1 g1 r1
+__device__ __forceinline__ void yuyv_pair(uint32_t m, int* o)
+{
+    int y0 = (int)(m & 0xff), u = (int)((m >> 8) & 0xff) - 128;
+    int y1 = (int)((m >> 16) & 0xff), v = (int)(m >> 24) - 128;
+    int c0 = 298 * (y0 - 16) + 128, c1 = 298 * (y1 - 16) + 128;
+    int db = 516 * u, dg = -100 * u - 208 * v, dr = 409 * v;
+    o[0] = c0 + db;
+    o[1] = c0 + dg;
+    o[2] = c0 + dr;
+    o[3] = c1 + db;
+    o[4] = c1 + dg;
+    o[5] = c1 + dr;
+}
+
+// pairs macropixels per frame; fast path: 8 macropixels (32 B in, 48 B out) per thread.
+__global__ __launch_bounds__(kBlock) void k_yuyv2bgr_vec(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                         size_t sfs, size_t dfs, size_t groups)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (size_t)gridDim.x * kBlock) {
+        const uint4* sp = (const uint4*)(s + g * 32);
+        uint4 a = sp[0], b = sp[1];
+        uint32_t m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        int by[48];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yuyv_pair(m[i], by + 6 * i);
+        uint32_t w[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w[i] = rcv_ashr_sat_pk4(by[4 * i], by[4 * i + 1], by[4 * i + 2], by[4 * i + 3], 8);
+        uint4* dp = (uint4*)(d + g * 48);
+        dp[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dp[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dp[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    }
+}
+
+// scalar path: one macropixel per thread, starting at macropixel `first`
+__global__ __launch_bounds__(kBlock) void k_yuyv2bgr_scalar(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                            size_t sfs, size_t dfs, size_t first, size_t pairs)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
+        const uint8_t* sp = s + i * 4;
+        uint32_t m = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+        int o[6];
+        yuyv_pair(m, o);
+        uint8_t* dp = d + i * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dp[k] = (uint8_t)rcv_ashr_sat1(o[k], 8);
+    }
+}
+
+// BGRA -> BGR: 16 pixels (64 B in, 48 B out) per thread.  v_perm_b32 packs 4 px -> 3 dwords.
+__device__ __forceinline__ void pack4_drop_alpha(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t* o)
+{
+    // __builtin_amdgcn_perm(hi, lo, sel): byte i of result = byte sel[i] of {hi:lo} (lo = bytes 0-3, hi = 4-7)
+    o[0] = __builtin_amdgcn_perm(p1, p0, 0x04020100u); // b0 g0 r0 b1
+    o[1] = __builtin_amdgcn_perm(p2, p1, 0x05040201u); // g1 r1 b2 g2
+    o[2] = __builtin_amdgcn_perm(p3, p2, 0x06050402u); // r2 b3 g3 r3
+}
+
+__global__ __launch_bounds__(kBlock) void k_bgra2bgr_vec(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                         size_t sfs, size_t dfs, size_t groups)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (size_t)gridDim.x * kBlock) {
+        const uint4* sp = (const uint4*)(s + g * 64);
+        uint4 a = sp[0], b = sp[1], c = sp[2], e = sp[3];
+        uint32_t w[12];
+        pack4_drop_alpha(a.x, a.y, a.z, a.w, w);
+        pack4_drop_alpha(b.x, b.y, b.z, b.w, w + 3);
+        pack4_drop_alpha(c.x, c.y, c.z, c.w, w + 6);
+        pack4_drop_alpha(e.x, e.y, e.z, e.w, w + 9);
+        uint4* dp = (uint4*)(d + g * 48);
+        dp[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dp[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dp[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bgra2bgr_scalar(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                            size_t sfs, size_t dfs, size_t first, size_t npx)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x; i < npx; i += (size_t)gridDim.x * kBlock) {
+        d[3 * i + 0] = s[4 * i + 0];
+        d[3 * i + 1] = s[4 * i + 1];
+        d[3 * i + 2] = s[4 * i + 2];
+    }
+}
+
+// RGB -> BGR: 4 px = 3 dwords in, 3 dwords out
+__device__ __forceinline__ void swap_rb4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t* o)
+{
+    // in bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 ; out: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+    o[0] = __builtin_amdgcn_perm(d1, d0, 0x05000102u); // b0 g0 r0 b1  (bytes 2,1,0 of d0 ; byte1 of d1)
+    // middle dword needs bytes from three dwords: g1(d1.0) r1(d0.3) b2(d2.0) g2(d1.3)
+    uint32_t t = __builtin_amdgcn_perm(d0, d1, 0x03000700u); // {hi=d0, lo=d1}: g1(lo0) r1(hi3) x g2(lo3)
+    o[1] = (t & 0xff00ffffu) | ((d2 & 0xffu) << 16);
+    // last dword: r2(d1.2) b3(d2.3) g3(d2.2) r3(d2.1)
+    o[2] = __builtin_amdgcn_perm(d2, d1, 0x05060702u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rgb2bgr_vec(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        size_t sfs, size_t dfs, size_t groups)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (size_t)gridDim.x * kBlock) {
+        const uint4* sp = (const uint4*)(s + g * 48);
+        uint4 a = sp[0], b = sp[1], c = sp[2];
+        uint32_t in[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        uint32_t w[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) swap_rb4(in[3 * i], in[3 * i + 1], in[3 * i + 2], w + 3 * i);
+        uint4* dp = (uint4*)(d + g * 48);
+        dp[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dp[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dp[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rgb2bgr_scalar(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                           size_t sfs, size_t dfs, size_t first, size_t npx)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    for (size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x; i < npx; i += (size_t)gridDim.x * kBlock) {
+        uint8_t r = s[3 * i], g = s[3 * i + 1], b = s[3 * i + 2];
+        d[3 * i + 0] = b;
+        d[3 * i + 1] = g;
+        d[3 * i + 2] = r;
+    }
+}
+
+// BGR -> gray, stride-aware.  Fast: 4 px (3 dwords) -> 1 dword per thread.
+__device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (1868u * b + 9617u * g + 4899u * r + 8192u) >> 14;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bgr2gray(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                     size_t sstep, size_t dstep, size_t sfs, size_t dfs,
+                                                     int rows, int cols, int vec)
+{
+    int y = blockIdx.y;
+    const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
+    uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * dstep;
+    int quads = vec ? cols / 4 : 0;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
+        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12);
+        uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
+        uint32_t g0 = gray1(d0 & 0xff, (d0 >> 8) & 0xff, (d0 >> 16) & 0xff);
+        uint32_t g1 = gray1(d0 >> 24, d1 & 0xff, (d1 >> 8) & 0xff);
+        uint32_t g2 = gray1((d1 >> 16) & 0xff, d1 >> 24, d2 & 0xff);
+        uint32_t g3 = gray1((d2 >> 8) & 0xff, (d2 >> 16) & 0xff, d2 >> 24);
+        *(uint32_t*)(d + (size_t)q * 4) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    }
+    for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock)
+        d[x] = (uint8_t)gray1(s[3 * x], s[3 * x + 1], s[3 * x + 2]);
+}
+
+// rectangle: one thread per (perimeter position, t).  Every write stores the same colour, so
+// overdraw order is irrelevant.  Index math is the reference's: 64-bit wrapping idx, guard idx+2 < len.
+__device__ __forceinline__ void set_pixel(uint8_t* data, size_t len, size_t step, int r, int c,
+                                          uint8_t b, uint8_t g, uint8_t rr)
+{
+    size_t idx = (size_t)(long long)r * step + (size_t)(long long)c * 3u;
+    if (idx + 2 < len && idx + 2 >= 2) {
+        data[idx] = b;
+        data[idx + 1] = g;
+        data[idx + 2] = rr;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rectangle(uint8_t* __restrict__ base, size_t fs, size_t cap, size_t step,
+                                                      int x_min, int y_min, int x_max, int y_max, long long thick,
+                                                      uint8_t b, uint8_t g, uint8_t r)
+{
+    uint8_t* data = base + (size_t)blockIdx.y * fs;
+    long long W = x_max - x_min, H = y_max - y_min;
+    long long total = (W + H) * thick;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        long long pos = i / thick;
+        int t = (int)(i - pos * thick);
+        if (pos < W) {
+            int c = x_min + (int)pos;
+            set_pixel(data, cap, step, y_min + t, c, b, g, r);
+            set_pixel(data, cap, step, y_max - 1 - t, c, b, g, r);
+        } else {
+            int rr = y_min + (int)(pos - W);
+            set_pixel(data, cap, step, rr, x_min + t, b, g, r);
+            set_pixel(data, cap, step, rr, x_max - 1 - t, b, g, r);
+        }
+    }
+}
+
+// Degenerate rectangles (thickness larger than the clipped rect, on a Mat whose step is not a
+// multiple of 3): wrapped pixels land off the 3-byte grid, writes of different channels overlap
+// and the reference's SEQUENTIAL order decides each byte.  One thread per frame replays that order.
+__global__ void k_rectangle_serial(uint8_t* __restrict__ base, size_t fs, size_t cap, size_t step,
+                                   int x_min, int y_min, int x_max, int y_max, long long thick,
+                                   uint8_t b, uint8_t g, uint8_t r)
+{
+    if (threadIdx.x != 0) return;
+    uint8_t* data = base + (size_t)blockIdx.x * fs;
+    for (int c = x_min; c < x_max; ++c)
+        for (long long t = 0; t < thick; ++t) {
+            set_pixel(data, cap, step, y_min + (int)t, c, b, g, r);
+            set_pixel(data, cap, step, y_max - 1 - (int)t, c, b, g, r);
+        }
+    for (int rr = y_min; rr < y_max; ++rr)
+        for (long long t = 0; t < thick; ++t) {
+            set_pixel(data, cap, step, rr, x_min + (int)t, b, g, r);
+            set_pixel(data, cap, step, rr, x_max - 1 - (int)t, b, g, r);
+        }
+}
+
+// ---- synthetic frames; same counter-based definition as oracle/rcv_oracle.c ----
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t synth_noise(uint64_t seed, uint64_t frame, int y, int x, int c)
+{
+    uint64_t ctr = (frame << 40) + ((uint64_t)y << 20) + ((uint64_t)x << 2) + (uint64_t)c;
+    return (uint32_t)(splitmix64(seed ^ ctr) >> 56);
+}
+
+__global__ __launch_bounds__(kBlock) void k_synth(uint8_t* __restrict__ base, size_t fs, size_t step, int rows, int cols,
+                                                  int ch, int family, uint64_t seed, uint64_t frame_base)
+{
+    int y = blockIdx.y;
+    uint64_t frame = frame_base + blockIdx.z;
+    uint8_t* row = base + (size_t)blockIdx.z * fs + (size_t)y * step;
+    int mx = cols - 200 > 1 ? cols - 200 : 1, my = rows - 200 > 1 ? rows - 200 : 1;
+    int sx0 = (int)((frame * 37u) % (uint64_t)mx), sy0 = (int)((frame * 23u) % (uint64_t)my);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock) {
+        if (family == RCV_SYNTH_YUYV) {
+            row[2 * x] = (uint8_t)synth_noise(seed, frame, y, x, 0);
+            row[2 * x + 1] = (uint8_t)synth_noise(seed ^ 0x9E3779B97F4A7C15ull, frame, y, x >> 1, (x & 1) ? 3 : 1);
+            continue;
+        }
+        for (int c = 0; c < ch; ++c) {
+            uint32_t n = synth_noise(seed, frame, y, x, c);
+            uint32_t v = n;
+            if (family == RCV_SYNTH_SCENE) {
+                uint32_t q = n >> 2;
+                if (x >= sx0 && x < sx0 + 200 && y >= sy0 && y < sy0 + 200) v = 255 - q;
+                else v = q + (uint32_t)(((long long)x * 96) / cols) + ((((x >> 6) + (y >> 6)) & 1) ? 64u : 0u);
+            }
+            row[(size_t)x * ch + c] = (uint8_t)v;
+        }
+    }
+}
+
+inline unsigned grid1d(size_t work_items)
+{
+    size_t b = (work_items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > 16384) b = 16384; // grid-stride beyond 16k blocks
+    return (unsigned)b;
+}
+
+bool aligned16(const void* p, size_t fs, int n) { return ((uintptr_t)p % 16 == 0) && (n <= 1 || fs % 16 == 0); }
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// entry points
+// ------------------------------------------------------------------------------------------------
+
+static int cvt_flat(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst)
+{
+    const rcv_mat* sm = &src->frame0;
+    rcv_mat* dm = &dst->frame0;
+    if (sm->device != RCV_DEVICE || dm->device != RCV_DEVICE) return RCV_ERR_ARG;
+    if (src->n != dst->n || src->n < 0) return RCV_ERR_ARG;
+    if (sm->depth != RCV_8U || dm->depth != RCV_8U) return RCV_ERR_UNSUPPORTED;
+    if (dm->rows < 0 || dm->cols < 0) return RCV_ERR_ARG;
+    int n = src->n;
+    size_t w = (size_t)dm->cols, h = (size_t)dm->rows;
+    size_t slen = sm->cap, dlen = dm->cap;
+    if (n > 1 && (src->frame_stride < slen || dst->frame_stride < dlen)) return RCV_ERR_SIZE;
+    size_t units = 0; // macropixels or pixels to convert
+    switch (code) {
+    case RCV_YUYV2BGR: // rustcv/src/videoio/mod.rs:345-348 : only src is checked
+        if (slen < w * h * 2) return RCV_NOOP;
+        units = w * h / 2;
+        if (dlen < units * 6) return RCV_ERR_SIZE; // reference would panic on the out-of-range index
+        break;
+    case RCV_YUYV2BGR_TWIN: // rustcv-camera/src/decode.rs:160-167
+        units = w * h / 2;
+        if (slen < units * 4 || dlen < units * 6) return RCV_NOOP;
+        break;
+    case RCV_BGRA2BGR: // rustcv/src/videoio/mod.rs:386-390
+        units = w * h;
+        if (slen < units * 4 || dlen < units * 3) return RCV_NOOP;
+        break;
+    case RCV_BGRA2BGR_TWIN: { // rustcv-camera/src/decode.rs:200-207 : zip of whole chunks
+        size_t a = slen / 4, b = dlen / 3;
+        units = a < b ? a : b;
+        break;
+    }
+    case RCV_RGB2BGR: { // rustcv-camera/src/decode.rs:213-219
+        size_t a = slen / 3, b = dlen / 3;
+        units = a < b ? a : b;
+        break;
+    }
+    default: return RCV_ERR_ARG;
+    }
+    if (units == 0 || n == 0) return RCV_OK;
+    if (!sm->data || !dm->data) return RCV_ERR_ARG;
+    const uint8_t* s = (const uint8_t*)sm->data;
+    uint8_t* d = (uint8_t*)dm->data;
+    size_t sfs = src->frame_stride, dfs = dst->frame_stride;
+    bool vec = aligned16(s, sfs, n) && aligned16(d, dfs, n);
+    hipStream_t st = ctx->stream;
+    if (code == RCV_YUYV2BGR || code == RCV_YUYV2BGR_TWIN) {
+        size_t groups = vec ? units / 8 : 0;
+        if (groups) hipLaunchKernelGGL(k_yuyv2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups * 8 < units)
+            hipLaunchKernelGGL(k_yuyv2bgr_scalar, dim3(grid1d(units - groups * 8), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 8, units);
+    } else if (code == RCV_BGRA2BGR || code == RCV_BGRA2BGR_TWIN) {
+        size_t groups = vec ? units / 16 : 0;
+        if (groups) hipLaunchKernelGGL(k_bgra2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups * 16 < units)
+            hipLaunchKernelGGL(k_bgra2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
+    } else {
+        size_t groups = vec ? units / 16 : 0;
+        if (groups) hipLaunchKernelGGL(k_rgb2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups * 16 < units)
+            hipLaunchKernelGGL(k_rgb2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
+    }
+    return rcv_launch_check(ctx);
+}
+
+static int cvt_gray(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst)
+{
+    View s, d;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (s.ch != 3 || d.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (s.rows != d.rows || s.cols != d.cols || s.n != d.n) return RCV_ERR_ARG;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int vec = ((uintptr_t)s.p % 4 == 0) && (s.step % 4 == 0) && (s.fstride % 4 == 0) &&
+              ((uintptr_t)d.p % 4 == 0) && (d.step % 4 == 0) && (d.fstride % 4 == 0);
+    dim3 grid(grid1d((size_t)(s.cols + 3) / 4), s.rows, s.n);
+    hipLaunchKernelGGL(k_bgr2gray, grid, dim3(kBlock), 0, ctx->stream, s.p, d.p, s.step, d.step, s.fstride, d.fstride,
+                       s.rows, s.cols, vec);
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_cvt_color_batch(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    RCV_TRY(rcv_bind(ctx));
+    if (code == RCV_BGR2GRAY) return cvt_gray(ctx, src, dst);
+    return cvt_flat(ctx, code, src, dst);
+}
+
+extern "C" int rcv_cvt_color(rcv_ctx* ctx, int code, const rcv_mat* src, rcv_mat* dst)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dd;
+    RCV_TRY(stage_in(&st, src, true, false, &ds));
+    // dst is uploaded too: the conversions may legitimately leave part of it untouched
+    RCV_TRY(stage_in(&st, dst, true, true, &dd));
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
+    int rc = rcv_cvt_color_batch(ctx, code, &bs, &bd);
+    return stage_finish(&st, rc);
+}
+
+extern "C" int rcv_rectangle_batch(rcv_ctx* ctx, rcv_batch* mats, int32_t x, int32_t y, int32_t w, int32_t h,
+                                   uint8_t b, uint8_t g, uint8_t r, int32_t thickness)
+{
+    if (!mats) return RCV_ERR_ARG;
+    RCV_TRY(rcv_bind(ctx));
+    const rcv_mat* m = &mats->frame0;
+    if (m->device != RCV_DEVICE || mats->n < 0) return RCV_ERR_ARG;
+    if (m->depth != RCV_8U) return RCV_ERR_UNSUPPORTED;
+    if (mats->n > 1 && mats->frame_stride < m->cap) return RCV_ERR_SIZE;
+    // rustcv/src/imgproc/drawing.rs:68-75
+    int32_t x_min = x > 0 ? x : 0, y_min = y > 0 ? y : 0;
+    int32_t xe = (int32_t)((uint32_t)x + (uint32_t)w), ye = (int32_t)((uint32_t)y + (uint32_t)h);
+    int32_t x_max = xe < m->cols ? xe : m->cols, y_max = ye < m->rows ? ye : m->rows;
+    if (x_min >= x_max || y_min >= y_max) return RCV_OK;
+    if (thickness <= 0 || mats->n == 0 || m->cap == 0) return RCV_OK;
+    if (!m->data) return RCV_ERR_ARG;
+    // beyond this many steps inward no index can pass the `idx+2 < len` guard any more
+    long long tcap = (long long)(m->cap / 3) + (long long)m->cols + (long long)m->rows + 2;
+    long long thick = thickness < tcap ? thickness : tcap;
+    long long total = ((long long)(x_max - x_min) + (long long)(y_max - y_min)) * thick;
+    // every generated (row, col) inside the Mat -> pixels are disjoint 3-byte cells, order is irrelevant;
+    // likewise when step % 3 == 0 (all writes sit on one 3-byte grid and carry the same colour).
+    bool in_range = (long long)y_min + thick <= m->rows && (long long)y_max - thick >= 0 &&
+                    (long long)x_min + thick <= m->cols && (long long)x_max - thick >= 0;
+    if (!in_range && m->step % 3 != 0) {
+        hipLaunchKernelGGL(k_rectangle_serial, dim3(mats->n), dim3(64), 0, ctx->stream, (uint8_t*)m->data, mats->frame_stride,
+                           m->cap, m->step, x_min, y_min, x_max, y_max, thick, b, g, r);
+        return rcv_launch_check(ctx);
+    }
+    hipLaunchKernelGGL(k_rectangle, dim3(grid1d((size_t)total), mats->n), dim3(kBlock), 0, ctx->stream, (uint8_t*)m->data,
+                       mats->frame_stride, m->cap, m->step, x_min, y_min, x_max, y_max, thick, b, g, r);
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_rectangle(rcv_ctx* ctx, rcv_mat* mat, int32_t x, int32_t y, int32_t w, int32_t h,
+                             uint8_t b, uint8_t g, uint8_t r, int32_t thickness)
+{
+    if (!mat) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat* dm;
+    RCV_TRY(stage_in(&st, mat, true, true, &dm));
+    rcv_batch bm = rcv_single(dm);
+    int rc = rcv_rectangle_batch(ctx, &bm, x, y, w, h, b, g, r, thickness);
+    return stage_finish(&st, rc);
+}
+
+extern "C" int rcv_synth_batch(rcv_ctx* ctx, rcv_batch* dst, int family, uint64_t seed, uint64_t frame_base)
+{
+    if (!dst) return RCV_ERR_ARG;
+    RCV_TRY(rcv_bind(ctx));
+    if (family != RCV_SYNTH_NOISE && family != RCV_SYNTH_SCENE && family != RCV_SYNTH_YUYV) return RCV_ERR_ARG;
+    View d;
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (family == RCV_SYNTH_YUYV && d.ch != 2) return RCV_ERR_ARG;
+    if (family != RCV_SYNTH_YUYV && d.ch != 1 && d.ch != 3 && d.ch != 4) return RCV_ERR_UNSUPPORTED;
+    if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
+    dim3 grid(grid1d((size_t)d.cols), d.rows, d.n);
+    hipLaunchKernelGGL(k_synth, grid, dim3(kBlock), 0, ctx->stream, d.p, d.fstride, d.step, d.rows, d.cols, d.ch, family, seed,
+                       frame_base);
+    return rcv_launch_check(ctx);
+}

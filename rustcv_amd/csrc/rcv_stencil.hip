@@ -1,0 +1,262 @@
+// rcv_stencil.hip -- GaussianBlur, filter2D (i8 / f32 weights) and Sobel: argument checking,
+// dispatch, and the GENERIC kernels (any size, any step, any channel count, ksize up to 15).
+// The generic kernels read taps straight from global memory through L1/L2 and resolve
+// BORDER_REFLECT_101 per tap; they are the correctness path for shapes the tiled kernels
+// (rcv_filter7_mfma.hip, rcv_stencil_tiled.hip) do not take.  None of these ops exists in the
+// reference; semantics are SURVEY.md 8-A, restated in oracle/rcv_oracle.c.
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include "rcv_device_utils.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+struct TapsI32 { int t[15]; int ksize; int D; };
+struct TapsF32 { float t[31]; int ksize; };
+struct KernI8 { int8_t k[225]; int ksize; int shift; };
+struct KernF32 { float k[225]; int ksize; float delta; };
+
+// one thread per output sample (byte column xb = x*ch + c)
+#define SAMPLE_LOOP_BEGIN                                                                        \
+    int y = blockIdx.y;                                                                          \
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;                                    \
+    uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride;                                          \
+    int rowb = s.cols * s.ch;                                                                    \
+    for (int xb = blockIdx.x * kBlock + threadIdx.x; xb < rowb; xb += gridDim.x * kBlock) {      \
+        int x = xb / s.ch, c = xb - x * s.ch;
+#define SAMPLE_LOOP_END }
+
+__global__ __launch_bounds__(kBlock) void k_gauss_int_generic(View s, View d, TapsI32 tp)
+{
+    int r = tp.ksize / 2;
+    SAMPLE_LOOP_BEGIN
+    int acc = 0;
+    for (int ky = 0; ky < tp.ksize; ++ky) {
+        const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
+        int h = 0;
+        for (int kx = 0; kx < tp.ksize; ++kx) h += tp.t[kx] * (int)row[(size_t)reflect101(x + kx - r, s.cols) * s.ch + c];
+        acc += tp.t[ky] * h;
+    }
+    df[(size_t)y * d.step + xb] = (uint8_t)((acc + tp.D / 2) / tp.D);
+    SAMPLE_LOOP_END
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_f32_generic(View s, View d, TapsF32 tp)
+{
+    int r = tp.ksize / 2;
+    SAMPLE_LOOP_BEGIN
+    float acc = 0.0f;
+    for (int ky = 0; ky < tp.ksize; ++ky) {
+        const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
+        float h = 0.0f; // horizontal pass of that row: fmaf chain in tap order from 0
+        for (int kx = 0; kx < tp.ksize; ++kx) h = fmaf(tp.t[kx], (float)row[(size_t)reflect101(x + kx - r, s.cols) * s.ch + c], h);
+        acc = fmaf(tp.t[ky], h, acc); // vertical pass
+    }
+    float v = rintf(acc);
+    df[(size_t)y * d.step + xb] = v < 0.0f ? 0 : (v > 255.0f ? 255 : (uint8_t)v);
+    SAMPLE_LOOP_END
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_i8_generic(View s, View d, KernI8 kw)
+{
+    int r = kw.ksize / 2;
+    int rnd = kw.shift > 0 ? (1 << (kw.shift - 1)) : 0;
+    SAMPLE_LOOP_BEGIN
+    int acc = 0;
+    for (int ky = 0; ky < kw.ksize; ++ky) {
+        const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
+        for (int kx = 0; kx < kw.ksize; ++kx)
+            acc += (int)kw.k[ky * kw.ksize + kx] * (int)row[(size_t)reflect101(x + kx - r, s.cols) * s.ch + c];
+    }
+    df[(size_t)y * d.step + xb] = (uint8_t)rcv_ashr_sat1(acc + rnd, kw.shift); // arithmetic shift == floor
+    SAMPLE_LOOP_END
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_f32_generic(View s, View d, KernF32 kw)
+{
+    int r = kw.ksize / 2;
+    SAMPLE_LOOP_BEGIN
+    float acc = kw.delta;
+    for (int ky = 0; ky < kw.ksize; ++ky) {
+        const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
+        for (int kx = 0; kx < kw.ksize; ++kx)
+            acc = fmaf(kw.k[ky * kw.ksize + kx], (float)row[(size_t)reflect101(x + kx - r, s.cols) * s.ch + c], acc);
+    }
+    float v = rintf(acc);
+    df[(size_t)y * d.step + xb] = v < 0.0f ? 0 : (v > 255.0f ? 255 : (uint8_t)v);
+    SAMPLE_LOOP_END
+}
+
+__global__ __launch_bounds__(kBlock) void k_sobel_generic(View s, View dx, View dy)
+{
+    int y = blockIdx.y;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    const uint8_t* r0 = sf + (size_t)reflect101(y - 1, s.rows) * s.step;
+    const uint8_t* r1 = sf + (size_t)y * s.step;
+    const uint8_t* r2 = sf + (size_t)reflect101(y + 1, s.rows) * s.step;
+    int16_t* ox = (int16_t*)(dx.p + (size_t)blockIdx.z * dx.fstride + (size_t)y * dx.step);
+    int16_t* oy = (int16_t*)(dy.p + (size_t)blockIdx.z * dy.fstride + (size_t)y * dy.step);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < s.cols; x += gridDim.x * kBlock) {
+        int xl = reflect101(x - 1, s.cols), xr = reflect101(x + 1, s.cols);
+        int gx = ((int)r0[xr] - (int)r0[xl]) + 2 * ((int)r1[xr] - (int)r1[xl]) + ((int)r2[xr] - (int)r2[xl]);
+        int gy = ((int)r2[xl] - (int)r0[xl]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xr] - (int)r0[xr]);
+        ox[x] = (int16_t)gx;
+        oy[x] = (int16_t)gy;
+    }
+}
+
+inline dim3 sample_grid(const View& v)
+{
+    size_t rowb = (size_t)v.cols * v.ch;
+    unsigned gx = (unsigned)((rowb + kBlock - 1) / kBlock);
+    if (gx > 1024) gx = 1024;
+    return dim3(gx, v.rows, v.n);
+}
+
+int check_pair(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, s));
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, d));
+    if (s->rows != d->rows || s->cols != d->cols || s->ch != d->ch || s->n != d->n) return RCV_ERR_ARG;
+    if (s->rows > 65535 || s->n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (s->p == d->p && s->rows > 0 && s->cols > 0) return RCV_ERR_ARG; // stencils are not in-place
+    return RCV_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, int ksize, double sigma)
+{
+    RCV_TRY(rcv_bind(ctx));
+    View s, d;
+    RCV_TRY(check_pair(src, dst, &s, &d));
+    if (sigma <= 0.0) {
+        if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_ARG;
+    } else if (!(ksize & 1) || ksize < 3 || ksize > 31) {
+        return RCV_ERR_ARG;
+    }
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    if (sigma <= 0.0) {
+        int rc = rcv_gauss_int_tiled(ctx, s, d, ksize);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+        static const int t3[3] = {1, 2, 1}, t5[5] = {1, 4, 6, 4, 1}, t7[7] = {2, 7, 14, 18, 14, 7, 2};
+        TapsI32 tp;
+        tp.ksize = ksize;
+        const int* t = ksize == 3 ? t3 : (ksize == 5 ? t5 : t7);
+        tp.D = ksize == 3 ? 16 : (ksize == 5 ? 256 : 4096);
+        for (int i = 0; i < ksize; ++i) tp.t[i] = t[i];
+        hipLaunchKernelGGL(k_gauss_int_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
+    } else {
+        TapsF32 tp;
+        tp.ksize = ksize;
+        RCV_TRY(rcv_gaussian_taps_f32(ksize, sigma, tp.t));
+        hipLaunchKernelGGL(k_gauss_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
+    }
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift)
+{
+    RCV_TRY(rcv_bind(ctx));
+    View s, d;
+    RCV_TRY(check_pair(src, dst, &s, &d));
+    if (!k || !(ksize & 1) || ksize < 1 || ksize > 15 || shift < 0 || shift > 24) return RCV_ERR_ARG;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int rc = rcv_filter_i8_fast(ctx, s, d, k, ksize, shift);
+    if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    KernI8 kw;
+    kw.ksize = ksize;
+    kw.shift = shift;
+    for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
+    hipLaunchKernelGGL(k_filter_i8_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw);
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* k, int ksize, float delta)
+{
+    RCV_TRY(rcv_bind(ctx));
+    View s, d;
+    RCV_TRY(check_pair(src, dst, &s, &d));
+    if (!k || !(ksize & 1) || ksize < 1 || ksize > 15) return RCV_ERR_ARG;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    KernF32 kw;
+    kw.ksize = ksize;
+    kw.delta = delta;
+    for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
+    hipLaunchKernelGGL(k_filter_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw);
+    return rcv_launch_check(ctx);
+}
+
+extern "C" int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dx || !dy) return RCV_ERR_ARG;
+    View s, vx, vy;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dx, RCV_16S, &vx));
+    RCV_TRY(rcv_view_batch(dy, RCV_16S, &vy));
+    if (s.ch != 1 || vx.ch != 1 || vy.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (s.rows != vx.rows || s.cols != vx.cols || s.n != vx.n || s.rows != vy.rows || s.cols != vy.cols || s.n != vy.n)
+        return RCV_ERR_ARG;
+    if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int rc = rcv_sobel_tiled(ctx, s, vx, vy);
+    if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    hipLaunchKernelGGL(k_sobel_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, vx, vy);
+    return rcv_launch_check(ctx);
+}
+
+// ---- single-Mat forms (host or device mats) -------------------------------------------------------
+
+#define RCV_UNARY_WRAPPER(call)                         \
+    if (!src || !dst) return RCV_ERR_ARG;               \
+    if (src->data == dst->data && src->data) return RCV_ERR_ARG; /* stencils are not in-place */ \
+    Stage st;                                           \
+    RCV_TRY(stage_begin(&st, ctx));                     \
+    rcv_mat *ds, *dd;                                   \
+    RCV_TRY(stage_in(&st, src, true, false, &ds));      \
+    RCV_TRY(stage_in(&st, dst, true, true, &dd));       \
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd); \
+    int rc = call;                                      \
+    return stage_finish(&st, rc);
+
+extern "C" int rcv_gaussian_blur(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, int ksize, double sigma)
+{
+    RCV_UNARY_WRAPPER(rcv_gaussian_blur_batch(ctx, &bs, &bd, ksize, sigma))
+}
+
+extern "C" int rcv_filter2d_i8(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const int8_t* k, int ksize, int shift)
+{
+    RCV_UNARY_WRAPPER(rcv_filter2d_i8_batch(ctx, &bs, &bd, k, ksize, shift))
+}
+
+extern "C" int rcv_filter2d_f32(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* k, int ksize, float delta)
+{
+    RCV_UNARY_WRAPPER(rcv_filter2d_f32_batch(ctx, &bs, &bd, k, ksize, delta))
+}
+
+extern "C" int rcv_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy)
+{
+    if (!src || !dx || !dy) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *d1, *d2;
+    RCV_TRY(stage_in(&st, src, true, false, &ds));
+    RCV_TRY(stage_in(&st, dx, true, true, &d1));
+    RCV_TRY(stage_in(&st, dy, true, true, &d2));
+    rcv_batch bs = rcv_single(ds), b1 = rcv_single(d1), b2 = rcv_single(d2);
+    int rc = rcv_sobel_batch(ctx, &bs, &b1, &b2);
+    return stage_finish(&st, rc);
+}

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (oracle/liboracle.so) -- the checker.  Built on demand with gcc."""
+    from oracle import pyoracle
+    pyoracle.build()
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One rcv_ctx on GPU 0.  No skip-if-missing: -m gpu tests must fail loudly without the HIP path."""
+    import rustcv_amd
+    c = rustcv_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture
+def rng():
+    return np.random.default_rng(0xC0FFEE)

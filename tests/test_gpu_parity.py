@@ -1,0 +1,354 @@
+"""GPU parity: every HIP entry point of librustcv_hip.so vs the CPU oracle, through the C ABI.
+
+Bit-exact for all u8 / i16 outputs and -- because the f32 evaluation order is fixed on both
+sides -- bit-exact for the f32 Harris response too (tolerance stated where it is looser).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rustcv_amd as rcv
+from rustcv_amd import _ffi, device, imgproc, videoio
+from rustcv_amd.core import Mat
+from rustcv_amd.imgproc import Rect, Scalar
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 33), (48, 64), (61, 127), (128, 240), (37, 515)]
+
+
+def rand_img(rng, rows, cols, ch):
+    a = rng.integers(0, 256, size=(rows, cols, ch), dtype=np.uint8)
+    return a[:, :, 0] if ch == 1 else a
+
+
+# ---- a1: YUYV -> BGR -----------------------------------------------------------------------------
+
+def test_yuyv_reference_tests(ctx):
+    # rustcv-camera/src/decode.rs:234-265 replayed on the GPU path
+    d = np.zeros(6, np.uint8)
+    assert videoio.yuyv_to_bgr(np.array([235, 128, 235, 128], np.uint8), d, 2, 1, ctx)
+    assert (d > 240).all()
+    assert videoio.yuyv_to_bgr(np.array([16, 128, 16, 128], np.uint8), d, 2, 1, ctx)
+    assert (d < 10).all()
+
+
+def test_yuyv_exhaustive_all_yuv_triples(ctx, oracle):
+    """All 2^24 (Y,U,V) triples (SURVEY.md §4 tier 3), 16.7 M macropixels, vector + scalar paths."""
+    y, u, v = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    src = np.stack([y, u, np.roll(y, 1, axis=0), v], axis=-1).reshape(-1)  # Y0,U,Y1,V with Y1 != Y0
+    w, h = 4096, 8192
+    assert src.size == w * h * 2
+    want = np.zeros(w * h * 3, np.uint8)
+    assert oracle.yuyv_to_bgr(src, want, w, h)
+    got = np.zeros_like(want)
+    assert videoio.yuyv_to_bgr(src, got, w, h, ctx)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(2, 1), (3, 1), (5, 3), (640, 480), (641, 3), (18, 1), (16, 1), (1, 1), (0, 0), (7, 9)])
+@pytest.mark.parametrize("code,variant", [(_ffi.RCV_YUYV2BGR, 0), (_ffi.RCV_YUYV2BGR_TWIN, 1)])
+def test_yuyv_shapes_and_guards(ctx, oracle, rng, w, h, code, variant):
+    for slack_src, slack_dst in [(0, 0), (5, 7), (-1, 0), (0, -1)]:
+        src = rng.integers(0, 256, size=max(w * h * 2 + slack_src, 0), dtype=np.uint8)
+        dst0 = rng.integers(0, 256, size=max(w * h * 3 + slack_dst, 0), dtype=np.uint8)
+        want = dst0.copy()
+        ran = oracle.yuyv_to_bgr(src, want, w, h, variant)
+        got = Mat(h, w, 3, data=dst0.copy())
+        got.data = dst0.copy()
+        s = Mat(1, src.size, 1, data=src)
+        sm, dm = s._as_rcv(), got._as_rcv()
+        rc = _ffi.lib().rcv_cvt_color(ctx.handle, code, C.byref(sm), C.byref(dm))
+        if variant == 0 and src.size >= w * h * 2 and dst0.size < (w * h // 2) * 6:
+            assert rc == _ffi.RCV_ERR_SIZE  # reference facade would panic; we refuse
+            continue
+        assert rc == (_ffi.RCV_OK if ran else _ffi.RCV_NOOP), (rc, ran)
+        assert np.array_equal(got.data, want)
+
+
+# ---- a2 / a4 ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("npx", [0, 1, 15, 16, 17, 640 * 480, 100003])
+def test_bgra_to_bgr(ctx, oracle, rng, npx):
+    src = rng.integers(0, 256, size=npx * 4, dtype=np.uint8)
+    want = np.full(npx * 3 + 5, 7, np.uint8)
+    got = want.copy()
+    w, h = (npx, 1) if npx else (0, 0)
+    assert oracle.bgra_to_bgr(src, want, w, h, 0)
+    assert videoio.bgra_to_bgr(src, got, w, h, ctx)
+    assert np.array_equal(got, want)
+    # facade guard: short src -> silent no-op
+    if npx:
+        got2 = np.full(npx * 3, 9, np.uint8)
+        assert not videoio.bgra_to_bgr(src[:-1], got2, w, h, ctx)
+        assert (got2 == 9).all()
+
+
+def test_rgb_to_bgr_reference_vector(ctx):
+    # rustcv-camera/src/decode.rs:267-273 -- the one exact vector the reference holds
+    d = np.zeros(6, np.uint8)
+    videoio.rgb_to_bgr(np.array([255, 0, 0, 0, 255, 0], np.uint8), d, ctx)
+    assert d.tolist() == [0, 0, 255, 0, 255, 0]
+
+
+@pytest.mark.parametrize("nsrc,ndst", [(48, 48), (49, 50), (3 * 1000 + 2, 3 * 999), (3 * 100003, 3 * 100003), (0, 6), (2, 9)])
+def test_rgb_to_bgr(ctx, oracle, rng, nsrc, ndst):
+    src = rng.integers(0, 256, size=nsrc, dtype=np.uint8)
+    want = np.full(ndst, 3, np.uint8)
+    got = want.copy()
+    oracle.rgb_to_bgr(src, want)
+    videoio.rgb_to_bgr(src, got, ctx)
+    assert np.array_equal(got, want)
+
+
+def test_decode_into_dispatch(ctx, oracle, rng):
+    w, h = 64, 48
+    m = Mat.empty()
+    yuyv = rng.integers(0, 256, size=w * h * 2, dtype=np.uint8)
+    videoio.decode_into(m, yuyv, videoio.YUYV, w, h, ctx)
+    want = np.zeros(w * h * 3, np.uint8)
+    oracle.yuyv_to_bgr(yuyv, want, w, h)
+    assert (m.rows, m.cols, m.channels, m.step) == (h, w, 3, w * 3) and np.array_equal(m.data, want)
+    bgra = rng.integers(0, 256, size=w * h * 4, dtype=np.uint8)
+    videoio.decode_into(m, bgra, videoio.BGRA, w, h, ctx)
+    oracle.bgra_to_bgr(bgra, want, w, h)
+    assert np.array_equal(m.data, want)
+    raw = rng.integers(0, 256, size=w * h * 3, dtype=np.uint8)
+    videoio.decode_into(m, raw, videoio.BGR3, w, h, ctx)  # unknown -> copy when the length matches
+    assert np.array_equal(m.data, raw)
+
+
+# ---- a3: rectangle ---------------------------------------------------------------------------------
+
+RECTS = [
+    (Rect(200, 150, 240, 240), 2), (Rect(0, 0, 640, 480), 1), (Rect(-10, -10, 50, 50), 3), (Rect(600, 440, 100, 100), 4),
+    (Rect(10, 10, 1, 1), 1), (Rect(10, 10, 5, 3), 9), (Rect(630, 5, 10, 400), 20), (Rect(700, 5, 10, 10), 2),
+    (Rect(5, 5, 0, 10), 2), (Rect(5, 5, 10, 10), 0), (Rect(5, 5, 10, 10), -1), (Rect(0, 470, 640, 10), 15), (Rect(3, 3, 600, 6), 700),
+]
+
+
+@pytest.mark.parametrize("rect,thick", RECTS)
+@pytest.mark.parametrize("pad", [0, 13])
+def test_rectangle(ctx, oracle, rng, rect, thick, pad):
+    rows, cols = 480, 640
+    step = cols * 3 + pad
+    base = rng.integers(0, 256, size=rows * step, dtype=np.uint8)
+    want = base.copy()
+    oracle.rectangle(want, rows, cols, step, rect.x, rect.y, rect.width, rect.height, 0, 255, 7, thick)
+    m = Mat(rows, cols, 3, step=step, data=base.copy())
+    imgproc.rectangle(m, rect, Scalar(0, 255, 7), thick, ctx)
+    assert np.array_equal(m.data, want)
+
+
+def test_rectangle_short_vec_guard(ctx, oracle, rng):
+    # data.len() shorter than rows*step: only the `idx+2 < len` guard protects memory (drawing.rs:82)
+    rows, cols, step = 20, 30, 90
+    base = rng.integers(0, 256, size=rows * step - 100, dtype=np.uint8)
+    want = base.copy()
+    oracle.rectangle(want, rows, cols, step, 2, 2, 26, 17, 1, 2, 3, 2)
+    m = Mat(rows, cols, 3, step=step, data=base.copy())
+    imgproc.rectangle(m, Rect(2, 2, 26, 17), Scalar(1, 2, 3), 2, ctx)
+    assert np.array_equal(m.data, want)
+
+
+# ---- build-defined ops -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_bgr2gray(ctx, oracle, rng, rows, cols):
+    img = rand_img(rng, rows, cols, 3)
+    for pad in (0, 5):
+        src = Mat.from_array(img, step=cols * 3 + pad)
+        dst = Mat(rows, cols, 1, step=cols + (3 if pad else 0))
+        imgproc.cvt_color(src, dst, _ffi.RCV_BGR2GRAY, ctx)
+        assert np.array_equal(dst.to_array(), oracle.bgr2gray(img))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_gaussian_int(ctx, oracle, rng, rows, cols, ch, ksize):
+    img = rand_img(rng, rows, cols, ch)
+    src = Mat.from_array(img, step=cols * ch + 16)
+    dst = Mat(rows, cols, ch)
+    imgproc.gaussian_blur(src, dst, ksize, 0.0, ctx)
+    assert np.array_equal(dst.to_array(), oracle.gaussian_blur(img, ksize, 0.0))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (17, 33), (61, 127)])
+@pytest.mark.parametrize("ksize,sigma", [(3, 0.8), (5, 1.1), (9, 2.0), (15, 3.3)])
+def test_gaussian_sigma(ctx, oracle, rng, rows, cols, ksize, sigma):
+    img = rand_img(rng, rows, cols, 3)
+    src, dst = Mat.from_array(img), Mat(rows, cols, 3)
+    imgproc.gaussian_blur(src, dst, ksize, sigma, ctx)
+    assert np.array_equal(dst.to_array(), oracle.gaussian_blur(img, ksize, sigma))  # bit-exact: same fmaf chains
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("ksize,shift", [(1, 0), (3, 4), (5, 0), (7, 6), (7, 9)])
+def test_filter2d_i8(ctx, oracle, rng, rows, cols, ch, ksize, shift):
+    img = rand_img(rng, rows, cols, ch)
+    k = rng.integers(-128, 128, size=(ksize, ksize), dtype=np.int8) if shift == 9 else rng.integers(-8, 9, size=(ksize, ksize)).astype(np.int8)
+    src = Mat.from_array(img, step=cols * ch + 7)
+    dst = Mat(rows, cols, ch)
+    imgproc.filter2d(src, dst, k, shift=shift, ctx=ctx)
+    assert np.array_equal(dst.to_array(), oracle.filter2d_i8(img, k, shift))
+
+
+def test_filter2d_i8_extremes(ctx, oracle):
+    img = np.full((40, 56, 3), 255, np.uint8)
+    for k in (np.full((7, 7), 127, np.int8), np.full((7, 7), -128, np.int8)):
+        for shift in (0, 6, 24):
+            dst = Mat(40, 56, 3)
+            imgproc.filter2d(Mat.from_array(img), dst, k, shift=shift, ctx=ctx)
+            assert np.array_equal(dst.to_array(), oracle.filter2d_i8(img, k, shift))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (17, 33), (61, 127)])
+@pytest.mark.parametrize("ksize", [1, 3, 7])
+def test_filter2d_f32(ctx, oracle, rng, rows, cols, ksize):
+    img = rand_img(rng, rows, cols, 3)
+    k = (rng.standard_normal((ksize, ksize)) / ksize).astype(np.float32)
+    src, dst = Mat.from_array(img), Mat(rows, cols, 3)
+    imgproc.filter2d(src, dst, k, delta=0.5, ctx=ctx)
+    assert np.array_equal(dst.to_array(), oracle.filter2d_f32(img, k, 0.5))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_sobel(ctx, oracle, rng, rows, cols):
+    img = rand_img(rng, rows, cols, 1)
+    src = Mat.from_array(img, step=cols + 3)
+    dx, dy = Mat(rows, cols, 1, _ffi.RCV_16S), Mat(rows, cols, 1, _ffi.RCV_16S, step=cols * 2 + 6)
+    imgproc.sobel(src, dx, dy, ctx)
+    wx, wy = oracle.sobel(img)
+    assert np.array_equal(dx.to_array(), wx) and np.array_equal(dy.to_array(), wy)
+
+
+@pytest.mark.parametrize("src_shape,dst_shape", [((48, 64), (12, 16)), ((48, 64), (48, 64)), ((17, 33), (40, 71)), ((61, 127), (13, 9)),
+                                                 ((1, 1), (5, 7)), ((4, 4), (1, 1)), ((128, 240), (32, 60)), ((30, 50), (31, 49))])
+@pytest.mark.parametrize("ch", [1, 3, 4])
+def test_resize(ctx, oracle, rng, src_shape, dst_shape, ch):
+    img = rand_img(rng, *src_shape, ch)
+    src, dst = Mat.from_array(img, step=src_shape[1] * ch + 5), Mat(*dst_shape, ch)
+    imgproc.resize(src, dst, ctx)
+    want = oracle.resize(img, *dst_shape)
+    assert np.array_equal(dst.to_array(), want)  # f32 path with a fixed op order: bit-exact (north_star allows 1 ULP)
+    if src_shape == (48, 64) and dst_shape == (12, 16):  # exact 4x == (a+b+c+d+2)>>2 of the centre 2x2
+        a = img.astype(np.int32).reshape(12, 4, 16, 4, -1)
+        box = (a[:, 1, :, 1] + a[:, 1, :, 2] + a[:, 2, :, 1] + a[:, 2, :, 2] + 2) >> 2
+        assert np.array_equal(want.reshape(12, 16, -1), box)
+
+
+def _rot(deg, cx, cy, tx, ty):
+    t = np.deg2rad(deg)
+    c, s = np.cos(t), np.sin(t)
+    return np.array([c, -s, cx - c * cx + s * cy + tx, s, c, cy - s * cx - c * cy + ty], np.float32)
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (61, 127), (1, 1), (5, 3)])
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("M", [np.array([1, 0, 0, 0, 1, 0], np.float32), np.array([1, 0, 0.5, 0, 1, 0.25], np.float32),
+                               np.array([1, 0, -30.75, 0, 1, 1000], np.float32), np.array([0.5, 0.1, 3, -0.2, 1.7, -4], np.float32),
+                               "rot7", np.array([1e9, 0, 0, 0, 1e-9, 0], np.float32)])
+def test_warp_affine(ctx, oracle, rng, shape, ch, M):
+    if isinstance(M, str):
+        M = _rot(7.0, shape[1] / 2, shape[0] / 2, 13.25, -8.5)
+    img = rand_img(rng, *shape, ch)
+    src, dst = Mat.from_array(img), Mat(shape[0] + 3, shape[1] + 5, ch)
+    imgproc.warp_affine(src, dst, M, ctx)
+    assert np.array_equal(dst.to_array(), oracle.warp_affine(img, M, shape[0] + 3, shape[1] + 5))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("block", [1, 2, 3, 5])
+def test_corner_harris(ctx, oracle, rng, rows, cols, block):
+    img = rand_img(rng, rows, cols, 1)
+    src, dst = Mat.from_array(img), Mat(rows, cols, 1, _ffi.RCV_32F)
+    imgproc.corner_harris(src, dst, block, 0.04, ctx)
+    want = oracle.corner_harris(img, block, 0.04)
+    assert np.array_equal(dst.to_array().view(np.uint32), want.view(np.uint32))  # bit-exact f32
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_nms3x3(ctx, oracle, rng, rows, cols):
+    resp = rng.standard_normal((rows, cols)).astype(np.float32)
+    resp[rng.random((rows, cols)) < 0.2] = 0.5  # plateaus: ties must be kept (>=)
+    src, dst = Mat.from_array(resp), Mat(rows, cols, 1)
+    imgproc.nms3x3(src, dst, 0.1, ctx)
+    assert np.array_equal(dst.to_array(), oracle.nms3x3(resp, 0.1))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES + [(200, 300)])
+@pytest.mark.parametrize("block", [2, 3])
+@pytest.mark.parametrize("want_resp", [False, True])
+def test_harris_pipeline(ctx, oracle, rows, cols, block, want_resp):
+    img = oracle.synth_frame(rows, cols, 3, 1, 0x5EED0005, 3)
+    src, mask = Mat.from_array(img), Mat(rows, cols, 1)
+    resp = Mat(rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+    thr = 1e-4
+    imgproc.harris_pipeline(src, mask, resp, block, 0.04, thr, ctx)
+    if want_resp:
+        wm, wr = oracle.harris_pipeline(img, block, 0.04, thr, True)
+        assert np.array_equal(resp.to_array().view(np.uint32), wr.view(np.uint32))
+    else:
+        wm = oracle.harris_pipeline(img, block, 0.04, thr)
+    assert np.array_equal(mask.to_array(), wm)
+
+
+# ---- synthetic frames + device-resident batches -------------------------------------------------------
+
+@pytest.mark.parametrize("family,ch", [(0, 1), (0, 3), (0, 4), (1, 3), (1, 1)])
+def test_synth_matches_oracle(ctx, oracle, family, ch):
+    rows, cols, n = 70, 333, 3
+    b = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + 9)
+    b.memset(0)
+    device.synth(b, family, 0x5EED0003, 5)
+    got = b.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.synth_frame(rows, cols, ch, family, 0x5EED0003, 5 + i))
+    b.free()
+
+
+def test_synth_yuyv_matches_oracle(ctx, oracle):
+    rows, cols, n = 33, 64, 2
+    b = device.DeviceBatch(ctx, n, rows, cols, 2)
+    device.synth(b, _ffi.RCV_SYNTH_YUYV, 0x5EED0001, 0)
+    got = b.download().reshape(n, rows, cols * 2)
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.synth_yuyv(rows, cols, 0x5EED0001, i))
+    b.free()
+
+
+def test_batch_equals_single_frames(ctx, oracle):
+    """Batch entry points: frame i of the batch == the single-frame result (no cross-frame leakage)."""
+    rows, cols, n = 96, 160, 5
+    k = oracle.bench_kernel7()
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    dst = device.DeviceBatch(ctx, n, rows, cols, 3)
+    device.synth(src, 1, 0x5EED0003, 0)
+    device.filter2d(src, dst, k, shift=6)
+    got = dst.download()
+    frames = src.download()
+    for i in range(n):
+        assert np.array_equal(frames[i], oracle.synth_frame(rows, cols, 3, 1, 0x5EED0003, i))
+        assert np.array_equal(got[i], oracle.filter2d_i8(frames[i], k, 6))
+    src.free()
+    dst.free()
+
+
+def test_errors_do_not_cross_the_abi(ctx):
+    L = _ffi.lib()
+    m = Mat(4, 4, 3)
+    a, b = m._as_rcv(), Mat(4, 5, 3)._as_rcv()
+    k = (C.c_int8 * 9)(*([1] * 9))
+    assert L.rcv_filter2d_i8(ctx.handle, C.byref(a), C.byref(b), k, 3, 0) == _ffi.RCV_ERR_ARG      # shape mismatch
+    assert L.rcv_filter2d_i8(ctx.handle, C.byref(a), C.byref(a), k, 3, 0) == _ffi.RCV_ERR_ARG      # in-place
+    assert L.rcv_filter2d_i8(ctx.handle, C.byref(a), C.byref(b), k, 4, 0) == _ffi.RCV_ERR_ARG      # even ksize
+    short = Mat(4, 4, 3)
+    short.data = short.data[:-1]
+    s = short._as_rcv()
+    c = Mat(4, 4, 3)._as_rcv()
+    assert L.rcv_filter2d_i8(ctx.handle, C.byref(s), C.byref(c), k, 3, 0) == _ffi.RCV_ERR_SIZE
+    assert L.rcv_cvt_color(ctx.handle, 99, C.byref(a), C.byref(c)) == _ffi.RCV_ERR_ARG
+    assert L.rcv_filter2d_i8(None, C.byref(a), C.byref(c), k, 3, 0) == _ffi.RCV_ERR_ARG
