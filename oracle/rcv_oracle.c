@@ -153,6 +153,14 @@ int orc_reflect101(int i, int n)
     return i;
 }
 
+/* byte offset of reflected pixel (i - r) for i in [0, n + 2r): hoists the border map out of the tap loops */
+static int* reflect_table(int n, int r, int ch)
+{
+    int* t = (int*)malloc((size_t)(n + 2 * r) * sizeof(int));
+    if (t) for (int i = 0; i < n + 2 * r; ++i) t[i] = orc_reflect101(i - r, n) * ch;
+    return t;
+}
+
 static inline uint8_t sat_u8_i(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v); }
 
 /* g = (1868 B + 9617 G + 4899 R + 8192) >> 14 */
@@ -244,20 +252,24 @@ int orc_filter2d_i8(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep
     if (!(ksize & 1) || ksize < 1 || ksize > 15 || shift < 0 || shift > 24) return -2;
     int r = ksize / 2;
     int32_t rnd = shift > 0 ? (1 << (shift - 1)) : 0;
+    int* xm = reflect_table(cols, r, ch);
+    if (!xm) return -5;
 #pragma omp parallel for schedule(static)
-    for (int y = 0; y < rows; ++y)
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t* rp[15];
+        for (int ky = 0; ky < ksize; ++ky) rp[ky] = src + (size_t)orc_reflect101(y + ky - r, rows) * sstep;
         for (int x = 0; x < cols; ++x)
             for (int c = 0; c < ch; ++c) {
                 int32_t acc = 0;
-                for (int ky = 0; ky < ksize; ++ky) {
-                    const uint8_t* s = src + (size_t)orc_reflect101(y + ky - r, rows) * sstep;
+                for (int ky = 0; ky < ksize; ++ky)
                     for (int kx = 0; kx < ksize; ++kx)
-                        acc += (int32_t)k[ky * ksize + kx] * (int32_t)s[(size_t)orc_reflect101(x + kx - r, cols) * ch + c];
-                }
+                        acc += (int32_t)k[ky * ksize + kx] * (int32_t)rp[ky][xm[x + kx] + c];
                 int32_t v = acc + rnd;
                 v = v >= 0 ? (v >> shift) : -((-v + ((1 << shift) - 1)) >> shift); /* floor division == arithmetic shift */
                 dst[(size_t)y * dstep + (size_t)x * ch + c] = sat_u8_i(v);
             }
+    }
+    free(xm);
     return 0;
 }
 

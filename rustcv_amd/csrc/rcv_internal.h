@@ -20,6 +20,10 @@ struct rcv_ctx {
     // small device scratch for per-call constants (filter taps, weight tables)
     uint8_t* kconst;     // 64 KiB
     int cu_count;
+    // cached banded-weight table of the MFMA filter (rcv_filter7_mfma.hip), lives in kconst[0..4096)
+    bool f7_valid;
+    int f7_ksize;
+    int8_t f7_k[49];
 };
 
 // Kernel-facing description of a (batch of) strided image(s).
