@@ -33,14 +33,19 @@
 #include "rcv_device_utils.h"
 #include <string.h>
 
+int rcv_debug_flags = 0;
+extern "C" void rcv__debug_set(int flags) { rcv_debug_flags = flags; }
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kWaves = 5;
+constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
-constexpr int kTiles = 15;            // 16-px tiles per strip
-constexpr int kPitch = 272;           // bytes per planar row in LDS (xx = 0..255 used, +16 pad)
+constexpr int kTiles = 15;            // 16-px tiles per strip (240 px); wave w computes tiles 4w..4w+3 (tile 15 is a dummy)
+constexpr int kPitch = 288;           // bytes per planar row in LDS: 18 x 16 B.  Row stride == 2 (mod 16) sixteen-byte
+                                      // slots makes every ds_read_b128 lane group (8 rows at x, 8 rows at x+16) hit 16
+                                      // distinct slots: conflict-free (272 B measured 46 % conflict cycles).
 constexpr int kSlots = 48;            // ring of 3 blocks x 16 rows
 constexpr int kPlane = kSlots * kPitch;
 
@@ -48,9 +53,11 @@ struct F7Args {
     const uint8_t* src;
     uint8_t* dst;
     const uint4* wtab;   // 4 MFMAs x 64 lanes x 16 B (A operands), device memory
+    uint8_t* dump;       // 64 x 16 B scratch: masked-off lanes store here so that every store is unconditional
     size_t sstep, dstep, sfs, dfs;
     int rows, cols;
     int ntiles_total, nstrips, seg_rows, nsegs;
+    int total_wgs, wgs_per_xcd;
     int shift, acc_init;
 };
 
@@ -66,12 +73,21 @@ __device__ __forceinline__ void deint4(uint32_t d0, uint32_t d1, uint32_t d2, ui
     pr = __builtin_amdgcn_perm(d2, t, 0x07040100u);  // + r2(d2.0) r3(d2.3)
 }
 
+struct U2 { uint32_t a, b; };
+struct U3 { uint32_t a, b, c; };
+
+// DBG: ablation bits for profiling builds (-DRCV_ABLATE): 1 skip global stores, 2 skip global loads, 4 skip MFMA
+template <int DBG>
 __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * kPlane];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
+    // XCD-aware order: hardware places block b on XCD b % 8 (speed only, never correctness).  Give each XCD a
+    // contiguous run of (frame, segment, strip) ids so horizontally adjacent strips -- which share halo
+    // columns and, at 720 B per strip row, partial 128-B lines -- are co-resident on one L2.
+    int bid = (blockIdx.x & 7) * a.wgs_per_xcd + (blockIdx.x >> 3);
+    if (bid >= a.total_wgs) return;
     const int strip = bid % a.nstrips;
     bid /= a.nstrips;
     const int seg = bid % a.nsegs;
@@ -96,104 +112,137 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         A[p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
     }
 
-    // ---- staging task of this thread: (row r of a block, 16-pixel chunk q of the strip) ----
+    // ---- staging task of this thread: (row sr of a block, 16-pixel chunk sq of the strip) ----
+    // The chunk's 16 pixels are image x = x0 - 3 + 16q .. +15: bytes [7, 55) of the four 16-B vectors that
+    // start at row byte 3*x0 + 48q - 16.  Only dwords 1..13 of those 64 bytes are needed -> 13 VGPRs.
+    // EVERY load below is unconditional (no branch may enclose a VMEM op in the main loop, otherwise the
+    // compiler can only wait with vmcnt(0) and the register prefetch pipeline collapses): vectors that fall
+    // outside the row are clamped into it -- their bytes are either reflected halo (patched in registers
+    // below) or multiplied by zero weights -- and rows past the segment re-read its last row (cache hits).
     const int sr = tid >> 4, sq = tid & 15;
-    const bool stager = tid < 256 && sq <= ntiles;
-    const int soff0 = 3 * x0 + 48 * sq - 16;  // byte offset in the source row of the first of 4 vectors
-    uint4 L[4];
+    const int soff0 = 3 * x0 + 48 * sq - 16;
+    const int hi = rowbytes - 16;
+    const int o0 = min(max(soff0, 0), hi) + 4, o1 = min(max(soff0 + 16, 0), hi), o2 = min(max(soff0 + 32, 0), hi),
+              o3 = min(max(soff0 + 48, 0), hi);
+    const int xa = x0 - 3 + 16 * sq;                    // image x of the chunk's first pixel
+    const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
+    const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
+    const int ry_last = ye + 2;                         // last source row (before reflection) this segment needs
 
-    auto load_block = [&](int b) {
-        const int ry = ys - 3 + 16 * b + sr;
-        const bool act = stager && ry <= ye + 2;
+    auto load_block = [&](int b, uint32_t (&L)[13]) {
+        const int ry = min(ys - 3 + 16 * b + sr, ry_last);
         const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-        const uint8_t* base = sframe + (size_t)srow * a.sstep;
+        const uint8_t* p = sframe + (size_t)srow * a.sstep;
+        if (DBG & 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = soff0 + 16 * j;
-            const bool ok = act && o >= 0 && o + 16 <= rowbytes;
-            L[j] = ok ? *(const uint4*)(base + o) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 13; ++i) L[i] = 0;
+            return;
         }
+        const U3 v0 = *(const U3*)(p + o0);
+        const uint4 v1 = *(const uint4*)(p + o1);
+        const uint4 v2 = *(const uint4*)(p + o2);
+        const U2 v3 = *(const U2*)(p + o3);
+        L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
+        L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
+        L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
+        L[11] = v3.a; L[12] = v3.b;
     };
 
-    auto store_block = [&](int b) {
-        const int rr = 16 * b + sr;
-        const int ry = ys - 3 + rr;
-        if (!(stager && ry <= ye + 2)) return;
-        const uint32_t w[16] = {L[0].x, L[0].y, L[0].z, L[0].w, L[1].x, L[1].y, L[1].z, L[1].w,
-                                L[2].x, L[2].y, L[2].z, L[2].w, L[3].x, L[3].y, L[3].z, L[3].w};
+    auto store_block = [&](int b, const uint32_t (&L)[13]) {
         uint32_t s[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(w[i + 2], w[i + 1], 3);  // bytes [7+4i, 11+4i)
+        for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
         uint32_t pb[4], pg[4], pr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
-        const int slot = rr % kSlots;
+        // BORDER_REFLECT_101 in x, in registers (first / last strip only; branch-free selects elsewhere).
+        //  left : chunk 0 holds x = -3..12 ; x = -3,-2,-1 mirror x = 3,2,1 = bytes 6,5,4 of the same chunk.
+        //  right: chunk `ntiles` holds x = cols-3..cols+12 ; x = cols,cols+1,cols+2 (bytes 3,4,5) mirror
+        //         x = cols-2,cols-3,cols-4 = bytes 1, 0 of this chunk and byte 15 of the previous chunk (lane - 1).
+        const uint32_t nb = __builtin_amdgcn_update_dpp(0u, pb[3], 0x111, 0xf, 0xf, false);  // row_shr:1 -> lane-1's dword
+        const uint32_t ng = __builtin_amdgcn_update_dpp(0u, pg[3], 0x111, 0xf, 0xf, false);
+        const uint32_t nr = __builtin_amdgcn_update_dpp(0u, pr[3], 0x111, 0xf, 0xf, false);
+        if (xleft) {
+            pb[0] = __builtin_amdgcn_perm(pb[1], pb[0], 0x03040506u);
+            pg[0] = __builtin_amdgcn_perm(pg[1], pg[0], 0x03040506u);
+            pr[0] = __builtin_amdgcn_perm(pr[1], pr[0], 0x03040506u);
+        }
+        if (xright) {
+            uint32_t t;
+            t = __builtin_amdgcn_perm(nb, pb[0], 0x00000700u);
+            pb[1] = __builtin_amdgcn_perm(pb[1], t, 0x07060100u);
+            pb[0] = __builtin_amdgcn_perm(pb[0], pb[0], 0x01020100u);
+            t = __builtin_amdgcn_perm(ng, pg[0], 0x00000700u);
+            pg[1] = __builtin_amdgcn_perm(pg[1], t, 0x07060100u);
+            pg[0] = __builtin_amdgcn_perm(pg[0], pg[0], 0x01020100u);
+            t = __builtin_amdgcn_perm(nr, pr[0], 0x00000700u);
+            pr[1] = __builtin_amdgcn_perm(pr[1], t, 0x07060100u);
+            pr[0] = __builtin_amdgcn_perm(pr[0], pr[0], 0x01020100u);
+        }
+        if (sq > ntiles || ys - 3 + 16 * b + sr > ry_last) return;  // chunk / row not needed (LDS ops may be conditional)
+        const int slot = (16 * b + sr) % kSlots;
         uint8_t* dstp = lds + slot * kPitch + 16 * sq;
         *(uint4*)(dstp) = make_uint4(pb[0] ^ 0x80808080u, pb[1] ^ 0x80808080u, pb[2] ^ 0x80808080u, pb[3] ^ 0x80808080u);
         *(uint4*)(dstp + kPlane) = make_uint4(pg[0] ^ 0x80808080u, pg[1] ^ 0x80808080u, pg[2] ^ 0x80808080u, pg[3] ^ 0x80808080u);
         *(uint4*)(dstp + 2 * kPlane) = make_uint4(pr[0] ^ 0x80808080u, pr[1] ^ 0x80808080u, pr[2] ^ 0x80808080u, pr[3] ^ 0x80808080u);
-        // BORDER_REFLECT_101 in x: the chunk's pixel e is image x = x0 - 3 + 16*sq + e
-        const int xa = x0 - 3 + 16 * sq;
-        if (xa < 0 || xa + 5 >= a.cols) {
-            const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-            const uint8_t* base = sframe + (size_t)srow * a.sstep;
-            for (int e = 0; e < 6; ++e) {
-                const int x = xa + e;
-                if (x >= 0 && x < a.cols) continue;
-                const int xs = x < 0 ? -x : 2 * a.cols - 2 - x;
-                if (xs < 0 || xs >= a.cols) continue;  // beyond the 3-px halo: multiplied by zero weights
-                dstp[e] = base[3 * xs] ^ 0x80;
-                dstp[kPlane + e] = base[3 * xs + 1] ^ 0x80;
-                dstp[2 * kPlane + e] = base[3 * xs + 2] ^ 0x80;
+    };
+
+    const int n = lane & 15, kb = lane >> 4;
+    const int kyl = kb >> 1, xh = (kb & 1) * 16;
+    uint8_t* const dumpp = a.dump + lane * 16;
+
+    auto compute = [&](int k) {
+        int off[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) off[p] = ((16 * k + n + 2 * p + kyl) % kSlots) * kPitch + xh + 64 * wave;
+        const int y = ys + 16 * k + n;
+        uint8_t* const orow = dframe + (size_t)y * a.dstep + 3 * (x0 + 64 * wave + 4 * kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v4i acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (DBG & 4) continue;
+                    const v4i b = *(const v4i*)(lds + c * kPlane + off[p] + 16 * i);
+                    acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], b, acc[c], 0, 0, 0);
+                }
+            }
+            // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row y (t = 4*wave + i): 12 interleaved bytes
+            const uint32_t w0 = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+            const uint32_t w1 = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+            const uint32_t w2 = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+            // rows past the segment and tiles past the strip store into the dump line instead (unconditional store)
+            const bool live = y < ye && 4 * wave + i < ntiles;
+            if (DBG & 1) {
+                if (acc[0][0] == 0x7fffffff) *(U3*)dumpp = U3{w0, w1, w2};
+            } else {
+                *(U3*)(live ? orow + 48 * i : dumpp) = U3{w0, w1, w2};
             }
         }
     };
 
-    // ---- prologue: blocks 0 and 1 ----
-    load_block(0);
-    store_block(0);
-    load_block(1);
-    store_block(1);
+    // ---- software pipeline: block k+3 is in flight in registers and block k+2 is written to the LDS ring while
+    // step k computes from blocks k, k+1.  Blocks 0..nsteps are needed; loads past that are harmless re-reads.
+    // Two register sets, loop unrolled by two so that the set index is static. ----
+    uint32_t LA[13], LB[13];
+    load_block(0, LA);
+    load_block(1, LB);
+    store_block(0, LA);
+    store_block(1, LB);
+    load_block(2, LA);
     __syncthreads();
 
-    const int n = lane & 15, kb = lane >> 4;
-    const int kyl = kb >> 1, xh = (kb & 1) * 16;
-
-    for (int k = 0; k < nsteps; ++k) {
-        const bool more = k + 1 < nsteps;
-        if (more) load_block(k + 2);
-
-        int off[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) off[p] = ((16 * k + n + 2 * p + kyl) % kSlots) * kPitch + xh;
-        const int y = ys + 16 * k + n;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = 3 * wave + i;
-            if (t < ntiles) {
-                v4i acc[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const v4i b = *(const v4i*)(lds + c * kPlane + off[p] + 16 * t);
-                        acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], b, acc[c], 0, 0, 0);
-                    }
-                }
-                if (y < ye) {
-                    // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} for row y: 12 interleaved bytes
-                    const uint32_t w0 = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
-                    const uint32_t w1 = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
-                    const uint32_t w2 = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
-                    uint32_t* o = (uint32_t*)(dframe + (size_t)y * a.dstep + 3 * (x0 + 16 * t + 4 * kb));
-                    struct U3 { uint32_t a, b, c; };
-                    *(U3*)o = U3{w0, w1, w2};
-                }
-            }
-        }
-
-        if (more) store_block(k + 2);
+    for (int k = 0; k < nsteps; k += 2) {
+        load_block(k + 3, LB);
+        compute(k);
+        store_block(k + 2, LA);
+        __syncthreads();
+        load_block(k + 4, LA);
+        compute(k + 1);   // (when nsteps is odd this last half-iteration computes a step past the segment: all dumped)
+        store_block(k + 3, LB);
         __syncthreads();
     }
 }
@@ -216,6 +265,13 @@ void build_wtab(const int8_t* k, int ksize, int8_t* tab /*4*64*16*/)
 }
 
 } // namespace
+
+extern "C" int rcv__debug_occupancy(void)
+{
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter7_mfma<0>, kThreads, 0) != hipSuccess) return -1;
+    return nb;
+}
 
 int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
 {
@@ -243,6 +299,7 @@ int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.src = s.p;
     a.dst = d.p;
     a.wtab = (const uint4*)ctx->kconst;
+    a.dump = ctx->kconst + 8192;
     a.sstep = s.step;
     a.dstep = d.step;
     a.sfs = s.fstride;
@@ -263,8 +320,24 @@ int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.nsegs = (s.rows + seg_rows - 1) / seg_rows;
     a.shift = shift;
     a.acc_init = 128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0);
-    long long grid = (long long)a.nstrips * a.nsegs * s.n;
-    if (grid > 0x7fffffffLL) return RCV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_filter7_mfma, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, a);
+    long long total = (long long)a.nstrips * a.nsegs * s.n;
+    if (total > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
+    a.total_wgs = (int)total;
+    a.wgs_per_xcd = (int)((total + 7) / 8);
+    const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
+#ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
+    switch (rcv_debug_flags & 7) {
+    case 1: hipLaunchKernelGGL(k_filter7_mfma<1>, grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(k_filter7_mfma<2>, grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(k_filter7_mfma<3>, grid, block, 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL(k_filter7_mfma<4>, grid, block, 0, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL(k_filter7_mfma<5>, grid, block, 0, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL(k_filter7_mfma<6>, grid, block, 0, ctx->stream, a); break;
+    case 7: hipLaunchKernelGGL(k_filter7_mfma<7>, grid, block, 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(k_filter7_mfma<0>, grid, block, 0, ctx->stream, a); break;
+    }
+#else
+    hipLaunchKernelGGL(k_filter7_mfma<0>, grid, block, 0, ctx->stream, a);
+#endif
     return rcv_launch_check(ctx);
 }
