@@ -75,6 +75,9 @@ __device__ __forceinline__ void deint4(uint32_t d0, uint32_t d1, uint32_t d2, ui
     pr = __builtin_amdgcn_perm(d2, t, 0x07040100u);  // + r2(d2.0) r3(d2.3)
 }
 
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 struct U2 { uint32_t a, b; };
 struct U3 { uint32_t a, b, c; };
 
@@ -140,14 +143,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             for (int i = 0; i < 13; ++i) L[i] = 0;
             return;
         }
-        const U3 v0 = *(const U3*)(p + o0);
-        const uint4 v1 = *(const uint4*)(p + o1);
-        const uint4 v2 = *(const uint4*)(p + o2);
-        const U2 v3 = *(const U2*)(p + o3);
-        L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
-        L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
-        L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
-        L[11] = v3.a; L[12] = v3.b;
+        // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
+        //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
+        const u3v v0 = *(const u3v*)(p + o0);
+        const u4v v1 = *(const u4v*)(p + o1);
+        const u4v v2 = *(const u4v*)(p + o2);
+        const u2v v3 = *(const u2v*)(p + o3);
+        L[0] = v0[0]; L[1] = v0[1]; L[2] = v0[2];
+        L[3] = v1[0]; L[4] = v1[1]; L[5] = v1[2]; L[6] = v1[3];
+        L[7] = v2[0]; L[8] = v2[1]; L[9] = v2[2]; L[10] = v2[3];
+        L[11] = v3[0]; L[12] = v3[1];
     };
 
     auto store_block = [&](int b, const uint32_t (&L)[13]) {
@@ -222,23 +227,34 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         int off[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) off[p] = ((16 * k + n + 2 * p + kyl) % kSlots) * kPitch + xh + 64 * wave;
+        // 48 MFMAs per step (4 tiles x 4 row-pairs x 3 planes), B operands read kAhead items ahead into a
+        // static register ring so LDS latency is covered inside the wave; the three planes' accumulators are
+        // interleaved so dependent MFMAs sit three issues apart.
+        constexpr int kAhead = 9;
+        v4i Bq[kAhead];
+        auto rd = [&](int it) -> v4i {
+            const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
+            return *(const v4i*)(lds + c * kPlane + off[p] + 16 * i);
+        };
+        v4i acc[3];
+        if (!(DBG & 4)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v4i acc[3];
+            for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it);
+        }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (DBG & 4) continue;
-                    const v4i b = *(const v4i*)(lds + c * kPlane + off[p] + 16 * i);
-                    acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], b, acc[c], 0, 0, 0);
-                }
+        for (int it = 0; it < 48; ++it) {
+            const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
+            if (r < 3) acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+            if (!(DBG & 4)) {
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], acc[c], 0, 0, 0);
+                if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead);
             }
-            // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row n (t = 4*wave + i): 12 interleaved bytes
-            *(uint32_t*)(obuf + woff[i][0]) = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
-            *(uint32_t*)(obuf + woff[i][1]) = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
-            *(uint32_t*)(obuf + woff[i][2]) = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+            if (r == 11) {
+                // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row n (t = 4*wave + i): 12 interleaved bytes
+                *(uint32_t*)(obuf + woff[i][0]) = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+                *(uint32_t*)(obuf + woff[i][1]) = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+                *(uint32_t*)(obuf + woff[i][2]) = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+            }
         }
         const int ybase = ys + 16 * k;
 #pragma unroll
