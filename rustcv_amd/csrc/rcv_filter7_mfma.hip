@@ -75,9 +75,6 @@ __device__ __forceinline__ void deint4(uint32_t d0, uint32_t d1, uint32_t d2, ui
     pr = __builtin_amdgcn_perm(d2, t, 0x07040100u);  // + r2(d2.0) r3(d2.3)
 }
 
-typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-typedef uint32_t u3v __attribute__((ext_vector_type(3)));
-typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 struct U2 { uint32_t a, b; };
 struct U3 { uint32_t a, b, c; };
 
@@ -145,14 +142,14 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         }
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
-        const u3v v0 = *(const u3v*)(p + o0);
-        const u4v v1 = *(const u4v*)(p + o1);
-        const u4v v2 = *(const u4v*)(p + o2);
-        const u2v v3 = *(const u2v*)(p + o3);
-        L[0] = v0[0]; L[1] = v0[1]; L[2] = v0[2];
-        L[3] = v1[0]; L[4] = v1[1]; L[5] = v1[2]; L[6] = v1[3];
-        L[7] = v2[0]; L[8] = v2[1]; L[9] = v2[2]; L[10] = v2[3];
-        L[11] = v3[0]; L[12] = v3[1];
+        const U3 v0 = *(const U3*)(p + o0);
+        const uint4 v1 = *(const uint4*)(p + o1);
+        const uint4 v2 = *(const uint4*)(p + o2);
+        const U2 v3 = *(const U2*)(p + o3);
+        L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
+        L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
+        L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
+        L[11] = v3.a; L[12] = v3.b;
     };
 
     auto store_block = [&](int b, const uint32_t (&L)[13]) {
