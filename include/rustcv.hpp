@@ -1,0 +1,169 @@
+// rustcv.hpp -- C++ host facade over the C ABI (include/rustcv_hip.h).
+//
+// The reference's host side is Rust (rustcv::core::Mat, rustcv::imgproc::*, the private colour helpers of
+// rustcv::videoio).  This image has no Rust toolchain, so the host side above the C ABI is written in C++
+// with the SAME names, argument order and behaviour, so that code and tests read like the reference's:
+//   rustcv::Mat                      <- rustcv/src/core/mat.rs:6-53
+//   rustcv::imgproc::{Point,Rect,Scalar,rectangle}  <- rustcv/src/imgproc/drawing.rs:8-106
+//   rustcv::videoio::{yuyv_to_bgr,bgra_to_bgr}      <- rustcv/src/videoio/mod.rs:344-399
+//   rustcv::decode::rgb_to_bgr                       <- rustcv-camera/src/decode.rs:213-219
+// The ops the reference does not have follow OpenCV's names.  Header-only; link with
+// -lrustcv_hip.  Errors: a negative rcv status becomes std::runtime_error (Rust: Err / panic); the
+// reference's silent length-guard returns stay silent (functions return false).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "rustcv_hip.h"
+
+namespace rustcv {
+
+struct Mat {
+    std::vector<uint8_t> data;
+    int32_t rows = 0, cols = 0;
+    size_t step = 0;
+    uint8_t channels = 0;
+
+    static Mat create(int32_t rows, int32_t cols, uint8_t channels)  // Mat::new (mat.rs:18-29)
+    {
+        Mat m;
+        m.rows = rows;
+        m.cols = cols;
+        m.channels = channels;
+        m.step = (size_t)cols * channels;
+        m.data.assign((size_t)rows * m.step, 0);
+        return m;
+    }
+    static Mat empty() { return Mat(); }                                   // mat.rs:31-39
+    bool is_empty() const { return data.empty() || rows == 0 || cols == 0; }  // mat.rs:42-44
+    const uint8_t* row_bytes(int32_t row) const { return data.data() + (size_t)row * step; }  // mat.rs:47-51 (cols*channels bytes)
+
+    rcv_mat view(uint8_t depth = RCV_8U)
+    {
+        rcv_mat v{};
+        v.data = data.empty() ? nullptr : data.data();
+        v.cap = data.size();
+        v.step = step;
+        v.rows = rows;
+        v.cols = cols;
+        v.channels = channels;
+        v.depth = depth;
+        v.device = RCV_HOST;
+        return v;
+    }
+};
+
+class Backend {  // one rcv_ctx per thread of use; Drop -> rcv_ctx_destroy (precedent macos/mod.rs:264-272)
+public:
+    explicit Backend(int device = 0)
+    {
+        int rc = rcv_ctx_create(device, &ctx_);
+        if (rc != RCV_OK) throw std::runtime_error(std::string("rcv_ctx_create: ") + rcv_strerror(rc));
+    }
+    ~Backend() { rcv_ctx_destroy(ctx_); }
+    Backend(const Backend&) = delete;
+    Backend& operator=(const Backend&) = delete;
+    rcv_ctx* ctx() const { return ctx_; }
+    static Backend& instance()
+    {
+        static thread_local Backend b(0);
+        return b;
+    }
+
+private:
+    rcv_ctx* ctx_ = nullptr;
+};
+
+inline int check(int rc, const char* what)
+{
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + rcv_strerror(rc));
+    return rc;
+}
+
+namespace imgproc {
+
+struct Point { int32_t x, y; };
+struct Rect { int32_t x, y, width, height; };
+struct Scalar {
+    uint8_t v0, v1, v2;  // blue, green, red
+    static Scalar all(uint8_t v) { return Scalar{v, v, v}; }
+};
+
+inline void rectangle(Mat& mat, Rect rect, Scalar color, int32_t thickness)  // drawing.rs:67
+{
+    rcv_mat m = mat.view();
+    check(rcv_rectangle(Backend::instance().ctx(), &m, rect.x, rect.y, rect.width, rect.height, color.v0, color.v1, color.v2, thickness),
+          "rectangle");
+}
+
+inline void GaussianBlur(Mat& src, Mat& dst, int ksize, double sigma = 0.0)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_gaussian_blur(Backend::instance().ctx(), &s, &d, ksize, sigma), "GaussianBlur");
+}
+inline void filter2D(Mat& src, Mat& dst, const int8_t* kernel, int ksize, int shift)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_filter2d_i8(Backend::instance().ctx(), &s, &d, kernel, ksize, shift), "filter2D");
+}
+inline void filter2D(Mat& src, Mat& dst, const float* kernel, int ksize, float delta = 0.0f)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_filter2d_f32(Backend::instance().ctx(), &s, &d, kernel, ksize, delta), "filter2D");
+}
+inline void resize(Mat& src, Mat& dst)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_resize(Backend::instance().ctx(), &s, &d), "resize");
+}
+inline void warpAffine(Mat& src, Mat& dst, const float M[6])
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_warp_affine(Backend::instance().ctx(), &s, &d, M), "warpAffine");
+}
+inline void cvtColor(Mat& src, Mat& dst, int code)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_cvt_color(Backend::instance().ctx(), code, &s, &d), "cvtColor");
+}
+
+}  // namespace imgproc
+
+namespace videoio {
+
+inline bool convert_flat(int code, const uint8_t* src, size_t src_len, std::vector<uint8_t>& dest, size_t width, size_t height)
+{
+    rcv_mat s{}, d{};
+    s.data = const_cast<uint8_t*>(src);
+    s.cap = s.step = src_len;
+    s.rows = src_len ? 1 : 0;
+    s.cols = (int32_t)src_len;
+    s.channels = 1;
+    d.data = dest.empty() ? nullptr : dest.data();
+    d.cap = dest.size();
+    d.step = width * 3;
+    d.rows = (int32_t)height;
+    d.cols = (int32_t)width;
+    d.channels = 3;
+    return check(rcv_cvt_color(Backend::instance().ctx(), code, &s, &d), "cvt_color") == RCV_OK;
+}
+// fn yuyv_to_bgr(src: &[u8], dest: &mut [u8], width: usize, height: usize)   (mod.rs:344)
+inline bool yuyv_to_bgr(const uint8_t* src, size_t src_len, std::vector<uint8_t>& dest, size_t width, size_t height)
+{
+    return convert_flat(RCV_YUYV2BGR, src, src_len, dest, width, height);
+}
+// fn bgra_to_bgr(src: &[u8], dest: &mut [u8], width: usize, height: usize)   (mod.rs:385)
+inline bool bgra_to_bgr(const uint8_t* src, size_t src_len, std::vector<uint8_t>& dest, size_t width, size_t height)
+{
+    return convert_flat(RCV_BGRA2BGR, src, src_len, dest, width, height);
+}
+
+}  // namespace videoio
+
+namespace decode {
+// fn rgb_to_bgr(src: &[u8], dst: &mut [u8])   (rustcv-camera/src/decode.rs:213)
+inline void rgb_to_bgr(const uint8_t* src, size_t src_len, std::vector<uint8_t>& dst) { videoio::convert_flat(RCV_RGB2BGR, src, src_len, dst, 0, 0); }
+}  // namespace decode
+
+}  // namespace rustcv

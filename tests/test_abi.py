@@ -1,0 +1,102 @@
+"""CPU tests of the drop-in boundary: the shared library loads, exports every symbol include/rustcv_hip.h
+declares (and ctypes agrees with the C struct layouts), host-only helpers work, and compute entry points
+fail loudly -- not silently fall back -- when there is no GPU."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import rustcv_amd
+from rustcv_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rustcv_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rcv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in syms if s not in exported]
+    assert not missing, missing
+    assert sorted(_ffi.SIGNATURES) == syms  # the ctypes table covers exactly the header
+    L = _ffi.lib()
+    assert L.rcv_abi_version() == 1
+
+
+def test_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rustcv_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(rcv_mat),offsetof(rcv_mat,cap),offsetof(rcv_mat,step),offsetof(rcv_mat,rows),offsetof(rcv_mat,channels),'
+                   'offsetof(rcv_mat,device),sizeof(rcv_batch),offsetof(rcv_batch,frame_stride),offsetof(rcv_batch,n));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = list(map(int, subprocess.check_output([str(exe)], text=True).split()))
+    m, b = _ffi.rcv_mat, _ffi.rcv_batch
+    want = [C.sizeof(m), m.cap.offset, m.step.offset, m.rows.offset, m.channels.offset, m.device.offset,
+            C.sizeof(b), b.frame_stride.offset, b.n.offset]
+    assert got == want
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if rustcv_amd.device_count() > 0:
+        pytest.skip("a GPU is present; this test is about the GPU-less container")
+    with pytest.raises(rustcv_amd.RcvError) as e:
+        rustcv_amd.Context(0)
+    assert e.value.code == _ffi.RCV_ERR_DEVICE
+    L = _ffi.lib()
+    m = rustcv_amd.Mat(4, 4, 3)._as_rcv()
+    assert L.rcv_rectangle(None, C.byref(m), 0, 0, 2, 2, 1, 2, 3, 1) == _ffi.RCV_ERR_ARG  # no ctx -> error, never a CPU path
+
+
+def test_product_never_references_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "rustcv_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                bad = re.search(r"liboracle|pyoracle|from\s+oracle|import\s+oracle|#include[^\n]*oracle|dlopen", txt)
+                assert not bad, (os.path.join(base, f), bad.group(0))
+    deps = subprocess.check_output(["readelf", "-d", _ffi.LIB_PATH], text=True)
+    assert "oracle" not in deps
+
+
+def test_fourcc_dispatch_mirrors_the_reference():
+    from rustcv_amd import videoio
+    L = _ffi.lib()
+    code = C.c_int(-1)
+    assert videoio.YUYV == 0x56595559  # 'Y','U','Y','V' little-endian (pixel_format.rs:10-12,39)
+    for fcc, want in ((videoio.YUYV, _ffi.RCV_YUYV2BGR), (videoio.BGRA, _ffi.RCV_BGRA2BGR), (videoio.BGR4, _ffi.RCV_BGRA2BGR),
+                      (videoio.RGB3, _ffi.RCV_RGB2BGR)):
+        assert L.rcv_fourcc_to_code(fcc, C.byref(code)) == 0 and code.value == want
+    assert L.rcv_fourcc_to_code(videoio.MJPEG, C.byref(code)) == _ffi.RCV_ERR_UNSUPPORTED
+    assert L.rcv_fourcc_to_code(0xDEADBEEF, C.byref(code)) == _ffi.RCV_ERR_UNSUPPORTED
+
+
+def test_gaussian_taps_helper_matches_oracle(oracle):
+    L = _ffi.lib()
+    for ks, sg in ((3, 0.8), (7, 1.5), (15, 3.3), (31, 6.0)):
+        t = (C.c_float * ks)()
+        assert L.rcv_gaussian_taps_f32(ks, sg, t) == 0
+        assert np.array_equal(np.array(t[:], np.float32).view(np.uint32), oracle.gaussian_taps_f32(ks, sg).view(np.uint32))
+    assert L.rcv_gaussian_taps_f32(4, 1.0, (C.c_float * 4)()) == _ffi.RCV_ERR_ARG
+    assert L.rcv_strerror(-3).decode().startswith("buffer too small")
+
+
+def test_cpp_facade_compiles_and_links(tmp_path):
+    """include/rustcv.hpp + tests/cpp/facade_test.cpp (the reference's tests, C++ spelling) build against the .so."""
+    exe = tmp_path / "facade_test"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "rustcv_amd"), "-lrustcv_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rustcv_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)

@@ -1,0 +1,89 @@
+"""CPU tests of the host-side mirror (Mat, shard ranges) and of the N>1 harness path with gloo, world_size 2."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rustcv_amd
+from rustcv_amd import shard
+from rustcv_amd.core import Mat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mat_mirrors_reference_constructors():
+    m = Mat.new(3, 5, 3)                       # mat.rs:18-29: step = cols*channels, zero filled
+    assert (m.rows, m.cols, m.channels, m.step, m.data.size) == (3, 5, 3, 15, 45) and not m.data.any()
+    assert Mat.empty().is_empty() and not m.is_empty()
+    p = Mat(2, 2, 3, step=8, data=np.arange(16, dtype=np.uint8))
+    assert p.row_bytes(1).tolist() == [8, 9, 10, 11, 12, 13]          # mat.rs:47-51: padding dropped
+    a = np.arange(24, dtype=np.uint8).reshape(2, 4, 3)
+    q = Mat.from_array(a, step=16)
+    assert q.step == 16 and np.array_equal(q.to_array(), a)
+    r = q._as_rcv()
+    assert (r.rows, r.cols, r.channels, r.step, r.cap, r.device) == (2, 4, 3, 16, 32, 0)
+
+
+@pytest.mark.parametrize("n,world", [(64, 1), (64, 8), (256, 8), (512, 8), (10, 4), (3, 8), (0, 2), (7, 7)])
+def test_frame_ranges_partition_the_batch(n, world):
+    r = shard.all_ranges(n, world)
+    assert r[0][0] == 0 and r[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    sizes = [b - a for a, b in r]
+    assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.frame_range(n, world, world)
+
+
+WORKER = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from rustcv_amd import shard
+from oracle import pyoracle as orc          # tests may use the oracle; it stands in for the GPU kernel here
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+N, rows, cols = 6, 40, 64
+f0, f1 = shard.frame_range(N, rank, world)
+k = orc.bench_kernel7()
+digs = []
+for f in range(f0, f1):
+    out = orc.filter2d_i8(orc.synth_frame(rows, cols, 3, 1, 0x5EED0003, f), k, 6)
+    digs.append(hashlib.sha256(out.tobytes()).hexdigest())
+elapsed = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+dist.barrier()
+dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)     # bench.py's max-over-ranks
+gathered = [None] * world
+dist.all_gather_object(gathered, (f0, f1, digs))
+if rank == 0:
+    print(json.dumps({"max": float(elapsed[0]), "parts": gathered}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_shard_equals_single_rank(tmp_path, oracle):
+    """world_size 2 over gloo: each rank filters its frame range; the concatenation must be byte-identical to
+    the 1-rank result, and the timing reduction is a MAX over ranks."""
+    import hashlib
+    import json
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), ROOT],
+                                  env=env, text=True, stderr=subprocess.DEVNULL, timeout=300)
+    res = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert res["max"] == pytest.approx(0.002)
+    parts = sorted(res["parts"])
+    assert [p[:2] for p in parts] == [[0, 3], [3, 6]]
+    got = [d for p in parts for d in p[2]]
+    k = oracle.bench_kernel7()
+    want = [hashlib.sha256(oracle.filter2d_i8(oracle.synth_frame(40, 64, 3, 1, 0x5EED0003, f), k, 6).tobytes()).hexdigest() for f in range(6)]
+    assert got == want
