@@ -229,10 +229,18 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // interleaved so dependent MFMAs sit three issues apart.
         constexpr int kAhead = 9;
         v4i Bq[kAhead];
+        // p == 3 pairs kernel row 6 with the non-existent row 7: the upper 32 lanes (kyl == 1) would read pixels that
+        // only meet zero weights, so they skip the LDS read (half the LDS cycles of that instruction).
+        const bool lowhalf = kyl == 0;
         auto rd = [&](int it) -> v4i {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
-            return *(const v4i*)(lds + c * kPlane + off[p] + 16 * i);
+            const v4i* src = (const v4i*)(lds + c * kPlane + off[p] + 16 * i);
+            if (p == 3) return lowhalf ? *src : v4i{0, 0, 0, 0};
+            return *src;
         };
+        // wave 3's fourth tile (tile 15) does not exist: its 12 MFMAs and LDS reads are skipped (wave-uniform,
+        // LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
+        const int nmf = (4 * wave + 3 < kTiles) ? 48 : 36;
         v4i acc[3];
         if (!(DBG & 4)) {
 #pragma unroll
@@ -241,6 +249,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 #pragma unroll
         for (int it = 0; it < 48; ++it) {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
+            if (it == 36 && nmf == 36) break;
             if (r < 3) acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
             if (!(DBG & 4)) {
                 acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], acc[c], 0, 0, 0);

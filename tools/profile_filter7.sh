@@ -16,5 +16,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
 done
 cd $REPO
-python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python tools/summarize_prof.py $OUT $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
