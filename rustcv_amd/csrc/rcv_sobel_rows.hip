@@ -1,0 +1,163 @@
+// rcv_sobel_rows.hip -- Sobel 3x3 (u8 gray -> i16 dx, dy) as a register sliding window.  HBM-bound: 1 B read and
+// 4 B written per pixel (5 algorithmic B/px).
+//
+// One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 and 63 only carry the +-1 px halo) and walks down a
+// row segment.  Per source row a lane loads its 8 pixels as one 8-byte vector (a wave instruction reads 512
+// contiguous bytes), gets the pixel left/right of its run from the neighbouring lanes with one DPP wave shift each,
+// and forms the horizontal parts with packed 16-bit math:
+//     h1(x) = p[x+1] - p[x-1]             h2(x) = p[x-1] + 2 p[x] + p[x+1]
+//     dx(y) = h1(y-1) + 2 h1(y) + h1(y+1)   dy(y) = h2(y+1) - h2(y-1)
+// The two previous rows' h1/h2 stay in registers, so every source row is read exactly once per strip and no LDS
+// is used.  Rows are prefetched a group of 8 ahead into registers; all loads and stores are unconditional
+// (clamped addresses / dump line) so the compiler can keep counted vmcnt waits.  BORDER_REFLECT_101: rows by
+// index reflection, the single reflected column at each image edge by a byte move inside the edge lane.
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include "rcv_device_utils.h"
+
+namespace {
+
+typedef short s2v __attribute__((ext_vector_type(2)));
+
+constexpr int kRowsAhead = 8;
+constexpr int kStripPx = 62 * 8;
+
+struct SobelArgs {
+    const uint8_t* src;
+    uint8_t *dx, *dy, *dump;
+    size_t sstep, xstep, ystep, sfs, xfs, yfs;
+    int rows, cols, nstrips, seg_rows, nsegs, total_waves;
+};
+
+__device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    s2v r = __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    s2v r = __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b)  // a + 2*b
+{
+    s2v r = __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2;
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+struct U2 { uint32_t lo, hi; };
+
+__global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= a.total_waves) return;
+    const int strip = wid % a.nstrips;
+    wid /= a.nstrips;
+    const int seg = wid % a.nsegs;
+    const int frame = wid / a.nsegs;
+    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    const int x = strip * kStripPx + 8 * (lane - 1);          // first pixel of this lane's run (may be -8 or >= cols)
+    const int xc = min(max(x, 0), a.cols - 8);                 // clamped load position
+    const bool edgeL = x < 0, edgeR = x == a.cols;             // lanes that hold the reflected column
+    const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    const uint8_t* sf = a.src + (size_t)frame * a.sfs + xc;
+    uint8_t* dxp = a.dx + (size_t)frame * a.xfs + 2 * (size_t)max(x, 0);
+    uint8_t* dyp = a.dy + (size_t)frame * a.yfs + 2 * (size_t)max(x, 0);
+    uint8_t* const dump = a.dump + lane * 16;
+
+    auto load_row = [&](int ry) -> U2 {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
+        ry = min(ry, ye);
+        const int r = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
+        return *(const U2*)(sf + (size_t)r * a.sstep);
+    };
+
+    uint32_t h1a[4], h1b[4], h2a[4], h2b[4];  // rows r-2 (a) and r-1 (b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
+
+    auto feed = [&](U2 v, int r) {  // r = index of the row just loaded; emits output row r-1 when r-1 >= ys
+        // reflected columns: x = -1 mirrors x = 1 (edge lane holds px 0..7 after clamping -> its byte 7 := byte 1);
+        // x = cols mirrors cols-2 (edge lane holds cols-8..cols-1 -> its byte 0 := byte 6)
+        if (edgeL) v.hi = pk(v.lo, v.hi, 0x05020100u);
+        if (edgeR) v.lo = pk(v.hi, v.lo, 0x03020106u);
+        const uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> lane-1's hi dword
+        const uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> lane+1's lo dword
+        // 16-bit pairs: L_j = (p[2j-1], p[2j]), C_j = (p[2j], p[2j+1]), R_j = (p[2j+1], p[2j+2]) = L_{j+1}
+        uint32_t L[5], Cc[4];
+        L[0] = pk(lf, v.lo, 0x0c000c07u);
+        L[1] = pk(v.lo, v.lo, 0x0c020c01u);
+        L[2] = pk(v.hi, v.lo, 0x0c040c03u);
+        L[3] = pk(v.hi, v.hi, 0x0c020c01u);
+        L[4] = pk(rt, v.hi, 0x0c040c03u);
+        Cc[0] = pk(v.lo, v.lo, 0x0c010c00u);
+        Cc[1] = pk(v.lo, v.lo, 0x0c030c02u);
+        Cc[2] = pk(v.hi, v.hi, 0x0c010c00u);
+        Cc[3] = pk(v.hi, v.hi, 0x0c030c02u);
+        uint32_t h1[4], h2[4], ox[4], oy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h1[j] = pk_sub(L[j + 1], L[j]);
+            h2[j] = pk_add2x(pk_add(L[j], L[j + 1]), Cc[j]);
+            ox[j] = pk_add2x(pk_add(h1a[j], h1[j]), h1b[j]);
+            oy[j] = pk_sub(h2[j], h2a[j]);
+            h1a[j] = h1b[j];
+            h1b[j] = h1[j];
+            h2a[j] = h2b[j];
+            h2b[j] = h2[j];
+        }
+        const int y = r - 1;
+        const bool st = live && y >= ys && y < ye;
+        *(uint4*)(st ? dxp + (size_t)y * a.xstep : dump) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+        *(uint4*)(st ? dyp + (size_t)y * a.ystep : dump) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+    };
+
+    // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kRowsAhead, next group in flight while this one computes
+    const int nrows = ye - ys + 2;
+    U2 cur[kRowsAhead], nxt[kRowsAhead];
+#pragma unroll
+    for (int i = 0; i < kRowsAhead; ++i) cur[i] = load_row(ys - 1 + i);
+    for (int g = 0; g < nrows; g += kRowsAhead) {
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i) nxt[i] = load_row(ys - 1 + g + kRowsAhead + i);
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i) feed(cur[i], ys - 1 + g + i);
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i) cur[i] = nxt[i];
+    }
+}
+
+} // namespace
+
+int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
+{
+    if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 2) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)dx.p % 16 || dx.step % 16 || (dx.n > 1 && dx.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)dy.p % 16 || dy.step % 16 || (dy.n > 1 && dy.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    SobelArgs a;
+    a.src = s.p;
+    a.dx = dx.p;
+    a.dy = dy.p;
+    a.dump = ctx->kconst + 8192;
+    a.sstep = s.step;
+    a.xstep = dx.step;
+    a.ystep = dy.step;
+    a.sfs = s.fstride;
+    a.xfs = dx.fstride;
+    a.yfs = dy.fstride;
+    a.rows = s.rows;
+    a.cols = s.cols;
+    a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
+    // enough waves to fill 256 CUs x 32 wave slots a few times; segments of >= 32 rows
+    int seg = s.rows;
+    while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 16384 && seg > 32) seg = (seg + 1) / 2;
+    a.seg_rows = seg;
+    a.nsegs = (s.rows + seg - 1) / seg;
+    long long waves = (long long)a.nstrips * a.nsegs * s.n;
+    if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
+    a.total_waves = (int)waves;
+    hipLaunchKernelGGL(k_sobel_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    return rcv_launch_check(ctx);
+}

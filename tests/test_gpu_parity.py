@@ -277,6 +277,29 @@ def test_sobel(ctx, oracle, rng, rows, cols):
     assert np.array_equal(dx.to_array(), wx) and np.array_equal(dy.to_array(), wy)
 
 
+@pytest.mark.parametrize("rows,cols", [(2, 8), (3, 16), (9, 496), (40, 504), (33, 1000), (70, 3840), (300, 64)])
+def test_sobel_rows_path(ctx, oracle, rng, rows, cols):
+    """shapes the register-sliding-window Sobel takes (cols % 8 == 0): strip seams at 496 px, segment seams, edges"""
+    img = rand_img(rng, rows, cols, 1)
+    img[:, 0] = 255
+    img[:, -1] = 0
+    n = 3
+    src = device.DeviceBatch(ctx, n, rows, cols, 1, step=cols + 8)
+    dx = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+    dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=cols * 2 + 16)
+    frames = np.stack([img, img[::-1].copy(), np.roll(img, 5, axis=1)])
+    src.upload(frames)
+    dx.memset(0x11)
+    dy.memset(0x22)
+    device.sobel(src, dx, dy)
+    gx, gy = dx.download(), dy.download()
+    for i in range(n):
+        wx, wy = oracle.sobel(frames[i])
+        assert np.array_equal(gx[i], wx) and np.array_equal(gy[i], wy)
+    for b in (src, dx, dy):
+        b.free()
+
+
 @pytest.mark.parametrize("src_shape,dst_shape", [((48, 64), (12, 16)), ((48, 64), (48, 64)), ((17, 33), (40, 71)), ((61, 127), (13, 9)),
                                                  ((1, 1), (5, 7)), ((4, 4), (1, 1)), ((128, 240), (32, 60)), ((30, 50), (31, 49))])
 @pytest.mark.parametrize("ch", [1, 3, 4])

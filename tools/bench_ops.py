@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""tools/bench_ops.py -- every op of the hot path at the BASELINE.json configs, device-resident, one GPU.
+
+For each op: ms per launch (HIP events on the context's stream), Mpix/s, algorithmic GB/s
+(SURVEY.md 8(d) bytes per pixel), fraction of the 8 TB/s HBM peak, and -- with --cpu -- the C oracle on
+the host cores on a bounded sample.  Writes one JSON document (default profiles/ops_bench.json) and a table.
+bench.py stays the single-line north-star bench; this is the per-row evidence for SURVEY.md §8.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import rustcv_amd as rcv  # noqa: E402
+from rustcv_amd import _ffi, device  # noqa: E402
+from rustcv_amd.imgproc import Rect, Scalar  # noqa: E402
+
+HBM = 8000.0
+SEED = 0x5EED0000
+
+
+def rot_matrix(deg, cx, cy, tx, ty):
+    t = np.deg2rad(deg)
+    c, s = np.cos(t), np.sin(t)
+    return np.array([c, -s, cx - c * cx + s * cy + tx, s, c, cy - s * cx - c * cy + ty], np.float32)
+
+
+def bench_kernel7():
+    def sm(z):
+        M = (1 << 64) - 1
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    return np.array([int((sm(0xF117E2D ^ i) >> 40) % 17) - 8 for i in range(49)], np.int8).reshape(7, 7)
+
+
+def timeit(ctx, fn, steps, warmup):
+    L = _ffi.lib()
+    for _ in range(warmup):
+        fn()
+    ctx.sync()
+    ms = C.c_float()
+    L.rcv_timer_start(ctx.handle)
+    for _ in range(steps):
+        fn()
+    L.rcv_timer_stop(ctx.handle, C.byref(ms))
+    return ms.value / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=float, default=1.0, help="scale the per-GPU batch sizes (1.0 = BASELINE per-GPU batches)")
+    ap.add_argument("--cpu", action="store_true", help="also time the oracle on the host (bounded sample)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "ops_bench.json"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    ctx = rcv.Context(0)
+    rows = []
+
+    def B(n, r, c, ch, depth=_ffi.RCV_8U):
+        return device.DeviceBatch(ctx, max(1, int(round(n * a.scale))), r, c, ch, depth)
+
+    def record(name, cfg, n, out_px, bpp, fn, note="", cpu=None):
+        if a.only and a.only not in name:
+            return
+        ms = timeit(ctx, fn, a.steps, a.warmup)
+        mpix = n * out_px / 1e6 / (ms * 1e-3)
+        gbs = n * out_px * bpp / (ms * 1e-3) / 1e9
+        row = {"op": name, "config": cfg, "frames": n, "ms_per_launch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3),
+               "mpix_s": round(mpix, 1), "alg_bytes_per_px": bpp, "alg_gb_s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM, 4), "note": note}
+        if a.cpu and cpu is not None:
+            row["cpu"] = cpu()
+        rows.append(row)
+        print(f"{name:34s} {cfg:34s} n={n:3d} {ms:9.4f} ms  {mpix:11.1f} Mpix/s  {gbs:8.1f} GB/s  {gbs / HBM * 100:5.1f} %  {row.get('cpu', '')}", flush=True)
+
+    def cpu_time(fn, px, budget=4.0):
+        from oracle import pyoracle as orc
+        cores = orc.set_threads(os.cpu_count() or 1)
+        fn(orc)
+        t0, k = time.perf_counter(), 0
+        while True:
+            fn(orc)
+            k += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or k >= 16:
+                break
+        return {"mpix_s": round(k * px / 1e6 / dt, 2), "cores": cores, "frames": k, "kind": "port"}
+
+    # ---- config 1: 640x480 YUYV -> BGR + rectangle (the reference's own path) --------------------------------
+    n = 64
+    y = B(n, 480, 640, 2)
+    o = B(n, 480, 640, 3)
+    device.synth(y, _ffi.RCV_SYNTH_YUYV, SEED + 1, 0)
+    record("cvtColor YUYV2BGR", "640x480", y.n, 640 * 480, 5, lambda: device.cvt_color(y, o, _ffi.RCV_YUYV2BGR),
+           cpu=lambda: cpu_time(lambda orc: orc.yuyv_to_bgr(np.zeros(640 * 480 * 2, np.uint8), np.zeros(640 * 480 * 3, np.uint8), 640, 480), 640 * 480))
+    record("rectangle t=2", "640x480 Rect(200,150,240,240)", o.n, 640 * 480, 0, lambda: device.rectangle(o, Rect(200, 150, 240, 240), Scalar(0, 255, 0), 2),
+           note="latency-bound: 1 920 pixel writes per frame")
+    y.free(); o.free()
+    # the same conversions at 4K (bandwidth regime)
+    n = 64
+    y = B(n, 2160, 3840, 2)
+    o = B(n, 2160, 3840, 3)
+    device.synth(y, _ffi.RCV_SYNTH_YUYV, SEED + 1, 0)
+    record("cvtColor YUYV2BGR", "4K", y.n, 3840 * 2160, 5, lambda: device.cvt_color(y, o, _ffi.RCV_YUYV2BGR))
+    y.free()
+    q = B(n, 2160, 3840, 4)
+    device.synth(q, 0, SEED + 1, 0)
+    record("cvtColor BGRA2BGR", "4K", q.n, 3840 * 2160, 7, lambda: device.cvt_color(q, o, _ffi.RCV_BGRA2BGR))
+    q.free()
+    g = B(n, 2160, 3840, 1)
+    record("cvtColor BGR2GRAY", "4K", o.n, 3840 * 2160, 4, lambda: device.cvt_color(o, g, _ffi.RCV_BGR2GRAY))
+    o.free()
+
+    # ---- config 3 (second half): Sobel on 4K gray, batch 64 -------------------------------------------------
+    dx, dy = B(n, 2160, 3840, 1, _ffi.RCV_16S), B(n, 2160, 3840, 1, _ffi.RCV_16S)
+    record("Sobel 3x3 -> dx,dy i16", "4K gray", g.n, 3840 * 2160, 5, lambda: device.sobel(g, dx, dy),
+           cpu=lambda: cpu_time(lambda orc: orc.sobel(np.zeros((2160, 3840), np.uint8)), 3840 * 2160))
+    dx.free(); dy.free(); g.free()
+
+    # ---- config 2: 1080p BGR 5x5 Gaussian, batch 1 (latency) and batch 64 (bandwidth) ------------------------
+    for nb in (1, 64):
+        s, d = B(nb, 1080, 1920, 3), B(nb, 1080, 1920, 3)
+        device.synth(s, 0, SEED + 2, 0)
+        record("GaussianBlur 5x5 (sigma=0)", f"1080p batch={s.n}", s.n, 1920 * 1080, 6, lambda: device.gaussian_blur(s, d, 5, 0.0),
+               note="batch 1 is L3-resident: read as latency" if nb == 1 else "",
+               cpu=(lambda: cpu_time(lambda orc: orc.gaussian_blur(np.zeros((1080, 1920, 3), np.uint8), 5, 0.0), 1920 * 1080)) if nb == 1 else None)
+        s.free(); d.free()
+
+    # ---- config 3: 4K 7x7 filter2D, batch 64 (north star; bench.py is the authoritative line) ---------------
+    s, d = B(64, 2160, 3840, 3), B(64, 2160, 3840, 3)
+    device.synth(s, 0, SEED + 3, 0)
+    k7 = bench_kernel7()
+    record("filter2D 7x7 i8 (>>6)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.filter2d(s, d, k7, shift=6))
+    kf = (k7.astype(np.float32) / 64.0)
+    record("filter2D 7x7 f32", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.filter2d(s, d, kf, delta=0.0),
+           note="VALU-bound by construction (49 dependent fmaf per sample), reported for completeness")
+    record("GaussianBlur 7x7 (sigma=0)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.gaussian_blur(s, d, 7, 0.0))
+    # ---- config 5: Harris pipeline on 4K BGR, 64 frames per GPU ----------------------------------------------
+    m = B(64, 2160, 3840, 1)
+    device.synth(s, 1, SEED + 5, 0)
+    record("Harris pipeline (BGR->mask)", "4K batch=64/GPU", s.n, 3840 * 2160, 4, lambda: device.harris_pipeline(s, m, None, 2, 0.04, 1e-4),
+           cpu=lambda: cpu_time(lambda orc: orc.harris_pipeline(np.zeros((2160, 3840, 3), np.uint8), 2, 0.04, 1e-4), 3840 * 2160))
+    s.free(); d.free(); m.free()
+
+    # ---- config 4: 8K warpAffine + resize -> 1080p, 32 frames per GPU ----------------------------------------
+    s, d = B(32, 4320, 7680, 3), B(32, 4320, 7680, 3)
+    device.synth(s, 0, SEED + 4, 0)
+    M = rot_matrix(7.0, 7680 / 2, 4320 / 2, 13.25, -8.5)
+    record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 6, lambda: device.warp_affine(s, d, M),
+           note="<= 6 B per output px (upper bound: every source px touched once)",
+           cpu=lambda: cpu_time(lambda orc: orc.warp_affine(np.zeros((4320, 7680, 3), np.uint8), M, 4320, 7680), 7680 * 4320, 6.0))
+    d.free()
+    d = B(32, 1080, 1920, 3)
+    record("resize 8K -> 1080p bilinear", "8K batch=32/GPU", s.n, 1920 * 1080, 15, lambda: device.resize(s, d),
+           note="15 B per OUTPUT px: exact 4x touches the centre 2x2 of each 4x4 block",
+           cpu=lambda: cpu_time(lambda orc: orc.resize(np.zeros((4320, 7680, 3), np.uint8), 1080, 1920), 1920 * 1080))
+    s.free(); d.free()
+
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump({"device": "MI355X (gfx950)", "steps": a.steps, "hbm_peak_gb_s": HBM, "rows": rows}, open(a.out, "w"), indent=1)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    main()
