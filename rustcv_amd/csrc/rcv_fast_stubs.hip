@@ -13,4 +13,3 @@ int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize)
         for (int x = 0; x < ksize; ++x) k[y * ksize + x] = (int8_t)(t[y] * t[x]);
     return rcv_filter_i8_fast(ctx, s, d, k, ksize, ksize == 3 ? 4 : 8);
 }
-int rcv_harris_fused(rcv_ctx*, const View&, const View&, const View*, int, float, float) { return RCV_ERR_UNSUPPORTED; }

@@ -1,0 +1,244 @@
+// rcv_harris_fused.hip -- BGR u8 -> gray -> Sobel -> Harris response (blockSize 2, aperture 3) -> 3x3 NMS mask in ONE
+// launch, as a register sliding window down the image.  Algorithmic traffic 3 B read + 1 B written per pixel
+// (+4 B when the f32 response is requested); the unfused path moves ~30 B/px through HBM.
+//
+// One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 / 63 carry halo only) and walks down a row segment.
+// Per source row a lane loads its 8 BGR pixels (3 x 8 B), converts to gray, and every stage pulls the one neighbour
+// value it needs from the adjacent lane with a DPP wave shift:
+//     gray      needs g[x-1], g[x+1]            (Sobel, packed i16 math as in rcv_sobel_rows.hip)
+//     box 2x2   needs P[x-1]  (P = Ix^2, IxIy, Iy^2 ; window offsets -1..0, anchor = blockSize/2 = 1)
+//     NMS 3x3   needs r[x-1], r[x+1]
+// Vertical neighbours are earlier rows kept in registers (2 rows of Sobel parts, 1 row of horizontal box sums,
+// 2 rows of NMS maxima).  The stream is fed VIRTUAL row indices v = ys-3 .. ye+1 resolved with BORDER_REFLECT_101,
+// which reproduces the box filter's reflection of the product image at the top border (P(-1) := P(1)) provided Iy
+// is negated on the mirrored row (a mirrored Sobel flips the sign of dy); the left border P(-1) := P(1) is a lane
+// fix-up; response values outside the image are -inf for the NMS.  f32 ops follow the oracle's order exactly
+// (six separate IEEE ops, -ffp-contract=off).
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include "rcv_device_utils.h"
+#include <math.h>
+
+namespace {
+
+typedef short s2v __attribute__((ext_vector_type(2)));
+constexpr int kAhead = 4;             // source rows in flight per lane (x 6 VGPRs)
+constexpr int kStripPx = 62 * 8;
+
+struct HArgs {
+    const uint8_t* src;
+    uint8_t *mask, *resp, *dump;
+    size_t sstep, mstep, rstep, sfs, mfs, rfs;
+    int rows, cols, nstrips, seg_rows, nsegs, total_waves;
+    float s2, k, thr;
+};
+
+__device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b)); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b)); }
+__device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2); }
+__device__ __forceinline__ uint32_t shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }  // from lane-1
+__device__ __forceinline__ uint32_t shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }  // from lane+1
+__device__ __forceinline__ float shr1f(float v) { return __builtin_bit_cast(float, shr1(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(float, shl1(__builtin_bit_cast(uint32_t, v))); }
+
+struct Row6 { uint32_t d[6]; };
+struct U2 { uint32_t a, b; };
+
+template <bool WANT_RESP>
+__global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= a.total_waves) return;
+    const int strip = wid % a.nstrips;
+    wid /= a.nstrips;
+    const int seg = wid % a.nsegs;
+    const int frame = wid / a.nsegs;
+    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    const int x = strip * kStripPx + 8 * (lane - 1);
+    const int xc = min(max(x, 0), a.cols - 8);
+    const bool edgeL = x < 0, edgeR = x == a.cols;
+    const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    const uint8_t* sf = a.src + (size_t)frame * a.sfs + 3 * (size_t)xc;
+    uint8_t* mp = a.mask + (size_t)frame * a.mfs + (size_t)max(x, 0);
+    uint8_t* rp = WANT_RESP ? a.resp + (size_t)frame * a.rfs + 4 * (size_t)max(x, 0) : nullptr;
+    uint8_t* const dump = a.dump + lane * 32;
+    const float NEG_INF = -INFINITY;
+
+    auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
+        v = min(v, ye + 1);
+        const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
+        const uint8_t* p = sf + (size_t)r * a.sstep;
+        const U2 q0 = *(const U2*)p, q1 = *(const U2*)(p + 8), q2 = *(const U2*)(p + 16);
+        return Row6{{q0.a, q0.b, q1.a, q1.b, q2.a, q2.b}};
+    };
+
+    // ---- pipeline state --------------------------------------------------------------------------------------
+    uint32_t h1a[4], h1b[4], h2a[4], h2b[4];      // Sobel horizontal parts of gray rows v-2, v-1 (packed i16 pairs)
+    int hsxx[8], hsxy[8], hsyy[8];                // horizontal box sums of product row u-1
+    float m3a[8], m3b[8], rc[8], mlr[8];          // NMS: rowmax3 of rows u-2, u-1; response and left/right max of row u-1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hsxx[j] = hsxy[j] = hsyy[j] = 0;
+        m3a[j] = m3b[j] = rc[j] = mlr[j] = NEG_INF;
+    }
+
+    auto feed = [&](const Row6& q, int v) {
+        // ---- gray (8 px) -----------------------------------------------------------------------------------------
+        uint32_t g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 3 * j;
+            const uint32_t b = (q.d[k0 >> 2] >> ((k0 & 3) * 8)) & 0xff, gg = (q.d[(k0 + 1) >> 2] >> (((k0 + 1) & 3) * 8)) & 0xff,
+                           r = (q.d[(k0 + 2) >> 2] >> (((k0 + 2) & 3) * 8)) & 0xff;
+            g[j] = (1868u * b + 9617u * gg + 4899u * r + 8192u) >> 14;
+        }
+        uint32_t lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+        if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
+        if (edgeR) lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+        const uint32_t lf = shr1(hi), rt = shl1(lo);
+        // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
+        uint32_t L[5], Cc[4];
+        L[0] = pk(lf, lo, 0x0c000c07u);
+        L[1] = pk(lo, lo, 0x0c020c01u);
+        L[2] = pk(hi, lo, 0x0c040c03u);
+        L[3] = pk(hi, hi, 0x0c020c01u);
+        L[4] = pk(rt, hi, 0x0c040c03u);
+        Cc[0] = pk(lo, lo, 0x0c010c00u);
+        Cc[1] = pk(lo, lo, 0x0c030c02u);
+        Cc[2] = pk(hi, hi, 0x0c010c00u);
+        Cc[3] = pk(hi, hi, 0x0c030c02u);
+        const int u = v - 1;
+        const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
+        int ix[8], iy[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t h1 = pk_sub(L[j + 1], L[j]);
+            const uint32_t h2 = pk_add2x(pk_add(L[j], L[j + 1]), Cc[j]);
+            const uint32_t ox = pk_add2x(pk_add(h1a[j], h1), h1b[j]);
+            const uint32_t oy = pk_sub(h2, h2a[j]);
+            h1a[j] = h1b[j];
+            h1b[j] = h1;
+            h2a[j] = h2b[j];
+            h2b[j] = h2;
+            ix[2 * j] = (int)(short)(ox & 0xffff);
+            ix[2 * j + 1] = (int)ox >> 16;
+            iy[2 * j] = (int)(short)(oy & 0xffff);
+            iy[2 * j + 1] = (int)oy >> 16;
+        }
+        // ---- products and 2x2 box sums: S(u) = Hs(u-1) + Hs(u), Hs(x) = P(x-1) + P(x) -------------------------------
+        int pxx[8], pxy[8], pyy[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int yy = mirrored ? -iy[j] : iy[j];
+            pxx[j] = ix[j] * ix[j];
+            pxy[j] = ix[j] * yy;
+            pyy[j] = yy * yy;
+        }
+        // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
+        const int exx = edgeL ? pxx[1] : pxx[7], exy = edgeL ? pxy[1] : pxy[7], eyy = edgeL ? pyy[1] : pyy[7];
+        const int lxx = (int)shr1((uint32_t)exx), lxy = (int)shr1((uint32_t)exy), lyy = (int)shr1((uint32_t)eyy);
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int nxx = (j ? pxx[j - 1] : lxx) + pxx[j], nxy = (j ? pxy[j - 1] : lxy) + pxy[j], nyy = (j ? pyy[j - 1] : lyy) + pyy[j];
+            const int sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;
+            hsxx[j] = nxx;
+            hsxy[j] = nxy;
+            hsyy[j] = nyy;
+            const float fa = (float)sxx * a.s2, fb = (float)sxy * a.s2, fc = (float)syy * a.s2;
+            const float t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+            const float t4 = a.k * t3;
+            const float t5 = t4 * t3;
+            r[j] = (t1 - t2) - t5;
+        }
+        if (WANT_RESP) {
+            const bool st = live && u >= ys && u < ye;
+            uint8_t* o = st ? rp + (size_t)u * a.rstep : dump;
+            *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
+            *(float4*)(o + 16) = make_float4(r[4], r[5], r[6], r[7]);
+        }
+        // ---- NMS: response outside the image is -inf ------------------------------------------------------------------
+        const bool outside = u < 0 || u >= a.rows;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (outside || x + j >= a.cols || x + j < 0) r[j] = NEG_INF;
+        const float rl = shr1f(edgeL ? NEG_INF : r[7]);   // r[x-1] of the lane's first pixel
+        const float rr = shl1f(r[0]);                      // r[x+8]
+        uint32_t mbits[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float left = j ? r[j - 1] : rl, right = j < 7 ? r[j + 1] : rr;
+            const float lrmax = fmaxf(left, right);
+            const float m3 = fmaxf(lrmax, r[j]);
+            // output row w = u-1: centre rc, neighbours = rowmax3(u-2), left/right of u-1, rowmax3(u)
+            const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);
+            const bool keep = rc[j] > a.thr && rc[j] >= m8;
+            mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+            m3a[j] = m3b[j];
+            m3b[j] = m3;
+            rc[j] = r[j];
+            mlr[j] = lrmax;
+        }
+        const int w = u - 1;
+        const bool st = live && w >= ys && w < ye;
+        *(U2*)(st ? mp + (size_t)w * a.mstep : dump) = U2{mbits[0], mbits[1]};
+    };
+
+    // virtual gray rows v = ys-3 .. ye+1  (mask row w is emitted when v = w + 2 arrives)
+    const int v0 = ys - 3, nrows = ye - ys + 5;
+    Row6 cur[kAhead], nxt[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) cur[i] = load_row(v0 + i);
+    for (int g0 = 0; g0 < nrows; g0 += kAhead) {
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) nxt[i] = load_row(v0 + g0 + kAhead + i);
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) feed(cur[i], v0 + g0 + i);
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) cur[i] = nxt[i];
+    }
+}
+
+} // namespace
+
+int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* resp, int block, float k, float thr)
+{
+    if (block != 2) return RCV_ERR_UNSUPPORTED;
+    if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8)) return RCV_ERR_UNSUPPORTED;
+    if (resp && ((uintptr_t)resp->p % 16 || resp->step % 16 || (resp->n > 1 && resp->fstride % 16))) return RCV_ERR_UNSUPPORTED;
+    HArgs a;
+    a.src = s.p;
+    a.mask = m.p;
+    a.resp = resp ? resp->p : nullptr;
+    a.dump = ctx->kconst + 8192;
+    a.sstep = s.step;
+    a.mstep = m.step;
+    a.rstep = resp ? resp->step : 0;
+    a.sfs = s.fstride;
+    a.mfs = m.fstride;
+    a.rfs = resp ? resp->fstride : 0;
+    a.rows = s.rows;
+    a.cols = s.cols;
+    a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
+    int seg = s.rows;
+    while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 8192 && seg > 64) seg = (seg + 1) / 2;
+    a.seg_rows = seg;
+    a.nsegs = (s.rows + seg - 1) / seg;
+    long long waves = (long long)a.nstrips * a.nsegs * s.n;
+    if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
+    a.total_waves = (int)waves;
+    double sc = 1.0 / (4.0 * 2.0 * 255.0);
+    a.s2 = (float)(sc * sc);
+    a.k = k;
+    a.thr = thr;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (resp) hipLaunchKernelGGL(k_harris_fused<true>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_harris_fused<false>, grid, dim3(256), 0, ctx->stream, a);
+    return rcv_launch_check(ctx);
+}

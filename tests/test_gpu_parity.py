@@ -371,6 +371,30 @@ def test_harris_pipeline(ctx, oracle, rows, cols, block, want_resp):
     assert np.array_equal(mask.to_array(), wm)
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 8), (5, 16), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64)])
+@pytest.mark.parametrize("want_resp", [False, True])
+def test_harris_fused_path(ctx, oracle, rows, cols, want_resp):
+    """shapes the fused register-window kernel takes (block 2, cols % 8 == 0, rows >= 4), batch of 3, padded steps"""
+    n = 3
+    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 8)
+    mask = device.DeviceBatch(ctx, n, rows, cols, 1, step=cols + 8)
+    resp = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+    device.synth(src, 1, 0x5EED0005, 11)
+    mask.memset(0x33)
+    thr = 1e-4
+    device.harris_pipeline(src, mask, resp, 2, 0.04, thr)
+    frames, got = src.download(), mask.download()
+    gr = resp.download() if want_resp else None
+    for i in range(n):
+        wm, wr = oracle.harris_pipeline(frames[i], 2, 0.04, thr, True)
+        if want_resp:
+            assert np.array_equal(gr[i].view(np.uint32), wr.view(np.uint32))
+        assert np.array_equal(got[i], wm)
+    assert got.any() or rows * cols < 4096  # the scene has real corners
+    for b in (src, mask) + ((resp,) if want_resp else ()):
+        b.free()
+
+
 # ---- synthetic frames + device-resident batches -------------------------------------------------------
 
 @pytest.mark.parametrize("family,ch", [(0, 1), (0, 3), (0, 4), (1, 3), (1, 1)])
