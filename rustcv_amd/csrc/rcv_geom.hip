@@ -13,6 +13,63 @@ __device__ __forceinline__ uint8_t round_half_up_u8(float v)
     return (uint8_t)min(max(iv, 0), 255);
 }
 
+// Two horizontally adjacent BGR taps (6 bytes at byte offset 3*x0 of a row) fetched with ONE 8-byte load instead of
+// six byte loads.  The load window is clamped into the row (rows are >= 8 bytes here), then shifted into place;
+// x0 may be -1 (left tap outside: its bytes are garbage and masked by the caller).
+__device__ __forceinline__ uint64_t load_taps6(const uint8_t* row, int x0, int rowbytes)
+{
+    const int off = 3 * x0;
+    const int offc = min(max(off, 0), rowbytes - 8);
+    uint64_t raw;
+    __builtin_memcpy(&raw, row + offc, 8);   // unaligned 8-byte global load
+    const int sh = (off - offc) * 8;         // -24 .. +56 bits
+    return sh >= 0 ? (raw >> sh) : (raw << (-sh));
+}
+
+// Exact integer down-scale by S in {2,4} (both axes), 3 channels: with half-pixel centres the bilinear sample point
+// falls exactly between the centre 2x2 pixels of each SxS block with weights 1/2, and the general f32 path
+// (round-half-up) reduces to (a+b+c+d+2)>>2 -- verified against the general oracle in tests.  One thread makes 4
+// output pixels from two 12*S-byte source runs (16-byte vector loads) and stores 12 bytes.
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_resize_box(View s, View d)
+{
+    const int y = blockIdx.y;
+    const int t = blockIdx.x * kBlock + threadIdx.x;      // group of 4 output pixels
+    if (4 * t >= d.cols) return;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    const uint8_t* ra = sf + (size_t)(S * y + S / 2 - 1) * s.step + (size_t)t * 12 * S;
+    const uint8_t* rb = ra + s.step;
+    uint32_t a[3 * S], b[3 * S];
+    if constexpr (S == 4) {   // 48-byte runs, 16-byte aligned
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint4 va = ((const uint4*)ra)[i], vb = ((const uint4*)rb)[i];
+            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+        }
+    } else {                  // 24-byte runs, 8-byte aligned
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint2 va = ((const uint2*)ra)[i], vb = ((const uint2*)rb)[i];
+            a[2 * i] = va.x; a[2 * i + 1] = va.y;
+            b[2 * i] = vb.x; b[2 * i + 1] = vb.y;
+        }
+    }
+    uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int k0 = 3 * (S * px + S / 2 - 1) + c, k1 = k0 + 3;   // byte index of the two centre pixels in the run
+            const uint32_t s4 = ((a[k0 >> 2] >> ((k0 & 3) * 8)) & 0xff) + ((a[k1 >> 2] >> ((k1 & 3) * 8)) & 0xff) +
+                                ((b[k0 >> 2] >> ((k0 & 3) * 8)) & 0xff) + ((b[k1 >> 2] >> ((k1 & 3) * 8)) & 0xff);
+            const int ob = 3 * px + c;
+            o[ob >> 2] |= ((s4 + 2) >> 2) << ((ob & 3) * 8);
+        }
+    struct U3 { uint32_t a, b, c; };
+    *(U3*)(d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step + (size_t)t * 12) = U3{o[0], o[1], o[2]};
+}
+
 // one thread per output pixel; rows on blockIdx.y, frames on blockIdx.z
 template <int CH>
 __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, float scy)
@@ -35,10 +92,28 @@ __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, fl
         int x0 = (int)floorf(sx);
         float fx = sx - (float)x0;
         int x1 = x0 + 1 < s.cols ? x0 + 1 : s.cols - 1;
+        uint64_t ta = 0, tb = 0;
+        const bool wide = CH == 3 && s.cols >= 3;
+        if (wide) {
+            ta = load_taps6(ra, x0, s.cols * 3);
+            tb = load_taps6(rb, x0, s.cols * 3);
+            if (x1 == x0) {  // right edge: the second tap is the first one again
+                ta = (ta & 0xffffffull) | ((ta & 0xffffffull) << 24);
+                tb = (tb & 0xffffffull) | ((tb & 0xffffffull) << 24);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            float p00 = (float)ra[(size_t)x0 * CH + c], p01 = (float)ra[(size_t)x1 * CH + c];
-            float p10 = (float)rb[(size_t)x0 * CH + c], p11 = (float)rb[(size_t)x1 * CH + c];
+            float p00, p01, p10, p11;
+            if (wide) {
+                p00 = (float)(uint32_t)((ta >> (8 * c)) & 0xff);
+                p01 = (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff);
+                p10 = (float)(uint32_t)((tb >> (8 * c)) & 0xff);
+                p11 = (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff);
+            } else {
+                p00 = (float)ra[(size_t)x0 * CH + c], p01 = (float)ra[(size_t)x1 * CH + c];
+                p10 = (float)rb[(size_t)x0 * CH + c], p11 = (float)rb[(size_t)x1 * CH + c];
+            }
             float top = fmaf(fx, p01 - p00, p00);
             float bot = fmaf(fx, p11 - p10, p10);
             float v = fmaf(fy, bot - top, top);
@@ -74,12 +149,26 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
         const uint8_t* ra = sf + (size_t)(vy0 ? y0 : 0) * s.step;
         const uint8_t* rb = sf + (size_t)(vy1 ? y1 : 0) * s.step;
         size_t xa = (size_t)(vx0 ? x0 : 0) * CH, xb = (size_t)(vx1 ? x1 : 0) * CH;
+        uint64_t ta = 0, tb = 0;
+        const bool wide = CH == 3 && s.cols >= 3;
+        if (wide) {
+            ta = load_taps6(ra, x0, s.cols * 3);
+            tb = load_taps6(rb, x0, s.cols * 3);
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            float p00 = (vx0 && vy0) ? (float)ra[xa + c] : 0.0f;
-            float p01 = (vx1 && vy0) ? (float)ra[xb + c] : 0.0f;
-            float p10 = (vx0 && vy1) ? (float)rb[xa + c] : 0.0f;
-            float p11 = (vx1 && vy1) ? (float)rb[xb + c] : 0.0f;
+            float p00, p01, p10, p11;
+            if (wide) {
+                p00 = (vx0 && vy0) ? (float)(uint32_t)((ta >> (8 * c)) & 0xff) : 0.0f;
+                p01 = (vx1 && vy0) ? (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff) : 0.0f;
+                p10 = (vx0 && vy1) ? (float)(uint32_t)((tb >> (8 * c)) & 0xff) : 0.0f;
+                p11 = (vx1 && vy1) ? (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff) : 0.0f;
+            } else {
+                p00 = (vx0 && vy0) ? (float)ra[xa + c] : 0.0f;
+                p01 = (vx1 && vy0) ? (float)ra[xb + c] : 0.0f;
+                p10 = (vx0 && vy1) ? (float)rb[xa + c] : 0.0f;
+                p11 = (vx1 && vy1) ? (float)rb[xb + c] : 0.0f;
+            }
             float top = fmaf(fx, p01 - p00, p00);
             float bot = fmaf(fx, p11 - p10, p10);
             float v = fmaf(fy, bot - top, top);
@@ -115,6 +204,15 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
     RCV_TRY(check_geom(src, dst, &s, &d));
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     if (s.rows == 0 || s.cols == 0) return RCV_ERR_ARG;
+    for (int S = 2; S <= 4; S += 2) {
+        if (s.ch == 3 && s.cols == S * d.cols && s.rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)s.p % 16 == 0 &&
+            s.step % 16 == 0 && s.fstride % 16 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
+            dim3 grid((unsigned)((d.cols / 4 + kBlock - 1) / kBlock), d.rows, d.n);
+            if (S == 2) hipLaunchKernelGGL(k_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d);
+            else hipLaunchKernelGGL(k_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d);
+            return rcv_launch_check(ctx);
+        }
+    }
     float scx = (float)s.cols / (float)d.cols, scy = (float)s.rows / (float)d.rows;
     if (s.ch == 1) hipLaunchKernelGGL(k_resize<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
     else if (s.ch == 3) hipLaunchKernelGGL(k_resize<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);

@@ -315,6 +315,41 @@ def test_resize(ctx, oracle, rng, src_shape, dst_shape, ch):
         assert np.array_equal(want.reshape(12, 16, -1), box)
 
 
+@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("dshape", [(1, 4), (5, 8), (27, 240), (270, 480)])
+def test_resize_box_fast_path(ctx, oracle, rng, scale, dshape):
+    """exact 2x / 4x down-scale kernel == the general bilinear oracle, batch of 2"""
+    dr, dc = dshape
+    n = 2
+    src = device.DeviceBatch(ctx, n, dr * scale, dc * scale, 3)
+    dst = device.DeviceBatch(ctx, n, dr, dc, 3)
+    frames = rng.integers(0, 256, size=(n, dr * scale, dc * scale, 3), dtype=np.uint8)
+    src.upload(frames)
+    device.resize(src, dst)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(frames[i], dr, dc))
+    src.free()
+    dst.free()
+
+
+def test_warp_and_resize_8k_to_1080p_slab(ctx, oracle):
+    """BASELINE configs[3] shapes on one frame: 8K rotate-7-degrees warp (rows of the result vs the oracle) and 8K -> 1080p"""
+    rows, cols = 4320, 7680
+    src = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    device.synth(src, 1, 0x5EED0004, 0)
+    frame = src.download()[0]
+    M = _rot(7.0, cols / 2, rows / 2, 13.25, -8.5)
+    dst = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    device.warp_affine(src, dst, M)
+    assert np.array_equal(dst.download()[0], oracle.warp_affine(frame, M, rows, cols))
+    small = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
+    device.resize(src, small)
+    assert np.array_equal(small.download()[0], oracle.resize(frame, 1080, 1920))
+    for b in (src, dst, small):
+        b.free()
+
+
 def _rot(deg, cx, cy, tx, ty):
     t = np.deg2rad(deg)
     c, s = np.cos(t), np.sin(t)
