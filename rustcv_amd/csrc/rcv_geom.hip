@@ -177,6 +177,87 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
     }
 }
 
+// Two adjacent BGR taps as two dwords {b0 g0 r0 b1 | g1 r1 x x}; the 8-byte window is used in place whenever it fits
+// in the row (all but the last two pixels and x0 = -1), so the common case needs no funnel shift.
+__device__ __forceinline__ void load_taps6_32(const uint8_t* row, int x0, int rowbytes, uint32_t& lo, uint32_t& hi)
+{
+    const int off = 3 * x0;
+    if (off >= 0 && off + 8 <= rowbytes) {
+        uint2 v;
+        __builtin_memcpy(&v, row + off, 8);
+        lo = v.x;
+        hi = v.y;
+    } else {
+        const uint64_t t = load_taps6(row, x0, rowbytes);
+        lo = (uint32_t)t;
+        hi = (uint32_t)(t >> 32);
+    }
+}
+
+// BGR fast path: one thread per output pixel (adjacent lanes -> adjacent source taps -> L1-friendly), byte -> float by
+// v_cvt_f32_ubyteN straight from the tap dwords, invalid taps zeroed once per pixel instead of once per channel, and
+// the three result bytes of four neighbouring lanes gathered with DPP so that every fourth lane stores 12 bytes.
+// Same f32 operations in the same order as k_warp_affine<3>.
+constexpr int kWarpRows = 8;   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
+
+__device__ __forceinline__ uint32_t warp_px_bgr(const View& s, const uint8_t* sf, const Affine& A, float fxx, float fyy, int rowbytes)
+{
+    const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+    const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+    uint32_t px = 0;
+    if (sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows) {
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float fx = sx - x0f, fy = sy - y0f;
+        const bool vx0 = x0 >= 0, vx1 = x0 + 1 < s.cols, vy0 = y0 >= 0, vy1 = y0 + 1 < s.rows;
+        uint32_t alo, ahi, blo, bhi;
+        load_taps6_32(sf + (size_t)(vy0 ? y0 : 0) * s.step, x0, rowbytes, alo, ahi);
+        load_taps6_32(sf + (size_t)(vy1 ? y0 + 1 : 0) * s.step, x0, rowbytes, blo, bhi);
+        // zero the taps that fall outside the source (constant border 0)
+        const uint32_t m0 = vx0 ? 0x00ffffffu : 0u, m1l = vx1 ? 0xff000000u : 0u, m1h = vx1 ? 0x0000ffffu : 0u;
+        alo &= vy0 ? (m0 | m1l) : 0u;
+        ahi &= vy0 ? m1h : 0u;
+        blo &= vy1 ? (m0 | m1l) : 0u;
+        bhi &= vy1 ? m1h : 0u;
+        const float p00[3] = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff), (float)((alo >> 16) & 0xff)};
+        const float p01[3] = {(float)(alo >> 24), (float)(ahi & 0xff), (float)((ahi >> 8) & 0xff)};
+        const float p10[3] = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff), (float)((blo >> 16) & 0xff)};
+        const float p11[3] = {(float)(blo >> 24), (float)(bhi & 0xff), (float)((bhi >> 8) & 0xff)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = fmaf(fx, p01[c] - p00[c], p00[c]);
+            const float bot = fmaf(fx, p11[c] - p10[c], p10[c]);
+            const float v = fmaf(fy, bot - top, top);
+            px |= (uint32_t)round_half_up_u8(v) << (8 * c);
+        }
+    }
+    return px;
+}
+
+__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
+{
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int rowbytes = s.cols * 3;
+    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0 and kBlock % 4 == 0: quads never straddle the row end
+    const int xq = min(x, d.cols - 1);
+    const float fxx = (float)xq;
+    const int ybase = blockIdx.y * kWarpRows;
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        const int y = min(ybase + r, d.rows - 1);
+        const uint32_t px = warp_px_bgr(s, sf, A, fxx, (float)y, rowbytes);
+        // lanes 4q..4q+3 -> 12 bytes stored by lane 4q  (row_shl:n brings lane+n's value; quads stay inside a DPP row of 16)
+        const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
+        const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
+        const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+        if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
+            struct U3 { uint32_t a, b, c; };
+            *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+        }
+    }
+}
+
 int check_geom(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
 {
     if (!src || !dst) return RCV_ERR_ARG;
@@ -229,6 +310,11 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     Affine A;
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
+        unsigned gx = (unsigned)((d.cols + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_warp_affine_bgr, dim3(gx, (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
+        return rcv_launch_check(ctx);
+    }
     if (s.ch == 1) hipLaunchKernelGGL(k_warp_affine<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     else if (s.ch == 3) hipLaunchKernelGGL(k_warp_affine<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     else hipLaunchKernelGGL(k_warp_affine<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
