@@ -79,7 +79,10 @@ struct U2 { uint32_t a, b; };
 struct U3 { uint32_t a, b, c; };
 
 // DBG: ablation bits for profiling builds (-DRCV_ABLATE): 1 skip global stores, 2 skip global loads, 4 skip MFMA
-template <int DBG>
+// DUAL: weights beyond the i8 range (integer GaussianBlur 7x7: taps up to 324) are split K = 4*Q + R with Q, R in i8;
+// the same pixel operand feeds two MFMAs (tables A and A2) and the epilogue forms acc + (acc2 << 2).  LDS traffic is
+// unchanged, only the matrix-pipe work doubles.
+template <int DBG, bool DUAL>
 __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * kPlane + kWaves * kOutWave];
@@ -107,11 +110,15 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
 
     // A operands (banded weights), constant for the whole launch
-    v4i A[4];
+    v4i A[4], A2[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         uint4 w = a.wtab[p * 64 + lane];
         A[p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+        if (DUAL) {
+            w = a.wtab[256 + p * 64 + lane];
+            A2[p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+        }
     }
 
     // ---- staging task of this thread: (row sr of a block, 16-pixel chunk sq of the strip) ----
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // wave 3's fourth tile (tile 15) does not exist: its 12 MFMAs and LDS reads are skipped (wave-uniform,
         // LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
         const int nmf = (4 * wave + 3 < kTiles) ? 48 : 36;
-        v4i acc[3];
+        v4i acc[3], acc2[3];
         if (!(DBG & 4)) {
 #pragma unroll
             for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it);
@@ -250,12 +257,20 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         for (int it = 0; it < 48; ++it) {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
             if (it == 36 && nmf == 36) break;
-            if (r < 3) acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+            if (r < 3) {
+                acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+                if (DUAL) acc2[c] = v4i{0, 0, 0, 0};
+            }
             if (!(DBG & 4)) {
                 acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], acc[c], 0, 0, 0);
+                if (DUAL) acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], acc2[c], 0, 0, 0);
                 if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead);
             }
             if (r == 11) {
+                if (DUAL) {
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) acc[cc] += acc2[cc] << 2;
+                }
                 // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row n (t = 4*wave + i): 12 interleaved bytes
                 *(uint32_t*)(obuf + woff[i][0]) = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
                 *(uint32_t*)(obuf + woff[i][1]) = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
@@ -300,20 +315,25 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     }
 }
 
-// host: banded A operands.  K7 is the kernel embedded (centred) in 7x7.
-void build_wtab(const int8_t* k, int ksize, int8_t* tab /*4*64*16*/)
+// host: banded A operands.  K7 is the kernel embedded (centred) in 7x7; `part` selects R (0), Q (1) of K = 4Q + R, or
+// the weights themselves (2, all within i8).
+void build_wtab(const int16_t* k, int ksize, int part, int8_t* tab /*4*64*16*/)
 {
-    int8_t K7[7][7];
+    int K7[7][7];
     memset(K7, 0, sizeof(K7));
     int o = (7 - ksize) / 2;
     for (int y = 0; y < ksize; ++y)
-        for (int x = 0; x < ksize; ++x) K7[y + o][x + o] = k[y * ksize + x];
+        for (int x = 0; x < ksize; ++x) {
+            int w = k[y * ksize + x];
+            int q = w >> 2;  // floor
+            K7[y + o][x + o] = part == 2 ? w : (part == 1 ? q : w - 4 * q);
+        }
     for (int p = 0; p < 4; ++p)
         for (int lane = 0; lane < 64; ++lane)
             for (int i = 0; i < 16; ++i) {
                 int m = lane & 15, kb = lane >> 4, kyl = kb >> 1, j = (kb & 1) * 16 + i;
                 int ky = 2 * p + kyl, tap = j - m;
-                tab[(p * 64 + lane) * 16 + i] = (ky < 7 && tap >= 0 && tap <= 6) ? K7[ky][tap] : 0;
+                tab[(p * 64 + lane) * 16 + i] = (int8_t)((ky < 7 && tap >= 0 && tap <= 6) ? K7[ky][tap] : 0);
             }
 }
 
@@ -322,37 +342,44 @@ void build_wtab(const int8_t* k, int ksize, int8_t* tab /*4*64*16*/)
 extern "C" int rcv__debug_occupancy(void)
 {
     int nb = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter7_mfma<0>, kThreads, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter7_mfma<0, false>, kThreads, 0) != hipSuccess) return -1;
     return nb;
 }
 
-int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+// weights k16 in [-512, 511]; those within [-128, 127] run the single-MFMA kernel
+int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
 {
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
     if (s.ch != 3) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    bool dual = false;
+    long long ksum = 0;
+    for (int i = 0; i < ksize * ksize; ++i) {
+        if (k[i] < -512 || k[i] > 511) return RCV_ERR_UNSUPPORTED;
+        if (k[i] < -128 || k[i] > 127) dual = true;
+        ksum += k[i];
+    }
 
-    // weight table: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered)
-    if (!ctx->f7_valid || ctx->f7_ksize != ksize || memcmp(ctx->f7_k, k, (size_t)ksize * ksize) != 0) {
-        int8_t tab[4 * 64 * 16];
-        build_wtab(k, ksize, tab);
+    // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered)
+    if (!ctx->f7_valid || ctx->f7_ksize != ksize || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
+        int8_t tab[2 * 4 * 64 * 16];
+        build_wtab(k, ksize, dual ? 0 : 2, tab);
+        if (dual) build_wtab(k, ksize, 1, tab + 4096);
         ctx->f7_valid = false;
-        RCV_TRY(rcv_upload_const(ctx, tab, sizeof(tab), 0));
+        RCV_TRY(rcv_upload_const(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0));
         RCV_HIP(hipStreamSynchronize(ctx->stream)); // `tab` is on this stack frame
-        memcpy(ctx->f7_k, k, (size_t)ksize * ksize);
+        memcpy(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t));
         ctx->f7_ksize = ksize;
         ctx->f7_valid = true;
     }
-    int ksum = 0;
-    for (int i = 0; i < ksize * ksize; ++i) ksum += k[i];
 
     F7Args a;
     a.src = s.p;
     a.dst = d.p;
     a.wtab = (const uint4*)ctx->kconst;
-    a.dump = ctx->kconst + 8192;
+    a.dump = ctx->kconst + 16384;
     a.sstep = s.step;
     a.dstep = d.step;
     a.sfs = s.fstride;
@@ -361,7 +388,7 @@ int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.cols = s.cols;
     a.ntiles_total = s.cols / 16;
     a.nstrips = (a.ntiles_total + kTiles - 1) / kTiles;
-    // segments: enough workgroups to fill 256 CUs x 4 several times over, >= 8 steps each
+    // segments: enough workgroups to fill 256 CUs x 3 several times over
     int seg_rows = 720;
     long long wgs = (long long)a.nstrips * ((s.rows + seg_rows - 1) / seg_rows) * s.n;
     while (wgs < 2048 && seg_rows > 128) {
@@ -372,25 +399,37 @@ int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.seg_rows = seg_rows;
     a.nsegs = (s.rows + seg_rows - 1) / seg_rows;
     a.shift = shift;
-    a.acc_init = 128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0);
+    a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     long long total = (long long)a.nstrips * a.nsegs * s.n;
     if (total > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     a.total_wgs = (int)total;
     a.wgs_per_xcd = (int)((total + 7) / 8);
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
+    if (dual) {
+        hipLaunchKernelGGL((k_filter7_mfma<0, true>), grid, block, 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
     switch (rcv_debug_flags & 7) {
-    case 1: hipLaunchKernelGGL(k_filter7_mfma<1>, grid, block, 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(k_filter7_mfma<2>, grid, block, 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(k_filter7_mfma<3>, grid, block, 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL(k_filter7_mfma<4>, grid, block, 0, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL(k_filter7_mfma<5>, grid, block, 0, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL(k_filter7_mfma<6>, grid, block, 0, ctx->stream, a); break;
-    case 7: hipLaunchKernelGGL(k_filter7_mfma<7>, grid, block, 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(k_filter7_mfma<0>, grid, block, 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_filter7_mfma<1, false>), grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_filter7_mfma<2, false>), grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_filter7_mfma<3, false>), grid, block, 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_filter7_mfma<4, false>), grid, block, 0, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL((k_filter7_mfma<5, false>), grid, block, 0, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL((k_filter7_mfma<6, false>), grid, block, 0, ctx->stream, a); break;
+    case 7: hipLaunchKernelGGL((k_filter7_mfma<7, false>), grid, block, 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_filter7_mfma<0, false>), grid, block, 0, ctx->stream, a); break;
     }
 #else
-    hipLaunchKernelGGL(k_filter7_mfma<0>, grid, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_filter7_mfma<0, false>), grid, block, 0, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
+}
+
+int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+{
+    if (ksize < 1 || ksize > 7) return RCV_ERR_UNSUPPORTED;
+    int16_t k16[49];
+    for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+    return rcv_filter_i16_fast(ctx, s, d, k16, ksize, shift);
 }

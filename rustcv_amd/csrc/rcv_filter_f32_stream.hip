@@ -1,0 +1,186 @@
+// rcv_filter_f32_stream.hip -- f32-weight filter2D and GaussianBlur(sigma > 0) as a streaming VALU kernel.
+//
+// These two ops are VALU-bound by construction: the parity contract fixes one fmaf per tap in a fixed order
+// (SURVEY.md 8-A), 49 dependent fmaf per sample for a dense 7x7 -- 49 flop per 2 algorithmic bytes against a chip
+// balance of ~20 flop/B.  (The exact f32 MFMA would reproduce the chain bit for bit but a banded
+// 16x16x4 operand wastes 15/22 of its MACs at the VECTOR rate, i.e. it is slower than the plain FMA loop.)
+//
+// One thread owns 4 adjacent byte columns (one dword of the interleaved row) and walks down a row segment.  Each
+// source row is read once per thread as NW aligned dwords covering the +-rad pixel window, bytes go to f32 with
+// v_cvt_f32_ubyteN, and every in-flight output (KS of them per column, one per kernel row) receives its fmaf in
+// (ky, kx) order -- rows arrive in increasing order, so each accumulator sees exactly the oracle's sequence:
+//     dense   : acc(y) = fmaf(k[ky][kx], p(y+ky-rad, x+kx-rad), acc)           KS*KS fmaf per sample
+//     Gaussian: h(r,x) = fmaf chain over kx from 0 ; acc(y) = fmaf(t[ky], h(y+ky-rad, x), acc)   2*KS fmaf per sample
+// The loop is unrolled by KS so accumulator slots (y mod KS) are static registers.  BORDER_REFLECT_101: rows by index;
+// threads whose window leaves the row gather their bytes one by one with reflected pixel indices (first/last threads
+// of a row only) -- done by a second, tiny launch of the generic kernel restricted to those byte columns.
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include "rcv_device_utils.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int KS, bool SEP>
+struct FWeights {
+    float w[SEP ? KS : KS * KS];
+    float delta;
+};
+
+template <int KS, int CH, bool SEP>
+__global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows)
+{
+    constexpr int RAD = KS / 2;
+    constexpr int LEAD = RAD * CH;                 // bytes of halo on each side of the 4 owned bytes
+    constexpr int LEADW = (LEAD + 3) / 4 * 4;      // window starts LEADW bytes before the owned dword
+    constexpr int OFF = LEADW - LEAD;              // first needed byte inside the window
+    constexpr int NW = (LEADW + 4 + LEAD + 3) / 4; // window dwords
+    const int rowbytes = s.cols * CH;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int xb0 = 4 * t;
+    if (xb0 >= rowbytes) return;
+    const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride + xb0;
+    // The window is clamped into the row, so the first/last few threads of a row compute garbage: the host
+    // re-does exactly those byte columns with the generic kernel right after this launch (no divergent slow path here).
+    const int wstart = min(max(xb0 - LEADW, 0), rowbytes - 4 * NW);
+
+    auto load_row = [&](int ry, uint32_t (&w)[NW]) __attribute__((always_inline)) {
+        ry = min(ry, ye - 1 + RAD);
+        const int r = rcv_reflect101(ry, s.rows);
+        const uint8_t* row = sf + (size_t)r * s.step + wstart;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+    };
+
+    float acc[KS][4];
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = SEP ? 0.0f : W.delta;
+
+    // feed row r (r mod KS == RHO, static): contributes kernel row ky to output y = r - ky + RAD, slot y mod KS
+    auto feed = [&](const uint32_t (&w)[NW], int r, auto rho_tag) __attribute__((always_inline)) {
+        constexpr int RHO = decltype(rho_tag)::value;
+        float p[2 * LEAD + 4];
+#pragma unroll
+        for (int b = 0; b < 2 * LEAD + 4; ++b) p[b] = (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
+        float h[4];
+        if (SEP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = 0.0f;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) a = fmaf(W.w[kx], p[j + kx * CH], a);
+                h[j] = a;
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (SEP) {
+                    acc[slot][j] = fmaf(W.w[ky], h[j], acc[slot][j]);
+                } else {
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) acc[slot][j] = fmaf(W.w[ky * KS + kx], p[j + kx * CH], acc[slot][j]);
+                }
+            }
+        }
+        // the output whose last kernel row (ky = KS-1) was just applied: y = r - RAD, slot (RHO + RAD + 1) % KS
+        constexpr int done = ((RHO - (KS - 1) + RAD) % KS + KS) % KS;
+        const int y = r - RAD;
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = rintf(acc[done][j]);
+            const uint32_t u = v < 0.0f ? 0u : (v > 255.0f ? 255u : (uint32_t)v);
+            o |= u << (8 * j);
+            acc[done][j] = SEP ? 0.0f : W.delta;
+        }
+        if (y >= ys && y < ye) *(uint32_t*)(df + (size_t)y * d.step) = o;
+    };
+
+    // rows ys-RAD .. ye-1+RAD; the unrolled body handles KS consecutive rows whose (row mod KS) is static when the
+    // stream starts at a multiple of KS: start at r0 = floor((ys - RAD) / KS) * KS (the extra leading rows only touch
+    // outputs above the segment, which are never stored).
+    int r0 = ys - RAD;
+    r0 = r0 >= 0 ? r0 / KS * KS : -((-r0 + KS - 1) / KS) * KS;
+    uint32_t cur[NW], nxt[NW];
+    load_row(r0, cur);
+    for (int rb = r0; rb <= ye - 1 + RAD; rb += KS) {
+        static_for<0, KS>([&](auto I) __attribute__((always_inline)) {
+            load_row(rb + I + 1, nxt);   // next row in flight while this one is consumed
+            feed(cur, rb + I, I);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) cur[q] = nxt[q];
+        });
+    }
+}
+
+template <int KS, int CH, bool SEP>
+int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta)
+{
+    constexpr int RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, NW = (LEADW + 4 + LEAD + 3) / 4;
+    const int rowbytes = s.cols * CH;
+    if (rowbytes < 4 * NW) return RCV_ERR_UNSUPPORTED;
+    FWeights<KS, SEP> W;
+    for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w[i] = w[i];
+    W.delta = delta;
+    const unsigned gx = (unsigned)((rowbytes / 4 + kBlock - 1) / kBlock);
+    int seg = s.rows;
+    while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
+    const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
+    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg);
+    RCV_TRY(rcv_launch_check(ctx));
+    // byte columns whose window left the row: [0, LEADW) and [rowbytes - (4*NW - LEADW) + 4, rowbytes)
+    const int lo_end = min(LEADW, rowbytes), hi_begin = max(lo_end, rowbytes - (4 * NW - LEADW) + 4);
+    if (SEP) {
+        RCV_TRY(rcv_gauss_f32_generic_range(ctx, s, d, w, KS, 0, lo_end));
+        if (hi_begin < rowbytes) RCV_TRY(rcv_gauss_f32_generic_range(ctx, s, d, w, KS, hi_begin, rowbytes));
+    } else {
+        RCV_TRY(rcv_filter_f32_generic_range(ctx, s, d, w, KS, delta, 0, lo_end));
+        if (hi_begin < rowbytes) RCV_TRY(rcv_filter_f32_generic_range(ctx, s, d, w, KS, delta, hi_begin, rowbytes));
+    }
+    return RCV_OK;
+}
+
+template <bool SEP>
+int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksize, float delta)
+{
+    if ((s.cols * s.ch) % 4 != 0) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)d.p % 4 || d.step % 4 || (d.n > 1 && d.fstride % 4)) return RCV_ERR_UNSUPPORTED;
+#define RCV_CASE(KS, CH) \
+    if (ksize == KS && s.ch == CH) return launch<KS, CH, SEP>(ctx, s, d, w, delta);
+    RCV_CASE(3, 1) RCV_CASE(5, 1) RCV_CASE(7, 1) RCV_CASE(3, 3) RCV_CASE(5, 3) RCV_CASE(7, 3)
+    if constexpr (SEP) { RCV_CASE(9, 1) RCV_CASE(11, 1) RCV_CASE(9, 3) RCV_CASE(11, 3) }
+#undef RCV_CASE
+    return RCV_ERR_UNSUPPORTED;
+}
+
+} // namespace
+
+int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta)
+{
+    return dispatch<false>(ctx, s, d, k, ksize, delta);
+}
+
+int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize)
+{
+    return dispatch<true>(ctx, s, d, taps, ksize, 0.0f);
+}

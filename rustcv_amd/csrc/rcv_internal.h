@@ -23,7 +23,7 @@ struct rcv_ctx {
     // cached banded-weight table of the MFMA filter (rcv_filter7_mfma.hip), lives in kconst[0..4096)
     bool f7_valid;
     int f7_ksize;
-    int8_t f7_k[49];
+    int16_t f7_k[49];
 };
 
 // Kernel-facing description of a (batch of) strided image(s).

@@ -6,5 +6,11 @@
 
 int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize);
 int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
+int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift);  // |k| <= 511
 int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy);
 int rcv_harris_fused(rcv_ctx* ctx, const View& bgr, const View& mask, const View* resp, int block, float k, float thr);
+int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
+int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
+// generic kernels restricted to the byte columns [xb_lo, xb_hi) of every row (edge fix-up of the streaming kernels)
+int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta, int xb_lo, int xb_hi);
+int rcv_gauss_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize, int xb_lo, int xb_hi);

@@ -34,6 +34,13 @@ struct KernF32 { float k[225]; int ksize; float delta; };
     for (int xb = blockIdx.x * kBlock + threadIdx.x; xb < rowb; xb += gridDim.x * kBlock) {      \
         int x = xb / s.ch, c = xb - x * s.ch;
 #define SAMPLE_LOOP_END }
+// same, restricted to byte columns [xlo, xhi)
+#define SAMPLE_RANGE_BEGIN(xlo, xhi)                                                             \
+    int y = blockIdx.y;                                                                          \
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;                                    \
+    uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride;                                          \
+    for (int xb = (xlo) + blockIdx.x * kBlock + threadIdx.x; xb < (xhi); xb += gridDim.x * kBlock) { \
+        int x = xb / s.ch, c = xb - x * s.ch;
 
 __global__ __launch_bounds__(kBlock) void k_gauss_int_generic(View s, View d, TapsI32 tp)
 {
@@ -50,10 +57,10 @@ __global__ __launch_bounds__(kBlock) void k_gauss_int_generic(View s, View d, Ta
     SAMPLE_LOOP_END
 }
 
-__global__ __launch_bounds__(kBlock) void k_gauss_f32_generic(View s, View d, TapsF32 tp)
+__global__ __launch_bounds__(kBlock) void k_gauss_f32_generic(View s, View d, TapsF32 tp, int xlo, int xhi)
 {
     int r = tp.ksize / 2;
-    SAMPLE_LOOP_BEGIN
+    SAMPLE_RANGE_BEGIN(xlo, xhi)
     float acc = 0.0f;
     for (int ky = 0; ky < tp.ksize; ++ky) {
         const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
@@ -81,10 +88,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_i8_generic(View s, View d, Ke
     SAMPLE_LOOP_END
 }
 
-__global__ __launch_bounds__(kBlock) void k_filter_f32_generic(View s, View d, KernF32 kw)
+__global__ __launch_bounds__(kBlock) void k_filter_f32_generic(View s, View d, KernF32 kw, int xlo, int xhi)
 {
     int r = kw.ksize / 2;
-    SAMPLE_LOOP_BEGIN
+    SAMPLE_RANGE_BEGIN(xlo, xhi)
     float acc = kw.delta;
     for (int ky = 0; ky < kw.ksize; ++ky) {
         const uint8_t* row = sf + (size_t)reflect101(y + ky - r, s.rows) * s.step;
@@ -162,7 +169,9 @@ extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_b
         TapsF32 tp;
         tp.ksize = ksize;
         RCV_TRY(rcv_gaussian_taps_f32(ksize, sigma, tp.t));
-        hipLaunchKernelGGL(k_gauss_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
+        int rc = rcv_gauss_f32_fast(ctx, s, d, tp.t, ksize);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+        hipLaunchKernelGGL(k_gauss_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp, 0, s.cols * s.ch);
     }
     return rcv_launch_check(ctx);
 }
@@ -191,11 +200,13 @@ extern "C" int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
     RCV_TRY(check_pair(src, dst, &s, &d));
     if (!k || !(ksize & 1) || ksize < 1 || ksize > 15) return RCV_ERR_ARG;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int rc = rcv_filter_f32_fast(ctx, s, d, k, ksize, delta);
+    if (rc != RCV_ERR_UNSUPPORTED) return rc;
     KernF32 kw;
     kw.ksize = ksize;
     kw.delta = delta;
     for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
-    hipLaunchKernelGGL(k_filter_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw);
+    hipLaunchKernelGGL(k_filter_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw, 0, s.cols * s.ch);
     return rcv_launch_check(ctx);
 }
 
@@ -215,6 +226,29 @@ extern "C" int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx
     int rc = rcv_sobel_tiled(ctx, s, vx, vy);
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
     hipLaunchKernelGGL(k_sobel_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, vx, vy);
+    return rcv_launch_check(ctx);
+}
+
+int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta, int xb_lo, int xb_hi)
+{
+    if (xb_hi <= xb_lo) return RCV_OK;
+    KernF32 kw;
+    kw.ksize = ksize;
+    kw.delta = delta;
+    for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
+    dim3 grid((unsigned)((xb_hi - xb_lo + kBlock - 1) / kBlock), s.rows, s.n);
+    hipLaunchKernelGGL(k_filter_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, kw, xb_lo, xb_hi);
+    return rcv_launch_check(ctx);
+}
+
+int rcv_gauss_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize, int xb_lo, int xb_hi)
+{
+    if (xb_hi <= xb_lo) return RCV_OK;
+    TapsF32 tp;
+    tp.ksize = ksize;
+    for (int i = 0; i < ksize; ++i) tp.t[i] = taps[i];
+    dim3 grid((unsigned)((xb_hi - xb_lo + kBlock - 1) / kBlock), s.rows, s.n);
+    hipLaunchKernelGGL(k_gauss_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, tp, xb_lo, xb_hi);
     return rcv_launch_check(ctx);
 }
 

@@ -216,6 +216,17 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, rows, cols, ksize, shift, pad):
         assert (padbytes == 0xAB).all()
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 16), (33, 240), (19, 496), (300, 272)])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_gaussian_int_mfma_path(ctx, oracle, rng, rows, cols, ksize):
+    """integer GaussianBlur on the MFMA strip kernel (ksize 7 = dual-table variant, weights up to 324)"""
+    img = rand_img(rng, rows, cols, 3)
+    img[: rows // 2] = 255  # saturating region: sums reach 255 * D exactly
+    src, dst = Mat.from_array(img), Mat(rows, cols, 3)
+    imgproc.gaussian_blur(src, dst, ksize, 0.0, ctx)
+    assert np.array_equal(dst.to_array(), oracle.gaussian_blur(img, ksize, 0.0))
+
+
 def test_filter2d_i8_mfma_batch_4k_properties(ctx, oracle):
     """Full-size frames (BASELINE configs[2] shape, small batch): (1) rows of frame 0 against the oracle on
     slabs; (2) linearity: filter(K1) + filter(K2) == filter(K1+K2) where nothing saturates (shift 0 is not
@@ -265,6 +276,36 @@ def test_filter2d_f32(ctx, oracle, rng, rows, cols, ksize):
     src, dst = Mat.from_array(img), Mat(rows, cols, 3)
     imgproc.filter2d(src, dst, k, delta=0.5, ctx=ctx)
     assert np.array_equal(dst.to_array(), oracle.filter2d_f32(img, k, 0.5))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 4), (2, 8), (7, 12), (33, 64), (61, 128), (40, 300)])
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_filter2d_f32_stream_path(ctx, oracle, rng, rows, cols, ch, ksize):
+    """shapes the streaming f32 kernel takes (cols*ch % 4 == 0): row-segment seams, edge threads, tiny images"""
+    img = rand_img(rng, rows, cols, ch)
+    k = (rng.standard_normal((ksize, ksize)) / ksize).astype(np.float32)
+    n = 2
+    src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + 4)
+    dst = device.DeviceBatch(ctx, n, rows, cols, ch)
+    frames = np.stack([img, img[::-1].copy()])
+    src.upload(frames)
+    device.filter2d(src, dst, k, delta=-3.5)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.filter2d_f32(frames[i], k, -3.5))
+    src.free()
+    dst.free()
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 4), (7, 12), (61, 128), (40, 300)])
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("ksize,sigma", [(3, 0.7), (5, 1.3), (7, 1.9), (9, 2.2), (11, 3.0), (13, 3.0)])
+def test_gaussian_sigma_stream_path(ctx, oracle, rng, rows, cols, ch, ksize, sigma):
+    img = rand_img(rng, rows, cols, ch)
+    src, dst = Mat.from_array(img), Mat(rows, cols, ch)
+    imgproc.gaussian_blur(src, dst, ksize, sigma, ctx)
+    assert np.array_equal(dst.to_array(), oracle.gaussian_blur(img, ksize, sigma))
 
 
 @pytest.mark.parametrize("rows,cols", SHAPES)

@@ -144,6 +144,8 @@ def main():
     record("filter2D 7x7 f32", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.filter2d(s, d, kf, delta=0.0),
            note="VALU-bound by construction (49 dependent fmaf per sample), reported for completeness")
     record("GaussianBlur 7x7 (sigma=0)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.gaussian_blur(s, d, 7, 0.0))
+    record("GaussianBlur 7x7 (sigma=1.5)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.gaussian_blur(s, d, 7, 1.5),
+           note="f32 separable path, 14 fmaf per sample")
     # ---- config 5: Harris pipeline on 4K BGR, 64 frames per GPU ----------------------------------------------
     m = B(64, 2160, 3840, 1)
     device.synth(s, 1, SEED + 5, 0)
