@@ -305,12 +305,12 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 
     for (int k = 0; k < nsteps; k += 2) {
         load_block(k + 3, LB);
+        store_block(k + 2, LA);   // block k+2's ring slots are free during step k: stage first, compute after
         compute(k);
-        store_block(k + 2, LA);
         __syncthreads();
         load_block(k + 4, LA);
-        compute(k + 1);   // (when nsteps is odd this last half-iteration computes a step past the segment: all dumped)
         store_block(k + 3, LB);
+        compute(k + 1);   // (when nsteps is odd this last half-iteration computes a step past the segment: all dumped)
         __syncthreads();
     }
 }
