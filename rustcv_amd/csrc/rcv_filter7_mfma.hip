@@ -31,6 +31,7 @@
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
+#include <stdlib.h>
 #include <string.h>
 
 int rcv_debug_flags = 0;
@@ -390,6 +391,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.nstrips = (a.ntiles_total + kTiles - 1) / kTiles;
     // segments: enough workgroups to fill 256 CUs x 3 several times over
     int seg_rows = 720;
+    if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
     long long wgs = (long long)a.nstrips * ((s.rows + seg_rows - 1) / seg_rows) * s.n;
     while (wgs < 2048 && seg_rows > 128) {
         seg_rows /= 2;
