@@ -1,4 +1,4 @@
-// temporary: shape-specialised kernels not written yet -> everything takes the generic HIP path
+// rcv_gauss_int.hip -- integer GaussianBlur (sigma <= 0) expressed as an integer filter2D on the MFMA strip kernel.
 #include "rcv_kernels.h"
 // GaussianBlur(sigma<=0) IS an integer filter2D: the 2-D weights are the outer product of the 1-D taps and
 // (sum + D/2) / D == (sum + (1 << (s-1))) >> s for D = 2^s and sum >= 0.  ksize 3 / 5 fit i8 (max 4 / 36); ksize 7 has

@@ -527,3 +527,55 @@ def test_errors_do_not_cross_the_abi(ctx):
     assert L.rcv_filter2d_i8(ctx.handle, C.byref(s), C.byref(c), k, 3, 0) == _ffi.RCV_ERR_SIZE
     assert L.rcv_cvt_color(ctx.handle, 99, C.byref(a), C.byref(c)) == _ffi.RCV_ERR_ARG
     assert L.rcv_filter2d_i8(None, C.byref(a), C.byref(c), k, 3, 0) == _ffi.RCV_ERR_ARG
+
+
+# ---- out-of-bounds canaries: padding between rows and between frames must survive every batch op -------------------
+
+def _canary_batch(ctx, n, rows, cols, ch, depth=_ffi.RCV_8U, pad=32):
+    esz = {_ffi.RCV_8U: 1, _ffi.RCV_16S: 2, _ffi.RCV_32F: 4}[depth]
+    step = cols * ch * esz + pad
+    b = device.DeviceBatch(ctx, n, rows, cols, ch, depth, step=step, frame_stride=rows * step + 512)
+    b.memset(0xCD)
+    return b
+
+
+def _assert_canaries(b):
+    raw = b.download_bytes()[: b.n * b.frame_stride].reshape(b.n, b.frame_stride)
+    esz = {_ffi.RCV_8U: 1, _ffi.RCV_16S: 2, _ffi.RCV_32F: 4}[b.depth]
+    rowb = b.cols * b.channels * esz
+    body = raw[:, : b.rows * b.step].reshape(b.n, b.rows, b.step)
+    assert (body[:, :, rowb:] == 0xCD).all(), "row padding overwritten"
+    assert (raw[:, b.rows * b.step:] == 0xCD).all(), "inter-frame gap overwritten"
+
+
+@pytest.mark.parametrize("rows,cols", [(20, 48), (37, 256), (130, 496)])
+def test_no_out_of_bounds_writes(ctx, oracle, rows, cols):
+    n = 2
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    device.synth(src, 1, 0x5EED0009, 0)
+    k = oracle.bench_kernel7()
+    d = _canary_batch(ctx, n, rows, cols, 3)
+    for fn in (lambda: device.filter2d(src, d, k, shift=6), lambda: device.gaussian_blur(src, d, 5, 0.0),
+               lambda: device.gaussian_blur(src, d, 7, 0.0), lambda: device.gaussian_blur(src, d, 7, 1.5),
+               lambda: device.filter2d(src, d, (k / 64).astype(np.float32), delta=0.0),
+               lambda: device.warp_affine(src, d, np.array([0.99, -0.12, 3.5, 0.12, 0.99, -2.25], np.float32)),
+               lambda: device.rectangle(d, Rect(3, 3, cols - 6, rows - 6), Scalar(1, 2, 3), 2)):
+        fn()
+        _assert_canaries(d)
+    g = _canary_batch(ctx, n, rows, cols, 1)
+    device.cvt_color(src, g, _ffi.RCV_BGR2GRAY)
+    _assert_canaries(g)
+    dx, dy = _canary_batch(ctx, n, rows, cols, 1, _ffi.RCV_16S), _canary_batch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+    device.sobel(g, dx, dy)
+    _assert_canaries(dx)
+    _assert_canaries(dy)
+    m, r = _canary_batch(ctx, n, rows, cols, 1), _canary_batch(ctx, n, rows, cols, 1, _ffi.RCV_32F)
+    device.harris_pipeline(src, m, r, 2, 0.04, 1e-4)
+    _assert_canaries(m)
+    _assert_canaries(r)
+    small = _canary_batch(ctx, n, rows // 2, cols // 2, 3)
+    device.resize(src, small)
+    _assert_canaries(small)
+    odd = _canary_batch(ctx, n, rows // 3 + 1, cols // 3 + 1, 3)
+    device.resize(src, odd)
+    _assert_canaries(odd)
