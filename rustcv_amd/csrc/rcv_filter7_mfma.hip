@@ -43,7 +43,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
-constexpr int kTiles = 15;            // 16-px tiles per strip (240 px); wave w computes tiles 4w..4w+3 (tile 15 is a dummy)
+constexpr int kTiles = 16;            // 16-px tiles per strip: 256 px = 768 B = six whole 128-B lines.  Strip seams that fall
+                                      // inside a line make two workgroups write one line: a pure-store replica of this
+                                      // traversal measured 3.5 TB/s with 720-B strips and 5.6 TB/s with 768-B strips.
 constexpr int kPitch = 288;           // bytes per planar row in LDS: 18 x 16 B.  Row stride == 2 (mod 16) sixteen-byte
                                       // slots makes every ds_read_b128 lane group (8 rows at x, 8 rows at x+16) hit 16
                                       // distinct slots: conflict-free (272 B measured 46 % conflict cycles).
@@ -138,15 +140,29 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
     const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
     const int ry_last = ye + 2;                         // last source row (before reflection) this segment needs
+    // A full strip (16 tiles) needs 6 more pixels than its 16 chunks hold: xx = 256..261 <- x = x0+253 .. x0+258.
+    // Their 18 bytes lie in the 32 bytes at row offset 3*x0 + 752; every wave fetches them for all 16 rows as one
+    // dwordx2 per lane (row lane>>2, piece lane&3) -- unconditional like all VMEM here; wave 0 then plants them.
+    const bool fullstrip = ntiles == kTiles;
+    const int er = lane >> 2, ep = lane & 3;
+    const int eoff = min(max(3 * x0 + 752 + 8 * ep, 0), rowbytes - 8);
+    const bool lastfull = fullstrip && x0 + 256 == a.cols;   // right image border inside the halo piece
 
-    auto load_block = [&](int b, uint32_t (&L)[13]) {
+    auto load_block = [&](int b, uint32_t (&L)[15]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
         const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
         const uint8_t* p = sframe + (size_t)srow * a.sstep;
         if (DBG & 2) {
 #pragma unroll
-            for (int i = 0; i < 13; ++i) L[i] = 0;
+            for (int i = 0; i < 15; ++i) L[i] = 0;
             return;
+        }
+        {
+            const int rye = min(ys - 3 + 16 * b + er, ry_last);
+            const int erow = rye < 0 ? -rye : (rye >= a.rows ? 2 * a.rows - 2 - rye : rye);
+            const U2 e = *(const U2*)(sframe + (size_t)erow * a.sstep + eoff);
+            L[13] = e.a;
+            L[14] = e.b;
         }
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
@@ -160,7 +176,32 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         L[11] = v3.a; L[12] = v3.b;
     };
 
-    auto store_block = [&](int b, const uint32_t (&L)[13]) {
+    auto store_block = [&](int b, const uint32_t (&L)[15]) {
+        if (fullstrip && wave == 0) {
+            // halo piece, all in registers: the four lanes of a row hold bytes [0,32) of the piece; dwords 1..6 (bytes
+            // 4..27) are exactly the 8 pixels x0+252 .. x0+259.  Lane ep==0 collects them from its quad with DPP
+            // row_shl, de-interleaves, and plants x0+253..x0+258 at xx = 256..261 (mirrored at the right image border).
+            const uint32_t w1 = L[14];
+            const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
+            const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
+            const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[13], 0x102, 0xf, 0xf, false);
+            const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[14], 0x102, 0xf, 0xf, false);
+            const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[13], 0x103, 0xf, 0xf, false);
+            uint32_t g1[3], g2[3];
+            deint4(w1, w2, w3, g1[0], g1[1], g1[2]);   // pixels x0+252 .. 255
+            deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
+            if (ep == 0 && ys - 3 + 16 * b + er <= ry_last) {
+                const int hslot = (16 * b + er) % kSlots;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t lo = lastfull ? __builtin_amdgcn_perm(g1[c], g1[c], 0x02030201u)   // 253 254 255 | 254
+                                                 : __builtin_amdgcn_perm(g2[c], g1[c], 0x04030201u);  // 253 254 255 | 256
+                    const uint32_t hi = lastfull ? __builtin_amdgcn_perm(g1[c], g1[c], 0x0c0c0001u)   // 253 252
+                                                 : (g2[c] >> 8);                                      // 257 258
+                    *(U2*)(lds + c * kPlane + hslot * kPitch + 256) = U2{lo ^ 0x80808080u, hi ^ 0x80808080u};
+                }
+            }
+        }
         uint32_t s[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
@@ -246,9 +287,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             if (p == 3) return lowhalf ? *src : v4i{0, 0, 0, 0};
             return *src;
         };
-        // wave 3's fourth tile (tile 15) does not exist: its 12 MFMAs and LDS reads are skipped (wave-uniform,
-        // LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
-        const int nmf = (4 * wave + 3 < kTiles) ? 48 : 36;
+        // (wave-uniform, LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
+        const int nmf = 12 * min(max(ntiles - 4 * wave, 0), 4);   // narrow last strips: tiles past the strip are skipped
         v4i acc[3], acc2[3];
         if (!(DBG & 4)) {
 #pragma unroll
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 #pragma unroll
         for (int it = 0; it < 48; ++it) {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
-            if (it == 36 && nmf == 36) break;
+            if (r == 0 && it >= nmf) break;
             if (r < 3) {
                 acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
                 if (DUAL) acc2[c] = v4i{0, 0, 0, 0};
@@ -296,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // ---- software pipeline: block k+3 is in flight in registers and block k+2 is written to the LDS ring while
     // step k computes from blocks k, k+1.  Blocks 0..nsteps are needed; loads past that are harmless re-reads.
     // Two register sets, loop unrolled by two so that the set index is static. ----
-    uint32_t LA[13], LB[13];
+    uint32_t LA[15], LB[15];
     load_block(0, LA);
     load_block(1, LB);
     store_block(0, LA);
@@ -389,15 +429,24 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.cols = s.cols;
     a.ntiles_total = s.cols / 16;
     a.nstrips = (a.ntiles_total + kTiles - 1) / kTiles;
-    // segments: enough workgroups to fill 256 CUs x 3 several times over
-    int seg_rows = 720;
-    if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
-    long long wgs = (long long)a.nstrips * ((s.rows + seg_rows - 1) / seg_rows) * s.n;
-    while (wgs < 2048 && seg_rows > 128) {
-        seg_rows /= 2;
-        seg_rows = (seg_rows + 15) & ~15;
-        wgs = (long long)a.nstrips * ((s.rows + seg_rows - 1) / seg_rows) * s.n;
+    // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs),
+    // each segment a multiple of 16 rows and at least 128 rows unless the image is smaller
+    int seg_rows = (s.rows + 15) & ~15;
+    {
+        const long long slots = 3LL * ctx->cu_count;
+        double best = 1e30;
+        for (int ns = 1; ns <= 32; ++ns) {
+            int sr = ((s.rows + ns - 1) / ns + 15) & ~15;
+            if (ns > 1 && sr < 128) break;
+            int nsegs = (s.rows + sr - 1) / sr;
+            long long tot = (long long)a.nstrips * nsegs * s.n;
+            long long rounds = (tot + slots - 1) / slots;
+            // cost model: time ~ rounds * rows-per-segment (+6 halo rows), slight penalty per segment
+            double cost = (double)rounds * (sr + 6 + 24);
+            if (cost < best) { best = cost; seg_rows = sr; }
+        }
     }
+    if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
     a.seg_rows = seg_rows;
     a.nsegs = (s.rows + seg_rows - 1) / seg_rows;
     a.shift = shift;
