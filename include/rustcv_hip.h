@@ -54,6 +54,14 @@ extern "C" {
 #define RCV_YUYV2BGR_TWIN  3  /* rustcv-camera/src/decode.rs:160-191 guard: pairs*4 / pairs*6  */
 #define RCV_BGRA2BGR_TWIN  4  /* rustcv-camera/src/decode.rs:200-207 (min whole pixels)        */
 #define RCV_BGR2GRAY       5  /* build-defined; stride-aware                  */
+/* "next" rows of the scope table: display / codec swizzles and stride-aware capture formats */
+#define RCV_BGR2BGRX       6  /* rustcv/src/highgui/mod.rs:125-141 mat_to_u32_buffer: flat BGR -> u32 0x00RRGGBB;
+                                 dst: 4 channels, rows*cols pixels, pixels past src.cap/3 are zero            */
+#define RCV_BGR2RGB        7  /* rustcv/src/imgcodecs/mod.rs:51-63 (imwrite): src honours step, dst packed    */
+#define RCV_YUYV2BGR_STRIDED 8  /* src 2 channels [Y0 U Y1 V], both sides honour step; odd last column untouched */
+#define RCV_UYVY2BGR_STRIDED 9  /* src 2 channels [U Y0 V Y1]                                                    */
+#define RCV_NV12_2BGR      10 /* src 1 channel, rows x cols luma then ceil(rows/2) rows of interleaved UV at the same
+                                 step (rustcv-backend-msmf/examples/camera_view/convert.rs:46-86); RCV_NOOP if short */
 
 /* ---- synthetic frame families (replaces the empty rustcv-simulation crate) */
 #define RCV_SYNTH_NOISE 0

@@ -50,6 +50,10 @@ def lib():
         _lib.orc_nms3x3.argtypes = [_f32p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_float]
         _lib.orc_harris_pipeline.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _f32p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
         _lib.orc_bench_kernel7.argtypes = [_i8p]
+        _lib.orc_bgr_to_u32.argtypes = [_u8p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t]
+        _lib.orc_bgr_to_rgb_rows.argtypes = [_u8p, C.c_size_t, _u8p, C.c_int, C.c_int]
+        _lib.orc_yuv422_to_bgr_strided.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        _lib.orc_nv12_to_bgr.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int]
     return _lib
 
 
@@ -100,6 +104,30 @@ def rectangle(data, rows, cols, step, x, y, w, h, b, g, r, thickness):
     """data: flat uint8 (Vec<u8>), modified in place"""
     assert data.dtype == np.uint8 and data.flags.c_contiguous
     lib().orc_rectangle(_p(data, _u8p), data.size, rows, cols, step, x, y, w, h, b, g, r, thickness)
+
+
+def bgr_to_u32(data, pixel_count):
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    out = np.zeros(pixel_count, np.uint32)
+    lib().orc_bgr_to_u32(_p(data, _u8p), data.size, out.ctypes.data_as(C.POINTER(C.c_uint32)), pixel_count)
+    return out
+
+
+def bgr_to_rgb_rows(data, step, rows, cols):
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    out = np.zeros(rows * cols * 3, np.uint8)
+    lib().orc_bgr_to_rgb_rows(_p(data, _u8p), step, _p(out, _u8p), rows, cols)
+    return out
+
+
+def yuv422_to_bgr_strided(data, sstep, rows, cols, uyvy, dst):
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    lib().orc_yuv422_to_bgr_strided(_p(data, _u8p), sstep, _p(dst, _u8p), cols * 3, rows, cols, int(uyvy))
+
+
+def nv12_to_bgr(data, sstep, rows, cols, dst):
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    return bool(lib().orc_nv12_to_bgr(_p(data, _u8p), data.size, sstep, _p(dst, _u8p), cols * 3, rows, cols))
 
 
 # ---- (B) build-defined ops ----------------------------------------------------------------------

@@ -138,6 +138,63 @@ void orc_rectangle(uint8_t* data, size_t data_len, int32_t rows, int32_t cols, s
         }
 }
 
+/* rustcv/src/highgui/mod.rs:125-141 mat_to_u32_buffer: chunks_exact(3) of the WHOLE data vector (step ignored)
+ * zipped with a zero-initialised rows*cols u32 buffer; pixel = (r << 16) | (g << 8) | b                        */
+void orc_bgr_to_u32(const uint8_t* src, size_t src_len, uint32_t* dst, size_t pixel_count)
+{
+    size_t n = src_len / 3 < pixel_count ? src_len / 3 : pixel_count;
+    for (size_t i = 0; i < pixel_count; ++i) dst[i] = 0;
+    for (size_t i = 0; i < n; ++i)
+        dst[i] = ((uint32_t)src[3 * i + 2] << 16) | ((uint32_t)src[3 * i + 1] << 8) | (uint32_t)src[3 * i];
+}
+
+/* rustcv/src/imgcodecs/mod.rs:51-63 (imwrite): for each row, row_bytes(r) (honours step), B,G,R -> R,G,B, packed */
+void orc_bgr_to_rgb_rows(const uint8_t* src, size_t sstep, uint8_t* dst, int rows, int cols)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const uint8_t* p = src + (size_t)y * sstep + (size_t)x * 3;
+            uint8_t* d = dst + ((size_t)y * cols + x) * 3;
+            d[0] = p[2];
+            d[1] = p[1];
+            d[2] = p[0];
+        }
+}
+
+/* "next" row f2: stride-aware capture formats.  Arithmetic = the reference's BT.601 integer formula
+ * (videoio/mod.rs:356-363); NV12 chroma sampling as in rustcv-backend-msmf/examples/camera_view/convert.rs:46-86
+ * (uv row = row/2, uv col = col/2, same stride for both planes).  uyvy = 0: [Y0 U Y1 V], 1: [U Y0 V Y1].
+ * Whole macropixels only: an odd last column is left untouched.                                                   */
+static inline void yuv_px(int y, int u, int v, uint8_t* d)
+{
+    int c = 298 * (y - 16) + 128;
+    d[0] = clamp_u8((c + 516 * u) >> 8);
+    d[1] = clamp_u8((c - 100 * u - 208 * v) >> 8);
+    d[2] = clamp_u8((c + 409 * v) >> 8);
+}
+void orc_yuv422_to_bgr_strided(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols, int uyvy)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x + 1 < cols; x += 2) {
+            const uint8_t* p = src + (size_t)y * sstep + (size_t)x * 2;
+            int y0 = uyvy ? p[1] : p[0], u = (uyvy ? p[0] : p[1]) - 128, y1 = uyvy ? p[3] : p[2], v = (uyvy ? p[2] : p[3]) - 128;
+            yuv_px(y0, u, v, dst + (size_t)y * dstep + (size_t)x * 3);
+            yuv_px(y1, u, v, dst + (size_t)y * dstep + (size_t)x * 3 + 3);
+        }
+}
+int orc_nv12_to_bgr(const uint8_t* src, size_t src_len, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols)
+{
+    size_t ysz = sstep * (size_t)rows, uvsz = sstep * (size_t)((rows + 1) / 2);
+    if (src_len < ysz + uvsz) return 0; /* convert.rs:56-58: silent return */
+    const uint8_t* uv = src + ysz;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const uint8_t* q = uv + (size_t)(y / 2) * sstep + (size_t)(x / 2) * 2;
+            yuv_px(src[(size_t)y * sstep + x], q[0] - 128, q[1] - 128, dst + (size_t)y * dstep + (size_t)x * 3);
+        }
+    return 1;
+}
+
 /* ========================================================================== */
 /* (B) build-defined ops, SURVEY.md 8-A                                       */
 /* ========================================================================== */

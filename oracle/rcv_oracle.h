@@ -54,6 +54,12 @@ void orc_rectangle(uint8_t* data, size_t data_len, int32_t rows, int32_t cols, s
                    int32_t x, int32_t y, int32_t w, int32_t h,
                    uint8_t b, uint8_t g, uint8_t r, int32_t thickness);
 
+/* "next" rows f2 / f4 */
+void orc_bgr_to_u32(const uint8_t* src, size_t src_len, uint32_t* dst, size_t pixel_count);      /* highgui/mod.rs:125-141 */
+void orc_bgr_to_rgb_rows(const uint8_t* src, size_t sstep, uint8_t* dst, int rows, int cols);    /* imgcodecs/mod.rs:51-63 */
+void orc_yuv422_to_bgr_strided(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols, int uyvy);
+int orc_nv12_to_bgr(const uint8_t* src, size_t src_len, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols);
+
 /* ---- (B) build-defined ops -------------------------------- */
 
 int orc_reflect101(int i, int n);

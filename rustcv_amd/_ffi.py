@@ -15,6 +15,7 @@ RCV_ERR_ARG, RCV_ERR_UNSUPPORTED, RCV_ERR_SIZE, RCV_ERR_DEVICE, RCV_ERR_OOM = -1
 RCV_8U, RCV_16S, RCV_32F = 0, 1, 2
 RCV_HOST, RCV_DEVICE = 0, 1
 RCV_YUYV2BGR, RCV_BGRA2BGR, RCV_RGB2BGR, RCV_YUYV2BGR_TWIN, RCV_BGRA2BGR_TWIN, RCV_BGR2GRAY = range(6)
+RCV_BGR2BGRX, RCV_BGR2RGB, RCV_YUYV2BGR_STRIDED, RCV_UYVY2BGR_STRIDED, RCV_NV12_2BGR = 6, 7, 8, 9, 10
 RCV_SYNTH_NOISE, RCV_SYNTH_SCENE, RCV_SYNTH_YUYV = 0, 1, 2
 
 

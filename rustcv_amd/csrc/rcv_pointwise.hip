@@ -156,6 +156,129 @@ __global__ __launch_bounds__(kBlock) void k_rgb2bgr_scalar(const uint8_t* __rest
     }
 }
 
+// ---- "next" rows f2 / f4: display swizzle, codec swizzle, stride-aware YUV 4:2:2 / NV12 ---------------------------
+// BGR (flat) -> u32 0x00RRGGBB == bytes B G R 0 (rustcv/src/highgui/mod.rs:125-141); pixels >= nconv are zero
+__global__ __launch_bounds__(kBlock) void k_bgr2bgrx(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t sfs, size_t dfs,
+                                                     size_t nconv, size_t npx, int vec)
+{
+    const uint8_t* s = src + (size_t)blockIdx.y * sfs;
+    uint8_t* d = dst + (size_t)blockIdx.y * dfs;
+    const size_t quads = vec ? nconv / 4 : 0;
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += (size_t)gridDim.x * kBlock) {
+        const uint32_t* sp = (const uint32_t*)(s + q * 12);
+        const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
+        uint4 o;
+        o.x = d0 & 0x00ffffffu;
+        o.y = __builtin_amdgcn_perm(d1, d0, 0x0c050403u);  // b1(d0.3) g1(d1.0) r1(d1.1) 0
+        o.z = __builtin_amdgcn_perm(d2, d1, 0x0c040302u);  // b2(d1.2) g2(d1.3) r2(d2.0) 0
+        o.w = d2 >> 8;
+        *(uint4*)(d + q * 16) = o;
+    }
+    for (size_t i = quads * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < npx; i += (size_t)gridDim.x * kBlock) {
+        uint32_t v = 0;
+        if (i < nconv) v = (uint32_t)s[3 * i] | ((uint32_t)s[3 * i + 1] << 8) | ((uint32_t)s[3 * i + 2] << 16);
+        d[4 * i] = (uint8_t)v;
+        d[4 * i + 1] = (uint8_t)(v >> 8);
+        d[4 * i + 2] = (uint8_t)(v >> 16);
+        d[4 * i + 3] = 0;
+    }
+}
+
+// BGR rows (strided) -> packed RGB (rustcv/src/imgcodecs/mod.rs:51-63)
+__global__ __launch_bounds__(kBlock) void k_bgr2rgb_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t sstep,
+                                                         size_t sfs, size_t dfs, int cols, int vec)
+{
+    const int y = blockIdx.y;
+    const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
+    uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * cols * 3;
+    const int quads = vec ? cols / 4 : 0;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
+        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12);
+        uint32_t w[3];
+        swap_rb4(sp[0], sp[1], sp[2], w);
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(d + (size_t)q * 12) = U3{w[0], w[1], w[2]};
+    }
+    for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock) {
+        d[3 * x] = s[3 * x + 2];
+        d[3 * x + 1] = s[3 * x + 1];
+        d[3 * x + 2] = s[3 * x];
+    }
+}
+
+__device__ __forceinline__ void yuv3(int y, int u, int v, int* o)
+{
+    const int c = 298 * (y - 16) + 128;
+    o[0] = c + 516 * u;
+    o[1] = c - 100 * u - 208 * v;
+    o[2] = c + 409 * v;
+}
+
+// YUYV / UYVY rows (strided) -> BGR rows (strided); 2 macropixels (8 B -> 12 B) per thread on the vector path
+__global__ __launch_bounds__(kBlock) void k_yuv422_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t sstep, size_t dstep,
+                                                        size_t sfs, size_t dfs, int cols, int uyvy, int vec)
+{
+    const int y = blockIdx.y;
+    const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
+    uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * dstep;
+    const int pairs = cols / 2;
+    const int duo = vec ? pairs / 2 : 0;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < duo; q += gridDim.x * kBlock) {
+        const uint2 m = *(const uint2*)(s + (size_t)q * 8);
+        int o[12];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t w = h ? m.y : m.x;
+            const int b0 = w & 0xff, b1 = (w >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
+            const int y0 = uyvy ? b1 : b0, u = (uyvy ? b0 : b1) - 128, y1 = uyvy ? b3 : b2, v = (uyvy ? b2 : b3) - 128;
+            yuv3(y0, u, v, o + 6 * h);
+            yuv3(y1, u, v, o + 6 * h + 3);
+        }
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(d + (size_t)q * 12) = U3{rcv_ashr_sat_pk4(o[0], o[1], o[2], o[3], 8), rcv_ashr_sat_pk4(o[4], o[5], o[6], o[7], 8),
+                                       rcv_ashr_sat_pk4(o[8], o[9], o[10], o[11], 8)};
+    }
+    for (int i = duo * 2 + blockIdx.x * kBlock + threadIdx.x; i < pairs; i += gridDim.x * kBlock) {
+        const uint8_t* p = s + (size_t)i * 4;
+        const int y0 = uyvy ? p[1] : p[0], u = (uyvy ? p[0] : p[1]) - 128, y1 = uyvy ? p[3] : p[2], v = (uyvy ? p[2] : p[3]) - 128;
+        int o[6];
+        yuv3(y0, u, v, o);
+        yuv3(y1, u, v, o + 3);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[(size_t)i * 6 + k] = (uint8_t)rcv_ashr_sat1(o[k], 8);
+    }
+}
+
+// NV12 (luma rows then interleaved chroma rows, one step) -> BGR rows; 4 px (4 B luma + 4 B chroma -> 12 B) per thread
+__global__ __launch_bounds__(kBlock) void k_nv12_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t sstep, size_t dstep,
+                                                      size_t sfs, size_t dfs, int rows, int cols, int vec)
+{
+    const int y = blockIdx.y;
+    const uint8_t* yr = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
+    const uint8_t* uv = src + (size_t)blockIdx.z * sfs + (size_t)rows * sstep + (size_t)(y / 2) * sstep;
+    uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * dstep;
+    const int quads = vec ? cols / 4 : 0;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
+        const uint32_t yy = *(const uint32_t*)(yr + (size_t)q * 4), cc = *(const uint32_t*)(uv + (size_t)q * 4);
+        const int u0 = (int)(cc & 0xff) - 128, v0 = (int)((cc >> 8) & 0xff) - 128, u1 = (int)((cc >> 16) & 0xff) - 128, v1 = (int)(cc >> 24) - 128;
+        int o[12];
+        yuv3(yy & 0xff, u0, v0, o);
+        yuv3((yy >> 8) & 0xff, u0, v0, o + 3);
+        yuv3((yy >> 16) & 0xff, u1, v1, o + 6);
+        yuv3(yy >> 24, u1, v1, o + 9);
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(d + (size_t)q * 12) = U3{rcv_ashr_sat_pk4(o[0], o[1], o[2], o[3], 8), rcv_ashr_sat_pk4(o[4], o[5], o[6], o[7], 8),
+                                       rcv_ashr_sat_pk4(o[8], o[9], o[10], o[11], 8)};
+    }
+    for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock) {
+        const uint8_t* c2 = uv + (size_t)(x / 2) * 2;
+        int o[3];
+        yuv3(yr[x], (int)c2[0] - 128, (int)c2[1] - 128, o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[(size_t)x * 3 + k] = (uint8_t)rcv_ashr_sat1(o[k], 8);
+    }
+}
+
 // BGR -> gray, stride-aware.  Fast: 4 px (3 dwords) -> 1 dword per thread.
 __device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
 {
@@ -378,11 +501,80 @@ static int cvt_gray(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst)
     return rcv_launch_check(ctx);
 }
 
+static inline bool al(const void* p, size_t step, size_t fs, int n, size_t a) { return (uintptr_t)p % a == 0 && step % a == 0 && (n <= 1 || fs % a == 0); }
+
+// f4: BGR (flat) -> BGRX u32 ; f4: BGR rows -> packed RGB ; f2: strided YUYV/UYVY and NV12 -> BGR
+static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst)
+{
+    const rcv_mat* sm = &src->frame0;
+    rcv_mat* dm = &dst->frame0;
+    if (sm->device != RCV_DEVICE || dm->device != RCV_DEVICE) return RCV_ERR_ARG;
+    if (src->n != dst->n || src->n < 0) return RCV_ERR_ARG;
+    if (sm->depth != RCV_8U || dm->depth != RCV_8U) return RCV_ERR_UNSUPPORTED;
+    const int n = src->n;
+    hipStream_t st = ctx->stream;
+    if (code == RCV_BGR2BGRX) {
+        if (dm->rows < 0 || dm->cols < 0 || dm->channels != 4) return RCV_ERR_ARG;
+        const size_t npx = (size_t)dm->rows * dm->cols;
+        if (dm->cap < npx * 4) return RCV_ERR_SIZE;
+        if (n > 1 && (src->frame_stride < sm->cap || dst->frame_stride < npx * 4)) return RCV_ERR_SIZE;
+        const size_t nconv = sm->cap / 3 < npx ? sm->cap / 3 : npx;
+        if (npx == 0 || n == 0) return RCV_OK;
+        if (!dm->data || (nconv && !sm->data)) return RCV_ERR_ARG;
+        const int vec = al(sm->data, 4, src->frame_stride, n, 4) && al(dm->data, 16, dst->frame_stride, n, 16);
+        hipLaunchKernelGGL(k_bgr2bgrx, dim3(grid1d((npx + 3) / 4), n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, (uint8_t*)dm->data,
+                           src->frame_stride, dst->frame_stride, nconv, npx, vec);
+        return rcv_launch_check(ctx);
+    }
+    View s;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    if (s.rows > 65535 || n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (code == RCV_BGR2RGB) {
+        if (s.ch != 3) return RCV_ERR_UNSUPPORTED;
+        const size_t need = (size_t)s.rows * s.cols * 3;
+        if (dm->cap < need) return RCV_ERR_SIZE;
+        if (n > 1 && dst->frame_stride < need) return RCV_ERR_SIZE;
+        if (need == 0 || n == 0) return RCV_OK;
+        if (!dm->data) return RCV_ERR_ARG;
+        const int vec = al(s.p, s.step, s.fstride, n, 4) && al(dm->data, (size_t)s.cols * 3, dst->frame_stride, n, 4);
+        hipLaunchKernelGGL(k_bgr2rgb_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, (uint8_t*)dm->data, s.step,
+                           s.fstride, dst->frame_stride, s.cols, vec);
+        return rcv_launch_check(ctx);
+    }
+    if (code == RCV_NV12_2BGR) {
+        // src describes the luma plane (rows x cols, 1 channel); the chroma plane follows at rows*step
+        if (sm->channels != 1 || sm->rows < 0 || sm->cols < 0) return RCV_ERR_ARG;
+        const size_t need = sm->step * ((size_t)sm->rows + (size_t)(sm->rows + 1) / 2);
+        if (sm->step < (size_t)sm->cols + (sm->cols & 1)) return RCV_ERR_SIZE;
+        if (sm->cap < need) return RCV_NOOP;  // convert.rs:56-58: silent return
+        View d;
+        RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+        if (d.ch != 3 || d.rows != sm->rows || d.cols != sm->cols) return RCV_ERR_ARG;
+        if (n > 1 && src->frame_stride < need) return RCV_ERR_SIZE;
+        if (d.rows == 0 || d.cols == 0 || n == 0) return RCV_OK;
+        if (!sm->data) return RCV_ERR_ARG;
+        const int vec = al(sm->data, sm->step, src->frame_stride, n, 4) && al(d.p, d.step, d.fstride, n, 4);
+        hipLaunchKernelGGL(k_nv12_rows, dim3(grid1d((size_t)(d.cols + 3) / 4), d.rows, n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, d.p,
+                           sm->step, d.step, src->frame_stride, d.fstride, d.rows, d.cols, vec);
+        return rcv_launch_check(ctx);
+    }
+    // RCV_YUYV2BGR_STRIDED / RCV_UYVY2BGR_STRIDED
+    View d;
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (s.ch != 2 || d.ch != 3 || s.rows != d.rows || s.cols != d.cols) return RCV_ERR_ARG;
+    if (s.rows == 0 || s.cols < 2 || n == 0) return RCV_OK;
+    const int vec = al(s.p, s.step, s.fstride, n, 8) && al(d.p, d.step, d.fstride, n, 4);
+    hipLaunchKernelGGL(k_yuv422_rows, dim3(grid1d((size_t)(s.cols / 4 + 1)), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step, s.fstride,
+                       d.fstride, s.cols, code == RCV_UYVY2BGR_STRIDED ? 1 : 0, vec);
+    return rcv_launch_check(ctx);
+}
+
 extern "C" int rcv_cvt_color_batch(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst)
 {
     if (!src || !dst) return RCV_ERR_ARG;
     RCV_TRY(rcv_bind(ctx));
     if (code == RCV_BGR2GRAY) return cvt_gray(ctx, src, dst);
+    if (code >= RCV_BGR2BGRX && code <= RCV_NV12_2BGR) return cvt_next_rows(ctx, code, src, dst);
     return cvt_flat(ctx, code, src, dst);
 }
 

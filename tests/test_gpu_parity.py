@@ -102,6 +102,62 @@ def test_rgb_to_bgr(ctx, oracle, rng, nsrc, ndst):
     assert np.array_equal(got, want)
 
 
+# ---- "next" rows f2 / f4 -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,cols,extra", [(1, 1, 0), (3, 5, 2), (48, 64, 0), (37, 515, -7), (480, 640, 0)])
+def test_bgr_to_u32_display_buffer(ctx, oracle, rng, rows, cols, extra):
+    """highgui mat_to_u32_buffer (highgui/mod.rs:125-141): flat chunks_exact(3), zero-filled tail"""
+    data = rng.integers(0, 256, size=max(rows * cols * 3 + extra, 0), dtype=np.uint8)
+    src = Mat(rows, cols, 3, data=data)
+    src.data = data
+    dst = Mat(rows, cols, 4)
+    dst.data[:] = 0x77
+    imgproc.cvt_color(src, dst, _ffi.RCV_BGR2BGRX, ctx)
+    assert np.array_equal(dst.data.view(np.uint32), oracle.bgr_to_u32(data, rows * cols))
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1, 1, 0), (3, 5, 1), (48, 64, 16), (37, 516, 8)])
+def test_bgr_rows_to_rgb(ctx, oracle, rng, rows, cols, pad):
+    """imwrite's BGR -> RGB loop over row_bytes (imgcodecs/mod.rs:51-63): honours step, packs the output"""
+    step = cols * 3 + pad
+    data = rng.integers(0, 256, size=rows * step, dtype=np.uint8)
+    src = Mat(rows, cols, 3, step=step, data=data)
+    dst = Mat(rows, cols, 3)
+    imgproc.cvt_color(src, dst, _ffi.RCV_BGR2RGB, ctx)
+    assert np.array_equal(dst.data, oracle.bgr_to_rgb_rows(data, step, rows, cols))
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1, 2, 0), (3, 5, 2), (48, 64, 16), (37, 516, 8), (33, 130, 4)])
+@pytest.mark.parametrize("uyvy", [False, True])
+def test_yuv422_strided(ctx, oracle, rng, rows, cols, pad, uyvy):
+    step = cols * 2 + pad
+    data = rng.integers(0, 256, size=rows * step, dtype=np.uint8)
+    src = Mat(rows, cols, 2, step=step, data=data)
+    dst = Mat(rows, cols, 3)
+    dst.data[:] = 0x55
+    want = dst.data.copy()
+    oracle.yuv422_to_bgr_strided(data, step, rows, cols, uyvy, want)
+    imgproc.cvt_color(src, dst, _ffi.RCV_UYVY2BGR_STRIDED if uyvy else _ffi.RCV_YUYV2BGR_STRIDED, ctx)
+    assert np.array_equal(dst.data, want)
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1, 2, 0), (2, 2, 0), (3, 5, 3), (48, 64, 16), (37, 516, 8), (33, 130, 2)])
+def test_nv12(ctx, oracle, rng, rows, cols, pad):
+    step = cols + (cols & 1) + pad
+    data = rng.integers(0, 256, size=step * (rows + (rows + 1) // 2), dtype=np.uint8)
+    src = Mat(rows, cols, 1, step=step, data=data)
+    src.data = data
+    dst = Mat(rows, cols, 3)
+    want = dst.data.copy()
+    assert oracle.nv12_to_bgr(data, step, rows, cols, want)
+    assert imgproc.cvt_color(src, dst, _ffi.RCV_NV12_2BGR, ctx) == _ffi.RCV_OK
+    assert np.array_equal(dst.data, want)
+    short = Mat(rows, cols, 1, step=step, data=data[:-1])
+    short.data = data[:-1]
+    dst.data[:] = 9
+    assert imgproc.cvt_color(short, dst, _ffi.RCV_NV12_2BGR, ctx) == _ffi.RCV_NOOP and (dst.data == 9).all()
+
+
 def test_decode_into_dispatch(ctx, oracle, rng):
     w, h = 64, 48
     m = Mat.empty()

@@ -249,3 +249,27 @@ def test_oracle_matches_golden(oracle, gold):
     assert np.array_equal(oracle.nms3x3(gold["harris_b2"], 1e-4), gold["nms"])
     assert np.array_equal(oracle.synth_frame(24, 40, 3, 1, 0x5EED0003, 2), gold["synth_scene"])
     assert np.array_equal(oracle.synth_frame(8, 8, 3, 0, 0x5EED0003, 0), gold["synth_noise"])
+
+
+# ---- "next" rows f2 / f4 -------------------------------------------------------------------------------
+
+def test_next_row_restatements(oracle, rng):
+    # mat_to_u32_buffer: (r << 16) | (g << 8) | b, flat, zero tail (highgui/mod.rs:125-141)
+    assert oracle.bgr_to_u32(np.array([1, 2, 3, 4, 5, 6, 7], np.uint8), 3).tolist() == [0x030201, 0x060504, 0]
+    # imwrite swizzle honours step (imgcodecs/mod.rs:51-63)
+    assert oracle.bgr_to_rgb_rows(np.array([1, 2, 3, 9, 4, 5, 6, 9], np.uint8), 4, 2, 1).tolist() == [3, 2, 1, 6, 5, 4]
+    # strided YUYV == the flat reference conversion when the rows are packed
+    yuyv = rng.integers(0, 256, size=8 * 6 * 2, dtype=np.uint8)
+    a, b = np.zeros(8 * 6 * 3, np.uint8), np.zeros(8 * 6 * 3, np.uint8)
+    oracle.yuyv_to_bgr(yuyv, a, 8, 6)
+    oracle.yuv422_to_bgr_strided(yuyv, 16, 6, 8, False, b)
+    assert np.array_equal(a, b)
+    uyvy = yuyv.reshape(-1, 2)[:, ::-1].reshape(-1)
+    oracle.yuv422_to_bgr_strided(uyvy, 16, 6, 8, True, b)
+    assert np.array_equal(a, b)
+    # NV12 with constant chroma == YUYV with the same chroma
+    nv = np.concatenate([yuyv.reshape(6, 8, 2)[:, :, 0].reshape(-1), np.full(8 * 3, 128, np.uint8)])
+    y2 = yuyv.copy().reshape(-1, 2)
+    y2[:, 1] = 128
+    oracle.yuyv_to_bgr(y2.reshape(-1), a, 8, 6)
+    assert oracle.nv12_to_bgr(nv, 8, 6, 8, b) and np.array_equal(a, b)
