@@ -18,11 +18,12 @@
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 typedef short s2v __attribute__((ext_vector_type(2)));
-constexpr int kAhead = 4;             // source rows in flight per lane (x 6 VGPRs)
+constexpr int kAhead = 3;             // source rows in flight per lane (x 6 VGPRs)
 constexpr int kStripPx = 62 * 8;
 
 struct HArgs {
@@ -76,25 +77,29 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
     // ---- pipeline state --------------------------------------------------------------------------------------
     uint32_t h1a[4], h1b[4], h2a[4], h2b[4];      // Sobel horizontal parts of gray rows v-2, v-1 (packed i16 pairs)
-    int hsxx[8], hsxy[8], hsyy[8];                // horizontal box sums of product row u-1
+    float hsxx[8], hsxy[8], hsyy[8];              // horizontal box sums of product row u-1 -- kept in f32: every product
+                                                  // (<= 1020^2) and every 2x2 sum (< 2^24) is an exactly representable
+                                                  // integer, so f32 adds/muls are exact and can use the packed f32 ALU
     float m3a[8], m3b[8], rc[8], mlr[8];          // NMS: rowmax3 of rows u-2, u-1; response and left/right max of row u-1
 #pragma unroll
     for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hsxx[j] = hsxy[j] = hsyy[j] = 0;
+        hsxx[j] = hsxy[j] = hsyy[j] = 0.0f;
         m3a[j] = m3b[j] = rc[j] = mlr[j] = NEG_INF;
     }
 
     auto feed = [&](const Row6& q, int v) {
         // ---- gray (8 px) -----------------------------------------------------------------------------------------
+        // weights 1868, 9617, 4899 = 256*{7,37,19} + {76,145,35}: two v_dot4_u32_u8 per pixel on the pixel's (B,G,R,x) dword
         uint32_t g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k0 = 3 * j;
-            const uint32_t b = (q.d[k0 >> 2] >> ((k0 & 3) * 8)) & 0xff, gg = (q.d[(k0 + 1) >> 2] >> (((k0 + 1) & 3) * 8)) & 0xff,
-                           r = (q.d[(k0 + 2) >> 2] >> (((k0 + 2) & 3) * 8)) & 0xff;
-            g[j] = (1868u * b + 9617u * gg + 4899u * r + 8192u) >> 14;
+            const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;   // pixel j = bytes k0..k0+2 of the 24-byte run
+            const uint32_t px = sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh);
+            const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);   // 7*B + 37*G + 19*R
+            const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);  // 76*B + 145*G + 35*R + 8192
+            g[j] = ((hi8 << 8) + lo8) >> 14;
         }
         uint32_t lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
         if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         Cc[3] = pk(hi, hi, 0x0c030c02u);
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
-        int ix[8], iy[8];
+        float ix[8], iy[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t h1 = pk_sub(L[j + 1], L[j]);
@@ -124,32 +129,32 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             h1b[j] = h1;
             h2a[j] = h2b[j];
             h2b[j] = h2;
-            ix[2 * j] = (int)(short)(ox & 0xffff);
-            ix[2 * j + 1] = (int)ox >> 16;
-            iy[2 * j] = (int)(short)(oy & 0xffff);
-            iy[2 * j + 1] = (int)oy >> 16;
+            ix[2 * j] = (float)(int)(short)(ox & 0xffff);
+            ix[2 * j + 1] = (float)((int)ox >> 16);
+            iy[2 * j] = (float)(int)(short)(oy & 0xffff);
+            iy[2 * j + 1] = (float)((int)oy >> 16);
         }
         // ---- products and 2x2 box sums: S(u) = Hs(u-1) + Hs(u), Hs(x) = P(x-1) + P(x) -------------------------------
-        int pxx[8], pxy[8], pyy[8];
+        float pxx[8], pxy[8], pyy[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int yy = mirrored ? -iy[j] : iy[j];
+            const float yy = mirrored ? -iy[j] : iy[j];
             pxx[j] = ix[j] * ix[j];
             pxy[j] = ix[j] * yy;
             pyy[j] = yy * yy;
         }
         // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
-        const int exx = edgeL ? pxx[1] : pxx[7], exy = edgeL ? pxy[1] : pxy[7], eyy = edgeL ? pyy[1] : pyy[7];
-        const int lxx = (int)shr1((uint32_t)exx), lxy = (int)shr1((uint32_t)exy), lyy = (int)shr1((uint32_t)eyy);
+        const float exx = edgeL ? pxx[1] : pxx[7], exy = edgeL ? pxy[1] : pxy[7], eyy = edgeL ? pyy[1] : pyy[7];
+        const float lxx = shr1f(exx), lxy = shr1f(exy), lyy = shr1f(eyy);
         float r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int nxx = (j ? pxx[j - 1] : lxx) + pxx[j], nxy = (j ? pxy[j - 1] : lxy) + pxy[j], nyy = (j ? pyy[j - 1] : lyy) + pyy[j];
-            const int sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;
+            const float nxx = (j ? pxx[j - 1] : lxx) + pxx[j], nxy = (j ? pxy[j - 1] : lxy) + pxy[j], nyy = (j ? pyy[j - 1] : lyy) + pyy[j];
+            const float sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;   // == (float)(exact integer sum)
             hsxx[j] = nxx;
             hsxy[j] = nxy;
             hsyy[j] = nyy;
-            const float fa = (float)sxx * a.s2, fb = (float)sxy * a.s2, fc = (float)syy * a.s2;
+            const float fa = sxx * a.s2, fb = sxy * a.s2, fc = syy * a.s2;
             const float t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
             const float t4 = a.k * t3;
             const float t5 = t4 * t3;
@@ -226,8 +231,21 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     a.rows = s.rows;
     a.cols = s.cols;
     a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
+    // row segments: whole rounds of the 3-waves-per-SIMD residency (12 waves per CU), >= 2 rounds, segments >= 64 rows
     int seg = s.rows;
-    while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 8192 && seg > 64) seg = (seg + 1) / 2;
+    {
+        const long long slots = 12LL * ctx->cu_count, per_seg = (long long)a.nstrips * s.n;
+        double best = 1e30;
+        for (int ns = 1; ns <= 64; ++ns) {
+            const int sr = (s.rows + ns - 1) / ns;
+            if (ns > 1 && sr < 64) break;
+            const long long tot = per_seg * ((s.rows + sr - 1) / sr);
+            const long long rounds = (tot + slots - 1) / slots;
+            const double cost = (double)rounds * (sr + 5 + 8) * (rounds < 2 ? 1.5 : 1.0);
+            if (cost < best) { best = cost; seg = sr; }
+        }
+    }
+    if (const char* e = getenv("RCV_HARRIS_SEG_ROWS")) seg = atoi(e) > 0 ? atoi(e) : seg;
     a.seg_rows = seg;
     a.nsegs = (s.rows + seg - 1) / seg;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
