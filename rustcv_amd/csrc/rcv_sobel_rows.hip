@@ -1,10 +1,12 @@
 // rcv_sobel_rows.hip -- Sobel 3x3 (u8 gray -> i16 dx, dy) as a register sliding window.  HBM-bound: 1 B read and
 // 4 B written per pixel (5 algorithmic B/px).
 //
-// One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 and 63 only carry the +-1 px halo) and walks down a
-// row segment.  Per source row a lane loads its 8 pixels as one 8-byte vector (a wave instruction reads 512
-// contiguous bytes), gets the pixel left/right of its run from the neighbouring lanes with one DPP wave shift each,
-// and forms the horizontal parts with packed 16-bit math:
+// One WAVE owns a strip of 512 px (64 lanes x 8 px: 512 B of gray, 1024 B of each i16 output per row -- whole 128-B
+// lines, so no two waves ever write parts of the same line; strips with seams inside a line measured ~35 % lower
+// store rates) and walks down a row segment.  Per source row a lane loads its 8 pixels as one
+// 8-byte vector, gets the pixel left/right of its run from the neighbouring lanes with one DPP wave shift each (the
+// wave's outermost two pixels come from one extra byte load per lane 0 / lane 63), and forms the horizontal parts
+// with packed 16-bit math:
 //     h1(x) = p[x+1] - p[x-1]             h2(x) = p[x-1] + 2 p[x] + p[x+1]
 //     dx(y) = h1(y-1) + 2 h1(y) + h1(y+1)   dy(y) = h2(y+1) - h2(y-1)
 // The two previous rows' h1/h2 stay in registers, so every source row is read exactly once per strip and no LDS
@@ -20,7 +22,7 @@ namespace {
 typedef short s2v __attribute__((ext_vector_type(2)));
 
 constexpr int kRowsAhead = 8;
-constexpr int kStripPx = 62 * 8;
+constexpr int kStripPx = 64 * 8;
 
 struct SobelArgs {
     const uint8_t* src;
@@ -58,32 +60,38 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     const int seg = wid % a.nsegs;
     const int frame = wid / a.nsegs;
     const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
-    const int x = strip * kStripPx + 8 * (lane - 1);          // first pixel of this lane's run (may be -8 or >= cols)
-    const int xc = min(max(x, 0), a.cols - 8);                 // clamped load position
-    const bool edgeL = x < 0, edgeR = x == a.cols;             // lanes that hold the reflected column
-    const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    const int x = strip * kStripPx + 8 * lane;                 // first pixel of this lane's run (may be >= cols in the last strip)
+    const int xc = min(x, a.cols - 8);                         // clamped load position
+    const bool edgeR = x == a.cols;                            // lane right of the image: supplies the mirrored column cols-2
+    const bool live = x < a.cols;
+    // the pixel outside the wave: lane 0 needs x-1 (mirror: 1), lane 63 needs x+8 (mirror: cols-2); other lanes load
+    // a harmless in-row byte so that the load stays unconditional
+    const int xe = lane == 0 ? (x == 0 ? 1 : x - 1) : min(x + 8 >= a.cols ? a.cols - 2 : x + 8, a.cols - 1);
+    const uint8_t* se = a.src + (size_t)frame * a.sfs + max(xe, 0);
     const uint8_t* sf = a.src + (size_t)frame * a.sfs + xc;
     uint8_t* dxp = a.dx + (size_t)frame * a.xfs + 2 * (size_t)max(x, 0);
     uint8_t* dyp = a.dy + (size_t)frame * a.yfs + 2 * (size_t)max(x, 0);
     uint8_t* const dump = a.dump + lane * 16;
 
-    auto load_row = [&](int ry) -> U2 {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
+    struct Row { U2 v; uint32_t e; };
+    auto load_row = [&](int ry) -> Row {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
         ry = min(ry, ye);
         const int r = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-        return *(const U2*)(sf + (size_t)r * a.sstep);
+        return Row{*(const U2*)(sf + (size_t)r * a.sstep), (uint32_t)se[(size_t)r * a.sstep]};
     };
 
     uint32_t h1a[4], h1b[4], h2a[4], h2b[4];  // rows r-2 (a) and r-1 (b)
 #pragma unroll
     for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
 
-    auto feed = [&](U2 v, int r) {  // r = index of the row just loaded; emits output row r-1 when r-1 >= ys
-        // reflected columns: x = -1 mirrors x = 1 (edge lane holds px 0..7 after clamping -> its byte 7 := byte 1);
-        // x = cols mirrors cols-2 (edge lane holds cols-8..cols-1 -> its byte 0 := byte 6)
-        if (edgeL) v.hi = pk(v.lo, v.hi, 0x05020100u);
+    auto feed = [&](const Row& rw, int r) {  // r = index of the row just loaded; emits output row r-1 when r-1 >= ys
+        U2 v = rw.v;
+        // x = cols mirrors cols-2: the lane just right of the image holds cols-8..cols-1 after clamping -> its byte 0 := byte 6
         if (edgeR) v.lo = pk(v.hi, v.lo, 0x03020106u);
-        const uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> lane-1's hi dword
-        const uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> lane+1's lo dword
+        uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> lane-1's hi dword
+        uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> lane+1's lo dword
+        if (lane == 0) lf = rw.e << 24;   // byte 3 of "lane -1's hi dword"
+        if (lane == 63) rt = rw.e;        // byte 0 of "lane 64's lo dword"
         // 16-bit pairs: L_j = (p[2j-1], p[2j]), C_j = (p[2j], p[2j+1]), R_j = (p[2j+1], p[2j+2]) = L_{j+1}
         uint32_t L[5], Cc[4];
         L[0] = pk(lf, v.lo, 0x0c000c07u);
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 
     // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kRowsAhead, next group in flight while this one computes
     const int nrows = ye - ys + 2;
-    U2 cur[kRowsAhead], nxt[kRowsAhead];
+    Row cur[kRowsAhead], nxt[kRowsAhead];
 #pragma unroll
     for (int i = 0; i < kRowsAhead; ++i) cur[i] = load_row(ys - 1 + i);
     for (int g = 0; g < nrows; g += kRowsAhead) {
