@@ -62,6 +62,7 @@ struct F7Args {
     size_t sstep, dstep, sfs, dfs;
     int rows, cols;
     int ntiles_total, nstrips, seg_rows, nsegs;
+    int tps;             // 16-px tiles per strip: 16 (256 px, line-aligned seams) or 15 (240 px, when that divides the width evenly)
     int total_wgs, wgs_per_xcd;
     int shift, acc_init;
 };
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int seg = bid % a.nsegs;
     const int frame = bid / a.nsegs;
 
-    const int tile0 = strip * kTiles;
-    const int ntiles = min(kTiles, a.ntiles_total - tile0);
+    const int tile0 = strip * a.tps;
+    const int ntiles = min(a.tps, a.ntiles_total - tile0);
     const int x0 = tile0 * 16;
     const int ys = seg * a.seg_rows;
     const int ye = min(a.rows, ys + a.seg_rows);
@@ -428,21 +429,25 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.rows = s.rows;
     a.cols = s.cols;
     a.ntiles_total = s.cols / 16;
-    a.nstrips = (a.ntiles_total + kTiles - 1) / kTiles;
-    // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs),
-    // each segment a multiple of 16 rows and at least 128 rows unless the image is smaller
+    // strips of 256 px have line-aligned seams; 240-px strips are used only where they split the row evenly and 256 does
+    // not (e.g. 1920 = 8 x 240 but 7.5 x 256), trading seam alignment for balanced workgroups
+    a.tps = (s.cols % 256 != 0 && s.cols % 240 == 0) ? 15 : kTiles;
+    if (const char* e = getenv("RCV_F7_TPS")) a.tps = atoi(e) == 15 ? 15 : 16;  // tuning knob
+    a.nstrips = (a.ntiles_total + a.tps - 1) / a.tps;
+    // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs), each
+    // segment a multiple of 16 rows (>= 32); the per-segment constant models the prologue (two synchronous blocks)
     int seg_rows = (s.rows + 15) & ~15;
     {
         const long long slots = 3LL * ctx->cu_count;
         double best = 1e30;
-        for (int ns = 1; ns <= 32; ++ns) {
+        for (int ns = 1; ns <= 64; ++ns) {
             int sr = ((s.rows + ns - 1) / ns + 15) & ~15;
-            if (ns > 1 && sr < 128) break;
+            if (ns > 1 && sr < 32) break;
             int nsegs = (s.rows + sr - 1) / sr;
             long long tot = (long long)a.nstrips * nsegs * s.n;
             long long rounds = (tot + slots - 1) / slots;
             // cost model: time ~ rounds * rows-per-segment (+6 halo rows), slight penalty per segment
-            double cost = (double)rounds * (sr + 6 + 24);
+            double cost = (double)rounds * (sr + 6 + 40);
             if (cost < best) { best = cost; seg_rows = sr; }
         }
     }
