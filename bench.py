@@ -177,7 +177,7 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "filter2d_i8 7x7", "launch_ms": round(launch_ms, 4), "alg_bytes_per_launch": alg_bytes},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # the CPU baseline leg runs at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -154,6 +154,12 @@ int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, co
 int rcv_filter2d_f32(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* k, int ksize, float delta);
 int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* k, int ksize, float delta);
 
+/* "next" row f1: the capture-side pipeline YUYV -> BGR -> integer filter2D in ONE launch.  src: 2-channel
+ * YUYV rows (step honoured, cols even), dst: BGR.  Result == rcv_cvt_color(RCV_YUYV2BGR_STRIDED) followed by
+ * rcv_filter2d_i8, bit for bit; the intermediate BGR image never reaches HBM on the fused path.                     */
+int rcv_filter2d_i8_yuyv(rcv_ctx* ctx, const rcv_mat* src_yuyv, rcv_mat* dst_bgr, const int8_t* k, int ksize, int shift);
+int rcv_filter2d_i8_yuyv_batch(rcv_ctx* ctx, const rcv_batch* src_yuyv, rcv_batch* dst_bgr, const int8_t* k, int ksize, int shift);
+
 /* src u8 1-ch; dx, dy i16 1-ch */
 int rcv_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy);
 int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "rcv_gaussian_blur_batch": (_i, [_ctx, _bat, _bat, _i, _d]),
     "rcv_filter2d_i8": (_i, [_ctx, _mat, _mat, _P(C.c_int8), _i, _i]),
     "rcv_filter2d_i8_batch": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i]),
+    "rcv_filter2d_i8_yuyv": (_i, [_ctx, _mat, _mat, _P(C.c_int8), _i, _i]),
+    "rcv_filter2d_i8_yuyv_batch": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i]),
     "rcv_filter2d_f32": (_i, [_ctx, _mat, _mat, _P(_f), _i, _f]),
     "rcv_filter2d_f32_batch": (_i, [_ctx, _bat, _bat, _P(_f), _i, _f]),
     "rcv_sobel": (_i, [_ctx, _mat, _mat, _mat]),

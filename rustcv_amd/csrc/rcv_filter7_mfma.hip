@@ -86,7 +86,10 @@ struct U3 { uint32_t a, b, c; };
 // DUAL: weights beyond the i8 range (integer GaussianBlur 7x7: taps up to 324) are split K = 4*Q + R with Q, R in i8;
 // the same pixel operand feeds two MFMAs (tables A and A2) and the epilogue forms acc + (acc2 << 2).  LDS traffic is
 // unchanged, only the matrix-pipe work doubles.
-template <int DBG, bool DUAL>
+// SRC: 0 = BGR source; 1 = packed YUYV source (2 B/px): the BT.601 conversion of the reference
+// (rustcv/src/videoio/mod.rs:356-363) runs at staging time, so the capture-side pipeline YUYV -> BGR -> filter2D is one
+// launch and the intermediate BGR image never touches HBM (5 instead of 11 algorithmic bytes per pixel).
+template <int DBG, bool DUAL, int SRC = 0>
 __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * kPlane + kWaves * kOutWave];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int ys = seg * a.seg_rows;
     const int ye = min(a.rows, ys + a.seg_rows);
     const int nsteps = (ye - ys + 15) >> 4;
-    const int rowbytes = a.cols * 3;
+    const int rowbytes = a.cols * (SRC == 1 ? 2 : 3);   // source row bytes
 
     const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
     uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
@@ -133,10 +136,13 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // outside the row are clamped into it -- their bytes are either reflected halo (patched in registers
     // below) or multiplied by zero weights -- and rows past the segment re-read its last row (cache hits).
     const int sr = tid >> 4, sq = tid & 15;
-    const int soff0 = 3 * x0 + 48 * sq - 16;
+    // (YUYV source: the 16 pixels + 1 on each side are the 9 macropixels = 36 bytes at row byte 2*x0 - 8 + 32q.)
+    const int soff0 = SRC == 1 ? 2 * x0 + 32 * sq - 8 : 3 * x0 + 48 * sq - 16;
     const int hi = rowbytes - 16;
-    const int o0 = min(max(soff0, 0), hi) + 4, o1 = min(max(soff0 + 16, 0), hi), o2 = min(max(soff0 + 32, 0), hi),
-              o3 = min(max(soff0 + 48, 0), hi);
+    const int o0 = SRC == 1 ? min(max(soff0, 0), rowbytes - 8) : min(max(soff0, 0), hi) + 4;
+    const int o1 = SRC == 1 ? min(max(soff0 + 8, 0), hi) : min(max(soff0 + 16, 0), hi);
+    const int o2 = SRC == 1 ? min(max(soff0 + 24, 0), rowbytes - 12) : min(max(soff0 + 32, 0), hi);
+    const int o3 = min(max(soff0 + 48, 0), hi);
     const int xa = x0 - 3 + 16 * sq;                    // image x of the chunk's first pixel
     const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
     const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // dwordx2 per lane (row lane>>2, piece lane&3) -- unconditional like all VMEM here; wave 0 then plants them.
     const bool fullstrip = ntiles == kTiles;
     const int er = lane >> 2, ep = lane & 3;
-    const int eoff = min(max(3 * x0 + 752 + 8 * ep, 0), rowbytes - 8);
+    const int eoff = min(max((SRC == 1 ? 2 * x0 + 504 : 3 * x0 + 752) + 8 * ep, 0), rowbytes - 8);
     const bool lastfull = fullstrip && x0 + 256 == a.cols;   // right image border inside the halo piece
 
     auto load_block = [&](int b, uint32_t (&L)[15]) {
@@ -167,14 +173,33 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         }
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
-        const U3 v0 = *(const U3*)(p + o0);
-        const uint4 v1 = *(const uint4*)(p + o1);
-        const uint4 v2 = *(const uint4*)(p + o2);
-        const U2 v3 = *(const U2*)(p + o3);
-        L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
-        L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
-        L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
-        L[11] = v3.a; L[12] = v3.b;
+        if constexpr (SRC == 1) {
+            const U2 v0 = *(const U2*)(p + o0);
+            const uint4 v1 = *(const uint4*)(p + o1);
+            const U3 v2 = *(const U3*)(p + o2);
+            L[0] = v0.a; L[1] = v0.b;
+            L[2] = v1.x; L[3] = v1.y; L[4] = v1.z; L[5] = v1.w;
+            L[6] = v2.a; L[7] = v2.b; L[8] = v2.c;
+            L[9] = L[10] = L[11] = L[12] = 0;
+        } else {
+            const U3 v0 = *(const U3*)(p + o0);
+            const uint4 v1 = *(const uint4*)(p + o1);
+            const uint4 v2 = *(const uint4*)(p + o2);
+            const U2 v3 = *(const U2*)(p + o3);
+            L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
+            L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
+            L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
+            L[11] = v3.a; L[12] = v3.b;
+        }
+    };
+
+    // one YUYV macropixel [Y0 U Y1 V] -> the six pre-shift BT.601 sums b0 g0 r0 b1 g1 r1 (>> 8 and saturate follow)
+    auto mp_sums = [](uint32_t m, int* o) __attribute__((always_inline)) {
+        const int y0 = (int)(m & 0xff), u = (int)((m >> 8) & 0xff) - 128, y1 = (int)((m >> 16) & 0xff), v = (int)(m >> 24) - 128;
+        const int c0 = 298 * (y0 - 16) + 128, c1 = 298 * (y1 - 16) + 128;
+        const int db = 516 * u, dg = -100 * u - 208 * v, dr = 409 * v;
+        o[0] = c0 + db; o[1] = c0 + dg; o[2] = c0 + dr;
+        o[3] = c1 + db; o[4] = c1 + dg; o[5] = c1 + dr;
     };
 
     auto store_block = [&](int b, const uint32_t (&L)[15]) {
@@ -182,15 +207,31 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             // halo piece, all in registers: the four lanes of a row hold bytes [0,32) of the piece; dwords 1..6 (bytes
             // 4..27) are exactly the 8 pixels x0+252 .. x0+259.  Lane ep==0 collects them from its quad with DPP
             // row_shl, de-interleaves, and plants x0+253..x0+258 at xx = 256..261 (mirrored at the right image border).
-            const uint32_t w1 = L[14];
-            const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
-            const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
-            const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[13], 0x102, 0xf, 0xf, false);
-            const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[14], 0x102, 0xf, 0xf, false);
-            const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[13], 0x103, 0xf, 0xf, false);
             uint32_t g1[3], g2[3];
-            deint4(w1, w2, w3, g1[0], g1[1], g1[2]);   // pixels x0+252 .. 255
-            deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
+            if constexpr (SRC == 1) {
+                // YUYV: lanes ep = 0, 1 of the quad hold macropixels (252,253)(254,255) | (256,257)(258,259)
+                const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
+                const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
+                int q[24];
+                mp_sums(L[13], q);
+                mp_sums(L[14], q + 6);
+                mp_sums(m2, q + 12);
+                mp_sums(m3, q + 18);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    g1[c] = rcv_ashr_sat_pk4(q[c], q[3 + c], q[6 + c], q[9 + c], 8);
+                    g2[c] = rcv_ashr_sat_pk4(q[12 + c], q[15 + c], q[18 + c], q[21 + c], 8);
+                }
+            } else {
+                const uint32_t w1 = L[14];
+                const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
+                const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
+                const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[13], 0x102, 0xf, 0xf, false);
+                const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[14], 0x102, 0xf, 0xf, false);
+                const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[13], 0x103, 0xf, 0xf, false);
+                deint4(w1, w2, w3, g1[0], g1[1], g1[2]);   // pixels x0+252 .. 255
+                deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
+            }
             if (ep == 0 && ys - 3 + 16 * b + er <= ry_last) {
                 const int hslot = (16 * b + er) % kSlots;
 #pragma unroll
@@ -203,12 +244,26 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                 }
             }
         }
-        uint32_t s[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
         uint32_t pb[4], pg[4], pr[4];
+        if constexpr (SRC == 1) {
+            // 9 macropixels = pixels x0-4+16q .. x0+13+16q; the chunk is pixels 1..16 of those 18
+            int q[54];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
+            for (int m = 0; m < 9; ++m) mp_sums(L[m], q + 6 * m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 3 * (1 + 4 * i);
+                pb[i] = rcv_ashr_sat_pk4(q[e], q[e + 3], q[e + 6], q[e + 9], 8);
+                pg[i] = rcv_ashr_sat_pk4(q[e + 1], q[e + 4], q[e + 7], q[e + 10], 8);
+                pr[i] = rcv_ashr_sat_pk4(q[e + 2], q[e + 5], q[e + 8], q[e + 11], 8);
+            }
+        } else {
+            uint32_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
+#pragma unroll
+            for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
+        }
         // BORDER_REFLECT_101 in x, in registers (first / last strip only; branch-free selects elsewhere).
         //  left : chunk 0 holds x = -3..12 ; x = -3,-2,-1 mirror x = 3,2,1 = bytes 6,5,4 of the same chunk.
         //  right: chunk `ntiles` holds x = cols-3..cols+12 ; x = cols,cols+1,cols+2 (bytes 3,4,5) mirror
@@ -389,10 +444,10 @@ extern "C" int rcv__debug_occupancy(void)
 }
 
 // weights k16 in [-512, 511]; those within [-128, 127] run the single-MFMA kernel
-int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
+int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv)
 {
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
-    if (s.ch != 3) return RCV_ERR_UNSUPPORTED;
+    if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
@@ -461,6 +516,11 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.total_wgs = (int)total;
     a.wgs_per_xcd = (int)((total + 7) / 8);
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
+    if (src_yuyv) {
+        if (dual) return RCV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_filter7_mfma<0, false, 1>), grid, block, 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
     if (dual) {
         hipLaunchKernelGGL((k_filter7_mfma<0, true>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
@@ -487,5 +547,14 @@ int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     if (ksize < 1 || ksize > 7) return RCV_ERR_UNSUPPORTED;
     int16_t k16[49];
     for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
-    return rcv_filter_i16_fast(ctx, s, d, k16, ksize, shift);
+    return rcv_filter_i16_fast(ctx, s, d, k16, ksize, shift, 0);
+}
+
+// fused capture pipeline: packed-or-strided YUYV (2 channels) -> BGR -> integer filter2D, one launch
+int rcv_filter_i8_yuyv_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+{
+    if (ksize < 1 || ksize > 7) return RCV_ERR_UNSUPPORTED;
+    int16_t k16[49];
+    for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+    return rcv_filter_i16_fast(ctx, s, d, k16, ksize, shift, 1);
 }

@@ -11,5 +11,5 @@ int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize)
     int16_t k[49];
     for (int y = 0; y < ksize; ++y)
         for (int x = 0; x < ksize; ++x) k[y * ksize + x] = (int16_t)(t[y] * t[x]);
-    return rcv_filter_i16_fast(ctx, s, d, k, ksize, ksize == 3 ? 4 : (ksize == 5 ? 8 : 12));
+    return rcv_filter_i16_fast(ctx, s, d, k, ksize, ksize == 3 ? 4 : (ksize == 5 ? 8 : 12), 0);
 }

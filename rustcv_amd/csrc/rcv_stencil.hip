@@ -193,6 +193,34 @@ extern "C" int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     return rcv_launch_check(ctx);
 }
 
+extern "C" int rcv_filter2d_i8_yuyv_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dst) return RCV_ERR_ARG;
+    View s, d;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (s.ch != 2 || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    if (s.rows != d.rows || s.cols != d.cols || s.n != d.n || (s.cols & 1)) return RCV_ERR_ARG;
+    if (!k || !(ksize & 1) || ksize < 1 || ksize > 15 || shift < 0 || shift > 24) return RCV_ERR_ARG;
+    if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    int rc = rcv_filter_i8_yuyv_fast(ctx, s, d, k, ksize, shift);
+    if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    // unfused HIP path: convert into the workspace, then the ordinary filter
+    const size_t tstep = ((size_t)s.cols * 3 + 15) & ~(size_t)15, tfs = tstep * s.rows;
+    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
+    uint8_t* tmp;
+    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
+    rcv_batch tb = *dst;
+    tb.frame0.data = tmp;
+    tb.frame0.cap = tfs;
+    tb.frame0.step = tstep;
+    tb.frame_stride = tfs;
+    RCV_TRY(rcv_cvt_color_batch(ctx, RCV_YUYV2BGR_STRIDED, src, &tb));
+    return rcv_filter2d_i8_batch(ctx, &tb, dst, k, ksize, shift);
+}
+
 extern "C" int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* k, int ksize, float delta)
 {
     RCV_TRY(rcv_bind(ctx));
@@ -274,6 +302,11 @@ extern "C" int rcv_gaussian_blur(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst,
 extern "C" int rcv_filter2d_i8(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const int8_t* k, int ksize, int shift)
 {
     RCV_UNARY_WRAPPER(rcv_filter2d_i8_batch(ctx, &bs, &bd, k, ksize, shift))
+}
+
+extern "C" int rcv_filter2d_i8_yuyv(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const int8_t* k, int ksize, int shift)
+{
+    RCV_UNARY_WRAPPER(rcv_filter2d_i8_yuyv_batch(ctx, &bs, &bd, k, ksize, shift))
 }
 
 extern "C" int rcv_filter2d_f32(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* k, int ksize, float delta)

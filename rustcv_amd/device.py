@@ -116,6 +116,14 @@ def filter2d(src, dst, kernel, shift=0, delta=0.0):
         raise TypeError("kernel dtype must be int8 or float32")
 
 
+def filter2d_yuyv(src_yuyv, dst_bgr, kernel, shift=0):
+    """fused capture pipeline: YUYV (2-channel batch) -> BGR -> integer filter2D in one launch"""
+    k = np.ascontiguousarray(kernel, dtype=np.int8)
+    a, b = src_yuyv.as_rcv(), dst_bgr.as_rcv()
+    _ffi.check(_ffi.lib().rcv_filter2d_i8_yuyv_batch(_h(src_yuyv), C.byref(a), C.byref(b), k.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                     k.shape[0], shift), "rcv_filter2d_i8_yuyv_batch")
+
+
 def sobel(src, dx, dy):
     a, b, c = src.as_rcv(), dx.as_rcv(), dy.as_rcv()
     _ffi.check(_ffi.lib().rcv_sobel_batch(_h(src), C.byref(a), C.byref(b), C.byref(c)), "rcv_sobel_batch")

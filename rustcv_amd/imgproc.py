@@ -80,6 +80,14 @@ def filter2d(src: Mat, dst: Mat, kernel, shift: int = 0, delta: float = 0.0, ctx
         raise TypeError("kernel dtype must be int8 or float32")
 
 
+def filter2d_yuyv(src_yuyv: Mat, dst_bgr: Mat, kernel, shift: int = 0, ctx=None):
+    """fused YUYV -> BGR -> integer filter2D (== cvt_color(YUYV2BGR_STRIDED) then filter2d, in one launch)"""
+    k = np.ascontiguousarray(kernel, dtype=np.int8)
+    s, d = src_yuyv._as_rcv(), dst_bgr._as_rcv()
+    _ffi.check(_ffi.lib().rcv_filter2d_i8_yuyv(_ctx(ctx), C.byref(s), C.byref(d), k.ctypes.data_as(C.POINTER(C.c_int8)), k.shape[0], shift),
+               "rcv_filter2d_i8_yuyv")
+
+
 def sobel(src: Mat, dx: Mat, dy: Mat, ctx=None):
     s, a, b = src._as_rcv(), dx._as_rcv(), dy._as_rcv()
     _ffi.check(_ffi.lib().rcv_sobel(_ctx(ctx), C.byref(s), C.byref(a), C.byref(b)), "rcv_sobel")

@@ -283,6 +283,28 @@ def test_gaussian_int_mfma_path(ctx, oracle, rng, rows, cols, ksize):
     assert np.array_equal(dst.to_array(), oracle.gaussian_blur(img, ksize, 0.0))
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 16), (5, 32), (33, 240), (40, 256), (19, 496), (70, 512), (300, 272), (9, 10), (6, 770)])
+@pytest.mark.parametrize("ksize,shift", [(7, 6), (3, 0), (5, 4)])
+def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
+    """f1: YUYV -> BGR -> filter2D in one launch == the two-step oracle composition (fused MFMA path when cols % 16 == 0,
+    unfused HIP path otherwise), batch of 2 with padded steps"""
+    n = 2
+    k = rng.integers(-9, 10, size=(ksize, ksize)).astype(np.int8)
+    src = device.DeviceBatch(ctx, n, rows, cols, 2, step=cols * 2 + 16)
+    dst = _canary_batch(ctx, n, rows, cols, 3, pad=16)
+    frames = rng.integers(0, 256, size=(n, rows, cols, 2), dtype=np.uint8)
+    src.upload(frames)
+    device.filter2d_yuyv(src, dst, k, shift=shift)
+    got = dst.download()
+    for i in range(n):
+        bgr = np.zeros(rows * cols * 3, np.uint8)
+        oracle.yuv422_to_bgr_strided(frames[i].reshape(-1), cols * 2, rows, cols, False, bgr)
+        assert np.array_equal(got[i], oracle.filter2d_i8(bgr.reshape(rows, cols, 3), k, shift))
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 def test_filter2d_i8_mfma_batch_4k_properties(ctx, oracle):
     """Full-size frames (BASELINE configs[2] shape, small batch): (1) rows of frame 0 against the oracle on
     slabs; (2) linearity: filter(K1) + filter(K2) == filter(K1+K2) where nothing saturates (shift 0 is not

@@ -111,6 +111,9 @@ def main():
     o = B(n, 2160, 3840, 3)
     device.synth(y, _ffi.RCV_SYNTH_YUYV, SEED + 1, 0)
     record("cvtColor YUYV2BGR", "4K", y.n, 3840 * 2160, 5, lambda: device.cvt_color(y, o, _ffi.RCV_YUYV2BGR))
+    k7c = bench_kernel7()
+    record("fused YUYV->BGR->filter2D 7x7", "4K batch=64", y.n, 3840 * 2160, 5, lambda: device.filter2d_yuyv(y, o, k7c, shift=6),
+           note="f1: one launch, 2 B read + 3 B written per px; the two-step path moves 11 B/px")
     y.free()
     q = B(n, 2160, 3840, 4)
     device.synth(q, 0, SEED + 1, 0)
