@@ -200,19 +200,49 @@ __device__ __forceinline__ void load_taps6_32(const uint8_t* row, int x0, int ro
 // Same f32 operations in the same order as k_warp_affine<3>.
 constexpr int kWarpRows = 8;   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
-__device__ __forceinline__ uint32_t warp_px_bgr(const View& s, const uint8_t* sf, const Affine& A, float fxx, float fyy, int rowbytes)
+// Two phases per thread so that all 16 tap loads of its 8 rows are in flight together: the loads are unconditional
+// (clamped tap windows) -- a branch around them would make the compiler wait vmcnt(0) row by row.
+__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
 {
-    const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-    const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-    uint32_t px = 0;
-    if (sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows) {
-        const float x0f = floorf(sx), y0f = floorf(sy);
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int rowbytes = s.cols * 3;
+    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0 and kBlock % 4 == 0: quads never straddle the row end
+    const float fxx = (float)min(x, d.cols - 1);
+    const int ybase = blockIdx.y * kWarpRows;
+
+    uint2 ta[kWarpRows], tb[kWarpRows];
+    float fx[kWarpRows], fy[kWarpRows];
+    int sh[kWarpRows];          // bit shift that puts the tap pair at bit 0 of the 8-byte window
+    uint32_t ok[kWarpRows];     // bit0 inside, bit1 vx0, bit2 vx1, bit3 vy0, bit4 vy1
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        const float fyy = (float)min(ybase + r, d.rows - 1);
+        const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        const bool inside = sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows;
+        const float x0f = floorf(inside ? sx : 0.0f), y0f = floorf(inside ? sy : 0.0f);
         const int x0 = (int)x0f, y0 = (int)y0f;
-        const float fx = sx - x0f, fy = sy - y0f;
+        fx[r] = (inside ? sx : 0.0f) - x0f;
+        fy[r] = (inside ? sy : 0.0f) - y0f;
         const bool vx0 = x0 >= 0, vx1 = x0 + 1 < s.cols, vy0 = y0 >= 0, vy1 = y0 + 1 < s.rows;
-        uint32_t alo, ahi, blo, bhi;
-        load_taps6_32(sf + (size_t)(vy0 ? y0 : 0) * s.step, x0, rowbytes, alo, ahi);
-        load_taps6_32(sf + (size_t)(vy1 ? y0 + 1 : 0) * s.step, x0, rowbytes, blo, bhi);
+        ok[r] = (inside ? 1u : 0u) | (vx0 ? 2u : 0u) | (vx1 ? 4u : 0u) | (vy0 ? 8u : 0u) | (vy1 ? 16u : 0u);
+        const int off = 3 * x0, offc = min(max(off, 0), rowbytes - 8);
+        sh[r] = (off - offc) * 8;
+        const uint8_t* ra = sf + (size_t)max(y0, 0) * s.step + offc;
+        const uint8_t* rb = sf + (size_t)min(y0 + 1, s.rows - 1) * s.step + offc;
+        __builtin_memcpy(&ta[r], ra, 8);
+        __builtin_memcpy(&tb[r], rb, 8);
+    }
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        uint64_t a64 = ((uint64_t)ta[r].y << 32) | ta[r].x, b64 = ((uint64_t)tb[r].y << 32) | tb[r].x;
+        if (sh[r] != 0) {   // only at the left / right source edge
+            a64 = sh[r] > 0 ? (a64 >> sh[r]) : (a64 << -sh[r]);
+            b64 = sh[r] > 0 ? (b64 >> sh[r]) : (b64 << -sh[r]);
+        }
+        uint32_t alo = (uint32_t)a64, ahi = (uint32_t)(a64 >> 32), blo = (uint32_t)b64, bhi = (uint32_t)(b64 >> 32);
+        const bool in = ok[r] & 1, vx0 = ok[r] & 2, vx1 = ok[r] & 4, vy0 = ok[r] & 8, vy1 = ok[r] & 16;
         // zero the taps that fall outside the source (constant border 0)
         const uint32_t m0 = vx0 ? 0x00ffffffu : 0u, m1l = vx1 ? 0xff000000u : 0u, m1h = vx1 ? 0x0000ffffu : 0u;
         alo &= vy0 ? (m0 | m1l) : 0u;
@@ -223,37 +253,23 @@ __device__ __forceinline__ uint32_t warp_px_bgr(const View& s, const uint8_t* sf
         const float p01[3] = {(float)(alo >> 24), (float)(ahi & 0xff), (float)((ahi >> 8) & 0xff)};
         const float p10[3] = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff), (float)((blo >> 16) & 0xff)};
         const float p11[3] = {(float)(blo >> 24), (float)(bhi & 0xff), (float)((bhi >> 8) & 0xff)};
+        uint32_t px = 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float top = fmaf(fx, p01[c] - p00[c], p00[c]);
-            const float bot = fmaf(fx, p11[c] - p10[c], p10[c]);
-            const float v = fmaf(fy, bot - top, top);
+            const float top = fmaf(fx[r], p01[c] - p00[c], p00[c]);
+            const float bot = fmaf(fx[r], p11[c] - p10[c], p10[c]);
+            const float v = fmaf(fy[r], bot - top, top);
             px |= (uint32_t)round_half_up_u8(v) << (8 * c);
         }
-    }
-    return px;
-}
-
-__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
-{
-    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
-    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
-    const int rowbytes = s.cols * 3;
-    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0 and kBlock % 4 == 0: quads never straddle the row end
-    const int xq = min(x, d.cols - 1);
-    const float fxx = (float)xq;
-    const int ybase = blockIdx.y * kWarpRows;
-#pragma unroll
-    for (int r = 0; r < kWarpRows; ++r) {
-        const int y = min(ybase + r, d.rows - 1);
-        const uint32_t px = warp_px_bgr(s, sf, A, fxx, (float)y, rowbytes);
+        px = in ? px : 0u;
         // lanes 4q..4q+3 -> 12 bytes stored by lane 4q  (row_shl:n brings lane+n's value; quads stay inside a DPP row of 16)
         const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
         const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
         const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+        // (stores may be conditional here: no load is outstanding any more)
         if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
             struct U3 { uint32_t a, b, c; };
-            *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+            *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
         }
     }
 }
