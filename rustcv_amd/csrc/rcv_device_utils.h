@@ -3,25 +3,31 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// v_ashr_pk_u8_i32 D, S0, S1, S2 (gfx950):  D[7:0] = sat_u8(S0 >> S2), D[15:8] = sat_u8(S1 >> S2),
-// D[31:16] are PRESERVED (measured on MI355X, scratch probe in DESIGN.md §5).  The ROCm 7.2 compiler
-// pattern-matches clamp(x >> s, 0, 255) pairs into this instruction but then treats D[31:16] as
-// zero, which silently corrupts the neighbouring bytes.  We therefore (a) emit it ourselves, with
-// the upper half declared garbage and dropped by v_perm_b32, and (b) never leave a raw
-// `clamp(x >> s)` pair for the compiler to find (csrc/Makefile `check-isa` enforces this: every
-// v_ashr_pk_u8_i32 in the ISA must carry the "rcv" marker below).
+// v_ashr_pk_u8_i32 D, S0, S1, S2 (gfx950):  D[7:0] = sat_u8(S0 >> S2), D[15:8] = sat_u8(S1 >> S2), D[31:16] are PRESERVED
+// (measured on MI355X: D preset to 0xDEADBEEF comes back 0xDEADxxxx).  The ROCm 7.2 compiler pattern-
+// matches pairs of clamp(x >> s, 0, 255) into this instruction and then treats D[31:16] as zero, which silently
+// corrupts the neighbouring bytes.  The BUILTIN, in contrast, is typed as a 16-bit result and is handled correctly, and
+// being a real instruction to the compiler it also gets the MFMA -> VALU wait states that an inline-asm copy would miss
+// (accumulators in VGPR form feed it directly).  So: (a) packed saturation goes through the builtin, one VALU op per two
+// values; (b) no raw `clamp(x >> s)` pair is ever left for the matcher (rcv_ashr_sat1 hides the shift behind an empty
+// asm); (c) `make check-isa` rebuilds every file with -DRCV_NO_PK_BUILTIN, where the helper avoids the instruction, and
+// fails if the compiler still emitted one on its own.
 __device__ __forceinline__ uint32_t rcv_ashr_sat_pk2(int a, int b, int sh)
 {
-    uint32_t d;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 ; rcv" : "=v"(d) : "v"(a), "v"(b), "v"(sh));
-    return d; // only bits [15:0] are meaningful
+#ifdef RCV_NO_PK_BUILTIN
+    int x = a >> sh, y = b >> sh;
+    asm("" : "+v"(x));
+    asm("" : "+v"(y));
+    return (uint32_t)min(max(x, 0), 255) | ((uint32_t)min(max(y, 0), 255) << 8);
+#else
+    return (uint32_t)(unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh);
+#endif
 }
 
-// four i32 -> (x >> sh) saturated to u8, packed little-endian into one dword: 3 VALU ops
+// four i32 -> (x >> sh) saturated to u8, packed little-endian into one dword: 4 VALU ops
 __device__ __forceinline__ uint32_t rcv_ashr_sat_pk4(int a, int b, int c, int d, int sh)
 {
-    uint32_t lo = rcv_ashr_sat_pk2(a, b, sh), hi = rcv_ashr_sat_pk2(c, d, sh);
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    return rcv_ashr_sat_pk2(a, b, sh) | (rcv_ashr_sat_pk2(c, d, sh) << 16);
 }
 
 // (x >> sh) saturated to [0,255]; opaque to the compiler's (broken) v_ashr_pk_u8_i32 matcher

@@ -326,9 +326,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     }
 
     auto compute = [&](int k) {
+        // ring slot of source row (16k + n + 2p + kyl): the block base is wave-uniform (scalar), the rest needs one
+        // conditional subtract; 24-bit multiply (full rate) instead of a 32-bit one (quarter rate)
+        const int sbase = (16 * k) % kSlots;
         int off[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) off[p] = ((16 * k + n + 2 * p + kyl) % kSlots) * kPitch + xh + 64 * wave;
+        for (int p = 0; p < 4; ++p) {
+            int t = sbase + n + 2 * p + kyl;
+            t = t >= kSlots ? t - kSlots : t;
+            off[p] = (int)__umul24((unsigned)t, (unsigned)kPitch) + xh + 64 * wave;
+        }
         // 48 MFMAs per step (4 tiles x 4 row-pairs x 3 planes), B operands read kAhead items ahead into a
         // static register ring so LDS latency is covered inside the wave; the three planes' accumulators are
         // interleaved so dependent MFMAs sit three issues apart.
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // (wave-uniform, LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
         const int nmf = 12 * min(max(ntiles - 4 * wave, 0), 4);   // narrow last strips: tiles past the strip are skipped
         v4i acc[3], acc2[3];
+        const v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init}, zerov = v4i{0, 0, 0, 0};
         if (!(DBG & 4)) {
 #pragma unroll
             for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it);
@@ -354,13 +362,12 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         for (int it = 0; it < 48; ++it) {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
             if (r == 0 && it >= nmf) break;
-            if (r < 3) {
-                acc[c] = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
-                if (DUAL) acc2[c] = v4i{0, 0, 0, 0};
-            }
-            if (!(DBG & 4)) {
-                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], acc[c], 0, 0, 0);
-                if (DUAL) acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], acc2[c], 0, 0, 0);
+            if (DBG & 4) {
+                if (r < 3) acc[c] = initv;
+            } else {
+                // the first MFMA of each accumulator takes the constant (128*sum(K) + round) vector as its C operand
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], r < 3 ? initv : acc[c], 0, 0, 0);
+                if (DUAL) acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], r < 3 ? zerov : acc2[c], 0, 0, 0);
                 if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead);
             }
             if (r == 11) {
