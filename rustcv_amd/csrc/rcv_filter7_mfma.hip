@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int nsteps = (ye - ys + 15) >> 4;
     const int rowbytes = a.cols * (SRC == 1 ? 2 : 3);   // source row bytes
 
+    const unsigned sstep24 = (unsigned)a.sstep, dstep24 = (unsigned)a.dstep;   // 24-bit multiplies run at full rate
     const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
     uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     auto load_block = [&](int b, uint32_t (&L)[15]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
         const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-        const uint8_t* p = sframe + (size_t)srow * a.sstep;
+        const uint8_t* p = sframe + __umul24((unsigned)srow, sstep24);   // frame bytes < 2^32, step < 2^24 (host check)
         if (DBG & 2) {
 #pragma unroll
             for (int i = 0; i < 15; ++i) L[i] = 0;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         {
             const int rye = min(ys - 3 + 16 * b + er, ry_last);
             const int erow = rye < 0 ? -rye : (rye >= a.rows ? 2 * a.rows - 2 - rye : rye);
-            const U2 e = *(const U2*)(sframe + (size_t)erow * a.sstep + eoff);
+            const U2 e = *(const U2*)(sframe + (__umul24((unsigned)erow, sstep24) + (unsigned)eoff));
             L[13] = e.a;
             L[14] = e.b;
         }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                 deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
             }
             if (ep == 0 && ys - 3 + 16 * b + er <= ry_last) {
-                const int hslot = (16 * b + er) % kSlots;
+                const int hslot = 16 * (b % 3) + er;   // ring slot of source row 16b + er (the block base is scalar)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const uint32_t lo = lastfull ? __builtin_amdgcn_perm(g1[c], g1[c], 0x02030201u)   // 253 254 255 | 254
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             pr[0] = __builtin_amdgcn_perm(pr[0], pr[0], 0x01020100u);
         }
         if (sq > ntiles || ys - 3 + 16 * b + sr > ry_last) return;  // chunk / row not needed (LDS ops may be conditional)
-        const int slot = (16 * b + sr) % kSlots;
+        const int slot = 16 * (b % 3) + sr;
         uint8_t* dstp = lds + slot * kPitch + 16 * sq;
         *(uint4*)(dstp) = make_uint4(pb[0] ^ 0x80808080u, pb[1] ^ 0x80808080u, pb[2] ^ 0x80808080u, pb[3] ^ 0x80808080u);
         *(uint4*)(dstp + kPlane) = make_uint4(pg[0] ^ 0x80808080u, pg[1] ^ 0x80808080u, pg[2] ^ 0x80808080u, pg[3] ^ 0x80808080u);
@@ -325,6 +326,11 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         gtile[j] = 4 * wave + c / 3 < ntiles;
     }
 
+    // accumulator start value 128*sum(K) + round as a resident VGPR quad (opaque to the compiler, which would otherwise
+    // rebuild it from the scalar before each of the 12 first-MFMAs of a step: 24 moves)
+    v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+    asm volatile("" : "+v"(initv));
+
     auto compute = [&](int k) {
         // ring slot of source row (16k + n + 2p + kyl): the block base is wave-uniform (scalar), the rest needs one
         // conditional subtract; 24-bit multiply (full rate) instead of a 32-bit one (quarter rate)
@@ -344,19 +350,21 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // p == 3 pairs kernel row 6 with the non-existent row 7: the upper 32 lanes (kyl == 1) would read pixels that
         // only meet zero weights, so they skip the LDS read (half the LDS cycles of that instruction).
         const bool lowhalf = kyl == 0;
-        auto rd = [&](int it) -> v4i {
+        // (the idle upper lanes keep whatever the ring register held before -- `old` -- so the masked read needs no
+        //  zero-fill moves: garbage times zero weights is still zero in integer arithmetic)
+        auto rd = [&](int it, const v4i& old) -> v4i {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
             const v4i* src = (const v4i*)(lds + c * kPlane + off[p] + 16 * i);
-            if (p == 3) return lowhalf ? *src : v4i{0, 0, 0, 0};
+            if (p == 3) return lowhalf ? *src : old;
             return *src;
         };
         // (wave-uniform, LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
         const int nmf = 12 * min(max(ntiles - 4 * wave, 0), 4);   // narrow last strips: tiles past the strip are skipped
         v4i acc[3], acc2[3];
-        const v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init}, zerov = v4i{0, 0, 0, 0};
+        const v4i zerov = v4i{0, 0, 0, 0};
         if (!(DBG & 4)) {
 #pragma unroll
-            for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it);
+            for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it, zerov);
         }
 #pragma unroll
         for (int it = 0; it < 48; ++it) {
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                 // the first MFMA of each accumulator takes the constant (128*sum(K) + round) vector as its C operand
                 acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], r < 3 ? initv : acc[c], 0, 0, 0);
                 if (DUAL) acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], r < 3 ? zerov : acc2[c], 0, 0, 0);
-                if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead);
+                if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead, Bq[it % kAhead]);
             }
             if (r == 11) {
                 if (DUAL) {
@@ -382,12 +390,15 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             }
         }
         const int ybase = ys + 16 * k;
+        uint4 ov[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ov[j] = *(const uint4*)(obuf + roff[j]);   // three reads in flight, then three stores
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const uint4 v = *(const uint4*)(obuf + roff[j]);
+            const uint4 v = ov[j];
             const int y = ybase + grow[j];
             // rows past the segment and tiles past the strip go to the dump line instead (the store stays unconditional)
-            uint8_t* dp = (y < ye && gtile[j]) ? dframe + (size_t)y * a.dstep + gcol[j] : dumpp;
+            uint8_t* dp = (y < ye && gtile[j]) ? dframe + (__umul24((unsigned)y, dstep24) + (unsigned)gcol[j]) : dumpp;
             if (DBG & 1) {
                 if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *(uint4*)dumpp = v;
             } else {
@@ -405,6 +416,12 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     store_block(0, LA);
     store_block(1, LB);
     load_block(2, LA);
+    // Three dummy stores: inside the loop the loads of a block are followed by the three output stores of the step
+    // before the next loads are issued.  Reproducing that order here makes the vmcnt bookkeeping of the loop-entry
+    // path identical to the back-edge path; without it the compiler merges the two conservatively and the first
+    // half-step of every iteration waits for its own output stores to be acknowledged (vmcnt(5) instead of (8)).
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *(uint4*)(dumpp + 1024 * j) = make_uint4(0u, 0u, 0u, 0u);   // dump area: 3 KiB at kconst + 16 KiB
     __syncthreads();
 
     for (int k = 0; k < nsteps; k += 2) {
@@ -458,6 +475,9 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    // in-frame byte offsets are formed with 24-bit multiplies and kept in 32 bits
+    if (s.step >= (1u << 24) || d.step >= (1u << 24) || s.rows >= (1 << 24)) return RCV_ERR_UNSUPPORTED;
+    if ((unsigned long long)s.rows * s.step >= (1ull << 32) || (unsigned long long)s.rows * d.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
     bool dual = false;
     long long ksum = 0;
     for (int i = 0; i < ksize * ksize; ++i) {
