@@ -82,7 +82,8 @@ __device__ __forceinline__ void deint4(uint32_t d0, uint32_t d1, uint32_t d2, ui
 struct U2 { uint32_t a, b; };
 struct U3 { uint32_t a, b, c; };
 
-// DBG: ablation bits for profiling builds (-DRCV_ABLATE): 1 skip global stores, 2 skip global loads, 4 skip MFMA
+// DBG: ablation bits for profiling builds (-DRCV_ABLATE): 1 skip global stores, 2 skip global loads, 4 skip MFMA,
+// 8 skip the staging realign/de-interleave, 16 skip the epilogue shift/saturate/pack
 // DUAL: weights beyond the i8 range (integer GaussianBlur 7x7: taps up to 324) are split K = 4*Q + R with Q, R in i8;
 // the same pixel operand feeds two MFMAs (tables A and A2) and the epilogue forms acc + (acc2 << 2).  LDS traffic is
 // unchanged, only the matrix-pipe work doubles.
@@ -259,11 +260,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                 pr[i] = rcv_ashr_sat_pk4(q[e + 2], q[e + 5], q[e + 8], q[e + 11], 8);
             }
         } else {
-            uint32_t s[12];
+            if (DBG & 8) {   // ablation: no realign / de-interleave
 #pragma unroll
-            for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
+                for (int i = 0; i < 4; ++i) { pb[i] = L[i]; pg[i] = L[4 + i]; pr[i] = L[8 + i]; }
+            } else {
+                uint32_t s[12];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
+                for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
+#pragma unroll
+                for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
+            }
         }
         // BORDER_REFLECT_101 in x, in registers (first / last strip only; branch-free selects elsewhere).
         //  left : chunk 0 holds x = -3..12 ; x = -3,-2,-1 mirror x = 3,2,1 = bytes 6,5,4 of the same chunk.
@@ -362,6 +368,9 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         const int nmf = 12 * min(max(ntiles - 4 * wave, 0), 4);   // narrow last strips: tiles past the strip are skipped
         v4i acc[3], acc2[3];
         const v4i zerov = v4i{0, 0, 0, 0};
+        // the MFMA phase is the longest dependent chain of a step: give it issue priority over the staging phases of the
+        // other workgroups' waves on this SIMD (measured -2 %)
+        __builtin_amdgcn_s_setprio(3);
         if (!(DBG & 4)) {
 #pragma unroll
             for (int it = 0; it < kAhead; ++it) Bq[it] = rd(it, zerov);
@@ -384,11 +393,18 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                     for (int cc = 0; cc < 3; ++cc) acc[cc] += acc2[cc] << 2;
                 }
                 // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row n (t = 4*wave + i): 12 interleaved bytes
+                if (DBG & 16) {   // ablation: no shift / saturate / pack
+                    *(uint32_t*)(obuf + woff[i][0]) = acc[0][0];
+                    *(uint32_t*)(obuf + woff[i][1]) = acc[1][1];
+                    *(uint32_t*)(obuf + woff[i][2]) = acc[2][2];
+                    continue;
+                }
                 *(uint32_t*)(obuf + woff[i][0]) = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
                 *(uint32_t*)(obuf + woff[i][1]) = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
                 *(uint32_t*)(obuf + woff[i][2]) = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         const int ybase = ys + 16 * k;
         uint4 ov[3];
 #pragma unroll
@@ -553,7 +569,10 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
-    switch (rcv_debug_flags & 7) {
+    switch (rcv_debug_flags & 31) {
+    case 8: hipLaunchKernelGGL((k_filter7_mfma<8, false>), grid, block, 0, ctx->stream, a); break;
+    case 16: hipLaunchKernelGGL((k_filter7_mfma<16, false>), grid, block, 0, ctx->stream, a); break;
+    case 24: hipLaunchKernelGGL((k_filter7_mfma<24, false>), grid, block, 0, ctx->stream, a); break;
     case 1: hipLaunchKernelGGL((k_filter7_mfma<1, false>), grid, block, 0, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((k_filter7_mfma<2, false>), grid, block, 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL((k_filter7_mfma<3, false>), grid, block, 0, ctx->stream, a); break;
