@@ -124,6 +124,52 @@ __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, fl
 
 struct Affine { float m[6]; };
 
+// One output pixel, any channel count, byte-granular taps: the reference formulation every fast path below must match.
+template <int CH>
+__device__ __forceinline__ void warp_px(const uint8_t* sf, const View& s, const Affine& A, float fxx, float fyy, uint8_t* o)
+{
+    float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+    float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+    if (!(sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows)) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) o[c] = 0;
+        return;
+    }
+    float x0f = floorf(sx), y0f = floorf(sy);
+    int x0 = (int)x0f, y0 = (int)y0f;
+    float fx = sx - x0f, fy = sy - y0f;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    bool vx0 = x0 >= 0, vx1 = x1 < s.cols, vy0 = y0 >= 0, vy1 = y1 < s.rows;
+    const uint8_t* ra = sf + (size_t)(vy0 ? y0 : 0) * s.step;
+    const uint8_t* rb = sf + (size_t)(vy1 ? y1 : 0) * s.step;
+    size_t xa = (size_t)(vx0 ? x0 : 0) * CH, xb = (size_t)(vx1 ? x1 : 0) * CH;
+    uint64_t ta = 0, tb = 0;
+    const bool wide = CH == 3 && s.cols >= 3;
+    if (wide) {
+        ta = load_taps6(ra, x0, s.cols * 3);
+        tb = load_taps6(rb, x0, s.cols * 3);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float p00, p01, p10, p11;
+        if (wide) {
+            p00 = (vx0 && vy0) ? (float)(uint32_t)((ta >> (8 * c)) & 0xff) : 0.0f;
+            p01 = (vx1 && vy0) ? (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff) : 0.0f;
+            p10 = (vx0 && vy1) ? (float)(uint32_t)((tb >> (8 * c)) & 0xff) : 0.0f;
+            p11 = (vx1 && vy1) ? (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff) : 0.0f;
+        } else {
+            p00 = (vx0 && vy0) ? (float)ra[xa + c] : 0.0f;
+            p01 = (vx1 && vy0) ? (float)ra[xb + c] : 0.0f;
+            p10 = (vx0 && vy1) ? (float)rb[xa + c] : 0.0f;
+            p11 = (vx1 && vy1) ? (float)rb[xb + c] : 0.0f;
+        }
+        float top = fmaf(fx, p01 - p00, p00);
+        float bot = fmaf(fx, p11 - p10, p10);
+        float v = fmaf(fy, bot - top, top);
+        o[c] = round_half_up_u8(v);
+    }
+}
+
 template <int CH>
 __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A)
 {
@@ -131,50 +177,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* drow = d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step;
     float fyy = (float)y;
-    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
-        float fxx = (float)x;
-        float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-        float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-        uint8_t* o = drow + (size_t)x * CH;
-        if (!(sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows)) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) o[c] = 0;
-            continue;
-        }
-        float x0f = floorf(sx), y0f = floorf(sy);
-        int x0 = (int)x0f, y0 = (int)y0f;
-        float fx = sx - x0f, fy = sy - y0f;
-        int x1 = x0 + 1, y1 = y0 + 1;
-        bool vx0 = x0 >= 0, vx1 = x1 < s.cols, vy0 = y0 >= 0, vy1 = y1 < s.rows;
-        const uint8_t* ra = sf + (size_t)(vy0 ? y0 : 0) * s.step;
-        const uint8_t* rb = sf + (size_t)(vy1 ? y1 : 0) * s.step;
-        size_t xa = (size_t)(vx0 ? x0 : 0) * CH, xb = (size_t)(vx1 ? x1 : 0) * CH;
-        uint64_t ta = 0, tb = 0;
-        const bool wide = CH == 3 && s.cols >= 3;
-        if (wide) {
-            ta = load_taps6(ra, x0, s.cols * 3);
-            tb = load_taps6(rb, x0, s.cols * 3);
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float p00, p01, p10, p11;
-            if (wide) {
-                p00 = (vx0 && vy0) ? (float)(uint32_t)((ta >> (8 * c)) & 0xff) : 0.0f;
-                p01 = (vx1 && vy0) ? (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff) : 0.0f;
-                p10 = (vx0 && vy1) ? (float)(uint32_t)((tb >> (8 * c)) & 0xff) : 0.0f;
-                p11 = (vx1 && vy1) ? (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff) : 0.0f;
-            } else {
-                p00 = (vx0 && vy0) ? (float)ra[xa + c] : 0.0f;
-                p01 = (vx1 && vy0) ? (float)ra[xb + c] : 0.0f;
-                p10 = (vx0 && vy1) ? (float)rb[xa + c] : 0.0f;
-                p11 = (vx1 && vy1) ? (float)rb[xb + c] : 0.0f;
-            }
-            float top = fmaf(fx, p01 - p00, p00);
-            float bot = fmaf(fx, p11 - p10, p10);
-            float v = fmaf(fy, bot - top, top);
-            o[c] = round_half_up_u8(v);
-        }
-    }
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock)
+        warp_px<CH>(sf, s, A, (float)x, fyy, drow + (size_t)x * CH);
 }
 
 // Two adjacent BGR taps as two dwords {b0 g0 r0 b1 | g1 r1 x x}; the 8-byte window is used in place whenever it fits
@@ -198,6 +202,7 @@ __device__ __forceinline__ void load_taps6_32(const uint8_t* row, int x0, int ro
 // v_cvt_f32_ubyteN straight from the tap dwords, invalid taps zeroed once per pixel instead of once per channel, and
 // the three result bytes of four neighbouring lanes gathered with DPP so that every fourth lane stores 12 bytes.
 // Same f32 operations in the same order as k_warp_affine<3>.
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kWarpRows = 8;   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
 // Two phases per thread so that all 16 tap loads of its 8 rows are in flight together: the loads are unconditional
@@ -210,6 +215,86 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0 and kBlock % 4 == 0: quads never straddle the row end
     const float fxx = (float)min(x, d.cols - 1);
     const int ybase = blockIdx.y * kWarpRows;
+
+    // ---- interior fast path (wave-uniform) ----
+    // The op is VALU-bound (the border version below spends ~160 VALU ops per pixel).  sx and sy are monotonic in the
+    // row index for a fixed lane (fmaf rounds monotonically), so testing the first and the last row of the thread
+    // bounds all eight.  If every lane of the wave keeps all four taps and the whole 8-byte tap window inside the source
+    // (0 <= sx < cols-2, 0 <= sy < rows-1) the validity masks, the clamps, the funnel shifts and the final saturation
+    // are all no-ops: ~65 VALU ops per pixel, same f32 operations in the same order.
+    {
+        const float fy0 = (float)min(ybase, d.rows - 1), fy1 = (float)min(ybase + kWarpRows - 1, d.rows - 1);
+        const float xa = fmaf(A.m[0], fxx, fmaf(A.m[1], fy0, A.m[2])), xb = fmaf(A.m[0], fxx, fmaf(A.m[1], fy1, A.m[2]));
+        const float ya = fmaf(A.m[3], fxx, fmaf(A.m[4], fy0, A.m[5])), yb = fmaf(A.m[3], fxx, fmaf(A.m[4], fy1, A.m[5]));
+        const float xl = (float)(s.cols - 3), yl = (float)(s.rows - 1);   // x0 <= cols-4: the 12-byte window below ends inside the row
+        const bool inter = fminf(xa, xb) >= 0.0f && fmaxf(xa, xb) < xl && fminf(ya, yb) >= 0.0f && fmaxf(ya, yb) < yl;   // NaN -> false
+        const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) &&
+                           d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
+        // all eight rows of every lane outside the source on the same side: constant border, nothing to load
+        const bool outside = !(fmaxf(xa, xb) > -1.0f) || !(fminf(xa, xb) < (float)s.cols) || !(fmaxf(ya, yb) > -1.0f) || !(fminf(ya, yb) < (float)s.rows);
+        if (__all(outside)) {
+            if ((threadIdx.x & 3) == 0 && x < d.cols) {
+                struct U3 { uint32_t a, b, c; };
+#pragma unroll
+                for (int r = 0; r < kWarpRows; ++r)
+                    if (ybase + r < d.rows) *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{0u, 0u, 0u};
+            }
+            return;
+        }
+        if (small && __all(inter)) {
+            const unsigned sstep = (unsigned)s.step;
+            // Tap pair = 6 bytes at byte 3*x0 of a row.  An UNALIGNED 8-byte load costs ~40 cycles per wave instruction
+            // (the address path serialises misaligned lanes; measured, same for ds_read_b64), so the taps are fetched as
+            // the three ALIGNED dwords that contain them and shifted into place with v_alignbyte.
+            struct U3 { uint32_t a, b, c; };
+            U3 ta[kWarpRows], tb[kWarpRows];
+            float fx[kWarpRows], fy[kWarpRows];
+            unsigned sh[kWarpRows];
+#pragma unroll
+            for (int r = 0; r < kWarpRows; ++r) {
+                const float fyy = (float)min(ybase + r, d.rows - 1);
+                const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+                const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+                const float x0f = floorf(sx), y0f = floorf(sy);
+                fx[r] = sx - x0f;
+                fy[r] = sy - y0f;
+                const unsigned x0 = (unsigned)(int)x0f, y0 = (unsigned)(int)y0f;
+                const unsigned off = __umul24(y0, sstep) + 3u * x0;   // rows start 4-byte aligned (checked by the caller)
+                sh[r] = off & 3u;
+                ta[r] = *(const U3*)(sf + (off & ~3u));
+                tb[r] = *(const U3*)(sf + ((off & ~3u) + sstep));
+            }
+#pragma unroll
+            for (int r = 0; r < kWarpRows; ++r) {
+                const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh[r]);
+                const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh[r]);
+                // taps {b0 g0 r0 b1 | g1 r1 . .}: channels 0,1 ride in packed-f32 pairs (v_pk_add/v_pk_fma: two IEEE
+                // operations per instruction, same results as the scalar ops), channel 2 pairs its top and bottom row
+                const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
+                const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
+                const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
+                const f2 fxx2 = {fx[r], fx[r]}, fyy2 = {fy[r], fy[r]}, half2 = {0.5f, 0.5f};
+                const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);      // channels 0,1, upper row
+                const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);      // channels 0,1, lower row
+                const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);      // channel 2: {top, bot}
+                const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
+                const float v2 = fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f;
+                // floor(v + 0.5) is an exact integer in [0, 255] here; v_cvt_pk_u8_f32 converts, saturates and packs
+                uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
+                px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
+                px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+                const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
+                const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
+                const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+                if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
+                    // 4 x {b g r 0} -> 12 bytes with three byte permutes
+                    *(U3*)(dfr + (__umul24((unsigned)(ybase + r), (unsigned)d.step) + 3u * (unsigned)x)) =
+                        U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+                }
+            }
+            return;
+        }
+    }
 
     uint2 ta[kWarpRows], tb[kWarpRows];
     float fx[kWarpRows], fy[kWarpRows];
