@@ -17,6 +17,8 @@
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
 
+extern int rcv_debug_flags;
+
 namespace {
 
 typedef short s2v __attribute__((ext_vector_type(2)));
@@ -50,6 +52,8 @@ __device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b)  // a + 2*b
 
 struct U2 { uint32_t lo, hi; };
 
+// DBG (profiling builds, -DRCV_ABLATE): 1 skip global stores, 2 skip global loads
+template <int DBG>
 __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     auto load_row = [&](int ry) -> Row {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
         ry = min(ry, ye);
         const int r = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
+        if (DBG & 2) return Row{U2{(uint32_t)r, (uint32_t)lane}, 0u};
         return Row{*(const U2*)(sf + (size_t)r * a.sstep), (uint32_t)se[(size_t)r * a.sstep]};
     };
 
@@ -117,6 +122,10 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
         }
         const int y = r - 1;
         const bool st = live && y >= ys && y < ye;
+        if (DBG & 1) {
+            if (ox[0] == 0x12345678u && oy[1] == 0x9abcdef0u) *(uint4*)dump = make_uint4(ox[0], ox[1], oy[2], oy[3]);
+            return;
+        }
         *(uint4*)(st ? dxp + (size_t)y * a.xstep : dump) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
         *(uint4*)(st ? dyp + (size_t)y * a.ystep : dump) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
     };
@@ -166,6 +175,16 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
-    hipLaunchKernelGGL(k_sobel_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+#ifdef RCV_ABLATE
+    switch (rcv_debug_flags & 3) {
+    case 1: hipLaunchKernelGGL(k_sobel_rows<1>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(k_sobel_rows<2>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(k_sobel_rows<3>, grid, dim3(256), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(k_sobel_rows<0>, grid, dim3(256), 0, ctx->stream, a); break;
+    }
+#else
+    hipLaunchKernelGGL(k_sobel_rows<0>, grid, dim3(256), 0, ctx->stream, a);
+#endif
     return rcv_launch_check(ctx);
 }
