@@ -172,6 +172,12 @@ int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst);
 int rcv_warp_affine(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M);
 int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M);
 
+/* "next" row f1: resize(warp_affine(src -> mid_rows x mid_cols), dst) in one call.  When mid is exactly
+ * 2x or 4x dst (BGR) the intermediate image is never materialised; other shapes run the two kernels through the context
+ * workspace.  Results are identical to calling rcv_warp_affine then rcv_resize. */
+int rcv_warp_affine_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M, int mid_rows, int mid_cols);
+int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int mid_rows, int mid_cols);
+
 /* gray u8 1-ch -> f32 response; aperture fixed at 3; block in 1..7 */
 int rcv_corner_harris(rcv_ctx* ctx, const rcv_mat* gray, rcv_mat* resp, int block, float k);
 int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_batch* resp, int block, float k);

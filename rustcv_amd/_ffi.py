@@ -77,6 +77,8 @@ SIGNATURES = {
     "rcv_resize_batch": (_i, [_ctx, _bat, _bat]),
     "rcv_warp_affine": (_i, [_ctx, _mat, _mat, _P(_f)]),
     "rcv_warp_affine_batch": (_i, [_ctx, _bat, _bat, _P(_f)]),
+    "rcv_warp_affine_resize": (_i, [_ctx, _mat, _mat, _P(_f), _i, _i]),
+    "rcv_warp_affine_resize_batch": (_i, [_ctx, _bat, _bat, _P(_f), _i, _i]),
     "rcv_corner_harris": (_i, [_ctx, _mat, _mat, _i, _f]),
     "rcv_corner_harris_batch": (_i, [_ctx, _bat, _bat, _i, _f]),
     "rcv_nms3x3": (_i, [_ctx, _mat, _mat, _f]),

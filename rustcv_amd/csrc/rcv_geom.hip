@@ -359,6 +359,87 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     }
 }
 
+// ---- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR ("next" row f1) ---------------------
+// resize(warp_affine(src -> mid), dst) with mid = S * dst.  For an exact integer factor the bilinear resize reads only
+// the centre 2x2 of every SxS block of `mid` (k_resize_box above), so the fused kernel evaluates just those four warped
+// pixels per output pixel -- bit for bit what the warp kernels produce (same f32 ops, same order, same rounding) -- and
+// averages them with (a+b+c+d+2)>>2.  `mid` never exists: 1/4 (S=2: all) of the warp arithmetic of the unfused pair and
+// none of its 2 x 3 B/px intermediate traffic.  One thread per output pixel, four lanes share a 12-byte store.
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affine A)
+{
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y;   // d.cols % 4 == 0: quads never straddle the row end
+    const int xq = min(x, d.cols - 1);
+    constexpr int o = S / 2 - 1;
+    float sx[4], sy[4];
+    bool inter = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * y + o + (i >> 1));
+        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
+    }
+    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+                       (unsigned long long)s.rows * s.step < (1ull << 32);
+    uint32_t p[4];
+    if (small && __all(inter)) {   // wave-uniform: every tap of every lane inside the source (see k_warp_affine_bgr)
+        struct U3 { uint32_t a, b, c; };
+        U3 ta[4], tb[4];
+        unsigned sh[4];
+        float fx[4], fy[4];
+        const unsigned sstep = (unsigned)s.step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
+            fx[i] = sx[i] - x0f;
+            fy[i] = sy[i] - y0f;
+            const unsigned off = __umul24((unsigned)(int)y0f, sstep) + 3u * (unsigned)(int)x0f;
+            sh[i] = off & 3u;
+            ta[i] = *(const U3*)(sf + (off & ~3u));
+            tb[i] = *(const U3*)(sf + ((off & ~3u) + sstep));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].b, ta[i].a, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].c, ta[i].b, sh[i]);
+            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].b, tb[i].a, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].c, tb[i].b, sh[i]);
+            const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
+            const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
+            const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
+            const f2 fxx2 = {fx[i], fx[i]}, fyy2 = {fy[i], fy[i]}, half2 = {0.5f, 0.5f};
+            const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
+            const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
+            const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
+            const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
+            const float v2 = fmaf(fy[i], tb2.y - tb2.x, tb2.x) + 0.5f;
+            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
+            p[i] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            uint8_t o3[3];
+            warp_px<3>(sf, s, A, (float)(S * xq + o + (i & 1)), (float)(S * y + o + (i >> 1)), o3);
+            p[i] = (uint32_t)o3[0] | ((uint32_t)o3[1] << 8) | ((uint32_t)o3[2] << 16);
+        }
+    }
+    // (a+b+c+d+2)>>2 per channel: B and R ride in the two 16-bit halves of one dword, G in another
+    const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
+    const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
+    const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
+    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
+    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
+    const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+    if ((threadIdx.x & 3) == 0 && x < d.cols) {
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) =
+            U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+    }
+}
+
 int check_geom(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
 {
     if (!src || !dst) return RCV_ERR_ARG;
@@ -420,6 +501,54 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     else if (s.ch == 3) hipLaunchKernelGGL(k_warp_affine<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     else hipLaunchKernelGGL(k_warp_affine<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     return rcv_launch_check(ctx);
+}
+
+// resize(warp_affine(src -> mid_rows x mid_cols), dst) without materialising `mid` when mid = S * dst, S in {2, 4};
+// any other shape runs the two ordinary kernels through the context workspace (same results either way).
+extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int mid_rows, int mid_cols)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!M || mid_rows < 0 || mid_cols < 0) return RCV_ERR_ARG;
+    View s, d;
+    RCV_TRY(check_geom(src, dst, &s, &d));
+    if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
+    if (mid_rows == 0 || mid_cols == 0) return RCV_ERR_ARG;
+    Affine A;
+    for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    for (int S = 2; S <= 4; S += 2) {
+        if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
+            d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
+            dim3 grid((unsigned)((d.cols + kBlock - 1) / kBlock), d.rows, d.n);
+            if (S == 2) hipLaunchKernelGGL(k_warp_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
+            else hipLaunchKernelGGL(k_warp_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
+            return rcv_launch_check(ctx);
+        }
+    }
+    const size_t tstep = ((size_t)mid_cols * s.ch + 15) & ~(size_t)15, tfs = tstep * mid_rows;
+    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
+    uint8_t* tmp;
+    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
+    rcv_batch tb = *dst;
+    tb.frame0.data = tmp;
+    tb.frame0.cap = tfs;
+    tb.frame0.step = tstep;
+    tb.frame0.rows = mid_rows;
+    tb.frame0.cols = mid_cols;
+    tb.frame_stride = tfs;
+    RCV_TRY(rcv_warp_affine_batch(ctx, src, &tb, M));
+    return rcv_resize_batch(ctx, &tb, dst);
+}
+
+extern "C" int rcv_warp_affine_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M, int mid_rows, int mid_cols)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dd;
+    RCV_TRY(stage_in(&st, src, true, false, &ds));
+    RCV_TRY(stage_in(&st, dst, true, true, &dd));
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
+    return stage_finish(&st, rcv_warp_affine_resize_batch(ctx, &bs, &bd, M, mid_rows, mid_cols));
 }
 
 extern "C" int rcv_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst)

@@ -141,6 +141,14 @@ def warp_affine(src, dst, M):
                "rcv_warp_affine_batch")
 
 
+def warp_affine_resize(src, dst, M, mid_rows, mid_cols):
+    """resize(warp_affine(src -> mid_rows x mid_cols), dst); fused when mid is exactly 2x / 4x dst (BGR)."""
+    m = np.ascontiguousarray(M, dtype=np.float32).reshape(6)
+    a, b = src.as_rcv(), dst.as_rcv()
+    _ffi.check(_ffi.lib().rcv_warp_affine_resize_batch(_h(src), C.byref(a), C.byref(b), m.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       int(mid_rows), int(mid_cols)), "rcv_warp_affine_resize_batch")
+
+
 def corner_harris(gray, resp, block_size=2, k=0.04):
     a, b = gray.as_rcv(), resp.as_rcv()
     _ffi.check(_ffi.lib().rcv_corner_harris_batch(_h(gray), C.byref(a), C.byref(b), block_size, float(k)), "rcv_corner_harris_batch")

@@ -105,6 +105,14 @@ def warp_affine(src: Mat, dst: Mat, M, ctx=None):
                "rcv_warp_affine")
 
 
+def warp_affine_resize(src: Mat, dst: Mat, M, mid_rows: int, mid_cols: int, ctx=None):
+    """resize(warp_affine(src -> mid_rows x mid_cols), dst) in one call (fused for exact 2x / 4x BGR down-scales)."""
+    m = np.ascontiguousarray(M, dtype=np.float32).reshape(6)
+    s, d = src._as_rcv(), dst._as_rcv()
+    _ffi.check(_ffi.lib().rcv_warp_affine_resize(_ctx(ctx), C.byref(s), C.byref(d), m.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 int(mid_rows), int(mid_cols)), "rcv_warp_affine_resize")
+
+
 def corner_harris(gray: Mat, resp: Mat, block_size: int = 2, k: float = 0.04, ctx=None):
     s, d = gray._as_rcv(), resp._as_rcv()
     _ffi.check(_ffi.lib().rcv_corner_harris(_ctx(ctx), C.byref(s), C.byref(d), block_size, float(k)), "rcv_corner_harris")

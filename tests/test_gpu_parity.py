@@ -461,10 +461,14 @@ def test_warp_and_resize_8k_to_1080p_slab(ctx, oracle):
     M = _rot(7.0, cols / 2, rows / 2, 13.25, -8.5)
     dst = device.DeviceBatch(ctx, 1, rows, cols, 3)
     device.warp_affine(src, dst, M)
-    assert np.array_equal(dst.download()[0], oracle.warp_affine(frame, M, rows, cols))
+    warped = oracle.warp_affine(frame, M, rows, cols)
+    assert np.array_equal(dst.download()[0], warped)
     small = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
     device.resize(src, small)
     assert np.array_equal(small.download()[0], oracle.resize(frame, 1080, 1920))
+    # "next" row f1: the fused warp + 4x down-scale equals the two-step composition
+    device.warp_affine_resize(src, small, M, rows, cols)
+    assert np.array_equal(small.download()[0], oracle.resize(warped, 1080, 1920))
     for b in (src, dst, small):
         b.free()
 
@@ -487,6 +491,50 @@ def test_warp_affine(ctx, oracle, rng, shape, ch, M):
     src, dst = Mat.from_array(img), Mat(shape[0] + 3, shape[1] + 5, ch)
     imgproc.warp_affine(src, dst, M, ctx)
     assert np.array_equal(dst.to_array(), oracle.warp_affine(img, M, shape[0] + 3, shape[1] + 5))
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("dshape", [(24, 32), (17, 260), (3, 4)])
+@pytest.mark.parametrize("M", ["ident", "shift", "rot7", "shrink", "far"])
+def test_warp_affine_resize_fused(ctx, oracle, rng, scale, dshape, M):
+    """fused warpAffine + exact down-scale == resize(warp_affine(.)) of the oracle, batch of 2 (interior, border and outside waves)"""
+    dr, dc = dshape
+    mr, mc = dr * scale, dc * scale
+    sr, sc = mr + 5, mc + 9            # source a little larger than the intermediate image
+    Ms = {"ident": np.array([1, 0, 4, 0, 1, 2], np.float32), "shift": np.array([1, 0, 0.5, 0, 1, 0.25], np.float32),
+          "rot7": _rot(7.0, mc / 2, mr / 2, 3.25, -1.5), "shrink": np.array([0.5, 0.1, 3, -0.2, 0.7, 4], np.float32),
+          "far": np.array([1, 0, 1e6, 0, 1, 0], np.float32)}[M]
+    n = 2
+    src = device.DeviceBatch(ctx, n, sr, sc, 3)
+    dst = device.DeviceBatch(ctx, n, dr, dc, 3)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    device.warp_affine_resize(src, dst, Ms, mr, mc)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc))
+    src.free()
+    dst.free()
+
+
+@pytest.mark.parametrize("ch,mid,dshape", [(3, (50, 70), (20, 28)), (1, (48, 64), (24, 32)), (3, (48, 66), (24, 33)), (4, (40, 40), (10, 10))])
+def test_warp_affine_resize_unfused_shapes(ctx, oracle, rng, ch, mid, dshape):
+    """shapes the fused kernel does not take (non-integer factor, 1/4 channels, width not a multiple of 4) run warp then resize"""
+    img = rand_img(rng, 45, 61, ch)
+    M = np.array([0.98, -0.1, 2.5, 0.1, 0.98, -1.25], np.float32)
+    src, dst = Mat.from_array(img), Mat(dshape[0], dshape[1], ch)
+    imgproc.warp_affine_resize(src, dst, M, mid[0], mid[1], ctx)
+    assert np.array_equal(dst.to_array(), oracle.resize(oracle.warp_affine(img, M, mid[0], mid[1]), dshape[0], dshape[1]))
+
+
+def test_warp_affine_resize_host_fused(ctx, oracle, rng):
+    img = rand_img(rng, 130, 200, 3)
+    M = _rot(-11.0, 100, 65, 0.5, 0.75)
+    src, dst = Mat.from_array(img), Mat(32, 48, 3)
+    imgproc.warp_affine_resize(src, dst, M, 128, 192, ctx)
+    assert np.array_equal(dst.to_array(), oracle.resize(oracle.warp_affine(img, M, 128, 192), 32, 48))
+    with pytest.raises(Exception):
+        imgproc.warp_affine_resize(src, dst, M, 0, 192, ctx)
 
 
 @pytest.mark.parametrize("rows,cols", SHAPES)

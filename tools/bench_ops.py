@@ -165,6 +165,10 @@ def main():
            cpu=lambda: cpu_time(lambda orc: orc.warp_affine(np.zeros((4320, 7680, 3), np.uint8), M, 4320, 7680), 7680 * 4320, 6.0))
     d.free()
     d = B(32, 1080, 1920, 3)
+    record("warpAffine + resize 8K -> 1080p FUSED (next row f1)", "8K batch=32/GPU", s.n, 1920 * 1080, 30,
+           lambda: device.warp_affine_resize(s, d, M, 4320, 7680),
+           note="30 B per OUTPUT px: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written; "
+                "the unfused pair moves 6 B/px of 8K intermediate on top")
     record("resize 8K -> 1080p bilinear", "8K batch=32/GPU", s.n, 1920 * 1080, 15, lambda: device.resize(s, d),
            note="15 B per OUTPUT px: exact 4x touches the centre 2x2 of each 4x4 block",
            cpu=lambda: cpu_time(lambda orc: orc.resize(np.zeros((4320, 7680, 3), np.uint8), 1080, 1920), 1920 * 1080))
