@@ -35,6 +35,7 @@ extern "C" {
 #define RCV_ERR_SIZE        (-3) /* a buffer is smaller than rows*step or than the op needs */
 #define RCV_ERR_DEVICE      (-4) /* no device, HIP error, kernel launch failure */
 #define RCV_ERR_OOM         (-5) /* device or host allocation failed */
+#define RCV_ERR_BUSY        (-6) /* staging ring full: retire a frame first */
 
 /* ---- element depth of an rcv_mat */
 #define RCV_8U  0
@@ -62,6 +63,8 @@ extern "C" {
 #define RCV_UYVY2BGR_STRIDED 9  /* src 2 channels [U Y0 V Y1]                                                    */
 #define RCV_NV12_2BGR      10 /* src 1 channel, rows x cols luma then ceil(rows/2) rows of interleaved UV at the same
                                  step (rustcv-backend-msmf/examples/camera_view/convert.rs:46-86); RCV_NOOP if short */
+#define RCV_BGRA2BGR_STRIDED 11 /* src 4 channels, both sides honour step: bgra_to_bgr per pixel (videoio/mod.rs:385-399)
+                                   for backends that report a real row stride (rustcv-backend-avf/src/stream.rs:250-254) */
 
 /* ---- synthetic frame families (replaces the empty rustcv-simulation crate) */
 #define RCV_SYNTH_NOISE 0
@@ -197,6 +200,31 @@ int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mas
  * family NOISE/SCENE: u8, channels 1/3/4.  family YUYV: 2 B/px packed, the mat is
  * described as channels=2.  Frame index of batch element i is frame_base+i.      */
 int rcv_synth_batch(rcv_ctx* ctx, rcv_batch* dst, int family, uint64_t seed, uint64_t frame_base);
+
+/* ---- pinned-host staging ring ("next" row f3) ------------------------------------------------------
+ * Replaces the upload -> compute -> download serialisation of the host-Mat entry points for streaming callers such as
+ * the reference's capture loop (rustcv/src/videoio/mod.rs:83-112): `depth` frames are in flight, H2D, kernels and D2H of
+ * different frames overlap on three streams.  The per-frame work is the caller's callback: it receives DEVICE mats and
+ * must enqueue on the context's stream without synchronising (every rcv_* entry point does exactly that for
+ * RCV_DEVICE mats).  rcv_ring_input exposes the next pinned input buffer so that a capture backend can fill it in
+ * place (the zero-copy hand-over the reference declares as AsDmaBuf, rustcv-core/src/frame.rs:58-65, and never
+ * implements). */
+typedef struct rcv_ring rcv_ring;
+typedef int (*rcv_ring_op)(rcv_ctx* ctx, const rcv_mat* dev_in, rcv_mat* dev_out, void* user);
+
+int  rcv_ring_create(rcv_ctx* ctx, int depth, int in_rows, int in_cols, int in_channels, int in_depth,
+                     int out_rows, int out_cols, int out_channels, int out_depth, rcv_ring** out);
+void rcv_ring_destroy(rcv_ring* ring);
+/* frames submitted and not yet retired */
+int  rcv_ring_in_flight(const rcv_ring* ring);
+/* the pinned host buffer the next submit will upload (fill it, then submit with host_in = NULL); RCV_ERR_BUSY if full */
+int  rcv_ring_input(rcv_ring* ring, rcv_mat* host_in);
+/* copy host_in (any step) into the slot, then enqueue H2D -> op -> D2H.  Returns the op's error code if it failed
+ * (the slot still has to be retired), RCV_ERR_BUSY if `depth` frames are already in flight */
+int  rcv_ring_submit(rcv_ring* ring, const rcv_mat* host_in, rcv_ring_op op, void* user);
+/* wait for the OLDEST frame; copy it to host_out (may be NULL) and/or describe the ring's own pinned output buffer in
+ * *pinned_out (may be NULL; valid until `depth` further submits).  RCV_NOOP if nothing is in flight */
+int  rcv_ring_retire(rcv_ring* ring, rcv_mat* host_out, rcv_mat* pinned_out);
 
 #ifdef __cplusplus
 }

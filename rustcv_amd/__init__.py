@@ -9,6 +9,7 @@ raises if it is missing.  There is no CPU fallback anywhere in this package.
 from . import _ffi
 from ._ffi import RcvError
 from .core import Context, Mat, default_context, device_count
-from . import imgproc, videoio, device, shard
+from . import imgproc, videoio, device, shard, ring
+from .ring import StagingRing
 
-__all__ = ["Mat", "Context", "RcvError", "default_context", "device_count", "imgproc", "videoio", "device", "shard", "_ffi"]
+__all__ = ["Mat", "Context", "RcvError", "default_context", "device_count", "imgproc", "videoio", "device", "shard", "ring", "StagingRing", "_ffi"]

@@ -11,11 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librustcv_hip.so")
 
 RCV_OK, RCV_NOOP = 0, 1
-RCV_ERR_ARG, RCV_ERR_UNSUPPORTED, RCV_ERR_SIZE, RCV_ERR_DEVICE, RCV_ERR_OOM = -1, -2, -3, -4, -5
+RCV_ERR_ARG, RCV_ERR_UNSUPPORTED, RCV_ERR_SIZE, RCV_ERR_DEVICE, RCV_ERR_OOM, RCV_ERR_BUSY = -1, -2, -3, -4, -5, -6
 RCV_8U, RCV_16S, RCV_32F = 0, 1, 2
 RCV_HOST, RCV_DEVICE = 0, 1
 RCV_YUYV2BGR, RCV_BGRA2BGR, RCV_RGB2BGR, RCV_YUYV2BGR_TWIN, RCV_BGRA2BGR_TWIN, RCV_BGR2GRAY = range(6)
-RCV_BGR2BGRX, RCV_BGR2RGB, RCV_YUYV2BGR_STRIDED, RCV_UYVY2BGR_STRIDED, RCV_NV12_2BGR = 6, 7, 8, 9, 10
+RCV_BGR2BGRX, RCV_BGR2RGB, RCV_YUYV2BGR_STRIDED, RCV_UYVY2BGR_STRIDED, RCV_NV12_2BGR, RCV_BGRA2BGR_STRIDED = 6, 7, 8, 9, 10, 11
 RCV_SYNTH_NOISE, RCV_SYNTH_SCENE, RCV_SYNTH_YUYV = 0, 1, 2
 
 
@@ -40,8 +40,18 @@ _ctx = C.c_void_p
 _mat, _bat = _P(rcv_mat), _P(rcv_batch)
 _i, _u8, _f, _d, _sz, _u64, _i32 = C.c_int, C.c_uint8, C.c_float, C.c_double, C.c_size_t, C.c_uint64, C.c_int32
 
+# callback of the staging ring: int op(rcv_ctx*, const rcv_mat* dev_in, rcv_mat* dev_out, void* user)
+RING_OP = C.CFUNCTYPE(C.c_int, C.c_void_p, _P(rcv_mat), _P(rcv_mat), C.c_void_p)
+_ring = C.c_void_p
+
 # name -> (restype, argtypes); the list every symbol in include/rustcv_hip.h must appear in
 SIGNATURES = {
+    "rcv_ring_create": (_i, [_ctx, _i, _i, _i, _i, _i, _i, _i, _i, _i, _P(_ring)]),
+    "rcv_ring_destroy": (None, [_ring]),
+    "rcv_ring_in_flight": (_i, [_ring]),
+    "rcv_ring_input": (_i, [_ring, _mat]),
+    "rcv_ring_submit": (_i, [_ring, _mat, RING_OP, C.c_void_p]),
+    "rcv_ring_retire": (_i, [_ring, _mat, _mat]),
     "rcv_abi_version": (_i, []),
     "rcv_strerror": (C.c_char_p, [_i]),
     "rcv_device_count": (_i, [_P(_i)]),

@@ -19,6 +19,7 @@ extern "C" const char* rcv_strerror(int code)
     case RCV_ERR_SIZE: return "buffer too small for the described image";
     case RCV_ERR_DEVICE: return "HIP device error (no gfx950 device, or a runtime/launch failure)";
     case RCV_ERR_OOM: return "out of memory";
+    case RCV_ERR_BUSY: return "staging ring full (retire a frame first)";
     default: return "unknown rustcv_hip status";
     }
 }

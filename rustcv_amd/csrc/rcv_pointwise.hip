@@ -206,6 +206,30 @@ __global__ __launch_bounds__(kBlock) void k_bgr2rgb_rows(const uint8_t* __restri
     }
 }
 
+// strided BGRA rows -> strided BGR rows: what bgra_to_bgr (rustcv/src/videoio/mod.rs:385-399) computes per pixel, but
+// honouring the row stride the capture backends report (rustcv-backend-avf/src/stream.rs:250-254 delivers BGRA with the
+// CVPixelBuffer's bytes_per_row; the reference helper ignores it).  4 px (16 B in, 12 B out) per thread.
+__global__ __launch_bounds__(kBlock) void k_bgra2bgr_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t sstep, size_t dstep,
+                                                          size_t sfs, size_t dfs, int cols, int vec)
+{
+    const int y = blockIdx.y;
+    const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
+    uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * dstep;
+    const int quads = vec ? cols / 4 : 0;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
+        const uint4 a = *(const uint4*)(s + (size_t)q * 16);
+        uint32_t w[3];
+        pack4_drop_alpha(a.x, a.y, a.z, a.w, w);
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(d + (size_t)q * 12) = U3{w[0], w[1], w[2]};
+    }
+    for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock) {
+        d[3 * x] = s[4 * x];
+        d[3 * x + 1] = s[4 * x + 1];
+        d[3 * x + 2] = s[4 * x + 2];
+    }
+}
+
 __device__ __forceinline__ void yuv3(int y, int u, int v, int* o)
 {
     const int c = 298 * (y - 16) + 128;
@@ -558,9 +582,17 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
                            sm->step, d.step, src->frame_stride, d.fstride, d.rows, d.cols, vec);
         return rcv_launch_check(ctx);
     }
-    // RCV_YUYV2BGR_STRIDED / RCV_UYVY2BGR_STRIDED
     View d;
     RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (code == RCV_BGRA2BGR_STRIDED) {
+        if (s.ch != 4 || d.ch != 3 || s.rows != d.rows || s.cols != d.cols) return RCV_ERR_ARG;
+        if (s.rows == 0 || s.cols == 0 || n == 0) return RCV_OK;
+        const int vec = al(s.p, s.step, s.fstride, n, 16) && al(d.p, d.step, d.fstride, n, 4);
+        hipLaunchKernelGGL(k_bgra2bgr_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step,
+                           s.fstride, d.fstride, s.cols, vec);
+        return rcv_launch_check(ctx);
+    }
+    // RCV_YUYV2BGR_STRIDED / RCV_UYVY2BGR_STRIDED
     if (s.ch != 2 || d.ch != 3 || s.rows != d.rows || s.cols != d.cols) return RCV_ERR_ARG;
     if (s.rows == 0 || s.cols < 2 || n == 0) return RCV_OK;
     const int vec = al(s.p, s.step, s.fstride, n, 8) && al(d.p, d.step, d.fstride, n, 4);
@@ -574,7 +606,7 @@ extern "C" int rcv_cvt_color_batch(rcv_ctx* ctx, int code, const rcv_batch* src,
     if (!src || !dst) return RCV_ERR_ARG;
     RCV_TRY(rcv_bind(ctx));
     if (code == RCV_BGR2GRAY) return cvt_gray(ctx, src, dst);
-    if (code >= RCV_BGR2BGRX && code <= RCV_NV12_2BGR) return cvt_next_rows(ctx, code, src, dst);
+    if (code >= RCV_BGR2BGRX && code <= RCV_BGRA2BGR_STRIDED) return cvt_next_rows(ctx, code, src, dst);
     return cvt_flat(ctx, code, src, dst);
 }
 

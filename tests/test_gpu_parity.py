@@ -141,6 +141,24 @@ def test_yuv422_strided(ctx, oracle, rng, rows, cols, pad, uyvy):
     assert np.array_equal(dst.data, want)
 
 
+@pytest.mark.parametrize("rows,cols,spad,dpad", [(1, 1, 0, 0), (3, 5, 4, 1), (48, 64, 16, 0), (37, 516, 48, 12), (33, 130, 8, 4), (20, 64, 3, 0)])
+def test_bgra_strided(ctx, oracle, rng, rows, cols, spad, dpad):
+    """f2: BGRA with a real row stride (AVF reports bytes_per_row) -> BGR with its own step == bgra_to_bgr applied row by row"""
+    sstep, dstep = cols * 4 + spad, cols * 3 + dpad
+    data = rng.integers(0, 256, size=rows * sstep, dtype=np.uint8)
+    src = Mat(rows, cols, 4, step=sstep, data=data)
+    dst = Mat(rows, cols, 3, step=dstep, data=np.full(rows * dstep, 0x55, np.uint8))
+    want = dst.data.copy()
+    for r in range(rows):
+        row = np.zeros(cols * 3, np.uint8)
+        assert oracle.bgra_to_bgr(data[r * sstep: r * sstep + cols * 4], row, cols, 1)
+        want[r * dstep: r * dstep + cols * 3] = row
+    assert imgproc.cvt_color(src, dst, _ffi.RCV_BGRA2BGR_STRIDED, ctx) == _ffi.RCV_OK
+    assert np.array_equal(dst.data, want)      # padding bytes untouched
+    with pytest.raises(Exception):
+        imgproc.cvt_color(Mat(rows, cols, 3), dst, _ffi.RCV_BGRA2BGR_STRIDED, ctx)
+
+
 @pytest.mark.parametrize("rows,cols,pad", [(1, 2, 0), (2, 2, 0), (3, 5, 3), (48, 64, 16), (37, 516, 8), (33, 130, 2)])
 def test_nv12(ctx, oracle, rng, rows, cols, pad):
     step = cols + (cols & 1) + pad
