@@ -36,6 +36,12 @@ pub struct rcv_batch {
     pub reserved: i32,
 }
 
+#[repr(C)]
+pub struct rcv_ring { _private: [u8; 0] }
+pub type rcv_ring_op = extern "C" fn(ctx: *mut rcv_ctx, dev_in: *const rcv_mat, dev_out: *mut rcv_mat, user: *mut c_void) -> c_int;
+
+pub const RCV_ERR_BUSY: c_int = -6;
+pub const RCV_BGRA2BGR_STRIDED: c_int = 11;
 pub const RCV_OK: c_int = 0;
 pub const RCV_NOOP: c_int = 1;
 pub const RCV_YUYV2BGR: c_int = 0;
@@ -63,6 +69,16 @@ extern "C" {
     pub fn rcv_sobel(ctx: *mut rcv_ctx, src: *const rcv_mat, dx: *mut rcv_mat, dy: *mut rcv_mat) -> c_int;
     pub fn rcv_resize(ctx: *mut rcv_ctx, src: *const rcv_mat, dst: *mut rcv_mat) -> c_int;
     pub fn rcv_warp_affine(ctx: *mut rcv_ctx, src: *const rcv_mat, dst: *mut rcv_mat, m: *const f32) -> c_int;
+    pub fn rcv_warp_affine_resize(ctx: *mut rcv_ctx, src: *const rcv_mat, dst: *mut rcv_mat, m: *const f32, mid_rows: c_int, mid_cols: c_int) -> c_int;
+    pub fn rcv_filter2d_i8_yuyv(ctx: *mut rcv_ctx, src_yuyv: *const rcv_mat, dst_bgr: *mut rcv_mat, k: *const i8, ksize: c_int, shift: c_int) -> c_int;
+    // pinned-host staging ring: `depth` frames in flight, H2D / kernels / D2H overlap
+    pub fn rcv_ring_create(ctx: *mut rcv_ctx, depth: c_int, in_rows: c_int, in_cols: c_int, in_channels: c_int, in_depth: c_int,
+                           out_rows: c_int, out_cols: c_int, out_channels: c_int, out_depth: c_int, out: *mut *mut rcv_ring) -> c_int;
+    pub fn rcv_ring_destroy(ring: *mut rcv_ring);
+    pub fn rcv_ring_in_flight(ring: *const rcv_ring) -> c_int;
+    pub fn rcv_ring_input(ring: *mut rcv_ring, host_in: *mut rcv_mat) -> c_int;
+    pub fn rcv_ring_submit(ring: *mut rcv_ring, host_in: *const rcv_mat, op: rcv_ring_op, user: *mut c_void) -> c_int;
+    pub fn rcv_ring_retire(ring: *mut rcv_ring, host_out: *mut rcv_mat, pinned_out: *mut rcv_mat) -> c_int;
     pub fn rcv_corner_harris(ctx: *mut rcv_ctx, gray: *const rcv_mat, resp: *mut rcv_mat, block: c_int, k: f32) -> c_int;
     pub fn rcv_nms3x3(ctx: *mut rcv_ctx, resp: *const rcv_mat, mask: *mut rcv_mat, thr: f32) -> c_int;
     pub fn rcv_harris_pipeline(ctx: *mut rcv_ctx, bgr: *const rcv_mat, mask: *mut rcv_mat, resp: *mut rcv_mat, block: c_int, k: f32, thr: f32) -> c_int;
