@@ -535,6 +535,31 @@ def test_warp_affine_resize_fused(ctx, oracle, rng, scale, dshape, M):
     dst.free()
 
 
+@pytest.mark.parametrize("M", [[np.nan, 0, 0, 0, 1, 0], [1, 0, np.nan, 0, 1, 0], [np.inf, 0, 0, 0, 1, 0], [1, np.inf, 3, 0, 1, 0],
+                               [1, 0, 0, -np.inf, 1, 0], [0, 0, 5.5, 0, 0, 7.25], [1e-30, 0, 1, 0, 1e-30, 2], [-1, 0, 63, 0, -1, 31],
+                               [1, 0, -0.999, 0, 1, -0.999], [1, 0, 0.999, 0, 1, 0.999], [1.0000001, 0, -1, 0, 1, -1]])
+def test_warp_affine_bgr_kernel_degenerate_matrices(ctx, oracle, rng, M):
+    """BGR fast kernels (width a multiple of 4: interior / outside / border paths and the fused down-scale) on NaN, inf,
+    singular, mirrored and edge-grazing maps: same bytes as the oracle"""
+    M = np.array(M, np.float32)
+    rows, cols, n = 32, 64, 2
+    frames = rng.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    src.upload(frames)
+    dst = device.DeviceBatch(ctx, n, rows, cols, 3)
+    device.warp_affine(src, dst, M)
+    got = dst.download()
+    small = device.DeviceBatch(ctx, n, rows // 2, cols // 2, 3)
+    device.warp_affine_resize(src, small, M, rows, cols)
+    got2 = small.download()
+    for i in range(n):
+        want = oracle.warp_affine(frames[i], M, rows, cols)
+        assert np.array_equal(got[i], want)
+        assert np.array_equal(got2[i], oracle.resize(want, rows // 2, cols // 2))
+    for b in (src, dst, small):
+        b.free()
+
+
 @pytest.mark.parametrize("ch,mid,dshape", [(3, (50, 70), (20, 28)), (1, (48, 64), (24, 32)), (3, (48, 66), (24, 33)), (4, (40, 40), (10, 10))])
 def test_warp_affine_resize_unfused_shapes(ctx, oracle, rng, ch, mid, dshape):
     """shapes the fused kernel does not take (non-integer factor, 1/4 channels, width not a multiple of 4) run warp then resize"""
