@@ -226,6 +226,19 @@ int  rcv_ring_submit(rcv_ring* ring, const rcv_mat* host_in, rcv_ring_op op, voi
  * *pinned_out (may be NULL; valid until `depth` further submits).  RCV_NOOP if nothing is in flight */
 int  rcv_ring_retire(rcv_ring* ring, rcv_mat* host_out, rcv_mat* pinned_out);
 
+/* ---- launch graphs -------------------------------------------------------------------------------------------------
+ * The small configurations of the path (the reference's 640x480 convert + rectangle loop, examples/camera_demo.rs:50-76;
+ * one 1080p blur) are bound by launch latency.  rcv_graph_begin .. rcv_graph_end records the rcv_*_batch calls (and
+ * single-Mat calls on RCV_DEVICE mats) made on `ctx` instead of executing them; rcv_graph_launch replays the chain as
+ * one submission on the context stream.  Replays use the same device pointers -- refresh the buffers' contents between
+ * launches.  Entry points that have to synchronise (host mats, rcv_sync, rcv_upload/rcv_download, timers, the ring,
+ * workspace growth) return RCV_ERR_UNSUPPORTED while recording. */
+typedef struct rcv_graph rcv_graph;
+int  rcv_graph_begin(rcv_ctx* ctx);
+int  rcv_graph_end(rcv_ctx* ctx, rcv_graph** out);
+int  rcv_graph_launch(rcv_ctx* ctx, rcv_graph* graph);
+void rcv_graph_destroy(rcv_graph* graph);
+
 #ifdef __cplusplus
 }
 #endif

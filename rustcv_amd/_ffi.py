@@ -46,6 +46,10 @@ _ring = C.c_void_p
 
 # name -> (restype, argtypes); the list every symbol in include/rustcv_hip.h must appear in
 SIGNATURES = {
+    "rcv_graph_begin": (_i, [_ctx]),
+    "rcv_graph_end": (_i, [_ctx, _P(C.c_void_p)]),
+    "rcv_graph_launch": (_i, [_ctx, C.c_void_p]),
+    "rcv_graph_destroy": (None, [C.c_void_p]),
     "rcv_ring_create": (_i, [_ctx, _i, _i, _i, _i, _i, _i, _i, _i, _i, _P(_ring)]),
     "rcv_ring_destroy": (None, [_ring]),
     "rcv_ring_in_flight": (_i, [_ring]),

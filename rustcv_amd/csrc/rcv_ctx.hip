@@ -56,6 +56,7 @@ extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&c->kconst, 65536);
@@ -79,6 +80,14 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
     if (c->kconst) (void)hipFree(c->kconst);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->capturing) {   // a capture was left open: close it and drop what it allocated
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(c->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        for (int i = 0; i < c->cap_nallocs; ++i) (void)hipFree(c->cap_allocs[i]);
+        (void)hipGetLastError();
+    }
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -98,6 +107,7 @@ int rcv_launch_check(rcv_ctx*)
 
 extern "C" int rcv_sync(rcv_ctx* ctx)
 {
+    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipStreamSynchronize(ctx->stream));
     return RCV_OK;
@@ -127,6 +137,7 @@ extern "C" int rcv_free(rcv_ctx* ctx, void* p)
 
 extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
+    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;   // pageable copies synchronise
     RCV_TRY(rcv_bind(ctx));
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
@@ -137,6 +148,7 @@ extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes
 
 extern "C" int rcv_download(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
+    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;   // pageable copies synchronise
     RCV_TRY(rcv_bind(ctx));
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
@@ -156,6 +168,7 @@ extern "C" int rcv_memset(rcv_ctx* ctx, void* dst, int value, size_t bytes)
 
 extern "C" int rcv_timer_start(rcv_ctx* ctx)
 {
+    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     return RCV_OK;
@@ -164,6 +177,7 @@ extern "C" int rcv_timer_start(rcv_ctx* ctx)
 extern "C" int rcv_timer_stop(rcv_ctx* ctx, float* ms)
 {
     if (!ms) return RCV_ERR_ARG;
+    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     RCV_HIP(hipEventSynchronize(ctx->ev1));
@@ -210,6 +224,7 @@ int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
 {
     ctx->ws_off = 0;
     if (total <= ctx->ws_cap) return RCV_OK;
+    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // growing means free + sync: run the op once before capturing
     RCV_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->ws) RCV_HIP(hipFree(ctx->ws));
     ctx->ws = nullptr;
@@ -234,6 +249,23 @@ int rcv_upload_const(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset
     // pageable source: hipMemcpyAsync snapshots it before returning, and the copy is
     // ordered on the ctx stream ahead of the kernel that reads it.
     RCV_HIP(hipMemcpyAsync(ctx->kconst + offset, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RCV_OK;
+}
+
+int rcv_const_table(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset, const uint8_t** dev)
+{
+    if (!ctx->capturing) {
+        RCV_TRY(rcv_upload_const(ctx, host, bytes, offset));
+        *dev = ctx->kconst + offset;
+        return RCV_OK;
+    }
+    if (ctx->cap_nallocs >= 64) return RCV_ERR_UNSUPPORTED;
+    void* p = nullptr;
+    RCV_HIP(hipMalloc(&p, bytes));
+    ctx->cap_allocs[ctx->cap_nallocs++] = p;
+    RCV_HIP(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->side));
+    RCV_HIP(hipStreamSynchronize(ctx->side));
+    *dev = (const uint8_t*)p;
     return RCV_OK;
 }
 
@@ -297,6 +329,7 @@ int stage_begin(Stage* s, rcv_ctx* ctx)
 int stage_in(Stage* s, const rcv_mat* m, bool upload, bool copy_back, rcv_mat** dev_out)
 {
     if (!m || !dev_out) return RCV_ERR_ARG;
+    if (m->device == RCV_HOST && s->ctx->capturing) return RCV_ERR_UNSUPPORTED;   // host staging synchronises: device mats only
     if (s->count >= RCV_MAX_STAGE) return RCV_ERR_ARG;
     rcv_ctx* ctx = s->ctx;
     StagedMat* sm = &s->m[s->count];

@@ -508,8 +508,15 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
 
-    // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered)
-    if (!ctx->f7_valid || ctx->f7_ksize != ksize || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
+    // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered).  While a graph is
+    // being recorded the table goes into a buffer the graph owns, so that replays never depend on this cache.
+    const uint8_t* wtab = ctx->kconst;
+    if (ctx->capturing) {
+        int8_t tab[2 * 4 * 64 * 16];
+        build_wtab(k, ksize, dual ? 0 : 2, tab);
+        if (dual) build_wtab(k, ksize, 1, tab + 4096);
+        RCV_TRY(rcv_const_table(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0, &wtab));
+    } else if (!ctx->f7_valid || ctx->f7_ksize != ksize || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
         int8_t tab[2 * 4 * 64 * 16];
         build_wtab(k, ksize, dual ? 0 : 2, tab);
         if (dual) build_wtab(k, ksize, 1, tab + 4096);
@@ -524,7 +531,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     F7Args a;
     a.src = s.p;
     a.dst = d.p;
-    a.wtab = (const uint4*)ctx->kconst;
+    a.wtab = (const uint4*)wtab;
     a.dump = ctx->kconst + 16384;
     a.sstep = s.step;
     a.dstep = d.step;

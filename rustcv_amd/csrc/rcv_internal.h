@@ -24,7 +24,18 @@ struct rcv_ctx {
     bool f7_valid;
     int f7_ksize;
     int16_t f7_k[49];
+    // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
+    // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
+    bool capturing;
+    hipStream_t side;            // upload stream for graph-owned constants (never captured)
+    void* cap_allocs[64];
+    int cap_nallocs;
 };
+
+// Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the
+// shared 64-KiB kconst area at `offset`, uploaded stream-ordered.  During capture: a fresh device buffer owned by the
+// graph, uploaded immediately on a side stream, so that replays do not depend on later contents of kconst.
+int rcv_const_table(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset, const uint8_t** dev);
 
 // Kernel-facing description of a (batch of) strided image(s).
 struct View {
