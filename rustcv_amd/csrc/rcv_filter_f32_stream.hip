@@ -17,11 +17,13 @@
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
+#include <string.h>
 #include <type_traits>
 #include <utility>
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = 256;
 
 template <int I, int N, class F>
@@ -33,22 +35,44 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
+// Weights travel as kernel arguments and stay in SGPRs, two per 64-bit pair: v_pk_fma_f32 broadcasts either half of the pair
+// to both of its lanes (op_sel / op_sel_hi), so a weight costs one SGPR, not a {w, w} pair (49 pairs would not fit).
 template <int KS, bool SEP>
 struct FWeights {
-    float w[SEP ? KS : KS * KS];
+    f2 w2[((SEP ? KS : KS * KS) + 1) / 2];
     float delta;
 };
 
-template <int KS, int CH, bool SEP>
-__global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows)
+// d = fma({w, w}, x, acc) with w = half HALF of the uniform pair `wp`
+// (`half` is a compile-time constant after unrolling: the branch folds)
+__device__ __forceinline__ f2 pk_fma_w(int half, f2 wp, f2 x, f2 acc)
+{
+    f2 d;
+    if (half == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(acc));
+    return d;
+}
+
+// EDGE = true is the same computation for the few threads per row whose byte window leaves the row: they gather their
+// 2*LEAD+4 window bytes one by one at BORDER_REFLECT_101 positions (offsets fixed per thread, computed once) and then
+// run the identical accumulation code -- so the border columns are bit-identical by construction and cost microseconds
+// (a second launch of the generic per-sample kernel over those columns used to take as long as the main kernel).
+template <int KS, int CH, bool SEP, bool EDGE>
+__global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows, int edge_nl, int edge_nr)
 {
     constexpr int RAD = KS / 2;
     constexpr int LEAD = RAD * CH;                 // bytes of halo on each side of the 4 owned bytes
     constexpr int LEADW = (LEAD + 3) / 4 * 4;      // window starts LEADW bytes before the owned dword
     constexpr int OFF = LEADW - LEAD;              // first needed byte inside the window
     constexpr int NW = (LEADW + 4 + LEAD + 3) / 4; // window dwords
+    constexpr int NB = 2 * LEAD + 4;               // window bytes
+    constexpr int NR = EDGE ? NB : NW;             // registers per staged row
     const int rowbytes = s.cols * CH;
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (EDGE) {
+        if (t >= edge_nl + edge_nr) return;
+        if (t >= edge_nl) t = rowbytes / 4 - edge_nr + (t - edge_nl);
+    }
     const int xb0 = 4 * t;
     if (xb0 >= rowbytes) return;
     const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
@@ -56,62 +80,79 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride + xb0;
     // The window is clamped into the row, so the first/last few threads of a row compute garbage: the host
     // re-does exactly those byte columns with the generic kernel right after this launch (no divergent slow path here).
-    const int wstart = min(max(xb0 - LEADW, 0), rowbytes - 4 * NW);
+    const int wstart = EDGE ? 0 : min(max(xb0 - LEADW, 0), rowbytes - 4 * NW);
+    int goff[EDGE ? NB : 1];                       // EDGE: row byte offset of window byte b (pixel index reflected, channel kept)
+    if (EDGE) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int gi = xb0 - LEAD + b;                              // interleaved sample index, may be < 0 or >= rowbytes
+            const int px = gi >= 0 ? gi / CH : -((-gi + CH - 1) / CH);  // floor
+            goff[b] = rcv_reflect101(px, s.cols) * CH + (gi - px * CH);
+        }
+    }
 
-    auto load_row = [&](int ry, uint32_t (&w)[NW]) __attribute__((always_inline)) {
+    auto load_row = [&](int ry, uint32_t (&w)[NR]) __attribute__((always_inline)) {
         ry = min(ry, ye - 1 + RAD);
         const int r = rcv_reflect101(ry, s.rows);
         const uint8_t* row = sf + (size_t)r * s.step + wstart;
+        if constexpr (EDGE) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+            for (int b = 0; b < NB; ++b) w[b] = row[goff[b]];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+        }
     };
 
-    float acc[KS][4];
+    // The four samples of a thread ride in two packed-f32 pairs (samples 0,1 and 2,3): v_pk_fma_f32 performs two IEEE
+    // fmaf per instruction with the weight broadcast to both halves -- the same per-sample chain as the scalar oracle, at
+    // half the issue cost.  Sample j of tap kx reads p[j + kx*CH]; the pair {p[m], p[m+1]} is formed by the compiler
+    // (v_pk_mov_b32 when m is odd).
+    f2 acc[KS][2];
 #pragma unroll
     for (int i = 0; i < KS; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = SEP ? 0.0f : W.delta;
+        for (int j = 0; j < 2; ++j) acc[i][j] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
 
     // feed row r (r mod KS == RHO, static): contributes kernel row ky to output y = r - ky + RAD, slot y mod KS
-    auto feed = [&](const uint32_t (&w)[NW], int r, auto rho_tag) __attribute__((always_inline)) {
+    auto feed = [&](const uint32_t (&w)[NR], int r, auto rho_tag) __attribute__((always_inline)) {
         constexpr int RHO = decltype(rho_tag)::value;
-        float p[2 * LEAD + 4];
+        float p[NB];
 #pragma unroll
-        for (int b = 0; b < 2 * LEAD + 4; ++b) p[b] = (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
-        float h[4];
+        for (int b = 0; b < NB; ++b) p[b] = EDGE ? (float)w[b] : (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
+        f2 h[2];
         if (SEP) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a = 0.0f;
+            for (int jj = 0; jj < 2; ++jj) {
+                f2 a = {0.0f, 0.0f};
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) a = fmaf(W.w[kx], p[j + kx * CH], a);
-                h[j] = a;
+                for (int kx = 0; kx < KS; ++kx) a = pk_fma_w(kx & 1, W.w2[kx >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, a);
+                h[jj] = a;
             }
         }
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int jj = 0; jj < 2; ++jj) {
                 if (SEP) {
-                    acc[slot][j] = fmaf(W.w[ky], h[j], acc[slot][j]);
+                    acc[slot][jj] = pk_fma_w(ky & 1, W.w2[ky >> 1], h[jj], acc[slot][jj]);
                 } else {
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) acc[slot][j] = fmaf(W.w[ky * KS + kx], p[j + kx * CH], acc[slot][j]);
+                    for (int kx = 0; kx < KS; ++kx)
+                        acc[slot][jj] = pk_fma_w((ky * KS + kx) & 1, W.w2[(ky * KS + kx) >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, acc[slot][jj]);
                 }
             }
         }
         // the output whose last kernel row (ky = KS-1) was just applied: y = r - RAD, slot (RHO + RAD + 1) % KS
         constexpr int done = ((RHO - (KS - 1) + RAD) % KS + KS) % KS;
         const int y = r - RAD;
-        uint32_t o = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = rintf(acc[done][j]);
-            const uint32_t u = v < 0.0f ? 0u : (v > 255.0f ? 255u : (uint32_t)v);
-            o |= u << (8 * j);
-            acc[done][j] = SEP ? 0.0f : W.delta;
-        }
+        // rintf (half to even) gives an exact integer; v_cvt_pk_u8_f32 converts it with saturation to [0, 255] and packs
+        uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][0].x), 0, 0u);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][0].y), 1, o);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][1].x), 2, o);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][1].y), 3, o);
+        acc[done][0] = acc[done][1] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
         if (y >= ys && y < ye) *(uint32_t*)(df + (size_t)y * d.step) = o;
     };
 
@@ -120,14 +161,14 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     // outputs above the segment, which are never stored).
     int r0 = ys - RAD;
     r0 = r0 >= 0 ? r0 / KS * KS : -((-r0 + KS - 1) / KS) * KS;
-    uint32_t cur[NW], nxt[NW];
+    uint32_t cur[NR], nxt[NR];
     load_row(r0, cur);
     for (int rb = r0; rb <= ye - 1 + RAD; rb += KS) {
         static_for<0, KS>([&](auto I) __attribute__((always_inline)) {
             load_row(rb + I + 1, nxt);   // next row in flight while this one is consumed
             feed(cur, rb + I, I);
 #pragma unroll
-            for (int q = 0; q < NW; ++q) cur[q] = nxt[q];
+            for (int q = 0; q < NR; ++q) cur[q] = nxt[q];
         });
     }
 }
@@ -139,24 +180,23 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     const int rowbytes = s.cols * CH;
     if (rowbytes < 4 * NW) return RCV_ERR_UNSUPPORTED;
     FWeights<KS, SEP> W;
-    for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w[i] = w[i];
+    memset(&W, 0, sizeof(W));
+    for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w2[i >> 1][i & 1] = w[i];
     W.delta = delta;
     const unsigned gx = (unsigned)((rowbytes / 4 + kBlock - 1) / kBlock);
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg);
+    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, false>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
-    // byte columns whose window left the row: [0, LEADW) and [rowbytes - (4*NW - LEADW) + 4, rowbytes)
+    // byte columns whose window left the row: [0, LEADW) and [rowbytes - (4*NW - LEADW) + 4, rowbytes) -- redone by the
+    // EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
     const int lo_end = min(LEADW, rowbytes), hi_begin = max(lo_end, rowbytes - (4 * NW - LEADW) + 4);
-    if (SEP) {
-        RCV_TRY(rcv_gauss_f32_generic_range(ctx, s, d, w, KS, 0, lo_end));
-        if (hi_begin < rowbytes) RCV_TRY(rcv_gauss_f32_generic_range(ctx, s, d, w, KS, hi_begin, rowbytes));
-    } else {
-        RCV_TRY(rcv_filter_f32_generic_range(ctx, s, d, w, KS, delta, 0, lo_end));
-        if (hi_begin < rowbytes) RCV_TRY(rcv_filter_f32_generic_range(ctx, s, d, w, KS, delta, hi_begin, rowbytes));
-    }
-    return RCV_OK;
+    const int nl = lo_end / 4, nr = (rowbytes - hi_begin) / 4;
+    const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
+    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, true>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
+                       dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr);
+    return rcv_launch_check(ctx);
 }
 
 template <bool SEP>
