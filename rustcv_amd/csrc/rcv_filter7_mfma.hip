@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // Their 18 bytes lie in the 32 bytes at row offset 3*x0 + 752; every wave fetches them for all 16 rows as one
     // dwordx2 per lane (row lane>>2, piece lane&3) -- unconditional like all VMEM here; wave 0 then plants them.
     const bool fullstrip = ntiles == kTiles;
+    const int wave0 = (__builtin_amdgcn_readfirstlane(wave) == 0 && fullstrip) ? 1 : 0;   // scalar
     const int er = lane >> 2, ep = lane & 3;
     const int eoff = min(max((SRC == 1 ? 2 * x0 + 504 : 3 * x0 + 752) + 8 * ep, 0), rowbytes - 8);
     const bool lastfull = fullstrip && x0 + 256 == a.cols;   // right image border inside the halo piece
@@ -172,10 +173,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             for (int i = 0; i < 15; ++i) L[i] = 0;
             return;
         }
-        {
+        // Only wave 0 plants the halo piece.  The load has to stay unconditional (a branch around it, even a scalar one,
+        // collapses the counted vmcnt waits), so the other waves fetch one fixed, always-cached 8 bytes instead: the
+        // piece is 16 scattered row lines per wave instruction, and with all four waves fetching it the loads-only rate
+        // of the kernel was 5.0 TB/s against 5.7 without it.
+        if (DBG & 32) {
+            L[13] = L[14] = 0;
+        } else {
             const int rye = min(ys - 3 + 16 * b + er, ry_last);
             const int erow = rye < 0 ? -rye : (rye >= a.rows ? 2 * a.rows - 2 - rye : rye);
-            const U2 e = *(const U2*)(sframe + (__umul24((unsigned)erow, sstep24) + (unsigned)eoff));
+            const U2 e = *(const U2*)(sframe + (wave0 ? __umul24((unsigned)erow, sstep24) + (unsigned)eoff : 0u));
             L[13] = e.a;
             L[14] = e.b;
         }
@@ -190,6 +197,13 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             L[6] = v2.a; L[7] = v2.b; L[8] = v2.c;
             L[9] = L[10] = L[11] = L[12] = 0;
         } else {
+            if (DBG & 64) {   // ablation: three aligned 16-byte vectors per lane (no shifted, overlapping window)
+                const int oa = min(max(soff0 + 16, 0), hi);
+                const uint4 a0 = *(const uint4*)(p + oa), a1 = *(const uint4*)(p + min(oa + 16, hi)), a2 = *(const uint4*)(p + min(oa + 32, hi));
+                L[0] = a0.x; L[1] = a0.y; L[2] = a0.z; L[3] = a0.w; L[4] = a1.x; L[5] = a1.y; L[6] = a1.z; L[7] = a1.w;
+                L[8] = a2.x; L[9] = a2.y; L[10] = a2.z; L[11] = a2.w; L[12] = a2.w;
+                return;
+            }
             const U3 v0 = *(const U3*)(p + o0);
             const uint4 v1 = *(const uint4*)(p + o1);
             const uint4 v2 = *(const uint4*)(p + o2);
@@ -582,7 +596,13 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
-    switch (rcv_debug_flags & 31) {
+    switch (rcv_debug_flags & 127) {
+    case 5 + 32: hipLaunchKernelGGL((k_filter7_mfma<5 + 32, false>), grid, block, 0, ctx->stream, a); break;
+    case 5 + 64: hipLaunchKernelGGL((k_filter7_mfma<5 + 64, false>), grid, block, 0, ctx->stream, a); break;
+    case 5 + 96: hipLaunchKernelGGL((k_filter7_mfma<5 + 96, false>), grid, block, 0, ctx->stream, a); break;
+    case 4 + 32: hipLaunchKernelGGL((k_filter7_mfma<4 + 32, false>), grid, block, 0, ctx->stream, a); break;
+    case 4 + 96: hipLaunchKernelGGL((k_filter7_mfma<4 + 96, false>), grid, block, 0, ctx->stream, a); break;
+    case 96: hipLaunchKernelGGL((k_filter7_mfma<96, false>), grid, block, 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL((k_filter7_mfma<8, false>), grid, block, 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL((k_filter7_mfma<16, false>), grid, block, 0, ctx->stream, a); break;
     case 24: hipLaunchKernelGGL((k_filter7_mfma<24, false>), grid, block, 0, ctx->stream, a); break;
