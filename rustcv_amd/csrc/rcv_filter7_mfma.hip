@@ -57,6 +57,7 @@ constexpr int kPitch = 288;           // bytes per planar row in LDS: 18 x 16 B.
                                       // distinct slots: conflict-free (272 B measured 46 % conflict cycles).
 constexpr int kSlots = 48;            // ring of 3 blocks x 16 rows
 constexpr int kPlane = kSlots * kPitch;
+constexpr int kLregs = 17;            // staging registers per block: 12 chunk dwords, 3 left-halo dwords, 2 halo-piece dwords
 constexpr int kOutWave = 16 * 192;    // per-wave output transpose buffer: 16 rows x 4 tiles x 48 B, unpadded; the 16-B
                                       // chunks of row n are rotated by n>>2 (mod 12): dword writes and b128 reads <= 2-way
 
@@ -137,20 +138,21 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     }
 
     // ---- staging task of this thread: (row sr of a block, 16-pixel chunk sq of the strip) ----
-    // The chunk's 16 pixels are image x = x0 - 3 + 16q .. +15: bytes [7, 55) of the four 16-B vectors that
-    // start at row byte 3*x0 + 48q - 16.  Only dwords 1..13 of those 64 bytes are needed -> 13 VGPRs.
+    // The chunk's 16 pixels are image x = x0 - 3 + 16q .. +15, i.e. the 48 row bytes starting 9 bytes BEFORE the lane's own
+    // aligned 48 bytes (row byte 3*x0 + 48q).  BGR source: the lane loads exactly its own 48 bytes as three aligned 16-byte
+    // vectors -- no lane re-reads its neighbour's bytes -- and takes the 9 bytes in front from the previous lane's last three
+    // dwords with DPP row_shr:1; lane 0 of a row (sq == 0) has no such neighbour and fetches the 12 bytes in front of the
+    // strip itself (one dwordx3; every other lane of that instruction reads one fixed cached address).  Shifted, mutually
+    // overlapping 52-byte windows per lane measured 5 % slower end to end (loads-only 5.2 vs 6.0 TB/s).
     // EVERY load below is unconditional (no branch may enclose a VMEM op in the main loop, otherwise the
     // compiler can only wait with vmcnt(0) and the register prefetch pipeline collapses): vectors that fall
     // outside the row are clamped into it -- their bytes are either reflected halo (patched in registers
     // below) or multiplied by zero weights -- and rows past the segment re-read its last row (cache hits).
     const int sr = tid >> 4, sq = tid & 15;
     // (YUYV source: the 16 pixels + 1 on each side are the 9 macropixels = 36 bytes at row byte 2*x0 - 8 + 32q.)
-    const int soff0 = SRC == 1 ? 2 * x0 + 32 * sq - 8 : 3 * x0 + 48 * sq - 16;
     const int hi = rowbytes - 16;
-    const int o0 = SRC == 1 ? min(max(soff0, 0), rowbytes - 8) : min(max(soff0, 0), hi) + 4;
-    const int o1 = SRC == 1 ? min(max(soff0 + 8, 0), hi) : min(max(soff0 + 16, 0), hi);
-    const int o2 = SRC == 1 ? min(max(soff0 + 24, 0), rowbytes - 12) : min(max(soff0 + 32, 0), hi);
-    const int o3 = min(max(soff0 + 48, 0), hi);
+    const int soff0 = 2 * x0 + 32 * sq - 8;             // YUYV window start
+    const int o0 = min(max(soff0, 0), rowbytes - 8), o1 = min(max(soff0 + 8, 0), hi), o2 = min(max(soff0 + 24, 0), rowbytes - 12);
     const int xa = x0 - 3 + 16 * sq;                    // image x of the chunk's first pixel
     const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
     const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
@@ -164,13 +166,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int eoff = min(max((SRC == 1 ? 2 * x0 + 504 : 3 * x0 + 752) + 8 * ep, 0), rowbytes - 8);
     const bool lastfull = fullstrip && x0 + 256 == a.cols;   // right image border inside the halo piece
 
-    auto load_block = [&](int b, uint32_t (&L)[15]) {
+    const unsigned oa0 = (unsigned)min(3 * x0 + 48 * sq, hi), oa1 = (unsigned)min(3 * x0 + 48 * sq + 16, hi), oa2 = (unsigned)min(3 * x0 + 48 * sq + 32, hi);
+    const unsigned olh = (unsigned)max(3 * x0 - 12, 0);   // the 12 bytes in front of the strip (first strip: unused, x = -3..-1 are reflected)
+
+    auto load_block = [&](int b, uint32_t (&L)[kLregs]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
         const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
         const uint8_t* p = sframe + __umul24((unsigned)srow, sstep24);   // frame bytes < 2^32, step < 2^24 (host check)
         if (DBG & 2) {
 #pragma unroll
-            for (int i = 0; i < 15; ++i) L[i] = 0;
+            for (int i = 0; i < kLregs; ++i) L[i] = 0;
             return;
         }
         // Only wave 0 plants the halo piece.  The load has to stay unconditional (a branch around it, even a scalar one,
@@ -178,13 +183,13 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // piece is 16 scattered row lines per wave instruction, and with all four waves fetching it the loads-only rate
         // of the kernel was 5.0 TB/s against 5.7 without it.
         if (DBG & 32) {
-            L[13] = L[14] = 0;
+            L[15] = L[16] = 0;
         } else {
             const int rye = min(ys - 3 + 16 * b + er, ry_last);
             const int erow = rye < 0 ? -rye : (rye >= a.rows ? 2 * a.rows - 2 - rye : rye);
             const U2 e = *(const U2*)(sframe + (wave0 ? __umul24((unsigned)erow, sstep24) + (unsigned)eoff : 0u));
-            L[13] = e.a;
-            L[14] = e.b;
+            L[15] = e.a;
+            L[16] = e.b;
         }
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
@@ -195,23 +200,17 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             L[0] = v0.a; L[1] = v0.b;
             L[2] = v1.x; L[3] = v1.y; L[4] = v1.z; L[5] = v1.w;
             L[6] = v2.a; L[7] = v2.b; L[8] = v2.c;
-            L[9] = L[10] = L[11] = L[12] = 0;
+            L[9] = L[10] = L[11] = L[12] = L[13] = L[14] = 0;
         } else {
-            if (DBG & 64) {   // ablation: three aligned 16-byte vectors per lane (no shifted, overlapping window)
-                const int oa = min(max(soff0 + 16, 0), hi);
-                const uint4 a0 = *(const uint4*)(p + oa), a1 = *(const uint4*)(p + min(oa + 16, hi)), a2 = *(const uint4*)(p + min(oa + 32, hi));
-                L[0] = a0.x; L[1] = a0.y; L[2] = a0.z; L[3] = a0.w; L[4] = a1.x; L[5] = a1.y; L[6] = a1.z; L[7] = a1.w;
-                L[8] = a2.x; L[9] = a2.y; L[10] = a2.z; L[11] = a2.w; L[12] = a2.w;
-                return;
-            }
-            const U3 v0 = *(const U3*)(p + o0);
-            const uint4 v1 = *(const uint4*)(p + o1);
-            const uint4 v2 = *(const uint4*)(p + o2);
-            const U2 v3 = *(const U2*)(p + o3);
-            L[0] = v0.a; L[1] = v0.b; L[2] = v0.c;
-            L[3] = v1.x; L[4] = v1.y; L[5] = v1.z; L[6] = v1.w;
-            L[7] = v2.x; L[8] = v2.y; L[9] = v2.z; L[10] = v2.w;
-            L[11] = v3.a; L[12] = v3.b;
+            const unsigned ro = __umul24((unsigned)srow, sstep24);
+            const uint4 v0 = *(const uint4*)(sframe + (ro + oa0));
+            const uint4 v1 = *(const uint4*)(sframe + (ro + oa1));
+            const uint4 v2 = *(const uint4*)(sframe + (ro + oa2));
+            const U3 lh = *(const U3*)(sframe + (sq == 0 ? ro + olh : 0u));
+            L[0] = v0.x; L[1] = v0.y; L[2] = v0.z; L[3] = v0.w;
+            L[4] = v1.x; L[5] = v1.y; L[6] = v1.z; L[7] = v1.w;
+            L[8] = v2.x; L[9] = v2.y; L[10] = v2.z; L[11] = v2.w;
+            L[12] = lh.a; L[13] = lh.b; L[14] = lh.c;
         }
     };
 
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         o[3] = c1 + db; o[4] = c1 + dg; o[5] = c1 + dr;
     };
 
-    auto store_block = [&](int b, const uint32_t (&L)[15]) {
+    auto store_block = [&](int b, const uint32_t (&L)[kLregs]) {
         if (fullstrip && wave == 0) {
             // halo piece, all in registers: the four lanes of a row hold bytes [0,32) of the piece; dwords 1..6 (bytes
             // 4..27) are exactly the 8 pixels x0+252 .. x0+259.  Lane ep==0 collects them from its quad with DPP
@@ -232,11 +231,11 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             uint32_t g1[3], g2[3];
             if constexpr (SRC == 1) {
                 // YUYV: lanes ep = 0, 1 of the quad hold macropixels (252,253)(254,255) | (256,257)(258,259)
-                const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
-                const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
+                const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
+                const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
                 int q[24];
-                mp_sums(L[13], q);
-                mp_sums(L[14], q + 6);
+                mp_sums(L[15], q);
+                mp_sums(L[16], q + 6);
                 mp_sums(m2, q + 12);
                 mp_sums(m3, q + 18);
 #pragma unroll
@@ -245,12 +244,12 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                     g2[c] = rcv_ashr_sat_pk4(q[12 + c], q[15 + c], q[18 + c], q[21 + c], 8);
                 }
             } else {
-                const uint32_t w1 = L[14];
-                const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[13], 0x101, 0xf, 0xf, false);
-                const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[14], 0x101, 0xf, 0xf, false);
-                const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[13], 0x102, 0xf, 0xf, false);
-                const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[14], 0x102, 0xf, 0xf, false);
-                const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[13], 0x103, 0xf, 0xf, false);
+                const uint32_t w1 = L[16];
+                const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
+                const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
+                const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[15], 0x102, 0xf, 0xf, false);
+                const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[16], 0x102, 0xf, 0xf, false);
+                const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[15], 0x103, 0xf, 0xf, false);
                 deint4(w1, w2, w3, g1[0], g1[1], g1[2]);   // pixels x0+252 .. 255
                 deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
             }
@@ -284,9 +283,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { pb[i] = L[i]; pg[i] = L[4 + i]; pr[i] = L[8 + i]; }
             } else {
-                uint32_t s[12];
+                // the previous lane's dwords 9..11 (its last 12 bytes); lane 0 of each row keeps `old` = its own left-halo load
+                const uint32_t pv0 = __builtin_amdgcn_update_dpp(L[12], L[9], 0x111, 0xf, 0xf, false);
+                const uint32_t pv1 = __builtin_amdgcn_update_dpp(L[13], L[10], 0x111, 0xf, 0xf, false);
+                const uint32_t pv2 = __builtin_amdgcn_update_dpp(L[14], L[11], 0x111, 0xf, 0xf, false);
+                uint32_t s[12];   // s[i] = bytes [4i - 9, 4i - 5) relative to the lane's own 48 bytes
+                s[0] = __builtin_amdgcn_alignbyte(pv1, pv0, 3);
+                s[1] = __builtin_amdgcn_alignbyte(pv2, pv1, 3);
+                s[2] = __builtin_amdgcn_alignbyte(L[0], pv2, 3);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i + 1], L[i], 3);  // bytes [7+4i, 11+4i) of the 64
+                for (int i = 3; i < 12; ++i) s[i] = __builtin_amdgcn_alignbyte(L[i - 2], L[i - 3], 3);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) deint4(s[3 * i], s[3 * i + 1], s[3 * i + 2], pb[i], pg[i], pr[i]);
             }
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // ---- software pipeline: block k+3 is in flight in registers and block k+2 is written to the LDS ring while
     // step k computes from blocks k, k+1.  Blocks 0..nsteps are needed; loads past that are harmless re-reads.
     // Two register sets, loop unrolled by two so that the set index is static. ----
-    uint32_t LA[15], LB[15];
+    uint32_t LA[kLregs], LB[kLregs];
     load_block(0, LA);
     load_block(1, LB);
     store_block(0, LA);
@@ -598,11 +604,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
     switch (rcv_debug_flags & 127) {
     case 5 + 32: hipLaunchKernelGGL((k_filter7_mfma<5 + 32, false>), grid, block, 0, ctx->stream, a); break;
-    case 5 + 64: hipLaunchKernelGGL((k_filter7_mfma<5 + 64, false>), grid, block, 0, ctx->stream, a); break;
-    case 5 + 96: hipLaunchKernelGGL((k_filter7_mfma<5 + 96, false>), grid, block, 0, ctx->stream, a); break;
     case 4 + 32: hipLaunchKernelGGL((k_filter7_mfma<4 + 32, false>), grid, block, 0, ctx->stream, a); break;
-    case 4 + 96: hipLaunchKernelGGL((k_filter7_mfma<4 + 96, false>), grid, block, 0, ctx->stream, a); break;
-    case 96: hipLaunchKernelGGL((k_filter7_mfma<96, false>), grid, block, 0, ctx->stream, a); break;
     case 8: hipLaunchKernelGGL((k_filter7_mfma<8, false>), grid, block, 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL((k_filter7_mfma<16, false>), grid, block, 0, ctx->stream, a); break;
     case 24: hipLaunchKernelGGL((k_filter7_mfma<24, false>), grid, block, 0, ctx->stream, a); break;
