@@ -168,6 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 
     const unsigned oa0 = (unsigned)min(3 * x0 + 48 * sq, hi), oa1 = (unsigned)min(3 * x0 + 48 * sq + 16, hi), oa2 = (unsigned)min(3 * x0 + 48 * sq + 32, hi);
     const unsigned olh = (unsigned)max(3 * x0 - 12, 0);   // the 12 bytes in front of the strip (first strip: unused, x = -3..-1 are reflected)
+    const unsigned orh = (unsigned)min(3 * x0 + 768, rowbytes - 12);   // the 12 bytes behind a full strip (last strip: unused, mirrored)
 
     auto load_block = [&](int b, uint32_t (&L)[kLregs]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
@@ -178,18 +179,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             for (int i = 0; i < kLregs; ++i) L[i] = 0;
             return;
         }
-        // Only wave 0 plants the halo piece.  The load has to stay unconditional (a branch around it, even a scalar one,
-        // collapses the counted vmcnt waits), so the other waves fetch one fixed, always-cached 8 bytes instead: the
-        // piece is 16 scattered row lines per wave instruction, and with all four waves fetching it the loads-only rate
-        // of the kernel was 5.0 TB/s against 5.7 without it.
-        if (DBG & 32) {
-            L[15] = L[16] = 0;
-        } else {
+        // YUYV source: only wave 0 plants the halo piece.  The load has to stay unconditional (a branch around it, even a
+        // scalar one, collapses the counted vmcnt waits), so the other waves fetch one fixed, always-cached 8 bytes instead.
+        if constexpr (SRC == 1) {
             const int rye = min(ys - 3 + 16 * b + er, ry_last);
             const int erow = rye < 0 ? -rye : (rye >= a.rows ? 2 * a.rows - 2 - rye : rye);
             const U2 e = *(const U2*)(sframe + (wave0 ? __umul24((unsigned)erow, sstep24) + (unsigned)eoff : 0u));
             L[15] = e.a;
             L[16] = e.b;
+        } else {
+            L[15] = L[16] = 0;
         }
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
@@ -206,7 +205,9 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             const uint4 v0 = *(const uint4*)(sframe + (ro + oa0));
             const uint4 v1 = *(const uint4*)(sframe + (ro + oa1));
             const uint4 v2 = *(const uint4*)(sframe + (ro + oa2));
-            const U3 lh = *(const U3*)(sframe + (sq == 0 ? ro + olh : 0u));
+            // side load: lane 0 of a row fetches the 12 bytes in front of the strip, lane 15 the 12 bytes behind it (the
+            // right halo piece), every other lane one fixed cached address
+            const U3 lh = *(const U3*)(sframe + (sq == 0 ? ro + olh : (sq == 15 ? ro + orh : 0u)));
             L[0] = v0.x; L[1] = v0.y; L[2] = v0.z; L[3] = v0.w;
             L[4] = v1.x; L[5] = v1.y; L[6] = v1.z; L[7] = v1.w;
             L[8] = v2.x; L[9] = v2.y; L[10] = v2.z; L[11] = v2.w;
@@ -224,34 +225,40 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     };
 
     auto store_block = [&](int b, const uint32_t (&L)[kLregs]) {
-        if (fullstrip && wave == 0) {
-            // halo piece, all in registers: the four lanes of a row hold bytes [0,32) of the piece; dwords 1..6 (bytes
-            // 4..27) are exactly the 8 pixels x0+252 .. x0+259.  Lane ep==0 collects them from its quad with DPP
-            // row_shl, de-interleaves, and plants x0+253..x0+258 at xx = 256..261 (mirrored at the right image border).
-            uint32_t g1[3], g2[3];
-            if constexpr (SRC == 1) {
-                // YUYV: lanes ep = 0, 1 of the quad hold macropixels (252,253)(254,255) | (256,257)(258,259)
-                const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
-                const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
-                int q[24];
-                mp_sums(L[15], q);
-                mp_sums(L[16], q + 6);
-                mp_sums(m2, q + 12);
-                mp_sums(m3, q + 18);
+        // ---- halo piece: the 6 pixels x0+253 .. x0+258 right of the strip's 16 chunks, planted at xx = 256..261 ----
+        if constexpr (SRC == 0) {
+            // The last lane of each row (sq == 15) holds pixels x0+252..255 in its own dwords 9..11 and has fetched the 12
+            // bytes behind the strip (pixels x0+256..259) with the side load: two de-interleaves, no extra traffic.
+            if (fullstrip && sq == 15 && ys - 3 + 16 * b + sr <= ry_last) {   // (no VMEM inside: LDS ops may be conditional)
+                uint32_t g1[3], g2[3];
+                deint4(L[9], L[10], L[11], g1[0], g1[1], g1[2]);     // pixels x0+252 .. 255
+                deint4(L[12], L[13], L[14], g2[0], g2[1], g2[2]);    // pixels x0+256 .. 259
+                const int hslot = 16 * (b % 3) + sr;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    g1[c] = rcv_ashr_sat_pk4(q[c], q[3 + c], q[6 + c], q[9 + c], 8);
-                    g2[c] = rcv_ashr_sat_pk4(q[12 + c], q[15 + c], q[18 + c], q[21 + c], 8);
+                    const uint32_t lo = lastfull ? __builtin_amdgcn_perm(g1[c], g1[c], 0x02030201u)   // 253 254 255 | 254
+                                                 : __builtin_amdgcn_perm(g2[c], g1[c], 0x04030201u);  // 253 254 255 | 256
+                    const uint32_t hi = lastfull ? __builtin_amdgcn_perm(g1[c], g1[c], 0x0c0c0001u)   // 253 252
+                                                 : (g2[c] >> 8);                                      // 257 258
+                    *(U2*)(lds + c * kPlane + hslot * kPitch + 256) = U2{lo ^ 0x80808080u, hi ^ 0x80808080u};
                 }
-            } else {
-                const uint32_t w1 = L[16];
-                const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
-                const uint32_t w3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
-                const uint32_t w4 = __builtin_amdgcn_update_dpp(0u, L[15], 0x102, 0xf, 0xf, false);
-                const uint32_t w5 = __builtin_amdgcn_update_dpp(0u, L[16], 0x102, 0xf, 0xf, false);
-                const uint32_t w6 = __builtin_amdgcn_update_dpp(0u, L[15], 0x103, 0xf, 0xf, false);
-                deint4(w1, w2, w3, g1[0], g1[1], g1[2]);   // pixels x0+252 .. 255
-                deint4(w4, w5, w6, g2[0], g2[1], g2[2]);   // pixels x0+256 .. 259
+            }
+        } else if (fullstrip && wave == 0) {
+            // YUYV source (wave 0 only): the four lanes of a row hold bytes [0,32) of the piece; lanes ep = 0, 1 of the quad
+            // hold macropixels (252,253)(254,255) | (256,257)(258,259).  Lane ep == 0 collects them with DPP row_shl,
+            // converts, and plants them (mirrored at the right image border).
+            uint32_t g1[3], g2[3];
+            const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
+            const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
+            int q[24];
+            mp_sums(L[15], q);
+            mp_sums(L[16], q + 6);
+            mp_sums(m2, q + 12);
+            mp_sums(m3, q + 18);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                g1[c] = rcv_ashr_sat_pk4(q[c], q[3 + c], q[6 + c], q[9 + c], 8);
+                g2[c] = rcv_ashr_sat_pk4(q[12 + c], q[15 + c], q[18 + c], q[21 + c], 8);
             }
             if (ep == 0 && ys - 3 + 16 * b + er <= ry_last) {
                 const int hslot = 16 * (b % 3) + er;   // ring slot of source row 16b + er (the block base is scalar)
@@ -602,9 +609,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
-    switch (rcv_debug_flags & 127) {
-    case 5 + 32: hipLaunchKernelGGL((k_filter7_mfma<5 + 32, false>), grid, block, 0, ctx->stream, a); break;
-    case 4 + 32: hipLaunchKernelGGL((k_filter7_mfma<4 + 32, false>), grid, block, 0, ctx->stream, a); break;
+    switch (rcv_debug_flags & 31) {
     case 8: hipLaunchKernelGGL((k_filter7_mfma<8, false>), grid, block, 0, ctx->stream, a); break;
     case 16: hipLaunchKernelGGL((k_filter7_mfma<16, false>), grid, block, 0, ctx->stream, a); break;
     case 24: hipLaunchKernelGGL((k_filter7_mfma<24, false>), grid, block, 0, ctx->stream, a); break;
