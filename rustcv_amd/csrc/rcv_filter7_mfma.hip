@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // 48 MFMAs per step (4 tiles x 4 row-pairs x 3 planes), B operands read kAhead items ahead into a
         // static register ring so LDS latency is covered inside the wave; the three planes' accumulators are
         // interleaved so dependent MFMAs sit three issues apart.
-        constexpr int kAhead = 9;
+        constexpr int kAhead = DUAL ? 5 : 9;   // (the dual-table kernel carries 28 more registers: a shorter read-ahead keeps it at 3 waves per SIMD)
         v4i Bq[kAhead];
         // p == 3 pairs kernel row 6 with the non-existent row 7: the upper 32 lanes (kyl == 1) would read pixels that
         // only meet zero weights, so they skip the LDS read (half the LDS cycles of that instruction).
