@@ -231,10 +231,20 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     a.rows = s.rows;
     a.cols = s.cols;
     a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
-    // row segments: whole rounds of the 3-waves-per-SIMD residency (12 waves per CU), >= 2 rounds, segments >= 64 rows
+    // row segments: whole rounds of the kernel's residency (register-limited; asked from the runtime once), >= 2 rounds,
+    // segments >= 64 rows
     int seg = s.rows;
     {
-        const long long slots = 12LL * ctx->cu_count, per_seg = (long long)a.nstrips * s.n;
+        static int waves_per_cu[2] = {0, 0};
+        int& wpc = waves_per_cu[resp ? 1 : 0];
+        if (wpc == 0) {
+            int nb = 0;
+            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false>, 256, 0);
+            wpc = (e == hipSuccess && nb > 0) ? 4 * nb : 8;
+            (void)hipGetLastError();
+        }
+        const long long slots = (long long)wpc * ctx->cu_count, per_seg = (long long)a.nstrips * s.n;
         double best = 1e30;
         for (int ns = 1; ns <= 64; ++ns) {
             const int sr = (s.rows + ns - 1) / ns;
