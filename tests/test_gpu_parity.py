@@ -640,6 +640,53 @@ def test_harris_fused_path(ctx, oracle, rows, cols, want_resp):
         b.free()
 
 
+def test_baseline_configs_at_full_size(ctx, oracle):
+    """one or two frames of every BASELINE.json configuration that has no full-size test of its own, bit for bit against the
+    oracle: config 1 (640x480 YUYV -> BGR + rectangle), config 2 (1080p 5x5 Gaussian), config 3's Sobel on 4K gray,
+    config 5 (4K Harris pipeline with the response).  Full sizes exercise every strip/segment seam and the partial last strip."""
+    # config 1
+    y = device.DeviceBatch(ctx, 2, 480, 640, 2)
+    b = device.DeviceBatch(ctx, 2, 480, 640, 3)
+    device.synth(y, 2, 0x5EED0001, 0)
+    device.cvt_color(y, b, _ffi.RCV_YUYV2BGR)
+    device.rectangle(b, imgproc.Rect(200, 150, 240, 240), imgproc.Scalar(0, 255, 0), 2)
+    fy, fb = y.download(), b.download()
+    for i in range(2):
+        want = np.zeros(480 * 640 * 3, np.uint8)
+        assert oracle.yuyv_to_bgr(fy[i].reshape(-1), want, 640, 480)
+        oracle.rectangle(want, 480, 640, 640 * 3, 200, 150, 240, 240, 0, 255, 0, 2)
+        assert np.array_equal(fb[i].reshape(-1), want)
+    y.free(); b.free()
+    # config 2
+    s = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
+    d = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
+    device.synth(s, 1, 0x5EED0002, 0)
+    device.gaussian_blur(s, d, 5, 0.0)
+    assert np.array_equal(d.download()[0], oracle.gaussian_blur(s.download()[0], 5, 0.0))
+    s.free(); d.free()
+    # config 3 (second half) and config 5 on one 4K frame
+    s = device.DeviceBatch(ctx, 1, 2160, 3840, 3)
+    g = device.DeviceBatch(ctx, 1, 2160, 3840, 1)
+    dx = device.DeviceBatch(ctx, 1, 2160, 3840, 1, _ffi.RCV_16S)
+    dy = device.DeviceBatch(ctx, 1, 2160, 3840, 1, _ffi.RCV_16S)
+    m = device.DeviceBatch(ctx, 1, 2160, 3840, 1)
+    r = device.DeviceBatch(ctx, 1, 2160, 3840, 1, _ffi.RCV_32F)
+    device.synth(s, 1, 0x5EED0005, 0)
+    device.cvt_color(s, g, _ffi.RCV_BGR2GRAY)
+    device.sobel(g, dx, dy)
+    device.harris_pipeline(s, m, r, 2, 0.04, 1e-4)
+    frame = s.download()[0]
+    gray = oracle.bgr2gray(frame)
+    assert np.array_equal(g.download()[0], gray)
+    wx, wy = oracle.sobel(gray)
+    assert np.array_equal(dx.download()[0], wx) and np.array_equal(dy.download()[0], wy)
+    wm, wr = oracle.harris_pipeline(frame, 2, 0.04, 1e-4, True)
+    assert np.array_equal(r.download()[0].view(np.uint32), wr.view(np.uint32))
+    assert np.array_equal(m.download()[0], wm) and wm.any()
+    for x in (s, g, dx, dy, m, r):
+        x.free()
+
+
 # ---- synthetic frames + device-resident batches -------------------------------------------------------
 
 @pytest.mark.parametrize("family,ch", [(0, 1), (0, 3), (0, 4), (1, 3), (1, 1)])
