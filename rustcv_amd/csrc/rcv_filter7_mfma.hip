@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int sr = tid >> 4, sq = tid & 15;
     // (YUYV source: the 16 pixels + 1 on each side are the 9 macropixels = 36 bytes at row byte 2*x0 - 8 + 32q.)
     const int hi = rowbytes - 16;
-    const int soff0 = 2 * x0 + 32 * sq - 8;             // YUYV window start
-    const int o0 = min(max(soff0, 0), rowbytes - 8), o1 = min(max(soff0 + 8, 0), hi), o2 = min(max(soff0 + 24, 0), rowbytes - 12);
+    const unsigned ya0 = (unsigned)min(2 * x0 + 32 * sq, hi), ya1 = (unsigned)min(2 * x0 + 32 * sq + 16, hi);   // YUYV: own 32 bytes
+    const unsigned ylh = (unsigned)max(2 * x0 - 8, 0);                                                            // YUYV: 8 bytes in front of the strip
     const int xa = x0 - 3 + 16 * sq;                    // image x of the chunk's first pixel
     const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
     const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     auto load_block = [&](int b, uint32_t (&L)[kLregs]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
         const int srow = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-        const uint8_t* p = sframe + __umul24((unsigned)srow, sstep24);   // frame bytes < 2^32, step < 2^24 (host check)
+        const unsigned ro = __umul24((unsigned)srow, sstep24);   // row offset: frame bytes < 2^32, step < 2^24 (host check)
         if (DBG & 2) {
 #pragma unroll
             for (int i = 0; i < kLregs; ++i) L[i] = 0;
@@ -193,15 +193,16 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         // (plain loads: the four vectors of neighbouring lanes share 128-B lines, and non-temporal loads lose
         //  that L1/L2 reuse -- measured 0.77 -> 1.03 ms)
         if constexpr (SRC == 1) {
-            const U2 v0 = *(const U2*)(p + o0);
-            const uint4 v1 = *(const uint4*)(p + o1);
-            const U3 v2 = *(const U3*)(p + o2);
-            L[0] = v0.a; L[1] = v0.b;
-            L[2] = v1.x; L[3] = v1.y; L[4] = v1.z; L[5] = v1.w;
-            L[6] = v2.a; L[7] = v2.b; L[8] = v2.c;
-            L[9] = L[10] = L[11] = L[12] = L[13] = L[14] = 0;
+            // YUYV: the lane's own 16 pixels are 8 macropixels = two aligned 16-byte vectors; the two macropixels in front
+            // (pixels -4..-1 of the chunk) come from the previous lane by DPP, for lane 0 of a row from a side load
+            const uint4 v0 = *(const uint4*)(sframe + (ro + ya0));
+            const uint4 v1 = *(const uint4*)(sframe + (ro + ya1));
+            const U2 lh = *(const U2*)(sframe + (sq == 0 ? ro + ylh : 0u));
+            L[0] = v0.x; L[1] = v0.y; L[2] = v0.z; L[3] = v0.w;
+            L[4] = v1.x; L[5] = v1.y; L[6] = v1.z; L[7] = v1.w;
+            L[8] = L[9] = L[10] = L[11] = L[14] = 0;
+            L[12] = lh.a; L[13] = lh.b;
         } else {
-            const unsigned ro = __umul24((unsigned)srow, sstep24);
             const uint4 v0 = *(const uint4*)(sframe + (ro + oa0));
             const uint4 v1 = *(const uint4*)(sframe + (ro + oa1));
             const uint4 v2 = *(const uint4*)(sframe + (ro + oa2));
@@ -274,10 +275,15 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         }
         uint32_t pb[4], pg[4], pr[4];
         if constexpr (SRC == 1) {
-            // 9 macropixels = pixels x0-4+16q .. x0+13+16q; the chunk is pixels 1..16 of those 18
+            // 9 macropixels = pixels x0-4+16q .. x0+13+16q (two from the previous lane, seven of the lane's own eight); the
+            // chunk is pixels 1..16 of those 18
+            const uint32_t pm0 = __builtin_amdgcn_update_dpp(L[12], L[6], 0x111, 0xf, 0xf, false);
+            const uint32_t pm1 = __builtin_amdgcn_update_dpp(L[13], L[7], 0x111, 0xf, 0xf, false);
             int q[54];
+            mp_sums(pm0, q);
+            mp_sums(pm1, q + 6);
 #pragma unroll
-            for (int m = 0; m < 9; ++m) mp_sums(L[m], q + 6 * m);
+            for (int m = 2; m < 9; ++m) mp_sums(L[m - 2], q + 6 * m);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = 3 * (1 + 4 * i);
