@@ -20,20 +20,21 @@
 //     SEGMENT, and walks down it in 16-row steps; each source row is fetched from HBM once per strip (halo: 6 px per
 //     256, 6 rows per segment).  Widths that are a multiple of 240 but not of 256 use 15-tile strips (balanced
 //     workgroups beat aligned seams there);
-//   * staging: lane (row r, chunk q) loads the 64 contiguous bytes that contain its 16 pixels shifted by the 3-pixel
-//     halo, realigns them with v_alignbyte, de-interleaves BGR -> three planar dwords x4 with v_perm, xors 0x80 and
-//     writes one ds_write_b128 per plane.  Planar rows live in a 48-slot ring (3 blocks of 16 rows) with a 288-byte
-//     pitch (conflict-free ds_read_b128); block k+3 is in flight in registers and block k+2 is written to the ring
-//     while step k is computed, one barrier per step;
-//   * the 6 pixels right of the strip's 16 chunks (the "halo piece") are fetched by one extra 8-byte load per lane and
-//     planted by wave 0 with DPP + v_perm, all in registers;
+//   * staging: lane (row r, chunk q) loads its own aligned 48 bytes (16 pixels) as three 16-byte vectors; the chunk it
+//     stages is shifted by the 3-pixel halo, so the 9 bytes in front come from the previous lane's last dwords by DPP
+//     row_shr:1 (lane 0 / lane 15 of a row fetch the 12 bytes in front of / behind the strip with one shared side load).
+//     v_alignbyte realigns, v_perm de-interleaves BGR -> three planar dwords x4, xor 0x80, one ds_write_b128 per plane.
+//     Planar rows live in a 48-slot ring (3 blocks of 16 rows) with a 288-byte pitch (conflict-free ds_read_b128);
+//     block k+3 is in flight in registers and block k+2 is written to the ring while step k is computed, one barrier
+//     per step;
+//   * the 6 pixels right of the strip's 16 chunks (the "halo piece") are made by lane 15 of each row from its own last
+//     four pixels and the side load;
 //   * BORDER_REFLECT_101 is resolved at staging: rows by picking the mirrored source row, the three left/right halo
 //     pixels of the first/last strip by byte permutes in registers;
 //   * epilogue: v_ashr_pk_u8_i32 does shift + saturate + pack, the 12 bytes a lane owns per tile go through a per-wave
 //     LDS transpose so that every global store is a 16-byte vector in 192-byte contiguous runs.
-// Measured on MI355X (4K, 64 frames): ~0.69-0.72 ms per launch = 56-58 % of 8 TB/s; the same launch with
-// the MFMAs and LDS reads removed takes 0.66 ms, loads alone 0.32 ms, stores alone 0.29 ms -- the kernel sits within
-// ~5 % of what its own memory traffic costs.
+// Measured on MI355X (4K, 64 frames, sustained clocks): 0.59-0.66 ms per launch = 60-67 % of 8 TB/s; the
+// same launch with the MFMAs and LDS reads removed takes ~0.58 ms, loads alone ~0.27-0.31 ms, stores alone 0.29 ms.
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
