@@ -18,8 +18,7 @@
 // Data movement (all global accesses are aligned vectors; all of them are unconditional -- see load_block):
 //   * a workgroup (4 waves) owns a STRIP 256 px wide (16 tiles, 768 B = six whole 128-B lines per row) x a row
 //     SEGMENT, and walks down it in 16-row steps; each source row is fetched from HBM once per strip (halo: 6 px per
-//     256, 6 rows per segment).  Widths that are a multiple of 240 but not of 256 use 15-tile strips (balanced
-//     workgroups beat aligned seams there);
+//     256, 6 rows per segment).  A width that is not a multiple of 256 ends in a partial strip;
 //   * staging: lane (row r, chunk q) loads its own aligned 48 bytes (16 pixels) as three 16-byte vectors; the chunk it
 //     stages is shifted by the 3-pixel halo, so the 9 bytes in front come from the previous lane's last dwords by DPP
 //     row_shr:1 (lane 0 / lane 15 of a row fetch the 12 bytes in front of / behind the strip with one shared side load).
