@@ -1,0 +1,27 @@
+#!/bin/bash
+# rocprofv3 evidence for the other ops of the path (run on the GPU box from the repo root):  bash tools/profile_ops.sh
+# One --kernel-trace --stats run and separate --pmc passes per op (never a --pmc together with a trace domain other than
+# --kernel-trace), on `tools/bench_ops.py --only <op>`; writes gpurun_out/prof_ops/<tag>.txt (copy into profiles/).
+set -u
+REPO=$PWD
+OUTROOT=$REPO/gpurun_out/prof_ops
+mkdir -p $OUTROOT
+cd /tmp && export TMPDIR=/tmp
+run_op() {  # tag, --only pattern, kernel substring, algorithmic bytes per launch
+  local TAG=$1 PAT=$2 KSUB=$3 ALG=$4
+  local OUT=/tmp/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
+  local CMD="python $REPO/tools/bench_ops.py --steps 5 --warmup 2 --only $PAT --out $OUT/bench.json"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE"; do
+    name=$(echo $set | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
+  done
+  python $REPO/tools/summarize_op_prof.py $OUT "$KSUB" $ALG "$PAT" > $OUTROOT/$TAG.txt 2>&1
+  cat $OUTROOT/$TAG.txt
+}
+PX4K=$((64*2160*3840)); PX8K=$((32*4320*7680))
+run_op yuyv2bgr_4k "YUYV2BGR" "k_yuyv2bgr_vec" $((PX4K*5))
+run_op bgr2gray_4k "BGR2GRAY" "k_bgr2gray16" $((PX4K*4))
+run_op sobel_4k "Sobel" "k_sobel_rows" $((PX4K*5))
+run_op harris_4k "Harris" "k_harris_fused" $((PX4K*4))
+run_op warp_8k "warpAffine_bilinear" "k_warp_affine_bgr" $((PX8K*6))
