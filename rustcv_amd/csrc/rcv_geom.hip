@@ -71,55 +71,69 @@ __global__ __launch_bounds__(kBlock) void k_resize_box(View s, View d)
 }
 
 // one thread per output pixel; rows on blockIdx.y, frames on blockIdx.z
+// One output pixel of the bilinear resize, any channel count: the formulation every fast path must match.
+template <int CH>
+__device__ __forceinline__ void resize_px(const uint8_t* ra, const uint8_t* rb, const View& s, float scx, float fy, int x, uint8_t* o)
+{
+    float sx = ((float)x + 0.5f) * scx - 0.5f;
+    sx = sx < 0.0f ? 0.0f : sx;
+    sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
+    int x0 = (int)floorf(sx);
+    float fx = sx - (float)x0;
+    int x1 = x0 + 1 < s.cols ? x0 + 1 : s.cols - 1;
+    uint64_t ta = 0, tb = 0;
+    const bool wide = CH == 3 && s.cols >= 3;
+    if (wide) {
+        ta = load_taps6(ra, x0, s.cols * 3);
+        tb = load_taps6(rb, x0, s.cols * 3);
+        if (x1 == x0) {  // right edge: the second tap is the first one again
+            ta = (ta & 0xffffffull) | ((ta & 0xffffffull) << 24);
+            tb = (tb & 0xffffffull) | ((tb & 0xffffffull) << 24);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float p00, p01, p10, p11;
+        if (wide) {
+            p00 = (float)(uint32_t)((ta >> (8 * c)) & 0xff);
+            p01 = (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff);
+            p10 = (float)(uint32_t)((tb >> (8 * c)) & 0xff);
+            p11 = (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff);
+        } else {
+            p00 = (float)ra[(size_t)x0 * CH + c], p01 = (float)ra[(size_t)x1 * CH + c];
+            p10 = (float)rb[(size_t)x0 * CH + c], p11 = (float)rb[(size_t)x1 * CH + c];
+        }
+        float top = fmaf(fx, p01 - p00, p00);
+        float bot = fmaf(fx, p11 - p10, p10);
+        float v = fmaf(fy, bot - top, top);
+        o[c] = round_half_up_u8(v);
+    }
+}
+
+// source rows and vertical weight of output row y (uniform per row)
+__device__ __forceinline__ void resize_row(const View& s, float scy, int y, int& y0, int& y1, float& fy)
+{
+    float sy = ((float)y + 0.5f) * scy - 0.5f;
+    sy = sy < 0.0f ? 0.0f : sy;
+    sy = sy > (float)(s.rows - 1) ? (float)(s.rows - 1) : sy;
+    y0 = (int)floorf(sy);
+    fy = sy - (float)y0;
+    y1 = y0 + 1 < s.rows ? y0 + 1 : s.rows - 1;
+}
+
 template <int CH>
 __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, float scy)
 {
     int y = blockIdx.y;
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* drow = d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step;
-    float sy = ((float)y + 0.5f) * scy - 0.5f;
-    sy = sy < 0.0f ? 0.0f : sy;
-    sy = sy > (float)(s.rows - 1) ? (float)(s.rows - 1) : sy;
-    int y0 = (int)floorf(sy);
-    float fy = sy - (float)y0;
-    int y1 = y0 + 1 < s.rows ? y0 + 1 : s.rows - 1;
+    int y0, y1;
+    float fy;
+    resize_row(s, scy, y, y0, y1, fy);
     const uint8_t* ra = sf + (size_t)y0 * s.step;
     const uint8_t* rb = sf + (size_t)y1 * s.step;
-    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
-        float sx = ((float)x + 0.5f) * scx - 0.5f;
-        sx = sx < 0.0f ? 0.0f : sx;
-        sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
-        int x0 = (int)floorf(sx);
-        float fx = sx - (float)x0;
-        int x1 = x0 + 1 < s.cols ? x0 + 1 : s.cols - 1;
-        uint64_t ta = 0, tb = 0;
-        const bool wide = CH == 3 && s.cols >= 3;
-        if (wide) {
-            ta = load_taps6(ra, x0, s.cols * 3);
-            tb = load_taps6(rb, x0, s.cols * 3);
-            if (x1 == x0) {  // right edge: the second tap is the first one again
-                ta = (ta & 0xffffffull) | ((ta & 0xffffffull) << 24);
-                tb = (tb & 0xffffffull) | ((tb & 0xffffffull) << 24);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float p00, p01, p10, p11;
-            if (wide) {
-                p00 = (float)(uint32_t)((ta >> (8 * c)) & 0xff);
-                p01 = (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff);
-                p10 = (float)(uint32_t)((tb >> (8 * c)) & 0xff);
-                p11 = (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff);
-            } else {
-                p00 = (float)ra[(size_t)x0 * CH + c], p01 = (float)ra[(size_t)x1 * CH + c];
-                p10 = (float)rb[(size_t)x0 * CH + c], p11 = (float)rb[(size_t)x1 * CH + c];
-            }
-            float top = fmaf(fx, p01 - p00, p00);
-            float bot = fmaf(fx, p11 - p10, p10);
-            float v = fmaf(fy, bot - top, top);
-            drow[(size_t)x * CH + c] = round_half_up_u8(v);
-        }
-    }
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock)
+        resize_px<CH>(ra, rb, s, scx, fy, x, drow + (size_t)x * CH);
 }
 
 struct Affine { float m[6]; };
@@ -359,6 +373,78 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     }
 }
 
+// ---- bilinear resize, BGR, any scale: the register scheme of k_warp_affine_bgr ------------------------------------------
+// One thread per output column and kRszRows consecutive output rows: x0 and fx are computed once, every row costs two
+// aligned 12-byte tap windows (all in flight together), packed-f32 lerps, and four lanes share a 12-byte store.  A wave
+// whose lanes all have x0 <= cols-4 (the whole tap window inside the row) takes this path; the few waves at the right
+// edge run resize_px<3> per pixel.  Same f32 operations in the same order as resize_px<3>.
+constexpr int kRszRows = 4;
+
+__global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx, float scy)
+{
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0: quads never straddle the row end
+    const int xq = min(x, d.cols - 1);
+    const int ybase = blockIdx.y * kRszRows;
+    float sx = ((float)xq + 0.5f) * scx - 0.5f;
+    sx = sx < 0.0f ? 0.0f : sx;
+    sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
+    const float x0f = floorf(sx);
+    const int x0 = (int)x0f;
+    const float fx = sx - x0f;
+    struct U3 { uint32_t a, b, c; };
+    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+                       (unsigned long long)s.rows * s.step < (1ull << 32);
+    if (small && __all(x0 <= s.cols - 4)) {
+        U3 ta[kRszRows], tb[kRszRows];
+        float fy[kRszRows];
+        const unsigned xo = 3u * (unsigned)x0, sh = xo & 3u, xa = xo & ~3u;
+#pragma unroll
+        for (int r = 0; r < kRszRows; ++r) {
+            int y0, y1;
+            resize_row(s, scy, min(ybase + r, d.rows - 1), y0, y1, fy[r]);
+            ta[r] = *(const U3*)(sf + (__umul24((unsigned)y0, (unsigned)s.step) + xa));
+            tb[r] = *(const U3*)(sf + (__umul24((unsigned)y1, (unsigned)s.step) + xa));
+        }
+#pragma unroll
+        for (int r = 0; r < kRszRows; ++r) {
+            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh);
+            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh);
+            const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
+            const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
+            const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
+            const f2 fxx2 = {fx, fx}, fyy2 = {fy[r], fy[r]}, half2 = {0.5f, 0.5f};
+            const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
+            const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
+            const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
+            const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
+            const float v2 = fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f;
+            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);   // exact integers in [0, 255]
+            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+            const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
+            const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
+            const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+            if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows)
+                *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) =
+                    U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int r = 0; r < kRszRows; ++r) {
+        if (x >= d.cols || ybase + r >= d.rows) continue;
+        int y0, y1;
+        float fy;
+        resize_row(s, scy, ybase + r, y0, y1, fy);
+        uint8_t o[3];
+        resize_px<3>(sf + (size_t)y0 * s.step, sf + (size_t)y1 * s.step, s, scx, fy, x, o);
+        uint8_t* q = dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3;
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    }
+}
+
 // ---- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR ("next" row f1) ---------------------
 // resize(warp_affine(src -> mid), dst) with mid = S * dst.  For an exact integer factor the bilinear resize reads only
 // the centre 2x2 of every SxS block of `mid` (k_resize_box above), so the fused kernel evaluates just those four warped
@@ -477,6 +563,12 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
         }
     }
     float scx = (float)s.cols / (float)d.cols, scy = (float)s.rows / (float)d.rows;
+    if (s.ch == 3 && s.cols >= 4 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 &&
+        d.rows <= 65535 * kRszRows) {
+        hipLaunchKernelGGL(k_resize_bgr, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
+                           dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
+        return rcv_launch_check(ctx);
+    }
     if (s.ch == 1) hipLaunchKernelGGL(k_resize<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
     else if (s.ch == 3) hipLaunchKernelGGL(k_resize<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
     else hipLaunchKernelGGL(k_resize<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);

@@ -452,6 +452,25 @@ def test_resize(ctx, oracle, rng, src_shape, dst_shape, ch):
         assert np.array_equal(want.reshape(12, 16, -1), box)
 
 
+@pytest.mark.parametrize("src_shape,dst_shape", [((48, 64), (48, 64)), ((720, 1280), (480, 852)), ((61, 127), (40, 96)), ((17, 33), (40, 72)),
+                                                 ((30, 4), (7, 8)), ((5, 5), (9, 260)), ((270, 480), (181, 324)), ((9, 1000), (3, 12)),
+                                                 ((100, 100), (1, 4)), ((3, 700), (5, 1400))])
+def test_resize_bgr_fast_path(ctx, oracle, rng, src_shape, dst_shape):
+    """general-scale BGR kernel (output width a multiple of 4): up- and down-scales, right-edge waves, tiny sources, batch of 2"""
+    n = 2
+    src = device.DeviceBatch(ctx, n, src_shape[0], src_shape[1], 3)
+    dst = _canary_batch(ctx, n, dst_shape[0], dst_shape[1], 3, pad=8)
+    frames = rng.integers(0, 256, size=(n,) + src_shape + (3,), dtype=np.uint8)
+    src.upload(frames)
+    device.resize(src, dst)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(frames[i], dst_shape[0], dst_shape[1]))
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("scale", [2, 4])
 @pytest.mark.parametrize("dshape", [(1, 4), (5, 8), (27, 240), (270, 480)])
 def test_resize_box_fast_path(ctx, oracle, rng, scale, dshape):

@@ -178,6 +178,10 @@ def main():
            lambda: device.warp_affine_resize(s, d, M, 4320, 7680),
            note="30 B per OUTPUT px: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written; "
                 "the unfused pair moves 6 B/px of 8K intermediate on top")
+    d2 = B(32, 2880, 5120, 3)
+    record("resize 8K -> 5K bilinear (general 1.5x)", "8K batch=32/GPU", s.n, 5120 * 2880, 3 + 3 * 2.25, lambda: device.resize(s, d2),
+           note="3 B written + 2.25 source px (6.75 B) read per output px")
+    d2.free()
     record("resize 8K -> 1080p bilinear", "8K batch=32/GPU", s.n, 1920 * 1080, 15, lambda: device.resize(s, d),
            note="15 B per OUTPUT px: exact 4x touches the centre 2x2 of each 4x4 block",
            cpu=lambda: cpu_time(lambda orc: orc.resize(np.zeros((4320, 7680, 3), np.uint8), 1080, 1920), 1920 * 1080))
