@@ -24,14 +24,16 @@ struct Mat {
     int32_t rows = 0, cols = 0;
     size_t step = 0;
     uint8_t channels = 0;
+    uint8_t depth = RCV_8U;   // not in the reference (u8 only): i16 / f32 outputs of Sobel and the Harris response
 
-    static Mat create(int32_t rows, int32_t cols, uint8_t channels)  // Mat::new (mat.rs:18-29)
+    static Mat create(int32_t rows, int32_t cols, uint8_t channels, uint8_t depth = RCV_8U)  // Mat::new (mat.rs:18-29)
     {
         Mat m;
         m.rows = rows;
         m.cols = cols;
         m.channels = channels;
-        m.step = (size_t)cols * channels;
+        m.depth = depth;
+        m.step = (size_t)cols * channels * (depth == RCV_8U ? 1 : (depth == RCV_16S ? 2 : 4));
         m.data.assign((size_t)rows * m.step, 0);
         return m;
     }
@@ -39,7 +41,8 @@ struct Mat {
     bool is_empty() const { return data.empty() || rows == 0 || cols == 0; }  // mat.rs:42-44
     const uint8_t* row_bytes(int32_t row) const { return data.data() + (size_t)row * step; }  // mat.rs:47-51 (cols*channels bytes)
 
-    rcv_mat view(uint8_t depth = RCV_8U)
+    rcv_mat view() { return view(depth); }
+    rcv_mat view(uint8_t depth)
     {
         rcv_mat v{};
         v.data = data.empty() ? nullptr : data.data();
@@ -127,8 +130,70 @@ inline void cvtColor(Mat& src, Mat& dst, int code)
     rcv_mat s = src.view(), d = dst.view();
     check(rcv_cvt_color(Backend::instance().ctx(), code, &s, &d), "cvtColor");
 }
+// gray u8 -> dx, dy (i16 Mats: Mat::create(rows, cols, 1, RCV_16S))
+inline void Sobel(Mat& gray, Mat& dx, Mat& dy)
+{
+    rcv_mat s = gray.view(), a = dx.view(), b = dy.view();
+    check(rcv_sobel(Backend::instance().ctx(), &s, &a, &b), "Sobel");
+}
+// BGR -> corner mask (255 = 3x3 local maximum of the Harris response above thr); resp (f32) is optional
+inline void harrisCorners(Mat& bgr, Mat& mask, Mat* resp, int blockSize, float k, float thr)
+{
+    rcv_mat s = bgr.view(), m = mask.view(), r;
+    if (resp) r = resp->view();
+    check(rcv_harris_pipeline(Backend::instance().ctx(), &s, &m, resp ? &r : nullptr, blockSize, k, thr), "harrisCorners");
+}
+// resize(warpAffine(src -> mid_rows x mid_cols), dst) in one call ("next" row f1; fused for exact 2x / 4x BGR down-scales)
+inline void warpAffineResize(Mat& src, Mat& dst, const float M[6], int mid_rows, int mid_cols)
+{
+    rcv_mat s = src.view(), d = dst.view();
+    check(rcv_warp_affine_resize(Backend::instance().ctx(), &s, &d, M, mid_rows, mid_cols), "warpAffineResize");
+}
+// packed / strided YUYV -> BGR -> integer filter2D in one launch ("next" row f1)
+inline void filter2D_yuyv(Mat& src_yuyv, Mat& dst_bgr, const int8_t* kernel, int ksize, int shift)
+{
+    rcv_mat s = src_yuyv.view(), d = dst_bgr.view();
+    check(rcv_filter2d_i8_yuyv(Backend::instance().ctx(), &s, &d, kernel, ksize, shift), "filter2D_yuyv");
+}
 
 }  // namespace imgproc
+
+// Pinned-host staging ring ("next" row f3): the streaming replacement of the read() loop (rustcv/src/videoio/mod.rs:83-112).
+// `op` is a plain function that enqueues rcv_* calls on the context stream for one frame.
+class StagingRing {
+public:
+    StagingRing(int depth, int in_rows, int in_cols, int in_ch, int out_rows, int out_cols, int out_ch, int in_depth = RCV_8U, int out_depth = RCV_8U)
+    {
+        check(rcv_ring_create(Backend::instance().ctx(), depth, in_rows, in_cols, in_ch, in_depth, out_rows, out_cols, out_ch, out_depth, &ring_),
+              "rcv_ring_create");
+    }
+    ~StagingRing() { rcv_ring_destroy(ring_); }
+    StagingRing(const StagingRing&) = delete;
+    StagingRing& operator=(const StagingRing&) = delete;
+    int in_flight() const { return rcv_ring_in_flight(ring_); }
+    // the pinned buffer the next submit(nullptr, ...) uploads; fill it in place
+    rcv_mat input()
+    {
+        rcv_mat m;
+        check(rcv_ring_input(ring_, &m), "rcv_ring_input");
+        return m;
+    }
+    void submit(Mat* host_in, rcv_ring_op op, void* user = nullptr)
+    {
+        rcv_mat m;
+        if (host_in) m = host_in->view();
+        check(rcv_ring_submit(ring_, host_in ? &m : nullptr, op, user), "rcv_ring_submit");
+    }
+    // oldest frame -> out (copied); false when nothing was in flight
+    bool retire(Mat& out)
+    {
+        rcv_mat m = out.view();
+        return check(rcv_ring_retire(ring_, &m, nullptr), "rcv_ring_retire") == RCV_OK;
+    }
+
+private:
+    rcv_ring* ring_ = nullptr;
+};
 
 namespace videoio {
 

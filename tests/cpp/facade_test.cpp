@@ -57,8 +57,72 @@ static void rectangle_grows_inward()
         }
 }
 
+static void sobel_of_a_ramp()
+{
+    Mat g = Mat::create(9, 24, 1);
+    for (int y = 0; y < 9; ++y)
+        for (int x = 0; x < 24; ++x) g.data[(size_t)y * g.step + x] = (uint8_t)(3 * x);
+    Mat dx = Mat::create(9, 24, 1, RCV_16S), dy = Mat::create(9, 24, 1, RCV_16S);
+    imgproc::Sobel(g, dx, dy);
+    const int16_t* px = (const int16_t*)dx.data.data();
+    const int16_t* py = (const int16_t*)dy.data.data();
+    for (int y = 0; y < 9; ++y)
+        for (int x = 0; x < 24; ++x) {
+            ASSERT(py[y * 24 + x] == 0);
+            ASSERT(px[y * 24 + x] == ((x == 0 || x == 23) ? 0 : 24));   // (p[x+1]-p[x-1]) * (1+2+1); reflect-101 cancels at the edges
+        }
+}
+static void fused_warp_resize_identity_is_a_box_average()
+{
+    Mat s = Mat::create(8, 16, 3);
+    for (size_t i = 0; i < s.data.size(); ++i) s.data[i] = (uint8_t)((i * 37 + 11) & 0xff);
+    Mat d = Mat::create(4, 8, 3);
+    const float M[6] = {1, 0, 0, 0, 1, 0};
+    imgproc::warpAffineResize(s, d, M, 8, 16);
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 8; ++x)
+            for (int c = 0; c < 3; ++c) {
+                int sum = 2;
+                for (int j = 0; j < 2; ++j)
+                    for (int i = 0; i < 2; ++i) sum += s.row_bytes(2 * y + j)[3 * (2 * x + i) + c];
+                ASSERT(d.row_bytes(y)[3 * x + c] == (uint8_t)(sum >> 2));
+            }
+}
+static int bgra_to_bgr_op(rcv_ctx* ctx, const rcv_mat* din, rcv_mat* dout, void*) { return rcv_cvt_color(ctx, RCV_BGRA2BGR_STRIDED, din, dout); }
+static void staging_ring_streams_frames_in_order()
+{
+    StagingRing ring(2, 6, 10, 4, 6, 10, 3);
+    Mat out = Mat::create(6, 10, 3);
+    int retired = 0;
+    auto check_frame = [&](int f) {
+        for (int y = 0; y < 6; ++y)
+            for (int x = 0; x < 10; ++x)
+                for (int c = 0; c < 3; ++c) ASSERT(out.row_bytes(y)[3 * x + c] == (uint8_t)(f * 50 + y * 10 + x + c));
+    };
+    for (int f = 0; f < 5; ++f) {
+        if (ring.in_flight() == 2) {
+            ASSERT(ring.retire(out));
+            check_frame(retired++);
+        }
+        Mat in = Mat::create(6, 10, 4);
+        for (int y = 0; y < 6; ++y)
+            for (int x = 0; x < 10; ++x)
+                for (int c = 0; c < 4; ++c) in.data[(size_t)y * in.step + 4 * x + c] = (uint8_t)(f * 50 + y * 10 + x + c);
+        ring.submit(&in, bgra_to_bgr_op);
+    }
+    while (ring.in_flight()) {
+        ASSERT(ring.retire(out));
+        check_frame(retired++);
+    }
+    ASSERT(retired == 5);
+    ASSERT(!ring.retire(out));
+}
+
 int main()
 {
+    sobel_of_a_ramp();
+    fused_warp_resize_identity_is_a_box_average();
+    staging_ring_streams_frames_in_order();
     yuyv_to_bgr_basic();
     yuyv_to_bgr_black();
     rgb_to_bgr_swap();
