@@ -217,12 +217,58 @@ __device__ __forceinline__ void load_taps6_32(const uint8_t* row, int x0, int ro
 // the three result bytes of four neighbouring lanes gathered with DPP so that every fourth lane stores 12 bytes.
 // Same f32 operations in the same order as k_warp_affine<3>.
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int kWarpRows = 8;   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
+constexpr int kWarpRows = 8;
+
+// byte N of a dword -> f32 in one instruction (the compiler otherwise mixes shifts, masks and integer subtracts in)
+template <int N>
+__device__ __forceinline__ float ub(uint32_t v)
+{
+    float f;
+    if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v));
+    return f;
+}
+
+// Bilinear sample of one BGR pixel from its two tap dwords per row {b0 g0 r0 b1 | g1 r1 . .} (upper row a, lower row b),
+// packed {b, g, r, 0}.  The f32 operations and their order are those of warp_px<3> / resize_px<3>: per channel
+// top = fma(fx, p01 - p00, p00), bot = fma(fx, p11 - p10, p10), v = fma(fy, bot - top, top), floor(v + 0.5).  Channels 0 and 1
+// ride in packed-f32 pairs, channel 2 pairs its top and bottom row (v_pk_add / v_pk_fma: two IEEE operations per
+// instruction, bit-identical to the scalar ops).  All taps must be valid (interior), so the result is an exact integer in
+// [0, 255] and v_cvt_pk_u8_f32 converts, saturates and packs it.
+// PIN = true pins each byte conversion to one v_cvt_f32_ubyteN (fewer instructions: -2 % in the 8-row warp / 4-row resize
+// kernels); the fused down-scale kernel, which interleaves four pixels, schedules better with the compiler's own choice.
+template <bool PIN>
+__device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, float fx, float fy)
+{
+    f2 a0, a1, b0, b1, c0, c1;
+    if constexpr (PIN) {
+        a0 = f2{ub<0>(alo), ub<1>(alo)}; a1 = f2{ub<3>(alo), ub<0>(ahi)};
+        b0 = f2{ub<0>(blo), ub<1>(blo)}; b1 = f2{ub<3>(blo), ub<0>(bhi)};
+        c0 = f2{ub<2>(alo), ub<2>(blo)}; c1 = f2{ub<1>(ahi), ub<1>(bhi)};
+    } else {
+        a0 = f2{(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}; a1 = f2{(float)(alo >> 24), (float)(ahi & 0xff)};
+        b0 = f2{(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}; b1 = f2{(float)(blo >> 24), (float)(bhi & 0xff)};
+        c0 = f2{(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}; c1 = f2{(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
+    }
+    const f2 fxx2 = {fx, fx}, fyy2 = {fy, fy}, half2 = {0.5f, 0.5f};
+    const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
+    const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
+    const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
+    const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
+    const float v2 = fmaf(fy, tb2.y - tb2.x, tb2.x) + 0.5f;
+    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+}   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
 // Two phases per thread so that all 16 tap loads of its 8 rows are in flight together: the loads are unconditional
 // (clamped tap windows) -- a branch around them would make the compiler wait vmcnt(0) row by row.
 __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
 {
+    // (an XCD-aware block order that keeps vertically neighbouring bands on one L2 was measured: no gain, the kernel is bound
+    //  by the per-lane tap gathers and the arithmetic, not by the 1.4x source re-reads)
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
     const int rowbytes = s.cols * 3;
@@ -267,12 +313,14 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
 #pragma unroll
             for (int r = 0; r < kWarpRows; ++r) {
                 const float fyy = (float)min(ybase + r, d.rows - 1);
-                const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-                const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-                const float x0f = floorf(sx), y0f = floorf(sy);
-                fx[r] = sx - x0f;
-                fy[r] = sy - y0f;
-                const unsigned x0 = (unsigned)(int)x0f, y0 = (unsigned)(int)y0f;
+                // (sx, sy) as one packed pair: fmaf(m0, x, fmaf(m1, y, m2)) and fmaf(m3, x, fmaf(m4, y, m5))
+                const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx},
+                                                         __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
+                const f2 fl = {floorf(sxy.x), floorf(sxy.y)};
+                const f2 fr = sxy - fl;
+                fx[r] = fr.x;
+                fy[r] = fr.y;
+                const unsigned x0 = (unsigned)(int)fl.x, y0 = (unsigned)(int)fl.y;
                 const unsigned off = __umul24(y0, sstep) + 3u * x0;   // rows start 4-byte aligned (checked by the caller)
                 sh[r] = off & 3u;
                 ta[r] = *(const U3*)(sf + (off & ~3u));
@@ -282,21 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
             for (int r = 0; r < kWarpRows; ++r) {
                 const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh[r]);
                 const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh[r]);
-                // taps {b0 g0 r0 b1 | g1 r1 . .}: channels 0,1 ride in packed-f32 pairs (v_pk_add/v_pk_fma: two IEEE
-                // operations per instruction, same results as the scalar ops), channel 2 pairs its top and bottom row
-                const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
-                const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
-                const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
-                const f2 fxx2 = {fx[r], fx[r]}, fyy2 = {fy[r], fy[r]}, half2 = {0.5f, 0.5f};
-                const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);      // channels 0,1, upper row
-                const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);      // channels 0,1, lower row
-                const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);      // channel 2: {top, bot}
-                const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
-                const float v2 = fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f;
-                // floor(v + 0.5) is an exact integer in [0, 255] here; v_cvt_pk_u8_f32 converts, saturates and packs
-                uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
-                px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
-                px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+                const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fx[r], fy[r]);
                 const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
                 const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
                 const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
@@ -411,18 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
         for (int r = 0; r < kRszRows; ++r) {
             const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh);
             const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh);
-            const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
-            const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
-            const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
-            const f2 fxx2 = {fx, fx}, fyy2 = {fy[r], fy[r]}, half2 = {0.5f, 0.5f};
-            const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
-            const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
-            const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
-            const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
-            const float v2 = fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f;
-            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);   // exact integers in [0, 255]
-            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
-            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+            const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fx, fy[r]);
             const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
             const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
             const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
@@ -491,18 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
         for (int i = 0; i < 4; ++i) {
             const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].b, ta[i].a, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].c, ta[i].b, sh[i]);
             const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].b, tb[i].a, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].c, tb[i].b, sh[i]);
-            const f2 a0 = {(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}, a1 = {(float)(alo >> 24), (float)(ahi & 0xff)};
-            const f2 b0 = {(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}, b1 = {(float)(blo >> 24), (float)(bhi & 0xff)};
-            const f2 c0 = {(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}, c1 = {(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
-            const f2 fxx2 = {fx[i], fx[i]}, fyy2 = {fy[i], fy[i]}, half2 = {0.5f, 0.5f};
-            const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
-            const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
-            const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
-            const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
-            const float v2 = fmaf(fy[i], tb2.y - tb2.x, tb2.x) + 0.5f;
-            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
-            px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
-            p[i] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+            p[i] = bilerp_bgr<false>(alo, ahi, blo, bhi, fx[i], fy[i]);
         }
     } else {
 #pragma unroll 1
