@@ -23,7 +23,7 @@
 namespace {
 
 typedef short s2v __attribute__((ext_vector_type(2)));
-constexpr int kAhead = 3;             // source rows in flight per lane (x 6 VGPRs)
+constexpr int kAhead = 2;             // source rows in flight per lane (x 6 VGPRs); 2 keeps the kernel at 3 waves per SIMD
 constexpr int kStripPx = 62 * 8;
 
 struct HArgs {
