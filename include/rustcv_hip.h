@@ -163,7 +163,8 @@ int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, c
 int rcv_filter2d_i8_yuyv(rcv_ctx* ctx, const rcv_mat* src_yuyv, rcv_mat* dst_bgr, const int8_t* k, int ksize, int shift);
 int rcv_filter2d_i8_yuyv_batch(rcv_ctx* ctx, const rcv_batch* src_yuyv, rcv_batch* dst_bgr, const int8_t* k, int ksize, int shift);
 
-/* src u8 1-ch; dx, dy i16 1-ch */
+/* src u8 1-ch; dx, dy i16 1-ch.  A 3-channel BGR src gives the gradient of its gray conversion (RCV_BGR2GRAY), fused into
+ * one launch where the shape allows ("next" row f1: cvtColor -> Sobel chain) */
 int rcv_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy);
 int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy);
 

@@ -53,7 +53,9 @@ __device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b)  // a + 2*b
 struct U2 { uint32_t lo, hi; };
 
 // DBG (profiling builds, -DRCV_ABLATE): 1 skip global stores, 2 skip global loads
-template <int DBG>
+// BGR = true: the source is a BGR image and the gradient is taken of its gray conversion (the fixed-point BT.601 of
+// RCV_BGR2GRAY, two v_dot4 per pixel) -- cvtColor + Sobel in one launch, 7 instead of 9 bytes per pixel and no gray image.
+template <int DBG, bool BGR>
 __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -71,18 +73,62 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     // the pixel outside the wave: lane 0 needs x-1 (mirror: 1), lane 63 needs x+8 (mirror: cols-2); other lanes load
     // a harmless in-row byte so that the load stays unconditional
     const int xe = lane == 0 ? (x == 0 ? 1 : x - 1) : min(x + 8 >= a.cols ? a.cols - 2 : x + 8, a.cols - 1);
-    const uint8_t* se = a.src + (size_t)frame * a.sfs + max(xe, 0);
-    const uint8_t* sf = a.src + (size_t)frame * a.sfs + xc;
+    constexpr int PX = BGR ? 3 : 1;   // source bytes per pixel
+    // the one pixel outside the wave's 512: only lanes 0 and 63 use it, so every other lane reads one fixed cached address
+    const bool needs_edge = lane == 0 || lane == 63;
+    const unsigned eoff = needs_edge ? (unsigned)(PX * max(xe, 0)) : 0u;
+    const uint8_t* se = a.src + (size_t)frame * a.sfs;
+    const uint8_t* sf = a.src + (size_t)frame * a.sfs + PX * xc;
     uint8_t* dxp = a.dx + (size_t)frame * a.xfs + 2 * (size_t)max(x, 0);
     uint8_t* dyp = a.dy + (size_t)frame * a.yfs + 2 * (size_t)max(x, 0);
     uint8_t* const dump = a.dump + lane * 16;
 
+    auto gray_of = [](uint32_t px) -> uint32_t {   // (B,G,R,x) dword -> gray, bit-identical to k_bgr2gray
+        const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);       // 7*B + 37*G + 19*R
+        const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);    // 76*B + 145*G + 35*R + 8192
+        return ((hi8 << 8) + lo8) >> 14;
+    };
     struct Row { U2 v; uint32_t e; };
-    auto load_row = [&](int ry) -> Row {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
+    struct Raw { uint32_t d[BGR ? 6 : 2]; uint32_t e0, e1; };
+    auto load_raw = [&](int ry) -> Raw {   // ry in [ys-1, ...]: reflect, and clamp past the segment to a valid row
         ry = min(ry, ye);
         const int r = ry < 0 ? -ry : (ry >= a.rows ? 2 * a.rows - 2 - ry : ry);
-        if (DBG & 2) return Row{U2{(uint32_t)r, (uint32_t)lane}, 0u};
-        return Row{*(const U2*)(sf + (size_t)r * a.sstep), (uint32_t)se[(size_t)r * a.sstep]};
+        Raw w;
+        if (DBG & 2) {
+#pragma unroll
+            for (int i = 0; i < (BGR ? 6 : 2); ++i) w.d[i] = (uint32_t)(r + i + lane);
+            w.e0 = w.e1 = 0;
+            return w;
+        }
+        const uint8_t* row = sf + (size_t)r * a.sstep;
+        const U2 q0 = *(const U2*)row;
+        w.d[0] = q0.lo; w.d[1] = q0.hi;
+        if constexpr (BGR) {
+            const U2 q1 = *(const U2*)(row + 8), q2 = *(const U2*)(row + 16);
+            w.d[2] = q1.lo; w.d[3] = q1.hi; w.d[4] = q2.lo; w.d[5] = q2.hi;
+            // edge pixel = 3 bytes at byte eoff: the two aligned dwords that contain them (rows are 8-byte aligned)
+            const uint8_t* er = se + (size_t)r * a.sstep;
+            const unsigned a4 = eoff & ~3u, lim = (unsigned)(3 * a.cols - 4) & ~3u;
+            w.e0 = *(const uint32_t*)(er + a4);
+            w.e1 = *(const uint32_t*)(er + min(a4 + 4, lim));
+        } else {
+            w.e0 = se[(size_t)r * a.sstep + eoff];
+            w.e1 = 0;
+        }
+        return w;
+    };
+    auto to_row = [&](const Raw& w) -> Row {   // BGR: 8 pixels + the edge pixel to gray
+        if constexpr (!BGR) return Row{U2{w.d[0], w.d[1]}, w.e0};
+        else {
+            uint32_t g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;
+                g[j] = gray_of(sh == 0 ? w.d[w0] : __builtin_amdgcn_alignbyte(w.d[w0 + 1 < 6 ? w0 + 1 : 5], w.d[w0], sh));
+            }
+            const uint32_t ge = gray_of(__builtin_amdgcn_alignbyte(w.e1, w.e0, eoff & 3u));
+            return Row{U2{g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24)}, ge};
+        }
     };
 
     uint32_t h1a[4], h1b[4], h2a[4], h2b[4];  // rows r-2 (a) and r-1 (b)
@@ -132,16 +178,17 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 
     // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kRowsAhead, next group in flight while this one computes
     const int nrows = ye - ys + 2;
-    Row cur[kRowsAhead], nxt[kRowsAhead];
+    constexpr int kAheadRows = BGR ? 4 : kRowsAhead;   // (a BGR row is 8 registers per lane)
+    Raw cur[kAheadRows], nxt[kAheadRows];
 #pragma unroll
-    for (int i = 0; i < kRowsAhead; ++i) cur[i] = load_row(ys - 1 + i);
-    for (int g = 0; g < nrows; g += kRowsAhead) {
+    for (int i = 0; i < kAheadRows; ++i) cur[i] = load_raw(ys - 1 + i);
+    for (int g = 0; g < nrows; g += kAheadRows) {
 #pragma unroll
-        for (int i = 0; i < kRowsAhead; ++i) nxt[i] = load_row(ys - 1 + g + kRowsAhead + i);
+        for (int i = 0; i < kAheadRows; ++i) nxt[i] = load_raw(ys - 1 + g + kAheadRows + i);
 #pragma unroll
-        for (int i = 0; i < kRowsAhead; ++i) feed(cur[i], ys - 1 + g + i);
+        for (int i = 0; i < kAheadRows; ++i) feed(to_row(cur[i]), ys - 1 + g + i);
 #pragma unroll
-        for (int i = 0; i < kRowsAhead; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < kAheadRows; ++i) cur[i] = nxt[i];
     }
 }
 
@@ -149,6 +196,7 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 
 int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
 {
+    if (s.ch != 1 && s.ch != 3) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 2) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)dx.p % 16 || dx.step % 16 || (dx.n > 1 && dx.fstride % 16)) return RCV_ERR_UNSUPPORTED;
@@ -176,15 +224,19 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const dim3 grid((unsigned)((waves + 3) / 4));
+    if (s.ch == 3) {
+        hipLaunchKernelGGL((k_sobel_rows<0, true>), grid, dim3(256), 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
 #ifdef RCV_ABLATE
     switch (rcv_debug_flags & 3) {
-    case 1: hipLaunchKernelGGL(k_sobel_rows<1>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(k_sobel_rows<2>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(k_sobel_rows<3>, grid, dim3(256), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(k_sobel_rows<0>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_sobel_rows<1, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_sobel_rows<2, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_sobel_rows<3, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a); break;
     }
 #else
-    hipLaunchKernelGGL(k_sobel_rows<0>, grid, dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
 }

@@ -246,13 +246,28 @@ extern "C" int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx
     RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
     RCV_TRY(rcv_view_batch(dx, RCV_16S, &vx));
     RCV_TRY(rcv_view_batch(dy, RCV_16S, &vy));
-    if (s.ch != 1 || vx.ch != 1 || vy.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if ((s.ch != 1 && s.ch != 3) || vx.ch != 1 || vy.ch != 1) return RCV_ERR_UNSUPPORTED;
     if (s.rows != vx.rows || s.cols != vx.cols || s.n != vx.n || s.rows != vy.rows || s.cols != vy.cols || s.n != vy.n)
         return RCV_ERR_ARG;
     if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
-    int rc = rcv_sobel_tiled(ctx, s, vx, vy);
+    int rc = rcv_sobel_tiled(ctx, s, vx, vy);   // 1 channel, or BGR: gradient of its gray conversion in one launch
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    if (s.ch == 3) {
+        // unfused HIP path: gray into the workspace, then the ordinary Sobel
+        const size_t tstep = ((size_t)s.cols + 15) & ~(size_t)15, tfs = tstep * s.rows;
+        RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
+        uint8_t* tmp;
+        RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
+        rcv_batch tb = *src;
+        tb.frame0.data = tmp;
+        tb.frame0.cap = tfs;
+        tb.frame0.step = tstep;
+        tb.frame0.channels = 1;
+        tb.frame_stride = tfs;
+        RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, src, &tb));
+        return rcv_sobel_batch(ctx, &tb, dx, dy);
+    }
     hipLaunchKernelGGL(k_sobel_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, vx, vy);
     return rcv_launch_check(ctx);
 }

@@ -437,6 +437,37 @@ def test_sobel_rows_path(ctx, oracle, rng, rows, cols):
         b.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(2, 8), (9, 16), (33, 504), (40, 512), (70, 520), (19, 1032), (300, 64), (5, 10), (7, 3)])
+def test_sobel_of_bgr_source(ctx, oracle, rng, rows, cols):
+    """f1: Sobel on a BGR image == Sobel(BGR2GRAY(.)) of the oracle; fused register kernel when cols % 8 == 0, gray through the
+    workspace otherwise; batch of 2, padded steps, canaries around the i16 outputs"""
+    n = 2
+    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 8 if (cols * 3) % 8 == 0 else None)
+    dx = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+    dy = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+    frames = rng.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    src.upload(frames)
+    device.sobel(src, dx, dy)
+    gx, gy = dx.download(), dy.download()
+    for i in range(n):
+        wx, wy = oracle.sobel(oracle.bgr2gray(frames[i]))
+        assert np.array_equal(gx[i], wx) and np.array_equal(gy[i], wy)
+    _assert_canaries(dx)
+    _assert_canaries(dy)
+    for b in (src, dx, dy):
+        b.free()
+
+
+def test_sobel_of_bgr_source_host_mat(ctx, oracle, rng):
+    img = rand_img(rng, 31, 48, 3)
+    dx, dy = Mat(31, 48, 1, _ffi.RCV_16S), Mat(31, 48, 1, _ffi.RCV_16S)
+    imgproc.sobel(Mat.from_array(img), dx, dy, ctx)
+    wx, wy = oracle.sobel(oracle.bgr2gray(img))
+    assert np.array_equal(dx.to_array(), wx) and np.array_equal(dy.to_array(), wy)
+    with pytest.raises(Exception):
+        imgproc.sobel(Mat.from_array(rand_img(rng, 8, 8, 4)), Mat(8, 8, 1, _ffi.RCV_16S), Mat(8, 8, 1, _ffi.RCV_16S), ctx)
+
+
 @pytest.mark.parametrize("src_shape,dst_shape", [((48, 64), (12, 16)), ((48, 64), (48, 64)), ((17, 33), (40, 71)), ((61, 127), (13, 9)),
                                                  ((1, 1), (5, 7)), ((4, 4), (1, 1)), ((128, 240), (32, 60)), ((30, 50), (31, 49))])
 @pytest.mark.parametrize("ch", [1, 3, 4])

@@ -136,6 +136,11 @@ def main():
     dx, dy = B(n, 2160, 3840, 1, _ffi.RCV_16S), B(n, 2160, 3840, 1, _ffi.RCV_16S)
     record("Sobel 3x3 -> dx,dy i16", "4K gray", g.n, 3840 * 2160, 5, lambda: device.sobel(g, dx, dy),
            cpu=lambda: cpu_time(lambda orc: orc.sobel(np.zeros((2160, 3840), np.uint8)), 3840 * 2160))
+    o2 = B(n, 2160, 3840, 3)
+    device.synth(o2, 1, SEED + 3, 0)
+    record("Sobel of a BGR source, fused gray (next row f1)", "4K", o2.n, 3840 * 2160, 7, lambda: device.sobel(o2, dx, dy),
+           note="3 B read + 4 B written per px; the two-launch chain BGR2GRAY + Sobel moves 9")
+    o2.free()
     dx.free(); dy.free(); g.free()
 
     # ---- config 2: 1080p BGR 5x5 Gaussian, batch 1 (latency) and batch 64 (bandwidth) ------------------------
