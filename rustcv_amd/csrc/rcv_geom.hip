@@ -195,23 +195,6 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
         warp_px<CH>(sf, s, A, (float)x, fyy, drow + (size_t)x * CH);
 }
 
-// Two adjacent BGR taps as two dwords {b0 g0 r0 b1 | g1 r1 x x}; the 8-byte window is used in place whenever it fits
-// in the row (all but the last two pixels and x0 = -1), so the common case needs no funnel shift.
-__device__ __forceinline__ void load_taps6_32(const uint8_t* row, int x0, int rowbytes, uint32_t& lo, uint32_t& hi)
-{
-    const int off = 3 * x0;
-    if (off >= 0 && off + 8 <= rowbytes) {
-        uint2 v;
-        __builtin_memcpy(&v, row + off, 8);
-        lo = v.x;
-        hi = v.y;
-    } else {
-        const uint64_t t = load_taps6(row, x0, rowbytes);
-        lo = (uint32_t)t;
-        hi = (uint32_t)(t >> 32);
-    }
-}
-
 // BGR fast path: one thread per output pixel (adjacent lanes -> adjacent source taps -> L1-friendly), byte -> float by
 // v_cvt_f32_ubyteN straight from the tap dwords, invalid taps zeroed once per pixel instead of once per channel, and
 // the three result bytes of four neighbouring lanes gathered with DPP so that every fourth lane stores 12 bytes.
@@ -277,11 +260,11 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     const int ybase = blockIdx.y * kWarpRows;
 
     // ---- interior fast path (wave-uniform) ----
-    // The op is VALU-bound (the border version below spends ~160 VALU ops per pixel).  sx and sy are monotonic in the
-    // row index for a fixed lane (fmaf rounds monotonically), so testing the first and the last row of the thread
-    // bounds all eight.  If every lane of the wave keeps all four taps and the whole 8-byte tap window inside the source
-    // (0 <= sx < cols-2, 0 <= sy < rows-1) the validity masks, the clamps, the funnel shifts and the final saturation
-    // are all no-ops: ~65 VALU ops per pixel, same f32 operations in the same order.
+    // The border version below spends ~160 VALU ops per pixel and two unaligned 8-byte loads per row.  sx and sy are
+    // monotonic in the row index for a fixed lane (fmaf rounds monotonically), so testing the first and the last row of the
+    // thread bounds all eight.  If every lane of the wave keeps all four taps and the whole 12-byte aligned tap window
+    // inside the source (0 <= sx < cols-3, 0 <= sy < rows-1) the validity masks, the clamps, the funnel shifts and the final
+    // saturation are all no-ops: 59 VALU ops per pixel, same f32 operations in the same order.
     {
         const float fy0 = (float)min(ybase, d.rows - 1), fy1 = (float)min(ybase + kWarpRows - 1, d.rows - 1);
         const float xa = fmaf(A.m[0], fxx, fmaf(A.m[1], fy0, A.m[2])), xb = fmaf(A.m[0], fxx, fmaf(A.m[1], fy1, A.m[2]));
