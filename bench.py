@@ -138,6 +138,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:   # the first collective builds the RCCL communicator (hundreds of ms): keep that out of the run-up below
+        dist.barrier()
+        torch.cuda.synchronize()
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:   # untimed: clocks settle under the real load
         for _ in range(8):
