@@ -778,6 +778,36 @@ def test_batch_equals_single_frames(ctx, oracle):
     dst.free()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_frame_sharded_contexts_equal_one_batch(ctx, oracle, world):
+    """rank i of G owns frames [floor(iN/G), floor((i+1)N/G)) on its own context and stream; the concatenation of
+    the shards is byte-identical to the single-context result.  (All contexts sit on GPU 0 here: the box has one GPU.)"""
+    import rustcv_amd as rcv
+    from rustcv_amd import shard
+    rows, cols, n = 80, 256, 11
+    k = oracle.bench_kernel7()
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    dst = device.DeviceBatch(ctx, n, rows, cols, 3)
+    device.synth(src, 1, 0x5EED0003, 0)
+    device.filter2d(src, dst, k, shift=6)
+    whole = dst.download()
+    parts = []
+    for r in range(world):
+        f0, f1 = shard.frame_range(n, r, world)
+        if f1 == f0:
+            continue
+        c = rcv.Context(0)
+        s = device.DeviceBatch(c, f1 - f0, rows, cols, 3)
+        d = device.DeviceBatch(c, f1 - f0, rows, cols, 3)
+        device.synth(s, 1, 0x5EED0003, f0)          # frame_base = first global frame of the shard
+        device.filter2d(s, d, k, shift=6)
+        parts.append(d.download())
+        s.free(); d.free(); c.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), whole)
+    src.free()
+    dst.free()
+
+
 def test_errors_do_not_cross_the_abi(ctx):
     L = _ffi.lib()
     m = Mat(4, 4, 3)
