@@ -186,7 +186,9 @@ def main():
                        "frames_per_gpu": n, "global_batch": total_frames, "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "filter2d_i8 7x7", "launch_ms": round(launch_ms, 4), "alg_bytes_per_launch": alg_bytes},
+                         "kernel": "filter2d_i8 7x7", "launch_ms": round(launch_ms, 4), "alg_bytes_per_launch": alg_bytes,
+                         # context only: the guide's measured device-copy ceiling, 6.29 TB/s
+                         "frac_of_copy_ceiling_6290": round(ach / 6290.0, 4)},
         }
         if not a.no_cpu and world == 1:   # the CPU baseline leg runs at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
