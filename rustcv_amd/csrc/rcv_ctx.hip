@@ -75,6 +75,7 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->tmp2) (void)hipFree(c->tmp2);
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
         if (c->stage_buf[i]) (void)hipFree(c->stage_buf[i]);
     if (c->kconst) (void)hipFree(c->kconst);
@@ -231,6 +232,21 @@ int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
     ctx->ws_cap = 0;
     RCV_HIP(hipMalloc((void**)&ctx->ws, total));
     ctx->ws_cap = total;
+    return RCV_OK;
+}
+
+int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out)
+{
+    if (bytes > ctx->tmp2_cap) {
+        if (ctx->capturing) return RCV_ERR_UNSUPPORTED;
+        RCV_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->tmp2) RCV_HIP(hipFree(ctx->tmp2));
+        ctx->tmp2 = nullptr;
+        ctx->tmp2_cap = 0;
+        RCV_HIP(hipMalloc((void**)&ctx->tmp2, bytes));
+        ctx->tmp2_cap = bytes;
+    }
+    *out = ctx->tmp2;
     return RCV_OK;
 }
 

@@ -146,8 +146,9 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     View s, m, r;
     RCV_TRY(rcv_view_batch(bgr, RCV_8U, &s));
     RCV_TRY(rcv_view_batch(mask, RCV_8U, &m));
-    if (s.ch != 3 || m.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if ((s.ch != 3 && s.ch != 2) || m.ch != 1) return RCV_ERR_UNSUPPORTED;   // BGR, or packed YUYV (2 channels)
     if (s.rows != m.rows || s.cols != m.cols || s.n != m.n) return RCV_ERR_ARG;
+    if (s.ch == 2 && (s.cols & 1)) return RCV_ERR_ARG;
     if (resp) {
         RCV_TRY(rcv_view_batch(resp, RCV_32F, &r));
         if (r.ch != 1) return RCV_ERR_UNSUPPORTED;
@@ -157,6 +158,21 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
     int rc = rcv_harris_fused(ctx, s, m, resp ? &r : nullptr, block, k, thr);
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    if (s.ch == 2) {
+        // YUYV shapes the fused kernel does not take: convert into a side buffer (not the workspace, which the BGR pipeline
+        // below may carve for itself), then run the BGR pipeline
+        const size_t tstep = ((size_t)s.cols * 3 + 15) & ~(size_t)15, tfs = tstep * s.rows;
+        uint8_t* tmp;
+        RCV_TRY(rcv_side_reserve(ctx, tfs * s.n, &tmp));
+        rcv_batch tb = *bgr;
+        tb.frame0.data = tmp;
+        tb.frame0.cap = tfs;
+        tb.frame0.step = tstep;
+        tb.frame0.channels = 3;
+        tb.frame_stride = tfs;
+        RCV_TRY(rcv_cvt_color_batch(ctx, RCV_YUYV2BGR_STRIDED, bgr, &tb));
+        return rcv_harris_pipeline_batch(ctx, &tb, mask, resp, block, k, thr);
+    }
     // generic: gray, Ix, Iy (and the response when the caller does not want it) live in the workspace
     size_t npx = (size_t)s.n * s.rows * s.cols;
     RCV_TRY(rcv_ws_reserve(ctx, npx * (1 + 2 + 2 + (resp ? 0 : 4)) + 4 * 256));

@@ -46,7 +46,10 @@ __device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(floa
 struct Row6 { uint32_t d[6]; };
 struct U2 { uint32_t a, b; };
 
-template <bool WANT_RESP>
+// YUYV = true: the source is packed YUYV (2 B/px, SURVEY.md 8(d) config 5 "[or YUYV]"); each macropixel goes through the
+// reference's BT.601 conversion (rustcv/src/videoio/mod.rs:356-363, saturated to u8) and then the same gray formula, so the
+// result equals harris_pipeline(yuyv_to_bgr(.)) bit for bit with 3 instead of 4 algorithmic bytes per pixel.
+template <bool WANT_RESP, bool YUYV>
 __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const int xc = min(max(x, 0), a.cols - 8);
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
-    const uint8_t* sf = a.src + (size_t)frame * a.sfs + 3 * (size_t)xc;
+    const uint8_t* sf = a.src + (size_t)frame * a.sfs + (YUYV ? 2 : 3) * (size_t)xc;
     uint8_t* mp = a.mask + (size_t)frame * a.mfs + (size_t)max(x, 0);
     uint8_t* rp = WANT_RESP ? a.resp + (size_t)frame * a.rfs + 4 * (size_t)max(x, 0) : nullptr;
     uint8_t* const dump = a.dump + lane * 32;
@@ -71,8 +74,12 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         v = min(v, ye + 1);
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
         const uint8_t* p = sf + (size_t)r * a.sstep;
-        const U2 q0 = *(const U2*)p, q1 = *(const U2*)(p + 8), q2 = *(const U2*)(p + 16);
-        return Row6{{q0.a, q0.b, q1.a, q1.b, q2.a, q2.b}};
+        const U2 q0 = *(const U2*)p, q1 = *(const U2*)(p + 8);
+        if constexpr (YUYV) return Row6{{q0.a, q0.b, q1.a, q1.b, 0u, 0u}};
+        else {
+            const U2 q2 = *(const U2*)(p + 16);
+            return Row6{{q0.a, q0.b, q1.a, q1.b, q2.a, q2.b}};
+        }
     };
 
     // ---- pipeline state --------------------------------------------------------------------------------------
@@ -93,13 +100,27 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         // ---- gray (8 px) -----------------------------------------------------------------------------------------
         // weights 1868, 9617, 4899 = 256*{7,37,19} + {76,145,35}: two v_dot4_u32_u8 per pixel on the pixel's (B,G,R,x) dword
         uint32_t g[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;   // pixel j = bytes k0..k0+2 of the 24-byte run
-            const uint32_t px = sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh);
+        auto gray_of = [](uint32_t px) -> uint32_t {
             const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);   // 7*B + 37*G + 19*R
             const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);  // 76*B + 145*G + 35*R + 8192
-            g[j] = ((hi8 << 8) + lo8) >> 14;
+            return ((hi8 << 8) + lo8) >> 14;
+        };
+        if constexpr (YUYV) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {   // macropixel [Y0 U Y1 V] -> two (B,G,R,0) dwords, as the reference converts them
+                const uint32_t w = q.d[m];
+                const int y0 = (int)(w & 0xff), u = (int)((w >> 8) & 0xff) - 128, y1 = (int)((w >> 16) & 0xff), vv = (int)(w >> 24) - 128;
+                const int c0 = 298 * (y0 - 16) + 128, c1 = 298 * (y1 - 16) + 128;
+                const int db = 516 * u, dg = -100 * u - 208 * vv, dr = 409 * vv;
+                g[2 * m] = gray_of(rcv_ashr_sat_pk4(c0 + db, c0 + dg, c0 + dr, 0, 8));
+                g[2 * m + 1] = gray_of(rcv_ashr_sat_pk4(c1 + db, c1 + dg, c1 + dr, 0, 8));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;   // pixel j = bytes k0..k0+2 of the 24-byte run
+                g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
+            }
         }
         uint32_t lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
         if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
 int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* resp, int block, float k, float thr)
 {
-    if (block != 2) return RCV_ERR_UNSUPPORTED;
+    if (block != 2 || (s.ch != 3 && s.ch != 2)) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8)) return RCV_ERR_UNSUPPORTED;
@@ -239,8 +260,8 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
         int& wpc = waves_per_cu[resp ? 1 : 0];
         if (wpc == 0) {
             int nb = 0;
-            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true>, 256, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false>, 256, 0);
+            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, false>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false, false>, 256, 0);
             wpc = (e == hipSuccess && nb > 0) ? 4 * nb : 8;
             (void)hipGetLastError();
         }
@@ -266,7 +287,12 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     a.k = k;
     a.thr = thr;
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (resp) hipLaunchKernelGGL(k_harris_fused<true>, grid, dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_harris_fused<false>, grid, dim3(256), 0, ctx->stream, a);
+    if (s.ch == 2) {
+        if (resp) hipLaunchKernelGGL((k_harris_fused<true, true>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_harris_fused<false, true>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        if (resp) hipLaunchKernelGGL((k_harris_fused<true, false>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_harris_fused<false, false>), grid, dim3(256), 0, ctx->stream, a);
+    }
     return rcv_launch_check(ctx);
 }

@@ -17,6 +17,8 @@ struct rcv_ctx {
     // workspace for kernel-internal temporaries (reserve once per call, then carve)
     uint8_t* ws;
     size_t ws_cap, ws_off;
+    uint8_t* tmp2;       // second grow-only temporary (an intermediate image of a two-stage fallback whose second stage uses ws)
+    size_t tmp2_cap;
     // small device scratch for per-call constants (filter taps, weight tables)
     uint8_t* kconst;     // 64 KiB
     int cu_count;
@@ -68,6 +70,7 @@ int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ct
 int rcv_launch_check(rcv_ctx* ctx);                           // hipGetLastError -> code
 int rcv_ws_reserve(rcv_ctx* ctx, size_t total);               // (re)size the workspace, reset the carve pointer
 int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out);  // 256-B aligned carve
+int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out);   // the side buffer, grown if needed
 int rcv_upload_const(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset); // into ctx->kconst (async, stream ordered)
 
 // Validate a strided mat (step/cap vs rows/cols) and turn it into a View.

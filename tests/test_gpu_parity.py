@@ -737,6 +737,32 @@ def test_baseline_configs_at_full_size(ctx, oracle):
         x.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 8), (9, 496), (40, 504), (33, 1000), (130, 3840), (21, 10), (7, 6)])
+@pytest.mark.parametrize("want_resp", [False, True])
+def test_harris_pipeline_from_yuyv(ctx, oracle, rows, cols, want_resp):
+    """config 5 with a YUYV source: == harris_pipeline(yuyv_to_bgr(.)) of the oracle (fused kernel when cols % 8 == 0, the two-stage
+    HIP path otherwise), batch of 2, padded steps"""
+    n = 2
+    src = device.DeviceBatch(ctx, n, rows, cols, 2, step=cols * 2 + 8)
+    mask = device.DeviceBatch(ctx, n, rows, cols, 1, step=cols + 8)
+    resp = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+    device.synth(src, 2, 0x5EED0005, 3)
+    mask.memset(0x33)
+    thr = 1e-4
+    device.harris_pipeline(src, mask, resp, 2, 0.04, thr)
+    frames, got = src.download(), mask.download()
+    gr = resp.download() if want_resp else None
+    for i in range(n):
+        bgr = np.zeros(rows * cols * 3, np.uint8)
+        oracle.yuv422_to_bgr_strided(frames[i].reshape(-1), cols * 2, rows, cols, False, bgr)
+        wm, wr = oracle.harris_pipeline(bgr.reshape(rows, cols, 3), 2, 0.04, thr, True)
+        if want_resp:
+            assert np.array_equal(gr[i].view(np.uint32), wr.view(np.uint32))
+        assert np.array_equal(got[i], wm)
+    for b in (src, mask) + ((resp,) if want_resp else ()):
+        b.free()
+
+
 # ---- synthetic frames + device-resident batches -------------------------------------------------------
 
 @pytest.mark.parametrize("family,ch", [(0, 1), (0, 3), (0, 4), (1, 3), (1, 1)])

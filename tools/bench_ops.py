@@ -168,6 +168,11 @@ def main():
     device.synth(s, 1, SEED + 5, 0)
     record("Harris pipeline (BGR->mask)", "4K batch=64/GPU", s.n, 3840 * 2160, 4, lambda: device.harris_pipeline(s, m, None, 2, 0.04, 1e-4),
            cpu=lambda: cpu_time(lambda orc: orc.harris_pipeline(np.zeros((2160, 3840, 3), np.uint8), 2, 0.04, 1e-4), 3840 * 2160))
+    yq = B(64, 2160, 3840, 2)
+    device.synth(yq, 2, SEED + 5, 0)
+    record("Harris pipeline from a YUYV source (config 5 [or YUYV])", "4K batch=64/GPU", yq.n, 3840 * 2160, 3,
+           lambda: device.harris_pipeline(yq, m, None, 2, 0.04, 1e-4), note="2 B read + 1 B written per px; YUYV->BGR + pipeline as two launches moves 9")
+    yq.free()
     s.free(); d.free(); m.free()
 
     # ---- config 4: 8K warpAffine + resize -> 1080p, 32 frames per GPU ----------------------------------------
