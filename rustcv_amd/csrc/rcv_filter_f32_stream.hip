@@ -57,23 +57,25 @@ __device__ __forceinline__ f2 pk_fma_w(int half, f2 wp, f2 x, f2 acc)
 // 2*LEAD+4 window bytes one by one at BORDER_REFLECT_101 positions (offsets fixed per thread, computed once) and then
 // run the identical accumulation code -- so the border columns are bit-identical by construction and cost microseconds
 // (a second launch of the generic per-sample kernel over those columns used to take as long as the main kernel).
-template <int KS, int CH, bool SEP, bool EDGE>
+// BPT = owned bytes per thread (4 or 8): with 8 the 2*LEAD halo conversions are shared by twice as many samples.
+template <int KS, int CH, bool SEP, bool EDGE, int BPT>
 __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows, int edge_nl, int edge_nr)
 {
     constexpr int RAD = KS / 2;
     constexpr int LEAD = RAD * CH;                 // bytes of halo on each side of the 4 owned bytes
     constexpr int LEADW = (LEAD + 3) / 4 * 4;      // window starts LEADW bytes before the owned dword
     constexpr int OFF = LEADW - LEAD;              // first needed byte inside the window
-    constexpr int NW = (LEADW + 4 + LEAD + 3) / 4; // window dwords
-    constexpr int NB = 2 * LEAD + 4;               // window bytes
+    constexpr int NW = (LEADW + BPT + LEAD + 3) / 4; // window dwords
+    constexpr int NB = 2 * LEAD + BPT;               // window bytes
+    constexpr int NP = BPT / 2;                      // packed sample pairs per thread
     constexpr int NR = EDGE ? NB : NW;             // registers per staged row
     const int rowbytes = s.cols * CH;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (EDGE) {
         if (t >= edge_nl + edge_nr) return;
-        if (t >= edge_nl) t = rowbytes / 4 - edge_nr + (t - edge_nl);
+        if (t >= edge_nl) t = rowbytes / BPT - edge_nr + (t - edge_nl);
     }
-    const int xb0 = 4 * t;
+    const int xb0 = BPT * t;
     if (xb0 >= rowbytes) return;
     const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     // fmaf per instruction with the weight broadcast to both halves -- the same per-sample chain as the scalar oracle, at
     // half the issue cost.  Sample j of tap kx reads p[j + kx*CH]; the pair {p[m], p[m+1]} is formed by the compiler
     // (v_pk_mov_b32 when m is odd).
-    f2 acc[KS][2];
+    f2 acc[KS][NP];
 #pragma unroll
     for (int i = 0; i < KS; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
+        for (int j = 0; j < NP; ++j) acc[i][j] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
 
     // feed row r (r mod KS == RHO, static): contributes kernel row ky to output y = r - ky + RAD, slot y mod KS
     auto feed = [&](const uint32_t (&w)[NR], int r, auto rho_tag) __attribute__((always_inline)) {
@@ -120,10 +122,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         float p[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) p[b] = EDGE ? (float)w[b] : (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
-        f2 h[2];
+        f2 h[NP];
         if (SEP) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < NP; ++jj) {
                 f2 a = {0.0f, 0.0f};
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) a = pk_fma_w(kx & 1, W.w2[kx >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, a);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         for (int ky = 0; ky < KS; ++ky) {
             const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < NP; ++jj) {
                 if (SEP) {
                     acc[slot][jj] = pk_fma_w(ky & 1, W.w2[ky >> 1], h[jj], acc[slot][jj]);
                 } else {
@@ -148,12 +150,20 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         constexpr int done = ((RHO - (KS - 1) + RAD) % KS + KS) % KS;
         const int y = r - RAD;
         // rintf (half to even) gives an exact integer; v_cvt_pk_u8_f32 converts it with saturation to [0, 255] and packs
-        uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][0].x), 0, 0u);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][0].y), 1, o);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][1].x), 2, o);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][1].y), 3, o);
-        acc[done][0] = acc[done][1] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
-        if (y >= ys && y < ye) *(uint32_t*)(df + (size_t)y * d.step) = o;
+        uint32_t o[BPT / 4];
+#pragma unroll
+        for (int q = 0; q < BPT / 4; ++q) {
+            uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][2 * q].x), 0, 0u);
+            v = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][2 * q].y), 1, v);
+            v = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][2 * q + 1].x), 2, v);
+            o[q] = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc[done][2 * q + 1].y), 3, v);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[done][j] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
+        if (y >= ys && y < ye) {
+            if constexpr (BPT == 8) *(uint2*)(df + (size_t)y * d.step) = make_uint2(o[0], o[1]);
+            else *(uint32_t*)(df + (size_t)y * d.step) = o[0];
+        }
     };
 
     // rows ys-RAD .. ye-1+RAD; the unrolled body handles KS consecutive rows whose (row mod KS) is static when the
@@ -173,28 +183,29 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     }
 }
 
-template <int KS, int CH, bool SEP>
+template <int KS, int CH, bool SEP, int BPT>
 int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta)
 {
-    constexpr int RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, NW = (LEADW + 4 + LEAD + 3) / 4;
+    constexpr int RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, NW = (LEADW + BPT + LEAD + 3) / 4;
     const int rowbytes = s.cols * CH;
-    if (rowbytes < 4 * NW) return RCV_ERR_UNSUPPORTED;
+    if (rowbytes < 4 * NW || rowbytes % BPT != 0) return RCV_ERR_UNSUPPORTED;
     FWeights<KS, SEP> W;
     memset(&W, 0, sizeof(W));
     for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w2[i >> 1][i & 1] = w[i];
     W.delta = delta;
-    const unsigned gx = (unsigned)((rowbytes / 4 + kBlock - 1) / kBlock);
+    const unsigned gx = (unsigned)((rowbytes / BPT + kBlock - 1) / kBlock);
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, false>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, false, BPT>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
-    // byte columns whose window left the row: [0, LEADW) and [rowbytes - (4*NW - LEADW) + 4, rowbytes) -- redone by the
-    // EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
-    const int lo_end = min(LEADW, rowbytes), hi_begin = max(lo_end, rowbytes - (4 * NW - LEADW) + 4);
-    const int nl = lo_end / 4, nr = (rowbytes - hi_begin) / 4;
+    // threads whose window [xb0 - LEADW, xb0 - LEADW + 4 NW) left the row computed garbage: the first nl and the last nr of a
+    // row -- redone by the EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
+    const int limit = rowbytes - 4 * NW + LEADW;                  // last xb0 whose window still fits
+    const int hi_begin = (limit / BPT + 1) * BPT;
+    const int nl = min((LEADW + BPT - 1) / BPT, rowbytes / BPT), nr = max(0, min((rowbytes - hi_begin) / BPT, rowbytes / BPT - nl));
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
-    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, true>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
+    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, true, BPT>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
                        dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr);
     return rcv_launch_check(ctx);
 }
@@ -205,8 +216,17 @@ int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksi
     if ((s.cols * s.ch) % 4 != 0) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 4 || d.step % 4 || (d.n > 1 && d.fstride % 4)) return RCV_ERR_UNSUPPORTED;
-#define RCV_CASE(KS, CH) \
-    if (ksize == KS && s.ch == CH) return launch<KS, CH, SEP>(ctx, s, d, w, delta);
+    // 8 bytes per thread where rows and row ends are 8-byte aligned (the halo conversions are shared by twice the samples)
+    const bool wide = (s.cols * s.ch) % 8 == 0 && (uintptr_t)s.p % 8 == 0 && s.step % 8 == 0 && (s.n <= 1 || s.fstride % 8 == 0) &&
+                      (uintptr_t)d.p % 8 == 0 && d.step % 8 == 0 && (d.n <= 1 || d.fstride % 8 == 0);
+#define RCV_CASE(KS, CH)                                                                 \
+    if (ksize == KS && s.ch == CH) {                                                     \
+        if (wide) {                                                                      \
+            int rc = launch<KS, CH, SEP, 8>(ctx, s, d, w, delta);                        \
+            if (rc != RCV_ERR_UNSUPPORTED) return rc;                                    \
+        }                                                                                \
+        return launch<KS, CH, SEP, 4>(ctx, s, d, w, delta);                              \
+    }
     RCV_CASE(3, 1) RCV_CASE(5, 1) RCV_CASE(7, 1) RCV_CASE(3, 3) RCV_CASE(5, 3) RCV_CASE(7, 3)
     if constexpr (SEP) { RCV_CASE(9, 1) RCV_CASE(11, 1) RCV_CASE(9, 3) RCV_CASE(11, 3) }
 #undef RCV_CASE
