@@ -323,6 +323,43 @@ def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
     dst.free()
 
 
+def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
+    """40 seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
+    heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
+    padded steps, batch 1..3, BGR and YUYV sources"""
+    r = np.random.default_rng(0xF17E7)
+    for case in range(40):
+        cols = 16 * int(r.integers(1, 66))
+        rows = int(r.integers(4, 151))
+        ksize = int(r.choice([3, 5, 7]))
+        shift = int(r.integers(0, 13))
+        n = int(r.integers(1, 4))
+        k = r.integers(-128, 128, size=(ksize, ksize)).astype(np.int8)
+        yuyv = bool(case % 4 == 3)
+        sch = 2 if yuyv else 3
+        pad = 16 * int(r.integers(0, 3))
+        src = device.DeviceBatch(ctx, n, rows, cols, sch, step=cols * sch + pad)
+        dst = _canary_batch(ctx, n, rows, cols, 3, pad=16)
+        frames = r.integers(0, 256, size=(n, rows, cols, sch), dtype=np.uint8)
+        src.upload(frames)
+        if yuyv:
+            device.filter2d_yuyv(src, dst, k, shift=shift)
+        else:
+            device.filter2d(src, dst, k, shift=shift)
+        got = dst.download()
+        for i in range(n):
+            if yuyv:
+                bgr = np.zeros(rows * cols * 3, np.uint8)
+                oracle.yuv422_to_bgr_strided(frames[i].reshape(-1), cols * 2, rows, cols, False, bgr)
+                ref = bgr.reshape(rows, cols, 3)
+            else:
+                ref = frames[i]
+            assert np.array_equal(got[i], oracle.filter2d_i8(ref, k, shift)), (case, rows, cols, ksize, shift, n, yuyv)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 def test_filter2d_i8_mfma_batch_4k_properties(ctx, oracle):
     """Full-size frames (BASELINE configs[2] shape, small batch): (1) rows of frame 0 against the oracle on
     slabs; (2) linearity: filter(K1) + filter(K2) == filter(K1+K2) where nothing saturates (shift 0 is not
