@@ -360,6 +360,88 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
         dst.free()
 
 
+def test_register_window_kernels_random_shapes(ctx, oracle):
+    """24 seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
+    widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""
+    r = np.random.default_rng(0x50BE1)
+    for case in range(24):
+        cols = 8 * int(r.integers(1, 201))
+        rows = int(r.integers(4, 261))
+        n = int(r.integers(1, 3))
+        bgr = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+        pad = 8 * int(r.integers(0, 3))
+        if case % 2 == 0:     # Sobel, gray or BGR source
+            from_bgr = bool(case % 4 == 0)
+            src = device.DeviceBatch(ctx, n, rows, cols, 3 if from_bgr else 1, step=cols * (3 if from_bgr else 1) + pad)
+            grays = np.stack([oracle.bgr2gray(f) for f in bgr])
+            src.upload(bgr if from_bgr else grays[..., None])
+            dx = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+            dy = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+            device.sobel(src, dx, dy)
+            gx, gy = dx.download(), dy.download()
+            for i in range(n):
+                wx, wy = oracle.sobel(grays[i])
+                assert np.array_equal(gx[i], wx) and np.array_equal(gy[i], wy), (case, rows, cols, from_bgr)
+            _assert_canaries(dx)
+            _assert_canaries(dy)
+            for b in (src, dx, dy):
+                b.free()
+        else:                 # Harris pipeline, BGR or YUYV source, with the response
+            from_yuyv = bool(case % 4 == 1)
+            if from_yuyv:
+                yuyv = r.integers(0, 256, size=(n, rows, cols, 2), dtype=np.uint8)
+                src = device.DeviceBatch(ctx, n, rows, cols, 2, step=cols * 2 + pad)
+                src.upload(yuyv)
+                refs = []
+                for i in range(n):
+                    t = np.zeros(rows * cols * 3, np.uint8)
+                    oracle.yuv422_to_bgr_strided(yuyv[i].reshape(-1), cols * 2, rows, cols, False, t)
+                    refs.append(t.reshape(rows, cols, 3))
+            else:
+                src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + pad)
+                src.upload(bgr)
+                refs = list(bgr)
+            mask = _canary_batch(ctx, n, rows, cols, 1, pad=8)
+            resp = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F)
+            device.harris_pipeline(src, mask, resp, 2, 0.04, 1e-4)
+            gm, gr = mask.download(), resp.download()
+            for i in range(n):
+                wm, wr = oracle.harris_pipeline(refs[i], 2, 0.04, 1e-4, True)
+                assert np.array_equal(gr[i].view(np.uint32), wr.view(np.uint32)), (case, rows, cols, from_yuyv)
+                assert np.array_equal(gm[i], wm), (case, rows, cols, from_yuyv)
+            _assert_canaries(mask)
+            for b in (src, mask, resp):
+                b.free()
+
+
+def test_geometry_kernels_random_maps(ctx, oracle):
+    """20 seeded random affine maps / scales through the BGR warp, general resize and fused warp->down-scale kernels (output widths
+    multiples of 4): rotations, shears, scales 0.3..3, translations that push part or all of the footprint outside"""
+    r = np.random.default_rng(0x6E07)
+    for case in range(20):
+        sr, sc = int(r.integers(6, 200)), int(r.integers(6, 300))
+        dr, dc = int(r.integers(2, 120)), 4 * int(r.integers(1, 60))
+        img = r.integers(0, 256, size=(sr, sc, 3), dtype=np.uint8)
+        th, sx, sy = r.uniform(-3.2, 3.2), r.uniform(0.3, 3.0), r.uniform(0.3, 3.0)
+        M = np.array([sx * np.cos(th), -sy * np.sin(th) + r.uniform(-0.2, 0.2), r.uniform(-0.6 * sc, 0.6 * sc),
+                      sx * np.sin(th), sy * np.cos(th), r.uniform(-0.6 * sr, 0.6 * sr)], np.float32)
+        src = device.DeviceBatch(ctx, 1, sr, sc, 3)
+        src.upload(img[None])
+        dst = _canary_batch(ctx, 1, dr, dc, 3, pad=8)
+        device.warp_affine(src, dst, M)
+        assert np.array_equal(dst.download()[0], oracle.warp_affine(img, M, dr, dc)), (case, "warp", sr, sc, dr, dc)
+        _assert_canaries(dst)
+        device.resize(src, dst)
+        assert np.array_equal(dst.download()[0], oracle.resize(img, dr, dc)), (case, "resize", sr, sc, dr, dc)
+        _assert_canaries(dst)
+        S = 2 if case % 2 else 4
+        device.warp_affine_resize(src, dst, M, S * dr, S * dc)
+        assert np.array_equal(dst.download()[0], oracle.resize(oracle.warp_affine(img, M, S * dr, S * dc), dr, dc)), (case, "fused", S)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 def test_filter2d_i8_mfma_batch_4k_properties(ctx, oracle):
     """Full-size frames (BASELINE configs[2] shape, small batch): (1) rows of frame 0 against the oracle on
     slabs; (2) linearity: filter(K1) + filter(K2) == filter(K1+K2) where nothing saturates (shift 0 is not
