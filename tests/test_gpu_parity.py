@@ -493,6 +493,40 @@ def test_filter2d_f32(ctx, oracle, rng, rows, cols, ksize):
     assert np.array_equal(dst.to_array(), oracle.filter2d_f32(img, k, 0.5))
 
 
+def test_f32_stream_kernels_random_shapes(ctx, oracle):
+    """30 seeded random cases for the f32 streaming kernels (dense filter2D and separable Gaussian): 1 and 3 channels, ksize 3..11,
+    row bytes a multiple of 4 or of 8 (4- and 8-byte-per-thread variants, EDGE threads), 8-byte aligned and unaligned steps"""
+    r = np.random.default_rng(0xF32)
+    for case in range(30):
+        ch = int(r.choice([1, 3]))
+        cols = 4 * int(r.integers(3, 120)) if ch == 1 else 4 * int(r.integers(3, 80))
+        rows = int(r.integers(1, 120))
+        n = int(r.integers(1, 3))
+        pad = int(r.choice([0, 4, 8, 16]))
+        img = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+        src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + pad)
+        dst = _canary_batch(ctx, n, rows, cols, ch, pad=int(r.choice([4, 8])))
+        src.upload(img)
+        if case % 2 == 0:
+            ksize = int(r.choice([3, 5, 7]))
+            k = (r.standard_normal((ksize, ksize)) / ksize).astype(np.float32)
+            delta = float(r.uniform(-20, 20))
+            device.filter2d(src, dst, k, delta=delta)
+            want = [oracle.filter2d_f32(img[i].reshape(rows, cols, ch) if ch > 1 else img[i, :, :, 0], k, delta) for i in range(n)]
+        else:
+            ksize = int(r.choice([3, 5, 7, 9, 11]))
+            sigma = float(r.uniform(0.4, 3.0))
+            device.gaussian_blur(src, dst, ksize, sigma)
+            want = [oracle.gaussian_blur(img[i].reshape(rows, cols, ch) if ch > 1 else img[i, :, :, 0], ksize, sigma) for i in range(n)]
+        got = dst.download()
+        for i in range(n):
+            g = got[i] if ch > 1 else got[i].reshape(rows, cols)
+            assert np.array_equal(g, want[i].reshape(g.shape)), (case, rows, cols, ch, ksize, pad)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(1, 4), (2, 8), (7, 12), (33, 64), (61, 128), (40, 300)])
 @pytest.mark.parametrize("ch", [1, 3])
 @pytest.mark.parametrize("ksize", [3, 5, 7])
