@@ -5,6 +5,8 @@ sides -- bit-exact for the f32 Harris response too (tolerance stated where it is
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,10 @@ from rustcv_amd.core import Mat
 from rustcv_amd.imgproc import Rect, Scalar
 
 pytestmark = pytest.mark.gpu
+
+# soak runs: RCV_SOAK=N multiplies the case count of the seeded random tests, RCV_SOAK_SEED shifts their seeds
+_SOAK = max(1, int(os.environ.get("RCV_SOAK", "1")))
+_SOAK_SEED = int(os.environ.get("RCV_SOAK_SEED", "0"))
 
 SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 33), (48, 64), (61, 127), (128, 240), (37, 515)]
 
@@ -327,8 +333,8 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
     """40 seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
     heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
     padded steps, batch 1..3, BGR and YUYV sources"""
-    r = np.random.default_rng(0xF17E7)
-    for case in range(40):
+    r = np.random.default_rng(0xF17E7 + _SOAK_SEED)
+    for case in range(40 * _SOAK):
         cols = 16 * int(r.integers(1, 66))
         rows = int(r.integers(4, 151))
         ksize = int(r.choice([3, 5, 7]))
@@ -363,8 +369,8 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
 def test_register_window_kernels_random_shapes(ctx, oracle):
     """24 seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
     widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""
-    r = np.random.default_rng(0x50BE1)
-    for case in range(24):
+    r = np.random.default_rng(0x50BE1 + _SOAK_SEED)
+    for case in range(24 * _SOAK):
         cols = 8 * int(r.integers(1, 201))
         rows = int(r.integers(4, 261))
         n = int(r.integers(1, 3))
@@ -417,8 +423,8 @@ def test_register_window_kernels_random_shapes(ctx, oracle):
 def test_geometry_kernels_random_maps(ctx, oracle):
     """20 seeded random affine maps / scales through the BGR warp, general resize and fused warp->down-scale kernels (output widths
     multiples of 4): rotations, shears, scales 0.3..3, translations that push part or all of the footprint outside"""
-    r = np.random.default_rng(0x6E07)
-    for case in range(20):
+    r = np.random.default_rng(0x6E07 + _SOAK_SEED)
+    for case in range(20 * _SOAK):
         sr, sc = int(r.integers(6, 200)), int(r.integers(6, 300))
         dr, dc = int(r.integers(2, 120)), 4 * int(r.integers(1, 60))
         img = r.integers(0, 256, size=(sr, sc, 3), dtype=np.uint8)
@@ -496,8 +502,8 @@ def test_filter2d_f32(ctx, oracle, rng, rows, cols, ksize):
 def test_f32_stream_kernels_random_shapes(ctx, oracle):
     """30 seeded random cases for the f32 streaming kernels (dense filter2D and separable Gaussian): 1 and 3 channels, ksize 3..11,
     row bytes a multiple of 4 or of 8 (4- and 8-byte-per-thread variants, EDGE threads), 8-byte aligned and unaligned steps"""
-    r = np.random.default_rng(0xF32)
-    for case in range(30):
+    r = np.random.default_rng(0xF32 + _SOAK_SEED)
+    for case in range(30 * _SOAK):
         ch = int(r.choice([1, 3]))
         cols = 4 * int(r.integers(3, 120)) if ch == 1 else 4 * int(r.integers(3, 80))
         rows = int(r.integers(1, 120))
