@@ -52,7 +52,7 @@ def cpu_baseline(budget_s):
     """Oracle (port) on the host cores, all threads (OpenMP over rows), bounded sample of whole 4K frames."""
     import numpy as np
     from oracle import pyoracle as orc
-    cores = os.cpu_count() or 1
+    cores = orc.usable_cores()   # affinity capped by the cgroup CPU quota, not os.cpu_count()
     used = orc.set_threads(cores)
     k = orc.bench_kernel7()
     frame = orc.synth_frame(ROWS, COLS, CH, 0, SEED, 0)
@@ -63,7 +63,7 @@ def cpu_baseline(budget_s):
         orc.filter2d_i8(frame, k, 6)
         frames += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or frames >= 32:
+        if dt >= budget_s or frames >= 512:
             break
     mpix = frames * ROWS * COLS / 1e6 / dt
     # one-thread figure on a smaller slab (rows are independent), for the record

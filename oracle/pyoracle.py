@@ -57,6 +57,29 @@ def lib():
     return _lib
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (the GPU boxes report
+    256 logical CPUs but run under a 16-CPU quota; 256 OpenMP threads there are 6x slower than 16)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:   # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, math.ceil(q / p)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
     return lib().orc_threads()

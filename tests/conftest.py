@@ -19,6 +19,7 @@ def oracle():
     from oracle import pyoracle
     pyoracle.build()
     pyoracle.lib()
+    pyoracle.set_threads(pyoracle.usable_cores())   # OpenMP's default (every logical CPU) oversubscribes a cgroup-limited box
     return pyoracle
 
 

@@ -112,14 +112,14 @@ def main():
 
     def cpu_time(fn, px, budget=4.0):
         from oracle import pyoracle as orc
-        cores = orc.set_threads(os.cpu_count() or 1)
+        cores = orc.set_threads(orc.usable_cores())
         fn(orc)
         t0, k = time.perf_counter(), 0
         while True:
             fn(orc)
             k += 1
             dt = time.perf_counter() - t0
-            if dt > budget or k >= 16:
+            if dt > budget or k >= 4096:
                 break
         return {"mpix_s": round(k * px / 1e6 / dt, 2), "cores": cores, "frames": k, "kind": "port"}
 
