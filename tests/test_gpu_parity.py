@@ -18,7 +18,7 @@ from rustcv_amd.imgproc import Rect, Scalar
 pytestmark = pytest.mark.gpu
 
 # soak runs: RCV_SOAK=N multiplies the case count of the seeded random tests, RCV_SOAK_SEED shifts their seeds
-_SOAK = max(1, int(os.environ.get("RCV_SOAK", "1")))
+_SOAK = max(1, int(os.environ.get("RCV_SOAK", "10")))   # default: 200-400 cases per random test, a few seconds in total
 _SOAK_SEED = int(os.environ.get("RCV_SOAK_SEED", "0"))
 
 SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 33), (48, 64), (61, 127), (128, 240), (37, 515)]
@@ -330,7 +330,7 @@ def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
 
 
 def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
-    """40 seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
+    """40 x RCV_SOAK seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
     heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
     padded steps, batch 1..3, BGR and YUYV sources"""
     r = np.random.default_rng(0xF17E7 + _SOAK_SEED)
@@ -367,7 +367,7 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
 
 
 def test_register_window_kernels_random_shapes(ctx, oracle):
-    """24 seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
+    """24 x RCV_SOAK seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
     widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""
     r = np.random.default_rng(0x50BE1 + _SOAK_SEED)
     for case in range(24 * _SOAK):
@@ -421,7 +421,7 @@ def test_register_window_kernels_random_shapes(ctx, oracle):
 
 
 def test_geometry_kernels_random_maps(ctx, oracle):
-    """20 seeded random affine maps / scales through the BGR warp, general resize and fused warp->down-scale kernels (output widths
+    """20 x RCV_SOAK seeded random affine maps / scales through the BGR warp, general resize and fused warp->down-scale kernels (output widths
     multiples of 4): rotations, shears, scales 0.3..3, translations that push part or all of the footprint outside"""
     r = np.random.default_rng(0x6E07 + _SOAK_SEED)
     for case in range(20 * _SOAK):
@@ -500,7 +500,7 @@ def test_filter2d_f32(ctx, oracle, rng, rows, cols, ksize):
 
 
 def test_f32_stream_kernels_random_shapes(ctx, oracle):
-    """30 seeded random cases for the f32 streaming kernels (dense filter2D and separable Gaussian): 1 and 3 channels, ksize 3..11,
+    """30 x RCV_SOAK seeded random cases for the f32 streaming kernels (dense filter2D and separable Gaussian): 1 and 3 channels, ksize 3..11,
     row bytes a multiple of 4 or of 8 (4- and 8-byte-per-thread variants, EDGE threads), 8-byte aligned and unaligned steps"""
     r = np.random.default_rng(0xF32 + _SOAK_SEED)
     for case in range(30 * _SOAK):
