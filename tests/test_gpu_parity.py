@@ -1029,6 +1029,134 @@ def _assert_canaries(b):
     assert (raw[:, b.rows * b.step:] == 0xCD).all(), "inter-frame gap overwritten"
 
 
+class _Arena:
+    """one device allocation + host mirror; images are placed at arbitrary byte offsets / steps / frame strides inside it"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.dev = device.DeviceBatch(ctx, 1, 1, nbytes, 1)
+        self.host = np.full(nbytes, 0xCD, np.uint8)
+
+    def place(self, off, n, rows, cols, ch, depth, step, fs, frames=None):
+        esz = {_ffi.RCV_8U: 1, _ffi.RCV_16S: 2, _ffi.RCV_32F: 4}[depth]
+        rowb = cols * ch * esz
+        assert off + (n - 1) * fs + (rows - 1) * step + rowb <= self.nbytes
+        if frames is not None:
+            raw = np.ascontiguousarray(frames).view(np.uint8).reshape(n, rows, rowb)
+            for i in range(n):
+                for r in range(rows):
+                    o = off + i * fs + r * step
+                    self.host[o:o + rowb] = raw[i, r]
+        b = _ffi.rcv_batch()
+        m = b.frame0
+        m.data = self.dev.ptr.value + off
+        m.cap = (rows - 1) * step + rowb if rows else 0
+        m.step, m.rows, m.cols, m.channels, m.depth, m.device = step, rows, cols, ch, depth, _ffi.RCV_DEVICE
+        b.frame_stride, b.n = fs, n
+        return b, (off, n, rows, rowb, step, fs)
+
+    def upload(self):
+        self.dev.upload_bytes(self.host)
+
+    def check(self, geo, want, dtype):
+        """rows of the placed image == want, every other byte of the arena untouched"""
+        off, n, rows, rowb, step, fs = geo
+        got = self.dev.download_bytes()[: self.nbytes]
+        mask = np.ones(self.nbytes, bool)
+        w = np.ascontiguousarray(want).view(np.uint8).reshape(n, rows, rowb)
+        for i in range(n):
+            for r in range(rows):
+                o = off + i * fs + r * step
+                assert np.array_equal(got[o:o + rowb], w[i, r]), (i, r)
+                mask[o:o + rowb] = False
+        assert (got[mask] == 0xCD).all(), "bytes outside the image rows were written"
+
+    def free(self):
+        self.dev.free()
+
+
+def test_misaligned_views_random(ctx, oracle):
+    """every batch entry point on images that start at odd byte offsets with odd steps and frame strides: the dispatchers must fall
+    back from the vector kernels to the generic HIP kernels and still match the oracle without touching a byte outside the rows"""
+    L = _ffi.lib()
+    r = np.random.default_rng(0xA11 + _SOAK_SEED)
+    for case in range(12 * _SOAK):
+        rows, cols, n = int(r.integers(1, 40)), int(r.integers(1, 70)), int(r.integers(1, 3))
+        op = case % 9
+        sch = {0: 3, 1: 2, 2: 4, 3: 1}.get(op, 3)
+        if op == 1:
+            cols += cols & 1
+        srcf = r.integers(0, 256, size=(n, rows, cols, sch), dtype=np.uint8)
+        soff, sstep = int(r.integers(0, 16)), cols * sch + int(r.integers(0, 10))
+        sfs = rows * sstep + int(r.integers(0, 33))
+        src = _Arena(ctx, soff + n * sfs + 64)
+        bs, _ = src.place(soff, n, rows, cols, sch, _ffi.RCV_8U, sstep, sfs, srcf)
+        src.upload()
+
+        def dst_view(drows, dcols, ch, depth, align):
+            esz = {_ffi.RCV_8U: 1, _ffi.RCV_16S: 2, _ffi.RCV_32F: 4}[depth]
+            off = int(r.integers(0, 16)) // align * align
+            step = dcols * ch * esz + int(r.integers(0, 10)) // align * align
+            fs = drows * step + int(r.integers(0, 33)) // align * align
+            a = _Arena(ctx, off + n * fs + 64)
+            b, geo = a.place(off, n, drows, dcols, ch, depth, step, fs)
+            a.upload()
+            return a, b, geo
+
+        imgs = [srcf[i] if sch > 1 else srcf[i, :, :, 0] for i in range(n)]
+        outs = []
+        if op == 0:     # BGR -> gray
+            a, b, geo = dst_view(rows, cols, 1, _ffi.RCV_8U, 1)
+            assert L.rcv_cvt_color_batch(ctx.handle, _ffi.RCV_BGR2GRAY, C.byref(bs), C.byref(b)) == 0
+            outs.append((a, geo, np.stack([oracle.bgr2gray(im) for im in imgs]), np.uint8))
+        elif op == 1:   # strided YUYV -> BGR
+            a, b, geo = dst_view(rows, cols, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_cvt_color_batch(ctx.handle, _ffi.RCV_YUYV2BGR_STRIDED, C.byref(bs), C.byref(b)) == 0
+            want = np.zeros((n, rows * cols * 3), np.uint8)
+            for i in range(n):
+                oracle.yuv422_to_bgr_strided(srcf[i].reshape(-1), cols * 2, rows, cols, False, want[i])
+            outs.append((a, geo, want, np.uint8))
+        elif op == 2:   # strided BGRA -> BGR
+            a, b, geo = dst_view(rows, cols, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_cvt_color_batch(ctx.handle, _ffi.RCV_BGRA2BGR_STRIDED, C.byref(bs), C.byref(b)) == 0
+            outs.append((a, geo, srcf[..., :3], np.uint8))
+        elif op == 3:   # Sobel
+            ax, bx, gx = dst_view(rows, cols, 1, _ffi.RCV_16S, 2)
+            ay, by, gy = dst_view(rows, cols, 1, _ffi.RCV_16S, 2)
+            assert L.rcv_sobel_batch(ctx.handle, C.byref(bs), C.byref(bx), C.byref(by)) == 0
+            ws = [oracle.sobel(im) for im in imgs]
+            outs += [(ax, gx, np.stack([w[0] for w in ws]), np.int16), (ay, gy, np.stack([w[1] for w in ws]), np.int16)]
+        elif op == 4:   # integer Gaussian 5x5
+            a, b, geo = dst_view(rows, cols, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_gaussian_blur_batch(ctx.handle, C.byref(bs), C.byref(b), 5, 0.0) == 0
+            outs.append((a, geo, np.stack([oracle.gaussian_blur(im, 5, 0.0) for im in imgs]), np.uint8))
+        elif op == 5:   # f32 Gaussian
+            a, b, geo = dst_view(rows, cols, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_gaussian_blur_batch(ctx.handle, C.byref(bs), C.byref(b), 5, 1.2) == 0
+            outs.append((a, geo, np.stack([oracle.gaussian_blur(im, 5, 1.2) for im in imgs]), np.uint8))
+        elif op == 6:   # resize
+            dr, dc = int(r.integers(1, 30)), int(r.integers(1, 50))
+            a, b, geo = dst_view(dr, dc, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_resize_batch(ctx.handle, C.byref(bs), C.byref(b)) == 0
+            outs.append((a, geo, np.stack([oracle.resize(im, dr, dc) for im in imgs]), np.uint8))
+        elif op == 7:   # warpAffine
+            dr, dc = int(r.integers(1, 30)), int(r.integers(1, 50))
+            M = np.array([0.9, 0.15, r.uniform(-5, 5), -0.2, 1.1, r.uniform(-5, 5)], np.float32)
+            a, b, geo = dst_view(dr, dc, 3, _ffi.RCV_8U, 1)
+            assert L.rcv_warp_affine_batch(ctx.handle, C.byref(bs), C.byref(b), M.ctypes.data_as(C.POINTER(C.c_float))) == 0
+            outs.append((a, geo, np.stack([oracle.warp_affine(im, M, dr, dc) for im in imgs]), np.uint8))
+        else:           # Harris pipeline with the response
+            am, bm, gm = dst_view(rows, cols, 1, _ffi.RCV_8U, 1)
+            ar, br, gr = dst_view(rows, cols, 1, _ffi.RCV_32F, 4)
+            assert L.rcv_harris_pipeline_batch(ctx.handle, C.byref(bs), C.byref(bm), C.byref(br), 2, 0.04, 1e-4) == 0
+            ws = [oracle.harris_pipeline(im, 2, 0.04, 1e-4, True) for im in imgs]
+            outs += [(am, gm, np.stack([w[0] for w in ws]), np.uint8), (ar, gr, np.stack([w[1] for w in ws]), np.float32)]
+        for a, geo, want, dt in outs:
+            a.check(geo, want.astype(dt), dt)
+            a.free()
+        src.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(20, 48), (37, 256), (130, 496)])
 def test_no_out_of_bounds_writes(ctx, oracle, rows, cols):
     n = 2
