@@ -366,6 +366,36 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
         dst.free()
 
 
+def test_gray_dot4_filter_random_shapes(ctx, oracle):
+    """20 x RCV_SOAK seeded random cases for the one-channel dot4 streaming kernel: widths 12..1000 (multiples of 4), heights 1..150,
+    ksize 3/5/7, weights over the i8 range, integer GaussianBlur 3/5/7 (7x7 takes the split-weight path), padded steps, batch 1..3"""
+    r = np.random.default_rng(0x6A47 + _SOAK_SEED)
+    for case in range(20 * _SOAK):
+        cols = 4 * int(r.integers(3, 251))
+        rows = int(r.integers(1, 151))
+        n = int(r.integers(1, 4))
+        ksize = int(r.choice([3, 5, 7]))
+        pad = 4 * int(r.integers(0, 4))
+        frames = r.integers(0, 256, size=(n, rows, cols, 1), dtype=np.uint8)
+        src = device.DeviceBatch(ctx, n, rows, cols, 1, step=cols + pad)
+        dst = _canary_batch(ctx, n, rows, cols, 1, pad=int(r.choice([4, 8, 12])))
+        src.upload(frames)
+        if case % 3 == 2:
+            device.gaussian_blur(src, dst, ksize, 0.0)
+            want = [oracle.gaussian_blur(frames[i, :, :, 0], ksize, 0.0) for i in range(n)]
+        else:
+            k = r.integers(-128, 128, size=(ksize, ksize)).astype(np.int8)
+            shift = int(r.integers(0, 13))
+            device.filter2d(src, dst, k, shift=shift)
+            want = [oracle.filter2d_i8(frames[i, :, :, 0], k, shift) for i in range(n)]
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i].reshape(rows, cols), want[i]), (case, rows, cols, ksize)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 def test_register_window_kernels_random_shapes(ctx, oracle):
     """24 x RCV_SOAK seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
     widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""
