@@ -1059,6 +1059,53 @@ def _assert_canaries(b):
     assert (raw[:, b.rows * b.step:] == 0xCD).all(), "inter-frame gap overwritten"
 
 
+def test_image_beyond_4gib(ctx, oracle):
+    """one 50 000 x 30 000 BGR image (4.5 GB: in-frame byte offsets exceed 2^32, so the 24-bit / 32-bit offset fast paths must
+    step aside): row slabs of filter2D, gray filter2D, warpAffine and the Harris pipeline against the oracle, including rows
+    that lie beyond the 4 GiB mark"""
+    rows, cols = 50000, 30000
+    L = _ffi.lib()
+    src = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    dst = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    device.synth(src, 1, 77, 0)
+    k = oracle.bench_kernel7()
+
+    def slab(batch, y0, y1, ch):
+        n = (y1 - y0) * batch.step
+        raw = np.empty(n, np.uint8)
+        _ffi.check(L.rcv_download(ctx.handle, raw.ctypes.data, C.c_void_p(batch.ptr.value + y0 * batch.step), n), "rcv_download")
+        return raw.reshape(y1 - y0, cols, ch)
+
+    def check_stencil(sbatch, dbatch, ch, fn, halo):
+        for a, b in [(0, 30), (24990, 25030), (47710, 47750), (rows - 30, rows)]:
+            lo, hi = max(0, a - halo), min(rows, b + halo)
+            s = slab(sbatch, lo, hi, ch)
+            want = fn(s if ch > 1 else s[:, :, 0])
+            got = slab(dbatch, a, b, ch if dbatch.channels > 1 else 1)
+            got = got if dbatch.channels > 1 else got[:, :, 0]
+            assert np.array_equal(want[a - lo: a - lo + (b - a)], got), (a, b)
+
+    device.filter2d(src, dst, k, shift=6)
+    check_stencil(src, dst, 3, lambda im: oracle.filter2d_i8(im, k, 6), 3)
+    g = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    g2 = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    device.cvt_color(src, g, _ffi.RCV_BGR2GRAY)
+    device.filter2d(g, g2, k, shift=6)
+    check_stencil(g, g2, 1, lambda im: oracle.filter2d_i8(im, k, 6), 3)
+    m = g2
+    device.harris_pipeline(src, m, None, 2, 0.04, 1e-4)
+    check_stencil(src, m, 3, lambda im: oracle.harris_pipeline(im, 2, 0.04, 1e-4), 8)
+    M = np.array([1, 0, 0.5, 0, 1, 0.25], np.float32)   # fractional translation: output row y reads source rows y, y+1
+    device.warp_affine(src, dst, M)
+    for a, b in [(0, 20), (47720, 47760), (rows - 20, rows)]:
+        hi = min(rows, b + 2)
+        want = oracle.warp_affine(slab(src, a, hi, 3), M, hi - a, cols)
+        keep = (b - a) - (1 if hi == rows else 0)       # the image's last row taps the zero border, the slab's does not
+        assert np.array_equal(want[:keep], slab(dst, a, b, 3)[:keep]), (a, b)
+    for x in (src, dst, g, g2):
+        x.free()
+
+
 class _Arena:
     """one device allocation + host mirror; images are placed at arbitrary byte offsets / steps / frame strides inside it"""
 
