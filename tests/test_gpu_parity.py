@@ -1040,6 +1040,40 @@ def test_errors_do_not_cross_the_abi(ctx):
     assert L.rcv_filter2d_i8(None, C.byref(a), C.byref(c), k, 3, 0) == _ffi.RCV_ERR_ARG
 
 
+@pytest.mark.parametrize("rows,cols", [(0, 0), (0, 7), (5, 0)])
+def test_empty_images_are_successful_noops(ctx, rows, cols):
+    """the reference's Mat::empty() / zero-sized Mats flow through every op without touching memory and without an error"""
+    L = _ffi.lib()
+    def mat(ch, depth=_ffi.RCV_8U, r=rows, c=cols):
+        return Mat(r, c, ch, depth)
+    k8 = np.ones((3, 3), np.int8)
+    kf = np.ones((3, 3), np.float32) / 9
+    M = np.array([1, 0, 0, 0, 1, 0], np.float32)
+    imgproc.gaussian_blur(mat(3), mat(3), 5, 0.0, ctx)
+    imgproc.gaussian_blur(mat(3), mat(3), 5, 1.1, ctx)
+    imgproc.filter2d(mat(3), mat(3), k8, 0, ctx=ctx)
+    imgproc.filter2d(mat(1), mat(1), kf, ctx=ctx)
+    imgproc.sobel(mat(1), mat(1, _ffi.RCV_16S), mat(1, _ffi.RCV_16S), ctx)
+    imgproc.cvt_color(mat(3), mat(1), _ffi.RCV_BGR2GRAY, ctx)
+    imgproc.harris_pipeline(mat(3), mat(1), None, 2, 0.04, 0.0, ctx)
+    imgproc.corner_harris(mat(1), mat(1, _ffi.RCV_32F), 2, 0.04, ctx)
+    imgproc.warp_affine(Mat(4, 4, 3), mat(3), M, ctx)            # empty destination
+    imgproc.resize(Mat(4, 4, 3), mat(3), ctx)
+    imgproc.rectangle(mat(3), Rect(0, 0, 3, 3), Scalar(1, 2, 3), 1, ctx)
+    # device batches with zero frames
+    for n in (0,):
+        a = device.DeviceBatch(ctx, n, 8, 16, 3)
+        b = device.DeviceBatch(ctx, n, 8, 16, 3)
+        device.filter2d(a, b, k8, shift=0)
+        device.filter2d(a, b, kf)
+        device.gaussian_blur(a, b, 7, 0.0)
+        device.warp_affine(a, b, M)
+        device.resize(a, b)
+        a.free()
+        b.free()
+    ctx.sync()
+
+
 # ---- out-of-bounds canaries: padding between rows and between frames must survive every batch op -------------------
 
 def _canary_batch(ctx, n, rows, cols, ch, depth=_ffi.RCV_8U, pad=32):
