@@ -5,6 +5,7 @@
 // with the SAME names, argument order and behaviour, so that code and tests read like the reference's:
 //   rustcv::Mat                      <- rustcv/src/core/mat.rs:6-53
 //   rustcv::imgproc::{Point,Rect,Scalar,rectangle}  <- rustcv/src/imgproc/drawing.rs:8-106
+//   rustcv::imgproc::blendGlyphs                     <- the blend closure of put_text, drawing.rs:137-160
 //   rustcv::videoio::{yuyv_to_bgr,bgra_to_bgr}      <- rustcv/src/videoio/mod.rs:344-399
 //   rustcv::decode::rgb_to_bgr                       <- rustcv-camera/src/decode.rs:213-219
 // The ops the reference does not have follow OpenCV's names.  Header-only; link with
@@ -98,6 +99,29 @@ inline void rectangle(Mat& mat, Rect rect, Scalar color, int32_t thickness)  // 
     rcv_mat m = mat.view();
     check(rcv_rectangle(Backend::instance().ctx(), &m, rect.x, rect.y, rect.width, rect.height, color.v0, color.v1, color.v2, thickness),
           "rectangle");
+}
+
+// One rasterised glyph as put_text's loop has it in hand (drawing.rs:134-136): the pixel bounding box's min corner
+// and the coverage values `glyph.draw` yields, row-major h x w.
+struct Glyph {
+    int32_t x, y, w, h;
+    std::vector<float> coverage;
+};
+// The per-pixel half of put_text (drawing.rs:137-160): ordered alpha blend of the glyphs into the Mat.  Layout and
+// rasterisation (rusttype + a font blob) stay with the caller.
+inline void blendGlyphs(Mat& mat, const std::vector<Glyph>& glyphs, Scalar color)
+{
+    std::vector<rcv_glyph> tbl;
+    std::vector<float> cov;
+    for (const Glyph& g : glyphs) {
+        if (g.w < 0 || g.h < 0 || g.coverage.size() < (size_t)g.w * (size_t)g.h) throw std::runtime_error("blendGlyphs: coverage shorter than w*h");
+        tbl.push_back(rcv_glyph{g.x, g.y, g.w, g.h, (uint64_t)cov.size()});
+        cov.insert(cov.end(), g.coverage.begin(), g.coverage.begin() + (size_t)g.w * (size_t)g.h);
+    }
+    rcv_mat m = mat.view();
+    check(rcv_blend_glyphs(Backend::instance().ctx(), &m, tbl.data(), (int32_t)tbl.size(), cov.data(), cov.size(), color.v0, color.v1,
+                           color.v2),
+          "blendGlyphs");
 }
 
 inline void GaussianBlur(Mat& src, Mat& dst, int ksize, double sigma = 0.0)

@@ -146,6 +146,26 @@ int rcv_rectangle(rcv_ctx* ctx, rcv_mat* mat, int32_t x, int32_t y, int32_t w, i
 int rcv_rectangle_batch(rcv_ctx* ctx, rcv_batch* mats, int32_t x, int32_t y, int32_t w, int32_t h,
                         uint8_t b, uint8_t g, uint8_t r, int32_t thickness);
 
+/* ---- f4: the per-pixel half of put_text --------------------------------------- *
+ * replaces the blend closure of rustcv::imgproc::put_text (rustcv/src/imgproc/drawing.rs:137-160).
+ * Layout and rasterisation stay on the host (rusttype + a font blob: third-party): the caller hands
+ * over, per positioned glyph, the pixel bounding box (`glyph.pixel_bounding_box()`, :134) and the w*h coverage values
+ * `glyph.draw` produces (:136), row-major at coverage[offset ..].  The library blends them into the 3-channel u8 Mat in
+ * glyph order with the reference's arithmetic (separately rounded f32 multiply / subtract / add, `as u8` saturating
+ * truncation, a store after every glyph -- overlapping boxes compose in order), clipped per pixel to the Mat.
+ * `glyphs` and `coverage` are HOST pointers, snapshotted before the call returns.  Mats with channels != 3:
+ * RCV_ERR_UNSUPPORTED (the reference hard-codes 3, :132); boxes whose coverage range leaves n_coverage: RCV_ERR_SIZE. */
+typedef struct rcv_glyph {
+    int32_t  x, y;     /* bounding_box.min: top-left pixel of the box in the Mat (any sign; clipped per pixel) */
+    int32_t  w, h;     /* box size in pixels (>= 0) */
+    uint64_t offset;   /* index of the box's first coverage value */
+} rcv_glyph;
+int rcv_blend_glyphs(rcv_ctx* ctx, rcv_mat* mat, const rcv_glyph* glyphs, int32_t n_glyphs, const float* coverage,
+                     uint64_t n_coverage, uint8_t b, uint8_t g, uint8_t r);
+/* the same text on every frame of a device-resident batch */
+int rcv_blend_glyphs_batch(rcv_ctx* ctx, rcv_batch* mats, const rcv_glyph* glyphs, int32_t n_glyphs, const float* coverage,
+                           uint64_t n_coverage, uint8_t b, uint8_t g, uint8_t r);
+
 /* ---- build-defined ops (not in the reference; spec SURVEY.md 8-A) -------------- *
  * u8, channels in {1,3} unless stated, BORDER_REFLECT_101, arbitrary step.        */
 int rcv_gaussian_blur(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, int ksize, double sigma);

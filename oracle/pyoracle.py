@@ -54,6 +54,8 @@ def lib():
         _lib.orc_bgr_to_rgb_rows.argtypes = [_u8p, C.c_size_t, _u8p, C.c_int, C.c_int]
         _lib.orc_yuv422_to_bgr_strided.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         _lib.orc_nv12_to_bgr.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int]
+        _lib.orc_blend_glyph.restype = None
+        _lib.orc_blend_glyph.argtypes = [_u8p, C.c_int32, C.c_int32, C.c_size_t] + [C.c_int32] * 4 + [_f32p] + [C.c_uint8] * 3
     return _lib
 
 
@@ -151,6 +153,18 @@ def yuv422_to_bgr_strided(data, sstep, rows, cols, uyvy, dst):
 def nv12_to_bgr(data, sstep, rows, cols, dst):
     data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
     return bool(lib().orc_nv12_to_bgr(_p(data, _u8p), data.size, sstep, _p(dst, _u8p), cols * 3, rows, cols))
+
+
+def blend_glyphs(data, rows, cols, step, glyphs, b, g, r):
+    """put_text's per-pixel half (drawing.rs:137-160).  data: flat uint8 Mat buffer, modified in place; glyphs: iterable
+    of (min_x, min_y, coverage[h, w] float32) in drawing order."""
+    assert data.dtype == np.uint8 and data.flags.c_contiguous
+    assert rows == 0 or cols == 0 or data.size >= (rows - 1) * step + cols * 3
+    for gx, gy, cov in glyphs:
+        cov = np.ascontiguousarray(cov, dtype=np.float32)
+        h, w = cov.shape
+        if h and w:
+            lib().orc_blend_glyph(_p(data, _u8p), rows, cols, step, gx, gy, w, h, _p(cov, _f32p), b, g, r)
 
 
 # ---- (B) build-defined ops ----------------------------------------------------------------------

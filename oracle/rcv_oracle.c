@@ -195,6 +195,42 @@ int orc_nv12_to_bgr(const uint8_t* src, size_t src_len, size_t sstep, uint8_t* d
     return 1;
 }
 
+/* Rust `f32 as u8`: truncation toward zero, saturating, NaN -> 0 */
+static inline uint8_t f32_as_u8(float v)
+{
+    if (!(v > 0.0f)) return 0; /* negatives, -0, NaN */
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+
+/* rustcv/src/imgproc/drawing.rs:137-160 -- the per-pixel half of put_text: the closure `glyph.draw` calls for EVERY
+ * pixel (x, y, v) of one positioned glyph's pixel bounding box, v = coverage.  (Layout and rasterisation are rusttype's,
+ * a third-party crate working on a font blob the checkout does not hold: out of scope)  Separate f32
+ * multiply / subtract / add roundings, no fused operation (rustc does not contract), truncating store after EVERY
+ * glyph -- so overlapping boxes compose in glyph order.  No len guard in the reference (it would panic): the caller
+ * guarantees (rows-1)*step + cols*3 <= len. */
+void orc_blend_glyph(uint8_t* data, int32_t rows, int32_t cols, size_t step, int32_t min_x, int32_t min_y, int32_t w, int32_t h,
+                     const float* cov, uint8_t cb, uint8_t cg, uint8_t cr)
+{
+    for (int32_t y = 0; y < h; ++y)
+        for (int32_t x = 0; x < w; ++x) {
+            /* `x as i32 + bounding_box.min.x` (:140-141) */
+            int32_t px = (int32_t)((uint32_t)x + (uint32_t)min_x), py = (int32_t)((uint32_t)y + (uint32_t)min_y);
+            if (px >= 0 && px < cols && py >= 0 && py < rows) {
+                size_t idx = (size_t)py * step + (size_t)px * 3u;
+                float alpha = cov[(size_t)y * (size_t)w + (size_t)x];
+                float b_old = (float)data[idx], g_old = (float)data[idx + 1], r_old = (float)data[idx + 2];
+                float inv = 1.0f - alpha;
+                float b_new = ((float)cb * alpha) + (b_old * inv);
+                float g_new = ((float)cg * alpha) + (g_old * inv);
+                float r_new = ((float)cr * alpha) + (r_old * inv);
+                data[idx] = f32_as_u8(b_new);
+                data[idx + 1] = f32_as_u8(g_new);
+                data[idx + 2] = f32_as_u8(r_new);
+            }
+        }
+}
+
 /* ========================================================================== */
 /* (B) build-defined ops, SURVEY.md 8-A                                       */
 /* ========================================================================== */

@@ -13,13 +13,14 @@
  *        orc_bgra_to_bgr   rustcv/src/videoio/mod.rs:385-399, twin rustcv-camera/src/decode.rs:200-207
  *        orc_rgb_to_bgr    rustcv-camera/src/decode.rs:213-219
  *        orc_rectangle     rustcv/src/imgproc/drawing.rs:67-106
+ *        orc_blend_glyph   rustcv/src/imgproc/drawing.rs:137-160 (put_text's per-pixel closure)
  *      PINNING: the reference (Rust, no rustc/cargo in this image) cannot be
  *      built or run here.  It holds three tests for this path
  *      (rustcv-camera/src/decode.rs:234-273): two inequality checks for
  *      yuyv_to_bgr and one exact vector for rgb_to_bgr -- all three are
- *      replayed in tests/test_oracle.py.  bgra_to_bgr and rectangle have no
- *      reference test or fixture: for those two the oracle is a line-by-line
- *      restatement with PARITY UNPINNED.
+ *      replayed in tests/test_oracle.py.  bgra_to_bgr, rectangle and the
+ *      put_text blend have no reference test or fixture: for those three the
+ *      oracle is a line-by-line restatement with PARITY UNPINNED.
  *
  *  (B) build-defined ops that do NOT exist in the reference (SURVEY.md F1,
  *      spec in SURVEY.md 8-A): bgr2gray, gaussian_blur, filter2d_i8/f32, sobel,
@@ -59,6 +60,9 @@ void orc_bgr_to_u32(const uint8_t* src, size_t src_len, uint32_t* dst, size_t pi
 void orc_bgr_to_rgb_rows(const uint8_t* src, size_t sstep, uint8_t* dst, int rows, int cols);    /* imgcodecs/mod.rs:51-63 */
 void orc_yuv422_to_bgr_strided(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols, int uyvy);
 int orc_nv12_to_bgr(const uint8_t* src, size_t src_len, size_t sstep, uint8_t* dst, size_t dstep, int rows, int cols);
+/* put_text's blend closure for one rasterised glyph box, drawing.rs:137-160 (no reference test: PARITY UNPINNED) */
+void orc_blend_glyph(uint8_t* data, int32_t rows, int32_t cols, size_t step, int32_t min_x, int32_t min_y, int32_t w, int32_t h,
+                     const float* cov, uint8_t cb, uint8_t cg, uint8_t cr);
 
 /* ---- (B) build-defined ops -------------------------------- */
 

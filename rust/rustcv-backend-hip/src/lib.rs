@@ -36,6 +36,17 @@ pub struct rcv_batch {
     pub reserved: i32,
 }
 
+/// One rasterised glyph box: `bounding_box.min`, size, and where its w*h coverage values start.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rcv_glyph {
+    pub x: i32,
+    pub y: i32,
+    pub w: i32,
+    pub h: i32,
+    pub offset: u64,
+}
+
 #[repr(C)]
 pub struct rcv_ring { _private: [u8; 0] }
 pub type rcv_ring_op = extern "C" fn(ctx: *mut rcv_ctx, dev_in: *const rcv_mat, dev_out: *mut rcv_mat, user: *mut c_void) -> c_int;
@@ -62,6 +73,8 @@ extern "C" {
     pub fn rcv_cvt_color(ctx: *mut rcv_ctx, code: c_int, src: *const rcv_mat, dst: *mut rcv_mat) -> c_int;
     pub fn rcv_cvt_color_batch(ctx: *mut rcv_ctx, code: c_int, src: *const rcv_batch, dst: *mut rcv_batch) -> c_int;
     pub fn rcv_rectangle(ctx: *mut rcv_ctx, mat: *mut rcv_mat, x: i32, y: i32, w: i32, h: i32, b: u8, g: u8, r: u8, thickness: i32) -> c_int;
+    pub fn rcv_blend_glyphs(ctx: *mut rcv_ctx, mat: *mut rcv_mat, glyphs: *const rcv_glyph, n_glyphs: i32, coverage: *const f32,
+                            n_coverage: u64, b: u8, g: u8, r: u8) -> c_int;
     pub fn rcv_gaussian_blur(ctx: *mut rcv_ctx, src: *const rcv_mat, dst: *mut rcv_mat, ksize: c_int, sigma: f64) -> c_int;
     pub fn rcv_filter2d_i8(ctx: *mut rcv_ctx, src: *const rcv_mat, dst: *mut rcv_mat, k: *const i8, ksize: c_int, shift: c_int) -> c_int;
     pub fn rcv_filter2d_i8_batch(ctx: *mut rcv_ctx, src: *const rcv_batch, dst: *mut rcv_batch, k: *const i8, ksize: c_int, shift: c_int) -> c_int;
@@ -124,6 +137,21 @@ pub fn bgra_to_bgr(ctx: &HipContext, src: &[u8], dest: &mut [u8], width: usize, 
     let mut d = mat_view(dest, height as i32, width as i32, width * 3, 3);
     let rc = unsafe { rcv_cvt_color(ctx.raw, RCV_BGRA2BGR, &s, &mut d) };
     assert!(rc >= 0, "rustcv_hip: bgra_to_bgr failed ({rc})");
+}
+
+/// The per-pixel half of `put_text` (rustcv/src/imgproc/drawing.rs:123-163).  The caller keeps the layout loop
+/// (`font.layout(text, scale, start)`, :128) and, per glyph, pushes `bounding_box.min`, the box size and the values
+/// `glyph.draw` yields into `glyphs` / `coverage` instead of blending on the CPU (:137-160); this call then blends all
+/// of them on the GPU in the same order with the same f32 arithmetic.
+#[allow(clippy::too_many_arguments)]
+pub fn blend_glyphs(ctx: &HipContext, data: &mut [u8], rows: i32, cols: i32, step: usize,
+                    glyphs: &[rcv_glyph], coverage: &[f32], color: (u8, u8, u8)) {
+    let mut m = mat_view(data, rows, cols, step, 3);
+    let rc = unsafe {
+        rcv_blend_glyphs(ctx.raw, &mut m, glyphs.as_ptr(), glyphs.len() as i32, coverage.as_ptr(), coverage.len() as u64,
+                         color.0, color.1, color.2)
+    };
+    assert!(rc >= 0, "rustcv_hip: blend_glyphs failed ({rc})");
 }
 
 /// Replaces `pub fn rectangle(mat: &mut Mat, rect: Rect, color: Scalar, thickness: i32)`

@@ -35,6 +35,27 @@ class rcv_batch(C.Structure):
     _fields_ = [("frame0", rcv_mat), ("frame_stride", C.c_size_t), ("n", C.c_int32), ("reserved", C.c_int32)]
 
 
+class rcv_glyph(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("offset", C.c_uint64)]
+
+
+def pack_glyphs(glyphs):
+    """[(min_x, min_y, coverage[h, w] float32), ...] -> (rcv_glyph array, n, flat float32 coverage ndarray)"""
+    import numpy as np
+    glyphs = list(glyphs)
+    tbl = (rcv_glyph * max(1, len(glyphs)))()
+    covs, off = [], 0
+    for i, (gx, gy, cov) in enumerate(glyphs):
+        cov = np.ascontiguousarray(cov, dtype=np.float32)
+        if cov.ndim != 2:
+            raise ValueError("glyph coverage must be a 2-D (h, w) array")
+        tbl[i] = rcv_glyph(int(gx), int(gy), cov.shape[1], cov.shape[0], off)
+        covs.append(cov.reshape(-1))
+        off += cov.size
+    flat = np.concatenate(covs) if covs else np.zeros(0, np.float32)
+    return tbl, len(glyphs), np.ascontiguousarray(flat, dtype=np.float32)
+
+
 _P = C.POINTER
 _ctx = C.c_void_p
 _mat, _bat = _P(rcv_mat), _P(rcv_batch)
@@ -77,6 +98,8 @@ SIGNATURES = {
     "rcv_cvt_color_batch": (_i, [_ctx, _i, _bat, _bat]),
     "rcv_rectangle": (_i, [_ctx, _mat, _i32, _i32, _i32, _i32, _u8, _u8, _u8, _i32]),
     "rcv_rectangle_batch": (_i, [_ctx, _bat, _i32, _i32, _i32, _i32, _u8, _u8, _u8, _i32]),
+    "rcv_blend_glyphs": (_i, [_ctx, _mat, _P(rcv_glyph), _i32, _P(C.c_float), _u64, _u8, _u8, _u8]),
+    "rcv_blend_glyphs_batch": (_i, [_ctx, _bat, _P(rcv_glyph), _i32, _P(C.c_float), _u64, _u8, _u8, _u8]),
     "rcv_gaussian_blur": (_i, [_ctx, _mat, _mat, _i, _d]),
     "rcv_gaussian_blur_batch": (_i, [_ctx, _bat, _bat, _i, _d]),
     "rcv_filter2d_i8": (_i, [_ctx, _mat, _mat, _P(C.c_int8), _i, _i]),

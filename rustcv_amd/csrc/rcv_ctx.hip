@@ -79,6 +79,8 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
         if (c->stage_buf[i]) (void)hipFree(c->stage_buf[i]);
     if (c->kconst) (void)hipFree(c->kconst);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->capturing) {   // a capture was left open: close it and drop what it allocated

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[i][j] = W.acc_init;
-            if (DUAL) accq[i][j] = 0;
+            if constexpr (DUAL) accq[i][j] = 0;
         }
 
     // feed row r (r mod KS == RHO, static): contributes kernel row ky to output y = r - ky + RAD, slot y mod KS
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
 #pragma unroll
                 for (int h = 0; h < ND; ++h) {
                     acc[slot][j] = __builtin_amdgcn_sdot4((int)op[j][h], W.r[ky][h], acc[slot][j], false);
-                    if (DUAL) accq[slot][j] = __builtin_amdgcn_sdot4((int)op[j][h], W.q[ky][h], accq[slot][j], false);
+                    if constexpr (DUAL) accq[slot][j] = __builtin_amdgcn_sdot4((int)op[j][h], W.q[ky][h], accq[slot][j], false);
                 }
         }
         constexpr int done = ((RHO - (KS - 1) + RAD) % KS + KS) % KS;
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
         int v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] = DUAL ? acc[done][j] + (accq[done][j] << 2) : acc[done][j];
+            v[j] = acc[done][j];
+            if constexpr (DUAL) v[j] += accq[done][j] << 2;
             acc[done][j] = W.acc_init;
-            if (DUAL) accq[done][j] = 0;
+            if constexpr (DUAL) accq[done][j] = 0;
         }
         const uint32_t o = rcv_ashr_sat_pk4(v[0], v[1], v[2], v[3], W.shift);
         if (y >= ys && y < ye) *(uint32_t*)(df + (size_t)y * d.step) = o;

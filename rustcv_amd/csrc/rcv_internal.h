@@ -32,6 +32,10 @@ struct rcv_ctx {
     hipStream_t side;            // upload stream for graph-owned constants (never captured)
     void* cap_allocs[64];
     int cap_nallocs;
+    // grow-only pinned staging for small per-call host tables that outlive the call (rcv_text_blend.hip)
+    uint8_t* pin;
+    size_t pin_cap;
+    hipEvent_t pin_ev;           // recorded after the H2D that reads `pin`
 };
 
 // Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the

@@ -98,6 +98,14 @@ def rectangle(mats, rect, color, thickness):
                                               color.v0, color.v1, color.v2, thickness), "rcv_rectangle_batch")
 
 
+def blend_glyphs(mats, glyphs, color):
+    """put_text's blend (drawing.rs:137-160) of the same rasterised glyphs into every frame of a resident batch."""
+    tbl, n, cov = _ffi.pack_glyphs(glyphs)
+    b = mats.as_rcv()
+    _ffi.check(_ffi.lib().rcv_blend_glyphs_batch(_h(mats), C.byref(b), tbl, n, cov.ctypes.data_as(C.POINTER(C.c_float)), cov.size,
+                                                 color.v0, color.v1, color.v2), "rcv_blend_glyphs_batch")
+
+
 def gaussian_blur(src, dst, ksize, sigma=0.0):
     a, b = src.as_rcv(), dst.as_rcv()
     _ffi.check(_ffi.lib().rcv_gaussian_blur_batch(_h(src), C.byref(a), C.byref(b), ksize, float(sigma)), "rcv_gaussian_blur_batch")

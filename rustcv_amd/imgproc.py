@@ -52,6 +52,18 @@ def rectangle(mat: Mat, rect: Rect, color: Scalar, thickness: int, ctx=None):
                                         color.v0, color.v1, color.v2, thickness), "rcv_rectangle")
 
 
+def blend_glyphs(mat: Mat, glyphs, color: Scalar, ctx=None):
+    """The per-pixel half of `put_text` (drawing.rs:123-163): alpha-blend rasterised glyphs into the Mat, in order.
+
+    `glyphs`: iterable of `(min_x, min_y, coverage)` -- what the reference's loop has in hand for each positioned glyph:
+    `glyph.pixel_bounding_box().min` (:134) and the values `glyph.draw` yields (:136) as an (h, w) float32 array.  Layout
+    and rasterisation (rusttype on a font blob, third-party) stay with the caller."""
+    tbl, n, cov = _ffi.pack_glyphs(glyphs)
+    m = mat._as_rcv()
+    _ffi.check(_ffi.lib().rcv_blend_glyphs(_ctx(ctx), C.byref(m), tbl, n, cov.ctypes.data_as(C.POINTER(C.c_float)), cov.size,
+                                           color.v0, color.v1, color.v2), "rcv_blend_glyphs")
+
+
 # ---- build-defined ops ----------------------------------------------------------------------------
 
 def cvt_color(src: Mat, dst: Mat, code: int, ctx=None):

@@ -57,6 +57,24 @@ static void rectangle_grows_inward()
         }
 }
 
+// put_text's blend on hand-derived values (tests/golden/kat_reference.json "blend_hand_derived"), two overlapping
+// boxes composed in glyph order, one box clipped by the Mat
+static void glyph_blend_is_ordered_and_clipped()
+{
+    Mat m = Mat::create(4, 6, 3);
+    for (auto& v : m.data) v = 100;
+    std::vector<imgproc::Glyph> glyphs;
+    glyphs.push_back({1, 1, 2, 1, {0.5f, 1.0f}});        // (1,1): 177.5 -> 177 ; (2,1): colour
+    glyphs.push_back({2, 1, 2, 1, {0.5f, 0.25f}});       // (2,1): 255*.5 + 255*.5 = 255 ; (3,1): 63.75 + 75 = 138
+    glyphs.push_back({-1, 3, 2, 2, {1.f, 1.f, 1.f, 1.f}}); // only its (1,0) cell lies on the Mat: pixel (0,3)
+    imgproc::blendGlyphs(m, glyphs, imgproc::Scalar{255, 255, 255});
+    auto px = [&](int x, int y) { return (int)m.row_bytes(y)[3 * x]; };
+    ASSERT(px(1, 1) == 177 && px(2, 1) == 255 && px(3, 1) == 138 && px(0, 3) == 255);
+    ASSERT(px(0, 0) == 100 && px(4, 1) == 100 && px(1, 3) == 100 && px(0, 2) == 100);
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 6; ++x) ASSERT(m.row_bytes(y)[3 * x] == m.row_bytes(y)[3 * x + 1] && m.row_bytes(y)[3 * x] == m.row_bytes(y)[3 * x + 2]);
+}
+
 static void sobel_of_a_ramp()
 {
     Mat g = Mat::create(9, 24, 1);
@@ -128,6 +146,7 @@ int main()
     rgb_to_bgr_swap();
     short_source_is_a_silent_noop();
     rectangle_grows_inward();
+    glyph_blend_is_ordered_and_clipped();
     std::puts("facade_test: all passed");
     return 0;
 }

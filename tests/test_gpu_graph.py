@@ -76,6 +76,9 @@ def test_graph_refuses_synchronising_calls(ctx, rng):
         assert e.value.code == _ffi.RCV_ERR_UNSUPPORTED
         assert L.rcv_sync(ctx.handle) == _ffi.RCV_ERR_UNSUPPORTED
         assert L.rcv_graph_begin(ctx.handle) == _ffi.RCV_ERR_ARG      # no nesting
+        with pytest.raises(rcv.RcvError) as e:           # per-call host tables (glyph boxes, coverage) cannot be replayed
+            device.blend_glyphs(d, [(0, 0, np.ones((2, 2), np.float32))], imgproc.Scalar(1, 2, 3))
+        assert e.value.code == _ffi.RCV_ERR_UNSUPPORTED
         device.gaussian_blur(d, d2 := device.DeviceBatch(ctx, 1, 16, 32, 3), 3, 0.0)
     g.launch()
     ctx.sync()

@@ -232,6 +232,103 @@ def test_rectangle_short_vec_guard(ctx, oracle, rng):
     assert np.array_equal(m.data, want)
 
 
+# ---- f4: put_text's blend (drawing.rs:137-160) -------------------------------------------------------
+
+def _rand_glyphs(rng, rows, cols, n, special=True):
+    """boxes around and across the Mat (overlapping, clipped, outside, empty), coverage in [0, 1] with special values"""
+    out = []
+    for _ in range(n):
+        h, w = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        gx, gy = int(rng.integers(-45, cols + 10)), int(rng.integers(-45, rows + 10))
+        cov = rng.random((h, w), dtype=np.float32)
+        if special and cov.size:
+            flat = cov.reshape(-1)
+            k = rng.integers(0, flat.size, size=max(1, flat.size // 6))
+            flat[k] = rng.choice(np.array([0.0, 1.0, 0.5, -0.25, 1.25, 1e-40, np.nan, np.inf, -np.inf, 0.99999994], np.float32), size=k.size)
+        out.append((gx, gy, cov))
+    return out
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1, 1, 0), (48, 64, 0), (61, 127, 13), (128, 240, 5), (480, 640, 0)])
+def test_blend_glyphs_host_mat(ctx, oracle, rows, cols, pad):
+    for case in range(_SOAK):
+        rng = np.random.default_rng(7000 + 97 * case + rows + _SOAK_SEED)
+        step = cols * 3 + pad
+        base = rng.integers(0, 256, size=rows * step, dtype=np.uint8)
+        glyphs = _rand_glyphs(rng, rows, cols, int(rng.integers(0, 30)))
+        b, g, r = (int(v) for v in rng.integers(0, 256, 3))
+        want = base.copy()
+        oracle.blend_glyphs(want, rows, cols, step, glyphs, b, g, r)
+        m = Mat(rows, cols, 3, step=step, data=base.copy())
+        imgproc.blend_glyphs(m, glyphs, Scalar(b, g, r), ctx)
+        assert np.array_equal(m.data, want), (rows, cols, pad, case)
+
+
+def test_blend_glyphs_batch_many_glyphs_and_canaries(ctx, oracle):
+    """more glyphs than one launch takes (ordered chunks), the same text on every frame of a padded resident batch"""
+    rng = np.random.default_rng(424242 + _SOAK_SEED)
+    n, rows, cols = 3, 200, 320
+    bt = _canary_batch(ctx, n, rows, cols, 3)
+    raw = np.full(bt.nbytes, 0xCD, np.uint8)
+    for i in range(n):
+        v = raw[i * bt.frame_stride: i * bt.frame_stride + rows * bt.step].reshape(rows, bt.step)
+        v[:, : cols * 3] = rng.integers(0, 256, size=(rows, cols * 3), dtype=np.uint8)
+    bt.upload_bytes(raw)
+    glyphs = [(x, y, np.ascontiguousarray(c[:12, :12])) for x, y, c in _rand_glyphs(rng, rows, cols, 2500, special=False)]
+    device.blend_glyphs(bt, glyphs, Scalar(9, 200, 255))
+    want = raw.copy()
+    for i in range(n):
+        fr = want[i * bt.frame_stride: i * bt.frame_stride + rows * bt.step]      # a view: blended in place, padding included
+        oracle.blend_glyphs(fr, rows, cols, bt.step, glyphs, 9, 200, 255)
+    assert np.array_equal(bt.download_bytes(), want)
+    bt.free()
+
+
+def test_blend_glyphs_text_line_on_1080p(ctx, oracle):
+    """the shape of a real put_text call: one line of ~40 overlapping soft-edged boxes on a 1080p frame"""
+    rng = np.random.default_rng(5150 + _SOAK_SEED)
+    rows, cols = 1080, 1920
+    base = rng.integers(0, 256, size=rows * cols * 3, dtype=np.uint8)
+    yy, xx = np.mgrid[0:34, 0:24].astype(np.float32)
+    blob = np.clip(1.4 - np.hypot((xx - 11.5) / 9, (yy - 16.5) / 14), 0, 1).astype(np.float32)   # anti-aliased ellipse
+    glyphs = [(100 + 20 * i, 500 + (i % 3), blob) for i in range(40)]                            # advance < box width: boxes overlap
+    want = base.copy()
+    oracle.blend_glyphs(want, rows, cols, cols * 3, glyphs, 0, 255, 0)
+    m = Mat(rows, cols, 3, data=base.copy())
+    imgproc.blend_glyphs(m, glyphs, Scalar(0, 255, 0), ctx)
+    assert np.array_equal(m.data, want)
+    assert (m.data != base).sum() > 10000
+
+
+def test_blend_glyphs_errors(ctx):
+    L = _ffi.lib()
+    m = Mat(8, 8, 3)
+    a = m._as_rcv()
+    cov = (C.c_float * 16)(*([0.5] * 16))
+
+    def call(mat, gl, n, ncov=16):
+        tbl = (_ffi.rcv_glyph * max(1, len(gl)))(*gl)
+        return L.rcv_blend_glyphs(ctx.handle, C.byref(mat), tbl, n, cov, ncov, 1, 2, 3)
+
+    G = _ffi.rcv_glyph
+    assert call(a, [G(0, 0, 4, 4, 0)], 1) == _ffi.RCV_OK
+    assert call(a, [G(0, 0, 4, 4, 1)], 1) == _ffi.RCV_ERR_SIZE            # coverage range leaves the array
+    assert call(a, [G(0, 0, 5, 4, 0)], 1) == _ffi.RCV_ERR_SIZE
+    assert call(a, [G(0, 0, 1, 1, 17)], 1) == _ffi.RCV_ERR_SIZE
+    assert call(a, [G(0, 0, -1, 4, 0)], 1) == _ffi.RCV_ERR_ARG
+    assert call(a, [G(0, 0, 4, 4, 0)], -1) == _ffi.RCV_ERR_ARG
+    assert call(a, [G(2**31 - 1, -2**31, 4, 4, 0)], 1) == _ffi.RCV_OK     # far outside: nothing to do
+    assert call(a, [], 0) == _ffi.RCV_OK
+    assert L.rcv_blend_glyphs(ctx.handle, C.byref(a), None, 1, cov, 16, 1, 2, 3) == _ffi.RCV_ERR_ARG
+    g1 = Mat(8, 8, 1)._as_rcv()
+    assert call(g1, [G(0, 0, 4, 4, 0)], 1) == _ffi.RCV_ERR_UNSUPPORTED    # the reference hard-codes 3 channels
+    short = Mat(8, 8, 3)
+    short.data = short.data[:-1]
+    assert call(short._as_rcv(), [G(0, 0, 4, 4, 0)], 1) == _ffi.RCV_ERR_SIZE   # where the reference would panic
+    before = m.data.copy()
+    assert call(a, [G(0, 0, 2, 2, 0), G(0, 0, 4, 4, 1)], 2) == _ffi.RCV_ERR_SIZE and np.array_equal(m.data, before)   # all or nothing
+
+
 # ---- build-defined ops -------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("rows,cols", SHAPES)
@@ -1060,6 +1157,7 @@ def test_empty_images_are_successful_noops(ctx, rows, cols):
     imgproc.warp_affine(Mat(4, 4, 3), mat(3), M, ctx)            # empty destination
     imgproc.resize(Mat(4, 4, 3), mat(3), ctx)
     imgproc.rectangle(mat(3), Rect(0, 0, 3, 3), Scalar(1, 2, 3), 1, ctx)
+    imgproc.blend_glyphs(mat(3), [(0, 0, np.ones((2, 2), np.float32))], Scalar(1, 2, 3), ctx)
     # device batches with zero frames
     for n in (0,):
         a = device.DeviceBatch(ctx, n, 8, 16, 3)
@@ -1069,6 +1167,7 @@ def test_empty_images_are_successful_noops(ctx, rows, cols):
         device.gaussian_blur(a, b, 7, 0.0)
         device.warp_affine(a, b, M)
         device.resize(a, b)
+        device.blend_glyphs(a, [(0, 0, np.ones((2, 2), np.float32))], Scalar(1, 2, 3))
         a.free()
         b.free()
     ctx.sync()

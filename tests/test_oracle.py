@@ -273,3 +273,44 @@ def test_next_row_restatements(oracle, rng):
     y2[:, 1] = 128
     oracle.yuyv_to_bgr(y2.reshape(-1), a, 8, 6)
     assert oracle.nv12_to_bgr(nv, 8, 6, 8, b) and np.array_equal(a, b)
+
+
+# ---- put_text's blend closure (drawing.rs:137-160) -----------------------------------------------------
+
+def _np_blend(px, colour, alpha):
+    """the formula in numpy float32 scalars: every operation rounds separately, like the Rust source"""
+    f = np.float32
+    v = f(colour) * f(alpha) + f(px) * (f(1.0) - f(alpha))
+    return 0 if not v > 0 else (255 if v >= 255 else int(v))
+
+
+def test_blend_hand_derived_kats(oracle, kat):
+    for old, colour, alpha, new in kat["blend_hand_derived"]:
+        img = np.full(3, old, np.uint8)
+        oracle.blend_glyphs(img, 1, 1, 3, [(0, 0, np.array([[alpha]], np.float32))], colour, colour, colour)
+        assert img.tolist() == [new] * 3, (old, colour, alpha)
+        assert _np_blend(old, colour, alpha) == new
+
+
+def test_blend_order_clipping_and_special_values(oracle, rng):
+    rows, cols, step = 9, 11, 40
+    base = rng.integers(0, 256, size=rows * step, dtype=np.uint8)
+    glyphs = [(-2, -1, rng.random((4, 5), dtype=np.float32)), (1, 0, rng.random((6, 4), dtype=np.float32)),     # overlap
+              (8, 6, rng.random((5, 7), dtype=np.float32)), (20, 2, np.ones((2, 2), np.float32)),                # clipped / outside
+              (3, 3, np.array([[np.nan, -0.5, 1.5, 1e-40, np.inf]], np.float32)), (0, 8, np.zeros((1, 11), np.float32))]
+    got = base.copy()
+    oracle.blend_glyphs(got, rows, cols, step, glyphs, 250, 3, 128)
+    want = base.copy()
+    with np.errstate(all="ignore"):
+        for gx, gy, cov in glyphs:                      # glyph after glyph: later boxes read what earlier ones stored
+            for y in range(cov.shape[0]):
+                for x in range(cov.shape[1]):
+                    px, py = gx + x, gy + y
+                    if 0 <= px < cols and 0 <= py < rows:
+                        for c, col in enumerate((250, 3, 128)):
+                            i = py * step + px * 3 + c
+                            want[i] = _np_blend(want[i], col, cov[y, x])
+    assert np.array_equal(got, want)
+    pad = np.ones(rows * step, bool)
+    pad.reshape(rows, step)[:, : cols * 3] = False
+    assert np.array_equal(got[pad], base[pad])           # row padding untouched

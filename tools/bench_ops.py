@@ -132,6 +132,12 @@ def main():
            cpu=lambda: cpu_time(lambda orc: orc.yuyv_to_bgr(np.zeros(640 * 480 * 2, np.uint8), np.zeros(640 * 480 * 3, np.uint8), 640, 480), 640 * 480))
     record("rectangle t=2", "640x480 Rect(200,150,240,240)", o.n, 640 * 480, 0, lambda: device.rectangle(o, Rect(200, 150, 240, 240), Scalar(0, 255, 0), 2),
            note="latency-bound: 1 920 pixel writes per frame")
+    yy, xx = np.mgrid[0:34, 0:24].astype(np.float32)
+    blob = np.clip(1.4 - np.hypot((xx - 11.5) / 9, (yy - 16.5) / 14), 0, 1).astype(np.float32)
+    line = [(20 + 20 * i, 400 + (i % 3), blob) for i in range(28)]      # one text line: 28 overlapping soft-edged boxes
+    record("text blend, 28 glyphs (put_text)", "640x480", o.n, 640 * 480, 0, lambda: device.blend_glyphs(o, line, Scalar(0, 255, 0)),
+           note="f4: latency-bound (91 KB of coverage uploaded per call, ~22 800 blended pixels per frame)",
+           cpu=lambda: cpu_time(lambda orc: orc.blend_glyphs(np.zeros(640 * 480 * 3, np.uint8), 480, 640, 640 * 3, line, 0, 255, 0), 640 * 480))
     y.free(); o.free()
     # the same conversions at 4K (bandwidth regime)
     n = 64
