@@ -249,8 +249,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             // hold macropixels (252,253)(254,255) | (256,257)(258,259).  Lane ep == 0 collects them with DPP row_shl,
             // converts, and plants them (mirrored at the right image border).
             uint32_t g1[3], g2[3];
-            const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, false);
-            const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, false);
+            const uint32_t m2 = __builtin_amdgcn_update_dpp(0u, L[15], 0x101, 0xf, 0xf, true);
+            const uint32_t m3 = __builtin_amdgcn_update_dpp(0u, L[16], 0x101, 0xf, 0xf, true);
             int q[24];
             mp_sums(L[15], q);
             mp_sums(L[16], q + 6);
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         //  left : chunk 0 holds x = -3..12 ; x = -3,-2,-1 mirror x = 3,2,1 = bytes 6,5,4 of the same chunk.
         //  right: chunk `ntiles` holds x = cols-3..cols+12 ; x = cols,cols+1,cols+2 (bytes 3,4,5) mirror
         //         x = cols-2,cols-3,cols-4 = bytes 1, 0 of this chunk and byte 15 of the previous chunk (lane - 1).
-        const uint32_t nb = __builtin_amdgcn_update_dpp(0u, pb[3], 0x111, 0xf, 0xf, false);  // row_shr:1 -> lane-1's dword
-        const uint32_t ng = __builtin_amdgcn_update_dpp(0u, pg[3], 0x111, 0xf, 0xf, false);
-        const uint32_t nr = __builtin_amdgcn_update_dpp(0u, pr[3], 0x111, 0xf, 0xf, false);
+        const uint32_t nb = __builtin_amdgcn_update_dpp(0u, pb[3], 0x111, 0xf, 0xf, true);  // row_shr:1 -> lane-1's dword
+        const uint32_t ng = __builtin_amdgcn_update_dpp(0u, pg[3], 0x111, 0xf, 0xf, true);
+        const uint32_t nr = __builtin_amdgcn_update_dpp(0u, pr[3], 0x111, 0xf, 0xf, true);
         if (xleft) {
             pb[0] = __builtin_amdgcn_perm(pb[1], pb[0], 0x03040506u);
             pg[0] = __builtin_amdgcn_perm(pg[1], pg[0], 0x03040506u);

@@ -222,8 +222,19 @@ __device__ __forceinline__ float ub(uint32_t v)
 // [0, 255] and v_cvt_pk_u8_f32 converts, saturates and packs it.
 // PIN = true pins each byte conversion to one v_cvt_f32_ubyteN (fewer instructions: -2 % in the 8-row warp / 4-row resize
 // kernels); the fused down-scale kernel, which interleaves four pixels, schedules better with the compiler's own choice.
+// d = fma({w, w}, a, b) with w = the low (HI = 0) or the high (HI = 1) half of the register pair wp: op_sel broadcasts the
+// half, so the {fx, fy} pair the coordinate arithmetic leaves behind feeds all four lerps without a v_mov to duplicate it
+template <int HI>
+__device__ __forceinline__ f2 pk_fma_bc(f2 wp, f2 a, f2 b)
+{
+    f2 d;
+    if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(wp), "v"(a), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(wp), "v"(a), "v"(b));
+    return d;
+}
+
 template <bool PIN>
-__device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, float fx, float fy)
+__device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, f2 fxy)
 {
     f2 a0, a1, b0, b1, c0, c1;
     if constexpr (PIN) {
@@ -235,12 +246,12 @@ __device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint3
         b0 = f2{(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}; b1 = f2{(float)(blo >> 24), (float)(bhi & 0xff)};
         c0 = f2{(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}; c1 = f2{(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
     }
-    const f2 fxx2 = {fx, fx}, fyy2 = {fy, fy}, half2 = {0.5f, 0.5f};
-    const f2 top = __builtin_elementwise_fma(fxx2, a1 - a0, a0);
-    const f2 bot = __builtin_elementwise_fma(fxx2, b1 - b0, b0);
-    const f2 tb2 = __builtin_elementwise_fma(fxx2, c1 - c0, c0);
-    const f2 v01 = __builtin_elementwise_fma(fyy2, bot - top, top) + half2;
-    const float v2 = fmaf(fy, tb2.y - tb2.x, tb2.x) + 0.5f;
+    const f2 half2 = {0.5f, 0.5f};
+    const f2 top = pk_fma_bc<0>(fxy, a1 - a0, a0);
+    const f2 bot = pk_fma_bc<0>(fxy, b1 - b0, b0);
+    const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
+    const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
+    const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
     uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
     px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
     return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
             // the three ALIGNED dwords that contain them and shifted into place with v_alignbyte.
             struct U3 { uint32_t a, b, c; };
             U3 ta[kWarpRows], tb[kWarpRows];
-            float fx[kWarpRows], fy[kWarpRows];
+            f2 fxy[kWarpRows];
             unsigned sh[kWarpRows];
 #pragma unroll
             for (int r = 0; r < kWarpRows; ++r) {
@@ -299,11 +310,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
                 // (sx, sy) as one packed pair: fmaf(m0, x, fmaf(m1, y, m2)) and fmaf(m3, x, fmaf(m4, y, m5))
                 const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx},
                                                          __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-                const f2 fl = {floorf(sxy.x), floorf(sxy.y)};
-                const f2 fr = sxy - fl;
-                fx[r] = fr.x;
-                fy[r] = fr.y;
-                const unsigned x0 = (unsigned)(int)fl.x, y0 = (unsigned)(int)fl.y;
+                // sx, sy >= 0 here: the float -> int conversion (truncation) IS the floor, and v_fract_f32 returns the exact
+                // sx - floor(sx) the specification states (the difference is representable; no clamp can trigger below 2^23)
+                fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};
+                const unsigned x0 = (unsigned)(int)sxy.x, y0 = (unsigned)(int)sxy.y;
                 const unsigned off = __umul24(y0, sstep) + 3u * x0;   // rows start 4-byte aligned (checked by the caller)
                 sh[r] = off & 3u;
                 ta[r] = *(const U3*)(sf + (off & ~3u));
@@ -313,10 +323,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
             for (int r = 0; r < kWarpRows; ++r) {
                 const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh[r]);
                 const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh[r]);
-                const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fx[r], fy[r]);
-                const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
-                const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
-                const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+                const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[r]);
+                const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
+                const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
+                const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
                 if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
                     // 4 x {b g r 0} -> 12 bytes with three byte permutes
                     *(U3*)(dfr + (__umul24((unsigned)(ybase + r), (unsigned)d.step) + 3u * (unsigned)x)) =
@@ -379,9 +389,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
         }
         px = in ? px : 0u;
         // lanes 4q..4q+3 -> 12 bytes stored by lane 4q  (row_shl:n brings lane+n's value; quads stay inside a DPP row of 16)
-        const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
-        const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
-        const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+        const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
+        const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
+        const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
         // (stores may be conditional here: no load is outstanding any more)
         if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
             struct U3 { uint32_t a, b, c; };
@@ -428,10 +438,10 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
         for (int r = 0; r < kRszRows; ++r) {
             const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh);
             const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh);
-            const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fx, fy[r]);
-            const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
-            const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
-            const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+            const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, f2{fx, fy[r]});
+            const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
+            const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
+            const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
             if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows)
                 *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) =
                     U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
         for (int i = 0; i < 4; ++i) {
             const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].b, ta[i].a, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].c, ta[i].b, sh[i]);
             const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].b, tb[i].a, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].c, tb[i].b, sh[i]);
-            p[i] = bilerp_bgr<false>(alo, ahi, blo, bhi, fx[i], fy[i]);
+            p[i] = bilerp_bgr<false>(alo, ahi, blo, bhi, f2{fx[i], fy[i]});
         }
     } else {
 #pragma unroll 1
@@ -511,9 +521,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
     const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
     const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
-    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, false);
-    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, false);
-    const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, false);
+    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
+    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
+    const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
     if ((threadIdx.x & 3) == 0 && x < d.cols) {
         struct U3 { uint32_t a, b, c; };
         *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) =

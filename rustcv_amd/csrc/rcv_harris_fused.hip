@@ -23,6 +23,7 @@
 namespace {
 
 typedef short s2v __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kAhead = 2;             // source rows in flight per lane (x 6 VGPRs); 2 keeps the kernel at 3 waves per SIMD
 constexpr int kStripPx = 62 * 8;
 
@@ -38,8 +39,10 @@ __device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) {
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b)); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b)); }
 __device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2); }
-__device__ __forceinline__ uint32_t shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }  // from lane-1
-__device__ __forceinline__ uint32_t shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }  // from lane+1
+// bound_ctrl: a lane without a source lane (lane 0 / lane 63) reads 0 -- the same value `old = 0` would leave, without the
+// v_mov that initialises `old` before every DPP
+__device__ __forceinline__ uint32_t shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }  // from lane-1
+__device__ __forceinline__ uint32_t shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }  // from lane+1
 __device__ __forceinline__ float shr1f(float v) { return __builtin_bit_cast(float, shr1(__builtin_bit_cast(uint32_t, v))); }
 __device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(float, shl1(__builtin_bit_cast(uint32_t, v))); }
 
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
     // ---- pipeline state --------------------------------------------------------------------------------------
     uint32_t h1a[4], h1b[4], h2a[4], h2b[4];      // Sobel horizontal parts of gray rows v-2, v-1 (packed i16 pairs)
-    float hsxx[8], hsxy[8], hsyy[8];              // horizontal box sums of product row u-1 -- kept in f32: every product
+    f2 hsxx[4], hsxy[4], hsyy[4];                 // horizontal box sums of product row u-1 -- kept in f32: every product
                                                   // (<= 1020^2) and every 2x2 sum (< 2^24) is an exactly representable
                                                   // integer, so f32 adds/muls are exact and can use the packed f32 ALU
     float m3a[8], m3b[8], rc[8], mlr[8];          // NMS: rowmax3 of rows u-2, u-1; response and left/right max of row u-1
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hsxx[j] = hsxy[j] = hsyy[j] = 0.0f;
+        hsxx[j & 3] = hsxy[j & 3] = hsyy[j & 3] = f2{0.0f, 0.0f};
         m3a[j] = m3b[j] = rc[j] = mlr[j] = NEG_INF;
     }
 
@@ -139,7 +142,11 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         Cc[3] = pk(hi, hi, 0x0c030c02u);
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
-        float ix[8], iy[8];
+        // f32 stages on PACKED pairs {pixel j, pixel j+4} (v_pk_mul/add_f32): with this pairing the horizontal neighbour
+        // P(x-1) of a pair is simply the previous pair register (j >= 1) -- pairing adjacent pixels {2j, 2j+1} instead leaves
+        // every neighbour pair {2j-1, 2j} straddling two registers, and the compiler rebuilds it with ~3 v_mov per pixel
+        f2 ix2[4], iy2[4];
+        float ixs[8], iys[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t h1 = pk_sub(L[j + 1], L[j]);
@@ -150,36 +157,45 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             h1b[j] = h1;
             h2a[j] = h2b[j];
             h2b[j] = h2;
-            ix[2 * j] = (float)(int)(short)(ox & 0xffff);
-            ix[2 * j + 1] = (float)((int)ox >> 16);
-            iy[2 * j] = (float)(int)(short)(oy & 0xffff);
-            iy[2 * j + 1] = (float)((int)oy >> 16);
+            ixs[2 * j] = (float)(int)(short)(ox & 0xffff);
+            ixs[2 * j + 1] = (float)((int)ox >> 16);
+            iys[2 * j] = (float)(int)(short)(oy & 0xffff);
+            iys[2 * j + 1] = (float)((int)oy >> 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ix2[j] = f2{ixs[j], ixs[j + 4]};
+            iy2[j] = f2{iys[j], iys[j + 4]};
         }
         // ---- products and 2x2 box sums: S(u) = Hs(u-1) + Hs(u), Hs(x) = P(x-1) + P(x) -------------------------------
-        float pxx[8], pxy[8], pyy[8];
+        f2 pxx[4], pxy[4], pyy[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float yy = mirrored ? -iy[j] : iy[j];
-            pxx[j] = ix[j] * ix[j];
-            pxy[j] = ix[j] * yy;
+        for (int j = 0; j < 4; ++j) {
+            const f2 yy = mirrored ? -iy2[j] : iy2[j];
+            pxx[j] = ix2[j] * ix2[j];
+            pxy[j] = ix2[j] * yy;
             pyy[j] = yy * yy;
         }
         // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
-        const float exx = edgeL ? pxx[1] : pxx[7], exy = edgeL ? pxy[1] : pxy[7], eyy = edgeL ? pyy[1] : pyy[7];
+        const float exx = edgeL ? pxx[1].x : pxx[3].y, exy = edgeL ? pxy[1].x : pxy[3].y, eyy = edgeL ? pyy[1].x : pyy[3].y;
         const float lxx = shr1f(exx), lxy = shr1f(exy), lyy = shr1f(eyy);
         float r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float nxx = (j ? pxx[j - 1] : lxx) + pxx[j], nxy = (j ? pxy[j - 1] : lxy) + pxy[j], nyy = (j ? pyy[j - 1] : lyy) + pyy[j];
-            const float sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;   // == (float)(exact integer sum)
+        for (int j = 0; j < 4; ++j) {
+            // neighbours of pixels {j, j+4}: pixels {j-1, j+3}
+            const f2 qxx = j ? pxx[j - 1] : f2{lxx, pxx[3].x}, qxy = j ? pxy[j - 1] : f2{lxy, pxy[3].x}, qyy = j ? pyy[j - 1] : f2{lyy, pyy[3].x};
+            const f2 nxx = qxx + pxx[j], nxy = qxy + pxy[j], nyy = qyy + pyy[j];
+            const f2 sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;   // == (float)(exact integer sum)
             hsxx[j] = nxx;
             hsxy[j] = nxy;
             hsyy[j] = nyy;
-            const float fa = sxx * a.s2, fb = sxy * a.s2, fc = syy * a.s2;
-            const float t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
-            const float t4 = a.k * t3;
-            const float t5 = t4 * t3;
-            r[j] = (t1 - t2) - t5;
+            const f2 fa = sxx * a.s2, fb = sxy * a.s2, fc = syy * a.s2;
+            const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+            const f2 t4 = a.k * t3;
+            const f2 t5 = t4 * t3;
+            const f2 rr2 = (t1 - t2) - t5;
+            r[j] = rr2.x;
+            r[j + 4] = rr2.y;
         }
         if (WANT_RESP) {
             const bool st = live && u >= ys && u < ye;
@@ -216,16 +232,20 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
     // virtual gray rows v = ys-3 .. ye+1  (mask row w is emitted when v = w + 2 arrives)
     const int v0 = ys - 3, nrows = ye - ys + 5;
+    // two row groups per trip, the two buffers swapping roles, so that no group is copied from `nxt` to `cur`; rows fed
+    // past v = ye+1 (odd group count) re-read row ye+1 and write nothing (w >= ye goes to the dump line)
     Row6 cur[kAhead], nxt[kAhead];
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) cur[i] = load_row(v0 + i);
-    for (int g0 = 0; g0 < nrows; g0 += kAhead) {
+    for (int g0 = 0; g0 < nrows; g0 += 2 * kAhead) {
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) nxt[i] = load_row(v0 + g0 + kAhead + i);
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) feed(cur[i], v0 + g0 + i);
 #pragma unroll
-        for (int i = 0; i < kAhead; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < kAhead; ++i) cur[i] = load_row(v0 + g0 + 2 * kAhead + i);
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) feed(nxt[i], v0 + g0 + kAhead + i);
     }
 }
 

@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
         U2 v = rw.v;
         // x = cols mirrors cols-2: the lane just right of the image holds cols-8..cols-1 after clamping -> its byte 0 := byte 6
         if (edgeR) v.lo = pk(v.hi, v.lo, 0x03020106u);
-        uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> lane-1's hi dword
-        uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> lane+1's lo dword
+        uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, true);  // wave_shr:1 -> lane-1's hi dword
+        uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, true);  // wave_shl:1 -> lane+1's lo dword
         if (lane == 0) lf = rw.e << 24;   // byte 3 of "lane -1's hi dword"
         if (lane == 63) rt = rw.e;        // byte 0 of "lane 64's lo dword"
         // 16-bit pairs: L_j = (p[2j-1], p[2j]), C_j = (p[2j], p[2j+1]), R_j = (p[2j+1], p[2j+2]) = L_{j+1}
