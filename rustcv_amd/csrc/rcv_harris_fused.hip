@@ -29,7 +29,7 @@ constexpr int kStripPx = 62 * 8;
 
 struct HArgs {
     const uint8_t* src;
-    uint8_t *mask, *resp, *dump;
+    uint8_t *mask, *resp;
     size_t sstep, mstep, rstep, sfs, mfs, rfs;
     int rows, cols, nstrips, seg_rows, nsegs, total_waves;
     float s2, k, thr;
@@ -48,6 +48,12 @@ __device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(floa
 
 struct Row6 { uint32_t d[6]; };
 struct U2 { uint32_t a, b; };
+// global-address-space views: a pointer laundered through an SGPR constraint would otherwise decay to a flat pointer
+#define RCV_GLOBAL __attribute__((address_space(1)))
+typedef RCV_GLOBAL uint8_t* gptr;
+typedef const RCV_GLOBAL uint8_t* cgptr;
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 // YUYV = true: the source is packed YUYV (2 B/px, SURVEY.md 8(d) config 5 "[or YUYV]"); each macropixel goes through the
 // reference's BT.601 conversion (rustcv/src/videoio/mod.rs:356-363, saturated to u8) and then the same gray formula, so the
@@ -56,7 +62,9 @@ template <bool WANT_RESP, bool YUYV>
 __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
-    int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are
+    // then SALU work (as VALU work the 64-bit row multiplies alone were ~100 quarter-rate slots per four rows)
+    int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (wid >= a.total_waves) return;
     const int strip = wid % a.nstrips;
     wid /= a.nstrips;
@@ -67,21 +75,23 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const int xc = min(max(x, 0), a.cols - 8);
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
-    const uint8_t* sf = a.src + (size_t)frame * a.sfs + (YUYV ? 2 : 3) * (size_t)xc;
-    uint8_t* mp = a.mask + (size_t)frame * a.mfs + (size_t)max(x, 0);
-    uint8_t* rp = WANT_RESP ? a.resp + (size_t)frame * a.rfs + 4 * (size_t)max(x, 0) : nullptr;
-    uint8_t* const dump = a.dump + lane * 32;
+    // uniform frame bases + 32-bit per-lane offsets: the loads and stores take the scalar-base + vector-offset form
+    const uint8_t* const sf = a.src + (size_t)frame * a.sfs;
+    uint8_t* const mf = a.mask + (size_t)frame * a.mfs;
+    uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
+    const uint32_t sx = (uint32_t)((YUYV ? 2 : 3) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
 
     auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
         v = min(v, ye + 1);
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
-        const uint8_t* p = sf + (size_t)r * a.sstep;
-        const U2 q0 = *(const U2*)p, q1 = *(const U2*)(p + 8);
-        if constexpr (YUYV) return Row6{{q0.a, q0.b, q1.a, q1.b, 0u, 0u}};
+        cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
+        asm("" : "+s"(p));   // the row base stays in SGPRs: loads take the saddr + 32-bit voffset form, no VALU address math
+        const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx), q1 = *(const RCV_GLOBAL u2v*)(p + sx + 8);
+        if constexpr (YUYV) return Row6{{q0.x, q0.y, q1.x, q1.y, 0u, 0u}};
         else {
-            const U2 q2 = *(const U2*)(p + 16);
-            return Row6{{q0.a, q0.b, q1.a, q1.b, q2.a, q2.b}};
+            const u2v q2 = *(const RCV_GLOBAL u2v*)(p + sx + 16);
+            return Row6{{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y}};
         }
     };
 
@@ -198,10 +208,15 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             r[j + 4] = rr2.y;
         }
         if (WANT_RESP) {
-            const bool st = live && u >= ys && u < ye;
-            uint8_t* o = st ? rp + (size_t)u * a.rstep : dump;
-            *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
-            *(float4*)(o + 16) = make_float4(r[4], r[5], r[6], r[7]);
+            // (a branch around a store makes the compiler wait for every outstanding load first; harmless here -- the next
+            //  rows' loads were issued a whole row of arithmetic earlier)
+            if (live && u >= ys && u < ye) {
+                gptr orow = (gptr)(rf + (size_t)u * a.rstep);
+                asm("" : "+s"(orow));
+                gptr o = orow + 4 * mx;
+                *(RCV_GLOBAL f4v*)o = f4v{r[0], r[1], r[2], r[3]};
+                *(RCV_GLOBAL f4v*)(o + 16) = f4v{r[4], r[5], r[6], r[7]};
+            }
         }
         // ---- NMS: response outside the image is -inf ------------------------------------------------------------------
         const bool outside = u < 0 || u >= a.rows;
@@ -226,14 +241,17 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             mlr[j] = lrmax;
         }
         const int w = u - 1;
-        const bool st = live && w >= ys && w < ye;
-        *(U2*)(st ? mp + (size_t)w * a.mstep : dump) = U2{mbits[0], mbits[1]};
+        if (live && w >= ys && w < ye) {
+            gptr mrow = (gptr)(mf + (size_t)w * a.mstep);
+            asm("" : "+s"(mrow));
+            *(RCV_GLOBAL u2v*)(mrow + mx) = u2v{mbits[0], mbits[1]};
+        }
     };
 
     // virtual gray rows v = ys-3 .. ye+1  (mask row w is emitted when v = w + 2 arrives)
     const int v0 = ys - 3, nrows = ye - ys + 5;
     // two row groups per trip, the two buffers swapping roles, so that no group is copied from `nxt` to `cur`; rows fed
-    // past v = ye+1 (odd group count) re-read row ye+1 and write nothing (w >= ye goes to the dump line)
+    // past v = ye+1 (odd group count) re-read row ye+1 and write nothing (w >= ye)
     Row6 cur[kAhead], nxt[kAhead];
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) cur[i] = load_row(v0 + i);
@@ -262,7 +280,6 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     a.src = s.p;
     a.mask = m.p;
     a.resp = resp ? resp->p : nullptr;
-    a.dump = ctx->kconst + 8192;
     a.sstep = s.step;
     a.mstep = m.step;
     a.rstep = resp ? resp->step : 0;
