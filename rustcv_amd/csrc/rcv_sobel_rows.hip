@@ -59,7 +59,7 @@ template <int DBG, bool BGR>
 __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 {
     const int lane = threadIdx.x & 63;
-    int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row indices and row bases on the SALU
     if (wid >= a.total_waves) return;
     const int strip = wid % a.nstrips;
     wid /= a.nstrips;
