@@ -181,10 +181,17 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         f2 pxx[4], pxy[4], pyy[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f2 yy = mirrored ? -iy2[j] : iy2[j];
             pxx[j] = ix2[j] * ix2[j];
-            pxy[j] = ix2[j] * yy;
-            pyy[j] = yy * yy;
+            pyy[j] = iy2[j] * iy2[j];          // (-iy)^2 == iy^2 exactly
+        }
+        // `mirrored` is a scalar condition (rows outside the image only): a uniform branch between the product and its exact
+        // negation (a free source modifier) instead of one v_cndmask per pixel
+        if (mirrored) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * (-iy2[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * iy2[j];
         }
         // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
         const float exx = edgeL ? pxx[1].x : pxx[3].y, exy = edgeL ? pxy[1].x : pxy[3].y, eyy = edgeL ? pyy[1].x : pyy[3].y;
@@ -219,12 +226,15 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             }
         }
         // ---- NMS: response outside the image is -inf ------------------------------------------------------------------
-        const bool outside = u < 0 || u >= a.rows;
+        // A row outside the image (scalar condition, two rows per frame edge): every response is -inf.  Columns outside the
+        // image belong to whole lanes (cols % 8 == 0: the lane left of x = 0, lanes right of the last column) that never
+        // store; only the values they hand to their neighbours matter, and those are replaced right here.
+        if (u < 0 || u >= a.rows) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (outside || x + j >= a.cols || x + j < 0) r[j] = NEG_INF;
-        const float rl = shr1f(edgeL ? NEG_INF : r[7]);   // r[x-1] of the lane's first pixel
-        const float rr = shl1f(r[0]);                      // r[x+8]
+            for (int j = 0; j < 8; ++j) r[j] = NEG_INF;
+        }
+        const float rl = shr1f(edgeL ? NEG_INF : r[7]);              // r[x-1] of the lane's first pixel
+        const float rr = shl1f(x >= a.cols ? NEG_INF : r[0]);        // r[x+8]
         uint32_t mbits[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
