@@ -303,8 +303,7 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     // segments >= 64 rows
     int seg = s.rows;
     {
-        static int waves_per_cu[2] = {0, 0};
-        int& wpc = waves_per_cu[resp ? 1 : 0];
+        int& wpc = ctx->harris_wpc[resp ? 1 : 0];   // per context: contexts may be driven from different threads
         if (wpc == 0) {
             int nb = 0;
             hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, false>, 256, 0)

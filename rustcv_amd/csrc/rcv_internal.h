@@ -36,6 +36,7 @@ struct rcv_ctx {
     uint8_t* pin;
     size_t pin_cap;
     hipEvent_t pin_ev;           // recorded after the H2D that reads `pin`
+    int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
 // Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the

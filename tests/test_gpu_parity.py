@@ -1090,6 +1090,57 @@ def test_batch_equals_single_frames(ctx, oracle):
     dst.free()
 
 
+def test_contexts_driven_from_concurrent_threads(oracle):
+    """a context is single-threaded, but different contexts are independent and may be driven from different
+    threads at the same time (the one-host-thread-per-GPU model of 8(e)).  Four threads, each with its own context on GPU 0,
+    run a mix of ops (different kernels per thread: per-context weight tables, constant areas, workspaces, occupancy caches)
+    and every result must equal the oracle."""
+    import threading
+    import rustcv_amd as rcv
+    rows, cols = 96, 256
+    errors = []
+
+    def worker(tid):
+        try:
+            r = np.random.default_rng(900 + tid + _SOAK_SEED)
+            c = rcv.Context(0)
+            for it in range(6 * _SOAK):
+                img = r.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+                src = Mat.from_array(img)
+                which = (it + tid) % 4
+                if which == 0:
+                    ks = int(r.choice([3, 5, 7]))
+                    k = r.integers(-20, 21, size=(ks, ks)).astype(np.int8)
+                    dst = Mat(rows, cols, 3)
+                    imgproc.filter2d(src, dst, k, 5, ctx=c)
+                    ok = np.array_equal(dst.to_array(), oracle.filter2d_i8(img, k, 5))
+                elif which == 1:
+                    mask = Mat(rows, cols, 1)
+                    imgproc.harris_pipeline(src, mask, None, 2, 0.04, 1e-7, c)
+                    ok = np.array_equal(mask.to_array(), oracle.harris_pipeline(img, 2, 0.04, 1e-7))
+                elif which == 2:
+                    dst = Mat(rows, cols, 3)
+                    imgproc.gaussian_blur(src, dst, 5, 1.2, c)
+                    ok = np.array_equal(dst.to_array(), oracle.gaussian_blur(img, 5, 1.2))
+                else:
+                    M = np.array([0.98, -0.1, 3.5, 0.1, 0.98, -2.25], np.float32)
+                    dst = Mat(rows, cols, 3)
+                    imgproc.warp_affine(src, dst, M, c)
+                    ok = np.array_equal(dst.to_array(), oracle.warp_affine(img, M, rows, cols))
+                if not ok:
+                    errors.append((tid, it, which))
+            c.close()
+        except Exception as e:   # noqa: BLE001 -- reported through the list, the thread must not die silently
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_frame_sharded_contexts_equal_one_batch(ctx, oracle, world):
     """rank i of G owns frames [floor(iN/G), floor((i+1)N/G)) on its own context and stream; the concatenation of
