@@ -257,6 +257,24 @@ __device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint3
     return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
 }   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
+// 4 x 4 transpose of dwords inside every quad of lanes: on return lane 4q+i holds in a[j] what lane 4q+j held in a[i].
+// Two butterfly stages (lane distance 1, then 2), each a select between a register and a quad-permuted neighbour register:
+// 8 VALU instructions.  The kernels below use it to turn "row r of pixels, one per lane" into "4 pixels of one row per
+// lane", so that ONE full-wave 12-byte store covers four output rows instead of four quarter-wave stores.
+__device__ __forceinline__ void quad_transpose4(uint32_t (&a)[4], int lane)
+{
+    const bool odd = lane & 1, hi = lane & 2;
+    const uint32_t x1 = __builtin_amdgcn_update_dpp(0u, a[1], 0xB1, 0xf, 0xf, true), x0 = __builtin_amdgcn_update_dpp(0u, a[0], 0xB1, 0xf, 0xf, true);
+    const uint32_t x3 = __builtin_amdgcn_update_dpp(0u, a[3], 0xB1, 0xf, 0xf, true), x2 = __builtin_amdgcn_update_dpp(0u, a[2], 0xB1, 0xf, 0xf, true);
+    const uint32_t b0 = odd ? x1 : a[0], b1 = odd ? a[1] : x0, b2 = odd ? x3 : a[2], b3 = odd ? a[3] : x2;
+    const uint32_t y2 = __builtin_amdgcn_update_dpp(0u, b2, 0x4E, 0xf, 0xf, true), y0 = __builtin_amdgcn_update_dpp(0u, b0, 0x4E, 0xf, 0xf, true);
+    const uint32_t y3 = __builtin_amdgcn_update_dpp(0u, b3, 0x4E, 0xf, 0xf, true), y1 = __builtin_amdgcn_update_dpp(0u, b1, 0x4E, 0xf, 0xf, true);
+    a[0] = hi ? y2 : b0;
+    a[2] = hi ? b2 : y0;
+    a[1] = hi ? y3 : b1;
+    a[3] = hi ? b3 : y1;
+}
+
 // Two phases per thread so that all 16 tap loads of its 8 rows are in flight together: the loads are unconditional
 // (clamped tap windows) -- a branch around them would make the compiler wait vmcnt(0) row by row.
 __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
@@ -319,18 +337,24 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
                 ta[r] = *(const U3*)(sf + (off & ~3u));
                 tb[r] = *(const U3*)(sf + ((off & ~3u) + sstep));
             }
+            uint32_t px[kWarpRows];
 #pragma unroll
             for (int r = 0; r < kWarpRows; ++r) {
                 const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh[r]);
                 const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh[r]);
-                const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[r]);
-                const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
-                const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
-                const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
-                if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
+                px[r] = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[r]);
+            }
+            // four rows at a time: quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
+            const int lane = threadIdx.x & 63;
+            const int xq = x & ~3, yi = ybase + (lane & 3);
+#pragma unroll
+            for (int h = 0; h < kWarpRows / 4; ++h) {
+                uint32_t t[4] = {px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]};
+                quad_transpose4(t, lane);
+                if (xq < d.cols && yi + 4 * h < d.rows) {
                     // 4 x {b g r 0} -> 12 bytes with three byte permutes
-                    *(U3*)(dfr + (__umul24((unsigned)(ybase + r), (unsigned)d.step) + 3u * (unsigned)x)) =
-                        U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+                    *(U3*)(dfr + (__umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq)) =
+                        U3{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
                 }
             }
             return;
