@@ -458,18 +458,20 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
             ta[r] = *(const U3*)(sf + (__umul24((unsigned)y0, (unsigned)s.step) + xa));
             tb[r] = *(const U3*)(sf + (__umul24((unsigned)y1, (unsigned)s.step) + xa));
         }
+        uint32_t px[kRszRows];
 #pragma unroll
         for (int r = 0; r < kRszRows; ++r) {
             const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh);
             const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh);
-            const uint32_t px = bilerp_bgr<true>(alo, ahi, blo, bhi, f2{fx, fy[r]});
-            const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
-            const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
-            const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
-            if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows)
-                *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) =
-                    U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+            px[r] = bilerp_bgr<true>(alo, ahi, blo, bhi, f2{fx, fy[r]});
         }
+        // quad transpose: lane 4q+i stores pixels 4q..4q+3 of row ybase+i -- one full-wave store for the four rows
+        static_assert(kRszRows == 4, "one quad transpose per thread");
+        const int lane = threadIdx.x & 63, xs = x & ~3, yi = ybase + (lane & 3);
+        quad_transpose4(px, lane);
+        if (xs < d.cols && yi < d.rows)
+            *(U3*)(dfr + (size_t)yi * d.step + (size_t)xs * 3) =
+                U3{__builtin_amdgcn_perm(px[1], px[0], 0x04020100u), __builtin_amdgcn_perm(px[2], px[1], 0x05040201u), __builtin_amdgcn_perm(px[3], px[2], 0x06050402u)};
         return;
     }
 #pragma unroll 1
