@@ -32,7 +32,7 @@ struct HArgs {
     uint8_t *mask, *resp;
     size_t sstep, mstep, rstep, sfs, mfs, rfs;
     int rows, cols, nstrips, seg_rows, nsegs, total_waves;
-    float s2, k, thr;
+    float s2, k, thr_up;   // thr_up: smallest float > thr (+inf for a NaN threshold: nothing is kept, as `rc > NaN` is never true)
 };
 
 __device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -239,11 +239,14 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float left = j ? r[j - 1] : rl, right = j < 7 ? r[j + 1] : rr;
-            const float lrmax = fmaxf(left, right);
+            // The threshold rides in the neighbour maxima: rc > thr <=> rc >= thr_up (the next float above thr, set by the host;
+            // denormals are preserved in this kernel), and keep = (rc >= max(neighbours, thr_up)) -- one compare per pixel
+            // instead of two; that thr_up also enters the row maxima of the rows above / below changes nothing (a max of maxima).
+            const float lrmax = fmaxf(fmaxf(left, right), a.thr_up);
             const float m3 = fmaxf(lrmax, r[j]);
             // output row w = u-1: centre rc, neighbours = rowmax3(u-2), left/right of u-1, rowmax3(u)
             const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);
-            const bool keep = rc[j] > a.thr && rc[j] >= m8;
+            const bool keep = rc[j] >= m8;
             mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
             m3a[j] = m3b[j];
             m3b[j] = m3;
@@ -331,7 +334,7 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     double sc = 1.0 / (4.0 * 2.0 * 255.0);
     a.s2 = (float)(sc * sc);
     a.k = k;
-    a.thr = thr;
+    a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
     dim3 grid((unsigned)((waves + 3) / 4));
     if (s.ch == 2) {
         if (resp) hipLaunchKernelGGL((k_harris_fused<true, true>), grid, dim3(256), 0, ctx->stream, a);

@@ -976,6 +976,34 @@ def test_harris_fused_path(ctx, oracle, rows, cols, want_resp):
         b.free()
 
 
+def test_harris_fused_threshold_edge_values(ctx, oracle):
+    """`rc > thr` with thresholds at the edges of the float line: +-0 (flat regions have a response of exactly 0 and must not
+    pass), a denormal, the exact value of a local maximum present in the image (strict inequality), +-inf and NaN"""
+    rows, cols = 64, 256
+    img = np.zeros((rows, cols, 3), np.uint8)
+    img[:, :] = 40                                   # flat background: response exactly 0
+    rng = np.random.default_rng(77 + _SOAK_SEED)
+    for _ in range(12):                              # bright rectangles: corners and edges
+        y, x = int(rng.integers(2, rows - 12)), int(rng.integers(2, cols - 20))
+        img[y:y + int(rng.integers(3, 10)), x:x + int(rng.integers(3, 18))] = rng.integers(80, 256, 3)
+    _, resp = oracle.harris_pipeline(img, 2, 0.04, 0.0, True)
+    peak = float(resp.max())
+    assert peak > 0 and (resp == 0).any()
+    thrs = [0.0, -0.0, 1e-45, -1e-45, peak, float(np.nextafter(np.float32(peak), np.float32(0))), -np.inf, np.inf, np.nan, 1e-9]
+    src = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    mask = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    src.upload(img[None])
+    for thr in thrs:
+        device.harris_pipeline(src, mask, None, 2, 0.04, thr)
+        want = oracle.harris_pipeline(img, 2, 0.04, thr)
+        assert np.array_equal(mask.download()[0], want), thr
+    want_peak = oracle.harris_pipeline(img, 2, 0.04, peak)
+    assert want_peak[resp == peak].sum() == 0        # strict: the maximum itself does not exceed a threshold equal to it
+    assert oracle.harris_pipeline(img, 2, 0.04, 0.0)[resp == 0].sum() == 0 and oracle.harris_pipeline(img, 2, 0.04, 0.0).any()
+    src.free()
+    mask.free()
+
+
 def test_baseline_configs_at_full_size(ctx, oracle):
     """one or two frames of every BASELINE.json configuration that has no full-size test of its own, bit for bit against the
     oracle: config 1 (640x480 YUYV -> BGR + rectangle), config 2 (1080p 5x5 Gaussian), config 3's Sobel on 4K gray,
