@@ -201,6 +201,13 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
 // Same f32 operations in the same order as k_warp_affine<3>.
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kWarpRows = 8;
+#ifndef RCV_WARP_WW
+#define RCV_WARP_WW 64
+#endif
+#ifndef RCV_WARP_TW
+#define RCV_WARP_TW 256
+#endif
+constexpr int kWarpWW = RCV_WARP_WW, kWarpTW = RCV_WARP_TW;   // wave / workgroup width in pixels
 
 // byte N of a dword -> f32 in one instruction (the compiler otherwise mixes shifts, masks and integer subtracts in)
 template <int N>
@@ -284,9 +291,12 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
     const int rowbytes = s.cols * 3;
-    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0 and kBlock % 4 == 0: quads never straddle the row end
+    // lane -> pixel: a wave covers kWarpWW columns x (64 / kWarpWW) bands of kWarpRows rows, a workgroup kWarpTW columns
+    // (squarer source patches than one 256-pixel row band: more of every fetched line is used before it leaves L1 / L2)
+    const int wlane = threadIdx.x & 63, wwave = threadIdx.x >> 6;
+    const int x = blockIdx.x * kWarpTW + (wwave % (kWarpTW / kWarpWW)) * kWarpWW + (wlane % kWarpWW);   // d.cols % 4 == 0: quads never straddle the row end
     const float fxx = (float)min(x, d.cols - 1);
-    const int ybase = blockIdx.y * kWarpRows;
+    const int ybase = ((int)blockIdx.y * (kBlock / kWarpTW) + (wwave / (kWarpTW / kWarpWW)) * (64 / kWarpWW) + wlane / kWarpWW) * kWarpRows;
 
     // ---- interior fast path (wave-uniform) ----
     // The border version below spends ~160 VALU ops per pixel and two unaligned 8-byte loads per row.  sx and sy are
@@ -493,19 +503,35 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
 // pixels per output pixel -- bit for bit what the warp kernels produce (same f32 ops, same order, same rounding) -- and
 // averages them with (a+b+c+d+2)>>2.  `mid` never exists: 1/4 (S=2: all) of the warp arithmetic of the unfused pair and
 // none of its 2 x 3 B/px intermediate traffic.  One thread per output pixel, four lanes share a 12-byte store.
+#ifndef RCV_BOX_TW
+#define RCV_BOX_TW 64
+#endif
+constexpr int kBoxTileW = RCV_BOX_TW, kBoxTileH = 256 / RCV_BOX_TW;   // output tile of one workgroup (4 waves of 16 x 4)
+
 template <int S>
 __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affine A)
 {
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y;   // d.cols % 4 == 0: quads never straddle the row end
-    const int xq = min(x, d.cols - 1);
+    // A workgroup owns a 32 x 8 tile of output pixels, each wave a 16 x 4 sub-tile (lane = 16 * row + column): the taps of
+    // a wave then fall into a compact source patch (64 x 16 px for S = 4, plus the rotation's drift) that its eight tap loads
+    // reuse out of L1.  With one output ROW segment per wave (64 x 1) the same loads walked across 30 source rows at 7 degrees,
+    // every line was used by two lanes only and fetched again by the waves of the neighbouring rows (1.66x the algorithmic
+    // bytes from HBM; 64 % of the wave cycles waiting on memory).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef RCV_BOX_WW
+#define RCV_BOX_WW 32
+#endif
+    constexpr int WW = RCV_BOX_WW, WH = 64 / WW;   // wave sub-tile
+    const int x = blockIdx.x * kBoxTileW + (wave % (kBoxTileW / WW)) * WW + (lane % WW);   // d.cols % 4 == 0: quads never straddle the row end
+    const int y = blockIdx.y * kBoxTileH + (wave / (kBoxTileW / WW)) * WH + (lane / WW);
+    const int xq = min(x, d.cols - 1), yq = min(y, d.rows - 1);
     constexpr int o = S / 2 - 1;
     float sx[4], sy[4];
     bool inter = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * y + o + (i >> 1));
+        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
         sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
         sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
         inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
@@ -539,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) {
             uint8_t o3[3];
-            warp_px<3>(sf, s, A, (float)(S * xq + o + (i & 1)), (float)(S * y + o + (i >> 1)), o3);
+            warp_px<3>(sf, s, A, (float)(S * xq + o + (i & 1)), (float)(S * yq + o + (i >> 1)), o3);
             p[i] = (uint32_t)o3[0] | ((uint32_t)o3[1] << 8) | ((uint32_t)o3[2] << 16);
         }
     }
@@ -550,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
     const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
     const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
-    if ((threadIdx.x & 3) == 0 && x < d.cols) {
+    if ((threadIdx.x & 3) == 0 && x < d.cols && y < d.rows) {
         struct U3 { uint32_t a, b, c; };
         *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) =
             U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
@@ -616,8 +642,8 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     Affine A;
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
     if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
-        unsigned gx = (unsigned)((d.cols + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_warp_affine_bgr, dim3(gx, (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
+        const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
+        hipLaunchKernelGGL(k_warp_affine_bgr, dim3(gx, (d.rows + band - 1) / band, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1) hipLaunchKernelGGL(k_warp_affine<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
@@ -641,7 +667,7 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            dim3 grid((unsigned)((d.cols + kBlock - 1) / kBlock), d.rows, d.n);
+            dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             if (S == 2) hipLaunchKernelGGL(k_warp_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
             else hipLaunchKernelGGL(k_warp_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
             return rcv_launch_check(ctx);
