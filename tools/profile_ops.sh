@@ -24,3 +24,6 @@ run_op bgr2gray_4k "BGR2GRAY" "k_bgr2gray16" $((PX4K*4))
 run_op sobel_4k "Sobel_3x3" "k_sobel_rows<0, false>" $((PX4K*5))
 run_op harris_4k "Harris_pipeline_(BGR" "k_harris_fused<false, false>" $((PX4K*4))
 run_op warp_8k "warpAffine_bilinear" "k_warp_affine_bgr" $((PX8K*6))
+PXO=$((32*1080*1920))
+run_op warp_resize_fused "warpAffine_+_resize" "k_warp_resize_box" $((PXO*30))
+run_op resize_5k "resize_8K_->_5K" "k_resize_bgr" $((32*2880*5120*975/100))
