@@ -97,7 +97,7 @@ struct U3 { uint32_t a, b, c; };
 // SRC: 0 = BGR source; 1 = packed YUYV source (2 B/px): the BT.601 conversion of the reference
 // (rustcv/src/videoio/mod.rs:356-363) runs at staging time, so the capture-side pipeline YUYV -> BGR -> filter2D is one
 // launch and the intermediate BGR image never touches HBM (5 instead of 11 algorithmic bytes per pixel).
-template <int DBG, bool DUAL, int SRC = 0>
+template <int DBG, bool DUAL, int SRC = 0, bool LAT = false>
 __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * kPlane + kWaves * kOutWave];
@@ -466,6 +466,22 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     // step k computes from blocks k, k+1.  Blocks 0..nsteps are needed; loads past that are harmless re-reads.
     // Two register sets, loop unrolled by two so that the set index is static. ----
     uint32_t LA[kLregs], LB[kLregs];
+    if constexpr (LAT) {
+        // Latency variant for launches that fill the GPU at most once (a single 1080p frame is 544 workgroups of 16 rows):
+        // segments of <= 32 rows, so blocks 0..2 are all a workgroup ever needs -- requested together (ONE memory latency
+        // instead of two dependent ones), staged, and computed without any pipeline.
+        uint32_t LC[kLregs];
+        load_block(0, LA);
+        load_block(1, LB);
+        load_block(2, LC);
+        store_block(0, LA);
+        store_block(1, LB);
+        store_block(2, LC);
+        __syncthreads();
+        compute(0);
+        if (nsteps > 1) compute(1);
+        return;
+    }
     load_block(0, LA);
     load_block(1, LB);
     store_block(0, LA);
@@ -597,6 +613,17 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         }
     }
     if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
+    // small launches (everything resident in one round even with the shortest segments): the latency variant
+    bool lat = false;
+    if (!src_yuyv && !dual && !getenv("RCV_F7_NO_LAT")) {
+        for (int sr = 16; sr <= 32 && !lat; sr += 16) {
+            const long long tot = (long long)a.nstrips * ((s.rows + sr - 1) / sr) * s.n;
+            if (tot <= 3LL * ctx->cu_count) {
+                seg_rows = sr;
+                lat = true;
+            }
+        }
+    }
     a.seg_rows = seg_rows;
     a.nsegs = (s.rows + seg_rows - 1) / seg_rows;
     a.shift = shift;
@@ -613,6 +640,10 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     }
     if (dual) {
         hipLaunchKernelGGL((k_filter7_mfma<0, true>), grid, block, 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
+    if (lat) {
+        hipLaunchKernelGGL((k_filter7_mfma<0, false, 0, true>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA

@@ -380,7 +380,11 @@ MFMA_SHAPES = [(4, 16), (5, 32), (16, 16), (17, 48), (33, 240), (40, 256), (19, 
 @pytest.mark.parametrize("rows,cols", MFMA_SHAPES)
 @pytest.mark.parametrize("ksize,shift", [(7, 6), (5, 3), (3, 0), (7, 0)])
 @pytest.mark.parametrize("pad", [0, 32])
-def test_filter2d_i8_mfma_path(ctx, oracle, rng, rows, cols, ksize, shift, pad):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_filter2d_i8_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize, shift, pad, pipelined):
+    # small launches take the kernel's latency variant; RCV_F7_NO_LAT sends the same shapes through the pipelined one
+    if pipelined:
+        monkeypatch.setenv("RCV_F7_NO_LAT", "1")
     img = rand_img(rng, rows, cols, 3)
     k = rng.integers(-128, 128, size=(ksize, ksize), dtype=np.int8) if shift == 0 else rng.integers(-9, 10, size=(ksize, ksize)).astype(np.int8)
     src = Mat.from_array(img, step=cols * 3 + pad)
@@ -426,10 +430,13 @@ def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
     dst.free()
 
 
-def test_filter2d_i8_mfma_random_shapes(ctx, oracle):
-    """40 x RCV_SOAK seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_filter2d_i8_mfma_random_shapes(ctx, oracle, monkeypatch, pipelined):
+    """(latency variant of the kernel for these small launches, and -- RCV_F7_NO_LAT -- the pipelined one)  40 x RCV_SOAK seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
     heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
     padded steps, batch 1..3, BGR and YUYV sources"""
+    if pipelined:
+        monkeypatch.setenv("RCV_F7_NO_LAT", "1")
     r = np.random.default_rng(0xF17E7 + _SOAK_SEED)
     for case in range(40 * _SOAK):
         cols = 16 * int(r.integers(1, 66))
