@@ -97,7 +97,9 @@ struct U3 { uint32_t a, b, c; };
 // SRC: 0 = BGR source; 1 = packed YUYV source (2 B/px): the BT.601 conversion of the reference
 // (rustcv/src/videoio/mod.rs:356-363) runs at staging time, so the capture-side pipeline YUYV -> BGR -> filter2D is one
 // launch and the intermediate BGR image never touches HBM (5 instead of 11 algorithmic bytes per pixel).
-template <int DBG, bool DUAL, int SRC = 0, bool LAT = false>
+// DUAL: 0 = one weight table; 1 = K = 4Q + R, two full tables; 2 = K = K1 + 2*T2 with T2 confined to kernel rows 2..5
+// (the integer 7x7 Gaussian: only its 3x3 centre exceeds i8), so the second table costs 2 instead of 4 MFMAs per tile and plane
+template <int DBG, int DUAL, int SRC = 0, bool LAT = false>
 __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * kPlane + kWaves * kOutWave];
@@ -423,13 +425,14 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
             } else {
                 // the first MFMA of each accumulator takes the constant (128*sum(K) + round) vector as its C operand
                 acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p], Bq[it % kAhead], r < 3 ? initv : acc[c], 0, 0, 0);
-                if (DUAL) acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], r < 3 ? zerov : acc2[c], 0, 0, 0);
+                if (DUAL == 1 || (DUAL == 2 && (p == 1 || p == 2)))
+                    acc2[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[p], Bq[it % kAhead], (DUAL == 1 ? r < 3 : p == 1) ? zerov : acc2[c], 0, 0, 0);
                 if (it + kAhead < 48) Bq[it % kAhead] = rd(it + kAhead, Bq[it % kAhead]);
             }
             if (r == 11) {
                 if (DUAL) {
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) acc[cc] += acc2[cc] << 2;
+                    for (int cc = 0; cc < 3; ++cc) acc[cc] += acc2[cc] << (DUAL == 1 ? 2 : 1);
                 }
                 // lane holds x = x0 + 16t + 4*kb + {0,1,2,3} of row n (t = 4*wave + i): 12 interleaved bytes
                 if (DBG & 16) {   // ablation: no shift / saturate / pack
@@ -507,8 +510,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     }
 }
 
-// host: banded A operands.  K7 is the kernel embedded (centred) in 7x7; `part` selects R (0), Q (1) of K = 4Q + R, or
-// the weights themselves (2, all within i8).
+// host: banded A operands.  K7 is the kernel embedded (centred) in 7x7; `part` selects R (0), Q (1) of K = 4Q + R, the
+// weights themselves (2, all within i8), or K1 (3), T2 (4) of the centre split K = K1 + 2*T2.
 void build_wtab(const int16_t* k, int ksize, int part, int8_t* tab /*4*64*16*/)
 {
     int K7[7][7];
@@ -518,7 +521,9 @@ void build_wtab(const int16_t* k, int ksize, int part, int8_t* tab /*4*64*16*/)
         for (int x = 0; x < ksize; ++x) {
             int w = k[y * ksize + x];
             int q = w >> 2;  // floor
-            K7[y + o][x + o] = part == 2 ? w : (part == 1 ? q : w - 4 * q);
+            // centre split: T2 takes half of what lies beyond the i8 range (rounded away from zero), K1 = w - 2*T2 stays inside
+            int t2 = w > 127 ? (w - 127 + 1) / 2 : (w < -128 ? -((-w - 128 + 1) / 2) : 0);
+            K7[y + o][x + o] = part == 2 ? w : (part == 1 ? q : (part == 0 ? w - 4 * q : (part == 4 ? t2 : w - 2 * t2)));
         }
     for (int p = 0; p < 4; ++p)
         for (int lane = 0; lane < 64; ++lane)
@@ -534,7 +539,7 @@ void build_wtab(const int16_t* k, int ksize, int part, int8_t* tab /*4*64*16*/)
 extern "C" int rcv__debug_occupancy(void)
 {
     int nb = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter7_mfma<0, false>, kThreads, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter7_mfma<0, 0>, kThreads, 0) != hipSuccess) return -1;
     return nb;
 }
 
@@ -550,31 +555,37 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     // in-frame byte offsets are formed with 24-bit multiplies and kept in 32 bits
     if (s.step >= (1u << 24) || d.step >= (1u << 24) || s.rows >= (1 << 24)) return RCV_ERR_UNSUPPORTED;
     if ((unsigned long long)s.rows * s.step >= (1ull << 32) || (unsigned long long)s.rows * d.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
-    bool dual = false;
+    bool dual = false, centre = true;   // centre: every weight beyond i8 sits in (embedded) kernel rows 2..5 and splits as K1 + 2*T2
     long long ksum = 0;
     for (int i = 0; i < ksize * ksize; ++i) {
         if (k[i] < -512 || k[i] > 511) return RCV_ERR_UNSUPPORTED;
-        if (k[i] < -128 || k[i] > 127) dual = true;
+        if (k[i] < -128 || k[i] > 127) {
+            dual = true;
+            const int ky = i / ksize + (7 - ksize) / 2;
+            if (ky < 2 || ky > 5 || k[i] > 127 + 2 * 127 || k[i] < -128 - 2 * 128) centre = false;
+        }
         ksum += k[i];
     }
+    const int mode = !dual ? 0 : ((centre && !getenv("RCV_F7_DUAL_FULL")) ? 2 : 1);   // (the knob keeps the full-table kernel testable)
 
     // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered).  While a graph is
     // being recorded the table goes into a buffer the graph owns, so that replays never depend on this cache.
     const uint8_t* wtab = ctx->kconst;
     if (ctx->capturing) {
         int8_t tab[2 * 4 * 64 * 16];
-        build_wtab(k, ksize, dual ? 0 : 2, tab);
-        if (dual) build_wtab(k, ksize, 1, tab + 4096);
+        build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
+        if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
         RCV_TRY(rcv_const_table(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0, &wtab));
-    } else if (!ctx->f7_valid || ctx->f7_ksize != ksize || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
+    } else if (!ctx->f7_valid || ctx->f7_ksize != ksize || ctx->f7_mode != mode || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
         int8_t tab[2 * 4 * 64 * 16];
-        build_wtab(k, ksize, dual ? 0 : 2, tab);
-        if (dual) build_wtab(k, ksize, 1, tab + 4096);
+        build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
+        if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
         ctx->f7_valid = false;
         RCV_TRY(rcv_upload_const(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0));
         RCV_HIP(hipStreamSynchronize(ctx->stream)); // `tab` is on this stack frame
         memcpy(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t));
         ctx->f7_ksize = ksize;
+        ctx->f7_mode = mode;
         ctx->f7_valid = true;
     }
 
@@ -635,33 +646,34 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
     if (src_yuyv) {
         if (dual) return RCV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_filter7_mfma<0, false, 1>), grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_filter7_mfma<0, 0, 1>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
     if (dual) {
-        hipLaunchKernelGGL((k_filter7_mfma<0, true>), grid, block, 0, ctx->stream, a);
+        if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_filter7_mfma<0, 1>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
     if (lat) {
-        hipLaunchKernelGGL((k_filter7_mfma<0, false, 0, true>), grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_filter7_mfma<0, 0, 0, true>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
     switch (rcv_debug_flags & 31) {
-    case 8: hipLaunchKernelGGL((k_filter7_mfma<8, false>), grid, block, 0, ctx->stream, a); break;
-    case 16: hipLaunchKernelGGL((k_filter7_mfma<16, false>), grid, block, 0, ctx->stream, a); break;
-    case 24: hipLaunchKernelGGL((k_filter7_mfma<24, false>), grid, block, 0, ctx->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_filter7_mfma<1, false>), grid, block, 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_filter7_mfma<2, false>), grid, block, 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((k_filter7_mfma<3, false>), grid, block, 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_filter7_mfma<4, false>), grid, block, 0, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL((k_filter7_mfma<5, false>), grid, block, 0, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL((k_filter7_mfma<6, false>), grid, block, 0, ctx->stream, a); break;
-    case 7: hipLaunchKernelGGL((k_filter7_mfma<7, false>), grid, block, 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((k_filter7_mfma<0, false>), grid, block, 0, ctx->stream, a); break;
+    case 8: hipLaunchKernelGGL((k_filter7_mfma<8, 0>), grid, block, 0, ctx->stream, a); break;
+    case 16: hipLaunchKernelGGL((k_filter7_mfma<16, 0>), grid, block, 0, ctx->stream, a); break;
+    case 24: hipLaunchKernelGGL((k_filter7_mfma<24, 0>), grid, block, 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_filter7_mfma<1, 0>), grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_filter7_mfma<2, 0>), grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_filter7_mfma<3, 0>), grid, block, 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_filter7_mfma<4, 0>), grid, block, 0, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL((k_filter7_mfma<5, 0>), grid, block, 0, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL((k_filter7_mfma<6, 0>), grid, block, 0, ctx->stream, a); break;
+    case 7: hipLaunchKernelGGL((k_filter7_mfma<7, 0>), grid, block, 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a); break;
     }
 #else
-    hipLaunchKernelGGL((k_filter7_mfma<0, false>), grid, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
 }

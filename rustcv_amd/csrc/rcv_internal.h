@@ -25,6 +25,7 @@ struct rcv_ctx {
     // cached banded-weight table of the MFMA filter (rcv_filter7_mfma.hip), lives in kconst[0..4096)
     bool f7_valid;
     int f7_ksize;
+    int f7_mode;         // 0 one table, 1 K = 4Q + R, 2 K = K1 + 2*T2 (which tables the cache holds)
     int16_t f7_k[49];
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
     // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache

@@ -399,8 +399,12 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize,
 
 @pytest.mark.parametrize("rows,cols", [(4, 16), (33, 240), (19, 496), (300, 272)])
 @pytest.mark.parametrize("ksize", [3, 5, 7])
-def test_gaussian_int_mfma_path(ctx, oracle, rng, rows, cols, ksize):
-    """integer GaussianBlur on the MFMA strip kernel (ksize 7 = dual-table variant, weights up to 324)"""
+@pytest.mark.parametrize("full_tables", [False, True])
+def test_gaussian_int_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize, full_tables):
+    """integer GaussianBlur on the MFMA strip kernel.  ksize 7 has weights up to 324: two weight tables, by default the
+    centre split K = K1 + 2*T2 (second table in kernel rows 2..4 only), with RCV_F7_DUAL_FULL the general K = 4Q + R"""
+    if full_tables:
+        monkeypatch.setenv("RCV_F7_DUAL_FULL", "1")
     img = rand_img(rng, rows, cols, 3)
     img[: rows // 2] = 255  # saturating region: sums reach 255 * D exactly
     src, dst = Mat.from_array(img), Mat(rows, cols, 3)
