@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""profiles/ops_bench.json (tools/bench_ops.py --cpu) -> markdown table on stdout / profiles/ops_table.md"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "ops_bench.json")
+d = json.load(open(src))
+out = ["| op | config | frames | ms / launch | Gpix/s | algorithmic TB/s | % of 8 TB/s | CPU oracle Mpix/s (cores) |", "|---|---|---|---|---|---|---|---|"]
+for r in d["rows"]:
+    cpu = r.get("cpu")
+    cpu_s = f"{cpu['mpix_s']:.0f} ({cpu['cores']})" if cpu else ""
+    hbm = f"{r['alg_gb_s'] / 1e3:.2f} | {r['frac_hbm_peak'] * 100:.1f}" if r["alg_bytes_per_px"] else "– | –"
+    out.append(f"| {r['op']} | {r['config']} | {r['frames']} | {r['ms_per_launch']:.4f} | {r['mpix_s'] / 1e3:.0f} | {hbm} | {cpu_s} |")
+text = "\n".join(out) + "\n"
+sys.stdout.write(text)
+if len(sys.argv) <= 1:
+    with open(os.path.join(ROOT, "profiles", "ops_table.md"), "w") as f:
+        f.write("One MI355X, device-resident batches, sustained clocks (`python tools/bench_ops.py --cpu`; raw data: `ops_bench.json`).\n"
+                "Algorithmic bytes per pixel as DESIGN.md section 4 states them; launch-bound rows carry no roofline figure.\n\n" + text)
