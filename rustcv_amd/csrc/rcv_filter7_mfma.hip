@@ -57,6 +57,9 @@ constexpr int kPitch = 288;           // bytes per planar row in LDS: 18 x 16 B.
                                       // distinct slots: conflict-free (272 B measured 46 % conflict cycles).
 constexpr int kSlots = 48;            // ring of 3 blocks x 16 rows
 constexpr int kPlane = kSlots * kPitch;
+constexpr int kTilesG = 48;          // one-channel source: a strip is 768 px = 48 tiles = the same 768 row bytes as a BGR strip
+constexpr int kPitchG = 800;         // its single LDS plane: 774 bytes used, 50 x 16 B (== 2 mod 16 like kPitch)
+static_assert(kSlots * kPitchG <= 3 * kPlane, "the gray plane shares the BGR kernel's LDS");
 constexpr int kLregs = 17;            // staging registers per block: 12 chunk dwords, 3 left-halo dwords, 2 halo-piece dwords
 constexpr int kOutWave = 16 * 192;    // per-wave output transpose buffer: 16 rows x 4 tiles x 48 B, unpadded; the 16-B
                                       // chunks of row n are rotated by n>>2 (mod 12): dword writes and b128 reads <= 2-way
@@ -97,6 +100,11 @@ struct U3 { uint32_t a, b, c; };
 // SRC: 0 = BGR source; 1 = packed YUYV source (2 B/px): the BT.601 conversion of the reference
 // (rustcv/src/videoio/mod.rs:356-363) runs at staging time, so the capture-side pipeline YUYV -> BGR -> filter2D is one
 // launch and the intermediate BGR image never touches HBM (5 instead of 11 algorithmic bytes per pixel).
+// SRC = 2: ONE-channel (gray) source and destination.  A gray row is the same bytes-per-strip problem as a BGR row, so the
+// kernel keeps its shape: 768-byte strips, the same three aligned 16-byte loads per lane, 48 MFMAs per wave and step --
+// but the strip is 768 PIXELS (48 tiles), the lane's 48 bytes go to LDS as they are (shifted by the 3 halo pixels, no
+// de-interleave) into a single plane, and what the BGR kernel calls the three planes of a tile are three neighbouring tiles
+// (so that dependent MFMAs still sit three issues apart).
 // DUAL: 0 = one weight table; 1 = K = 4Q + R, two full tables; 2 = K = K1 + 2*T2 with T2 confined to kernel rows 2..5
 // (the integer 7x7 Gaussian: only its 3x3 centre exceeds i8), so the second table costs 2 instead of 4 MFMAs per tile and plane
 template <int DBG, int DUAL, int SRC = 0, bool LAT = false>
@@ -121,7 +129,10 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int ys = seg * a.seg_rows;
     const int ye = min(a.rows, ys + a.seg_rows);
     const int nsteps = (ye - ys + 15) >> 4;
-    const int rowbytes = a.cols * (SRC == 1 ? 2 : 3);   // source row bytes
+    constexpr int PXB = SRC == 2 ? 1 : (SRC == 1 ? 2 : 3);   // source bytes per pixel
+    constexpr int TPS = SRC == 2 ? kTilesG : kTiles;         // tiles of a full strip
+    constexpr int PITCH = SRC == 2 ? kPitchG : kPitch;       // LDS row pitch
+    const int rowbytes = a.cols * PXB;   // source row bytes
 
     const unsigned sstep24 = (unsigned)a.sstep, dstep24 = (unsigned)a.dstep;   // 24-bit multiplies run at full rate
     const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
@@ -155,22 +166,25 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     const int hi = rowbytes - 16;
     const unsigned ya0 = (unsigned)min(2 * x0 + 32 * sq, hi), ya1 = (unsigned)min(2 * x0 + 32 * sq + 16, hi);   // YUYV: own 32 bytes
     const unsigned ylh = (unsigned)max(2 * x0 - 8, 0);                                                            // YUYV: 8 bytes in front of the strip
-    const int xa = x0 - 3 + 16 * sq;                    // image x of the chunk's first pixel
+    const int xa = x0 - 3 + (SRC == 2 ? 48 : 16) * sq;   // image x of the chunk's first pixel (gray: 48-pixel chunks)
     const bool xleft = xa < 0;                          // chunk 0 of the first strip: x = -3..-1 are reflected
-    const bool xright = xa + 3 == a.cols;               // chunk `ntiles` of the last strip: x = cols..cols+2 reflected
+    // chunk `ntiles` of the last strip: x = cols..cols+2 reflected (gray: the lane whose 48-pixel chunk holds them, at tile
+    // ntiles % 3 of the chunk; a full last strip has them in the halo piece instead)
+    const bool xright = SRC == 2 ? (x0 + 16 * ntiles == a.cols && ntiles < TPS && sq == ntiles / 3) : xa + 3 == a.cols;
     const int ry_last = ye + 2;                         // last source row (before reflection) this segment needs
     // A full strip (16 tiles) needs 6 more pixels than its 16 chunks hold: xx = 256..261 <- x = x0+253 .. x0+258.
     // Their 18 bytes lie in the 32 bytes at row offset 3*x0 + 752; every wave fetches them for all 16 rows as one
     // dwordx2 per lane (row lane>>2, piece lane&3) -- unconditional like all VMEM here; wave 0 then plants them.
-    const bool fullstrip = ntiles == kTiles;
+    const bool fullstrip = ntiles == TPS;
     const int wave0 = (__builtin_amdgcn_readfirstlane(wave) == 0 && fullstrip) ? 1 : 0;   // scalar
     const int er = lane >> 2, ep = lane & 3;
     const int eoff = min(max((SRC == 1 ? 2 * x0 + 504 : 3 * x0 + 752) + 8 * ep, 0), rowbytes - 8);
-    const bool lastfull = fullstrip && x0 + 256 == a.cols;   // right image border inside the halo piece
+    const bool lastfull = fullstrip && x0 + 16 * TPS == a.cols;   // right image border inside the halo piece
 
-    const unsigned oa0 = (unsigned)min(3 * x0 + 48 * sq, hi), oa1 = (unsigned)min(3 * x0 + 48 * sq + 16, hi), oa2 = (unsigned)min(3 * x0 + 48 * sq + 32, hi);
-    const unsigned olh = (unsigned)max(3 * x0 - 12, 0);   // the 12 bytes in front of the strip (first strip: unused, x = -3..-1 are reflected)
-    const unsigned orh = (unsigned)min(3 * x0 + 768, rowbytes - 12);   // the 12 bytes behind a full strip (last strip: unused, mirrored)
+    constexpr int OB = SRC == 2 ? 1 : 3;   // (the BGR / gray staging below addresses the strip in bytes: OB per pixel)
+    const unsigned oa0 = (unsigned)min(OB * x0 + 48 * sq, hi), oa1 = (unsigned)min(OB * x0 + 48 * sq + 16, hi), oa2 = (unsigned)min(OB * x0 + 48 * sq + 32, hi);
+    const unsigned olh = (unsigned)max(OB * x0 - 12, 0);   // the 12 bytes in front of the strip (first strip: unused, x = -3..-1 are reflected)
+    const unsigned orh = (unsigned)min(OB * x0 + 768, rowbytes - 12);   // the 12 bytes behind a full strip (last strip: unused, mirrored)
 
     auto load_block = [&](int b, uint32_t (&L)[kLregs]) {
         const int ry = min(ys - 3 + 16 * b + sr, ry_last);
@@ -229,7 +243,18 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
 
     auto store_block = [&](int b, const uint32_t (&L)[kLregs]) {
         // ---- halo piece: the 6 pixels x0+253 .. x0+258 right of the strip's 16 chunks, planted at xx = 256..261 ----
-        if constexpr (SRC == 0) {
+        if constexpr (SRC == 2) {
+            // gray: the row's last lane holds pixels x0+764..767 in its dword 11 and has fetched x0+768..779 with the side load
+            if (fullstrip && sq == 15 && ys - 3 + 16 * b + sr <= ry_last) {
+                const int hslot = 16 * (b % 3) + sr;
+                const uint32_t g1 = L[11], g2 = L[12];
+                const uint32_t lo = lastfull ? __builtin_amdgcn_perm(g1, g1, 0x02030201u)   // 765 766 767 | 766
+                                             : __builtin_amdgcn_perm(g2, g1, 0x04030201u);  // 765 766 767 | 768
+                const uint32_t hi2 = lastfull ? __builtin_amdgcn_perm(g1, g1, 0x0c0c0001u)  // 765 764
+                                              : (g2 >> 8);                                   // 769 770
+                *(U2*)(lds + hslot * PITCH + 768) = U2{lo ^ 0x80808080u, hi2 ^ 0x80808080u};
+            }
+        } else if constexpr (SRC == 0) {
             // The last lane of each row (sq == 15) holds pixels x0+252..255 in its own dwords 9..11 and has fetched the 12
             // bytes behind the strip (pixels x0+256..259) with the side load: two de-interleaves, no extra traffic.
             if (fullstrip && sq == 15 && ys - 3 + 16 * b + sr <= ry_last) {   // (no VMEM inside: LDS ops may be conditional)
@@ -274,6 +299,37 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                     *(U2*)(lds + c * kPlane + hslot * kPitch + 256) = U2{lo ^ 0x80808080u, hi ^ 0x80808080u};
                 }
             }
+        }
+        if constexpr (SRC == 2) {
+            // s[i] = bytes [4i - 3, 4i + 1) relative to the lane's own 48 bytes: the previous lane's last dword by DPP (lane 0 of
+            // a row: the last dword of its side load), one v_alignbyte per dword, no de-interleave
+            const uint32_t pv = __builtin_amdgcn_update_dpp(L[14], L[11], 0x111, 0xf, 0xf, false);
+            uint32_t g[12];
+            g[0] = __builtin_amdgcn_alignbyte(L[0], pv, 1);
+#pragma unroll
+            for (int i = 1; i < 12; ++i) g[i] = __builtin_amdgcn_alignbyte(L[i], L[i - 1], 1);
+            // BORDER_REFLECT_101 in x: left as in the BGR kernel; right: x = cols..cols+2 are bytes 3 | 0, 1 of dwords 4m | 4m+1
+            // (m = ntiles % 3, uniform) and mirror x = cols-2, cols-3 (bytes 1, 0 of dword 4m) and cols-4 (byte 3 of the dword in
+            // front: the previous lane's last one for m == 0)
+            const uint32_t ng = __builtin_amdgcn_update_dpp(0u, g[11], 0x111, 0xf, 0xf, true);
+            if (xleft) g[0] = __builtin_amdgcn_perm(g[1], g[0], 0x03040506u);
+            if (xright) {
+                const int m = ntiles % 3;
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm)
+                    if (m == mm) {
+                        const uint32_t prev = mm == 0 ? ng : g[4 * mm - 1];
+                        const uint32_t t = __builtin_amdgcn_perm(prev, g[4 * mm], 0x00000700u);
+                        g[4 * mm + 1] = __builtin_amdgcn_perm(g[4 * mm + 1], t, 0x07060100u);
+                        g[4 * mm] = __builtin_amdgcn_perm(g[4 * mm], g[4 * mm], 0x01020100u);
+                    }
+            }
+            if (ys - 3 + 16 * b + sr > ry_last) return;   // row not needed (LDS ops may be conditional)
+            uint8_t* dstp = lds + (16 * (b % 3) + sr) * PITCH + 48 * sq;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                *(uint4*)(dstp + 16 * j) = make_uint4(g[4 * j] ^ 0x80808080u, g[4 * j + 1] ^ 0x80808080u, g[4 * j + 2] ^ 0x80808080u, g[4 * j + 3] ^ 0x80808080u);
+            return;
         }
         uint32_t pb[4], pg[4], pr[4];
         if constexpr (SRC == 1) {
@@ -359,7 +415,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int d = 12 * i + 3 * kb + j;
+            const int d = SRC == 2 ? 12 * i + 4 * j + kb : 12 * i + 3 * kb + j;   // gray: dword kb of tile j of group i
             woff[i][j] = n * 192 + (((d >> 2) + (n >> 2)) % 12) * 16 + (d & 3) * 4;
         }
     int roff[3], grow[3], gcol[3];
@@ -369,8 +425,8 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         const int f = lane + 64 * j, row = f / 12, c = f % 12;
         roff[j] = row * 192 + ((c + (row >> 2)) % 12) * 16;
         grow[j] = row;
-        gcol[j] = 3 * (x0 + 64 * wave) + 16 * c;
-        gtile[j] = 4 * wave + c / 3 < ntiles;
+        gcol[j] = SRC == 2 ? x0 + 192 * wave + 16 * c : 3 * (x0 + 64 * wave) + 16 * c;
+        gtile[j] = (SRC == 2 ? 12 * wave + c : 4 * wave + c / 3) < ntiles;
     }
 
     // accumulator start value 128*sum(K) + round as a resident VGPR quad (opaque to the compiler, which would otherwise
@@ -387,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         for (int p = 0; p < 4; ++p) {
             int t = sbase + n + 2 * p + kyl;
             t = t >= kSlots ? t - kSlots : t;
-            off[p] = (int)__umul24((unsigned)t, (unsigned)kPitch) + xh + 64 * wave;
+            off[p] = (int)__umul24((unsigned)t, (unsigned)PITCH) + xh + (SRC == 2 ? 192 : 64) * wave;
         }
         // 48 MFMAs per step (4 tiles x 4 row-pairs x 3 planes), B operands read kAhead items ahead into a
         // static register ring so LDS latency is covered inside the wave; the three planes' accumulators are
@@ -401,12 +457,13 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
         //  zero-fill moves: garbage times zero weights is still zero in integer arithmetic)
         auto rd = [&](int it, const v4i& old) -> v4i {
             const int i = it / 12, r = it % 12, p = r / 3, c = r % 3;
-            const v4i* src = (const v4i*)(lds + c * kPlane + off[p] + 16 * i);
+            const v4i* src = (const v4i*)(lds + (SRC == 2 ? 16 * (3 * i + c) : c * kPlane + 16 * i) + off[p]);
             if (p == 3) return lowhalf ? *src : old;
             return *src;
         };
         // (wave-uniform, LDS-only region -- no VMEM inside, so the vmcnt bookkeeping stays exact)
-        const int nmf = 12 * min(max(ntiles - 4 * wave, 0), 4);   // narrow last strips: tiles past the strip are skipped
+        // narrow last strips: tiles past the strip are skipped (gray: groups of three tiles)
+        const int nmf = 12 * min(max(SRC == 2 ? (ntiles - 12 * wave + 2) / 3 : ntiles - 4 * wave, 0), 4);
         v4i acc[3], acc2[3];
         const v4i zerov = v4i{0, 0, 0, 0};
         // the MFMA phase is the longest dependent chain of a step: give it issue priority over the staging phases of the
@@ -439,6 +496,11 @@ __global__ __launch_bounds__(kThreads) void k_filter7_mfma(F7Args a)
                     *(uint32_t*)(obuf + woff[i][0]) = acc[0][0];
                     *(uint32_t*)(obuf + woff[i][1]) = acc[1][1];
                     *(uint32_t*)(obuf + woff[i][2]) = acc[2][2];
+                    continue;
+                }
+                if constexpr (SRC == 2) {   // three tiles, four consecutive pixels each
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) *(uint32_t*)(obuf + woff[i][cc]) = rcv_ashr_sat_pk4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3], a.shift);
                     continue;
                 }
                 *(uint32_t*)(obuf + woff[i][0]) = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
@@ -547,8 +609,17 @@ extern "C" int rcv__debug_occupancy(void)
 int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv)
 {
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
-    if (!src_yuyv && s.ch == 1) return rcv_filter_i16_gray(ctx, s, d, k, ksize, shift);   // one channel: dot4 streaming kernel
-    if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    // one channel: the strip kernel's gray variant (SRC = 2) where the shape allows, else the dot4 streaming kernel
+    const bool gray = !src_yuyv && s.ch == 1;
+    if (gray) {
+        const bool ok = d.ch == 1 && s.cols % 16 == 0 && s.cols >= 16 && s.rows >= 4 && (uintptr_t)s.p % 16 == 0 && s.step % 16 == 0 &&
+                        (s.n <= 1 || s.fstride % 16 == 0) && (uintptr_t)d.p % 16 == 0 && d.step % 16 == 0 && (d.n <= 1 || d.fstride % 16 == 0) &&
+                        s.step < (1u << 24) && d.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) &&
+                        (unsigned long long)s.rows * d.step < (1ull << 32) && !getenv("RCV_F7_NO_GRAY");
+        if (!ok) return rcv_filter_i16_gray(ctx, s, d, k, ksize, shift);
+    } else {
+        if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    }
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
@@ -603,8 +674,8 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.ntiles_total = s.cols / 16;
     // strips of 256 px: line-aligned seams.  (240-px strips split widths such as 1920 evenly, but measured 3.5 % slower there
     // than 7 full strips + one half strip; the kernel still takes tps = 15 through the tuning knob below.)
-    a.tps = kTiles;
-    if (const char* e = getenv("RCV_F7_TPS")) a.tps = atoi(e) == 15 ? 15 : 16;  // tuning knob
+    a.tps = gray ? kTilesG : kTiles;
+    if (const char* e = getenv("RCV_F7_TPS")) a.tps = gray ? a.tps : (atoi(e) == 15 ? 15 : 16);  // tuning knob (BGR strips)
     a.nstrips = (a.ntiles_total + a.tps - 1) / a.tps;
     // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs), each
     // segment a multiple of 16 rows (>= 32); the per-segment constant models the prologue (two synchronous blocks)
@@ -626,7 +697,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
     // small launches (everything resident in one round even with the shortest segments): the latency variant
     bool lat = false;
-    if (!src_yuyv && !dual && !getenv("RCV_F7_NO_LAT")) {
+    if (!src_yuyv && !gray && !dual && !getenv("RCV_F7_NO_LAT")) {
         for (int sr = 16; sr <= 32 && !lat; sr += 16) {
             const long long tot = (long long)a.nstrips * ((s.rows + sr - 1) / sr) * s.n;
             if (tot <= 3LL * ctx->cu_count) {
@@ -644,6 +715,12 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.total_wgs = (int)total;
     a.wgs_per_xcd = (int)((total + 7) / 8);
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
+    if (gray) {
+        if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2, 2>), grid, block, 0, ctx->stream, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_filter7_mfma<0, 1, 2>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_filter7_mfma<0, 0, 2>), grid, block, 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
     if (src_yuyv) {
         if (dual) return RCV_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((k_filter7_mfma<0, 0, 1>), grid, block, 0, ctx->stream, a);

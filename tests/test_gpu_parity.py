@@ -504,6 +504,71 @@ def test_gray_dot4_filter_random_shapes(ctx, oracle):
         dst.free()
 
 
+GRAY_MFMA_COLS = [16, 32, 48, 64, 240, 752, 768, 784, 800, 816, 1520, 1536, 1552, 1568, 2320]
+
+
+@pytest.mark.parametrize("cols", GRAY_MFMA_COLS)
+@pytest.mark.parametrize("dot4", [False, True])
+def test_gray_filter_strip_kernel(ctx, oracle, monkeypatch, cols, dot4):
+    """one-channel images on 16-byte aligned rows take the MFMA strip kernel's gray variant (768-pixel strips of 48 tiles):
+    widths around the strip seams (one to three + strips; a last strip with 1, 2, 3, ... tiles -- every position ntiles % 3 of the
+    right border inside a lane's 48-pixel chunk -- and full last strips, whose border sits in the halo piece), heights across
+    several 16-row steps, ksize 3/5/7, full-range weights, the two-table integer Gaussian, padded steps, batches.
+    RCV_F7_NO_GRAY sends the same cases through the dot4 streaming kernel."""
+    if dot4:
+        monkeypatch.setenv("RCV_F7_NO_GRAY", "1")
+    r = np.random.default_rng(0x6A4700 + cols + _SOAK_SEED)
+    for case in range(max(2, _SOAK // 2)):
+        rows = int(r.integers(4, 120))
+        n = int(r.integers(1, 4))
+        ksize = int(r.choice([3, 5, 7]))
+        spad, dpad = 16 * int(r.integers(0, 3)), 16 * int(r.integers(0, 3))
+        frames = r.integers(0, 256, size=(n, rows, cols, 1), dtype=np.uint8)
+        if case % 4 == 1:
+            frames[:, :, cols // 2:] = 255       # saturating half
+        src = device.DeviceBatch(ctx, n, rows, cols, 1, step=cols + spad)
+        dst = _canary_batch(ctx, n, rows, cols, 1, pad=dpad)
+        src.upload(frames)
+        if case % 3 == 2:
+            device.gaussian_blur(src, dst, ksize, 0.0)
+            want = [oracle.gaussian_blur(frames[i, :, :, 0], ksize, 0.0) for i in range(n)]
+        else:
+            k = r.integers(-128, 128, size=(ksize, ksize)).astype(np.int8)
+            shift = int(r.integers(0, 13))
+            device.filter2d(src, dst, k, shift=shift)
+            want = [oracle.filter2d_i8(frames[i, :, :, 0], k, shift) for i in range(n)]
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i].reshape(rows, cols), want[i]), (case, rows, cols, ksize)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
+def test_gray_filter_strip_kernel_4k_batch(ctx, oracle):
+    """BASELINE-sized gray batch (4K x 8 frames, 5 full strips per row): row slabs of two frames against the oracle"""
+    rows, cols, n = 2160, 3840, 8
+    src = device.DeviceBatch(ctx, n, rows, cols, 1)
+    dst = device.DeviceBatch(ctx, n, rows, cols, 1)
+    device.synth(src, 0, 0x5EED0077, 0)
+    k = oracle.bench_kernel7()
+    device.filter2d(src, dst, k, shift=6)
+    frames, got = src.download(), dst.download()
+    for i in (0, n - 1):
+        for y0, y1 in ((0, 40), (1060, 1100), (2120, 2160)):
+            lo, hi = max(0, y0 - 3), min(rows, y1 + 3)
+            want = oracle.filter2d_i8(frames[i][lo:hi], k, 6) if (lo == 0 or hi == rows) else None
+            if want is None:
+                want = oracle.filter2d_i8(frames[i][lo:hi], k, 6)[y0 - lo: y1 - lo]
+                assert np.array_equal(got[i][y0:y1], want), (i, y0)
+            elif lo == 0:
+                assert np.array_equal(got[i][y0:y1], want[: y1 - y0]), (i, y0)
+            else:
+                assert np.array_equal(got[i][y0:y1], want[y0 - lo:]), (i, y0)
+    src.free()
+    dst.free()
+
+
 def test_register_window_kernels_random_shapes(ctx, oracle):
     """24 x RCV_SOAK seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
     widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""

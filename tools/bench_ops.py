@@ -158,7 +158,7 @@ def main():
     o.free()
 
     g2 = B(n, 2160, 3840, 1)
-    record("filter2D 7x7 i8 on a GRAY image (dot4 streaming kernel)", "4K gray", g.n, 3840 * 2160, 2, lambda: device.filter2d(g, g2, k7c, shift=6),
+    record("filter2D 7x7 i8 on a GRAY image", "4K gray", g.n, 3840 * 2160, 2, lambda: device.filter2d(g, g2, k7c, shift=6),
            note="1 B read + 1 B written per px, 49 MAC per px on v_dot4c_i32_i8")
     record("GaussianBlur 5x5 (sigma=0) on a GRAY image", "4K gray", g.n, 3840 * 2160, 2, lambda: device.gaussian_blur(g, g2, 5, 0.0))
     g2.free()
