@@ -697,7 +697,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
     // small launches (everything resident in one round even with the shortest segments): the latency variant
     bool lat = false;
-    if (!src_yuyv && !gray && !dual && !getenv("RCV_F7_NO_LAT")) {
+    if (!src_yuyv && !dual && !getenv("RCV_F7_NO_LAT")) {
         for (int sr = 16; sr <= 32 && !lat; sr += 16) {
             const long long tot = (long long)a.nstrips * ((s.rows + sr - 1) / sr) * s.n;
             if (tot <= 3LL * ctx->cu_count) {
@@ -716,7 +716,8 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.wgs_per_xcd = (int)((total + 7) / 8);
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
     if (gray) {
-        if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2, 2>), grid, block, 0, ctx->stream, a);
+        if (lat) hipLaunchKernelGGL((k_filter7_mfma<0, 0, 2, true>), grid, block, 0, ctx->stream, a);
+        else if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2, 2>), grid, block, 0, ctx->stream, a);
         else if (mode == 1) hipLaunchKernelGGL((k_filter7_mfma<0, 1, 2>), grid, block, 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_filter7_mfma<0, 0, 2>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);

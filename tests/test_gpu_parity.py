@@ -509,14 +509,19 @@ GRAY_MFMA_COLS = [16, 32, 48, 64, 240, 752, 768, 784, 800, 816, 1520, 1536, 1552
 
 @pytest.mark.parametrize("cols", GRAY_MFMA_COLS)
 @pytest.mark.parametrize("dot4", [False, True])
-def test_gray_filter_strip_kernel(ctx, oracle, monkeypatch, cols, dot4):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_gray_filter_strip_kernel(ctx, oracle, monkeypatch, cols, dot4, pipelined):
     """one-channel images on 16-byte aligned rows take the MFMA strip kernel's gray variant (768-pixel strips of 48 tiles):
     widths around the strip seams (one to three + strips; a last strip with 1, 2, 3, ... tiles -- every position ntiles % 3 of the
     right border inside a lane's 48-pixel chunk -- and full last strips, whose border sits in the halo piece), heights across
     several 16-row steps, ksize 3/5/7, full-range weights, the two-table integer Gaussian, padded steps, batches.
     RCV_F7_NO_GRAY sends the same cases through the dot4 streaming kernel."""
     if dot4:
+        if pipelined:
+            pytest.skip("the dot4 kernel has one variant")
         monkeypatch.setenv("RCV_F7_NO_GRAY", "1")
+    if pipelined:
+        monkeypatch.setenv("RCV_F7_NO_LAT", "1")   # (small launches would otherwise all take the strip kernel's latency variant)
     r = np.random.default_rng(0x6A4700 + cols + _SOAK_SEED)
     for case in range(max(2, _SOAK // 2)):
         rows = int(r.integers(4, 120))
