@@ -212,7 +212,8 @@ int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* mask, float
 
 /* fused BGR -> gray -> Sobel -> Harris response -> 3x3 NMS in one launch.
  * resp may be NULL (mask only).  A 2-channel src is packed YUYV (SURVEY.md 8(d) config 5 "[or YUYV]"): each macropixel
- * goes through yuyv_to_bgr (rustcv/src/videoio/mod.rs:356-363) first, inside the same launch.   */
+ * goes through yuyv_to_bgr (rustcv/src/videoio/mod.rs:356-363) first, inside the same launch; a 1-channel src is taken as
+ * the gray image itself.                                                                         */
 int rcv_harris_pipeline(rcv_ctx* ctx, const rcv_mat* bgr, rcv_mat* mask, rcv_mat* resp,
                         int block, float k, float thr);
 int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mask, rcv_batch* resp,

@@ -114,6 +114,10 @@ extern "C" int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_
     if (g.rows != r.rows || g.cols != r.cols || g.n != r.n) return RCV_ERR_ARG;
     if (g.rows > 65535 || g.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (g.rows == 0 || g.cols == 0 || g.n == 0) return RCV_OK;
+    {   // block 2 on aligned shapes: the fused register-window kernel, response only
+        const int rc = rcv_harris_fused(ctx, g, nullptr, &r, block, k, 0.0f);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
     size_t plane = (size_t)g.n * g.rows * g.cols * 2;
     RCV_TRY(rcv_ws_reserve(ctx, 2 * (plane + 256)));
     uint8_t *wix, *wiy;
@@ -146,7 +150,7 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     View s, m, r;
     RCV_TRY(rcv_view_batch(bgr, RCV_8U, &s));
     RCV_TRY(rcv_view_batch(mask, RCV_8U, &m));
-    if ((s.ch != 3 && s.ch != 2) || m.ch != 1) return RCV_ERR_UNSUPPORTED;   // BGR, or packed YUYV (2 channels)
+    if ((s.ch != 3 && s.ch != 2 && s.ch != 1) || m.ch != 1) return RCV_ERR_UNSUPPORTED;   // BGR, packed YUYV (2 channels), or gray
     if (s.rows != m.rows || s.cols != m.cols || s.n != m.n) return RCV_ERR_ARG;
     if (s.ch == 2 && (s.cols & 1)) return RCV_ERR_ARG;
     if (resp) {
@@ -156,7 +160,7 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     }
     if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
-    int rc = rcv_harris_fused(ctx, s, m, resp ? &r : nullptr, block, k, thr);
+    int rc = rcv_harris_fused(ctx, s, &m, resp ? &r : nullptr, block, k, thr);
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
     if (s.ch == 2) {
         // YUYV shapes the fused kernel does not take: convert into a side buffer (not the workspace, which the BGR pipeline
@@ -177,7 +181,7 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     size_t npx = (size_t)s.n * s.rows * s.cols;
     RCV_TRY(rcv_ws_reserve(ctx, npx * (1 + 2 + 2 + (resp ? 0 : 4)) + 4 * 256));
     uint8_t *wg, *wix, *wiy, *wr = nullptr;
-    RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));
+    RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));   // (unused for a gray source)
     RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wix));
     RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wiy));
     if (!resp) RCV_TRY(rcv_ws_alloc(ctx, npx * 4, &wr));
@@ -194,9 +198,12 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     gb.frame_stride = (size_t)s.rows * s.cols;
     gb.n = s.n;
     gb.reserved = 0;
-    RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
     View g;
-    RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
+    if (s.ch == 1) g = s;   // the source is the gray image
+    else {
+        RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
+        RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
+    }
     if (!resp) {
         r = g;
         r.p = wr;

@@ -58,7 +58,9 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // YUYV = true: the source is packed YUYV (2 B/px, SURVEY.md 8(d) config 5 "[or YUYV]"); each macropixel goes through the
 // reference's BT.601 conversion (rustcv/src/videoio/mod.rs:356-363, saturated to u8) and then the same gray formula, so the
 // result equals harris_pipeline(yuyv_to_bgr(.)) bit for bit with 3 instead of 4 algorithmic bytes per pixel.
-template <bool WANT_RESP, bool YUYV>
+// SRCK: 0 = BGR, 1 = packed YUYV, 2 = one-channel gray (cornerHarris' own input: the window starts at the Sobel stage).
+// WANT_MASK = false: response only (rcv_corner_harris): no NMS stage, no mask store.
+template <bool WANT_RESP, int SRCK, bool WANT_MASK = true>
 __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const uint8_t* const sf = a.src + (size_t)frame * a.sfs;
     uint8_t* const mf = a.mask + (size_t)frame * a.mfs;
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
-    const uint32_t sx = (uint32_t)((YUYV ? 2 : 3) * xc), mx = (uint32_t)max(x, 0);
+    constexpr bool YUYV = SRCK == 1, GRAY = SRCK == 2;
+    const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
 
     auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
@@ -87,6 +90,10 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
         cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
         asm("" : "+s"(p));   // the row base stays in SGPRs: loads take the saddr + 32-bit voffset form, no VALU address math
+        if constexpr (GRAY) {
+            const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx);
+            return Row6{{q0.x, q0.y, 0u, 0u, 0u, 0u}};
+        }
         const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx), q1 = *(const RCV_GLOBAL u2v*)(p + sx + 8);
         if constexpr (YUYV) return Row6{{q0.x, q0.y, q1.x, q1.y, 0u, 0u}};
         else {
@@ -118,7 +125,9 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);  // 76*B + 145*G + 35*R + 8192
             return ((hi8 << 8) + lo8) >> 14;
         };
-        if constexpr (YUYV) {
+        if constexpr (GRAY) {
+            // (the 8 gray pixels are the two source dwords themselves)
+        } else if constexpr (YUYV) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {   // macropixel [Y0 U Y1 V] -> two (B,G,R,0) dwords, as the reference converts them
                 const uint32_t w = q.d[m];
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
                 g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
             }
         }
-        uint32_t lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+        uint32_t lo = GRAY ? q.d[0] : g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = GRAY ? q.d[1] : g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
         if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
         if (edgeR) lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
         const uint32_t lf = shr1(hi), rt = shl1(lo);
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
                 *(RCV_GLOBAL f4v*)(o + 16) = f4v{r[4], r[5], r[6], r[7]};
             }
         }
+        if constexpr (!WANT_MASK) return;
         // ---- NMS: response outside the image is -inf ------------------------------------------------------------------
         // A row outside the image (scalar condition, two rows per frame edge): every response is -inf.  Columns outside the
         // image belong to whole lanes (cols % 8 == 0: the lane left of x = 0, lanes right of the last column) that never
@@ -282,12 +292,16 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
 } // namespace
 
-int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* resp, int block, float k, float thr)
+int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* resp, int block, float k, float thr)
 {
-    if (block != 2 || (s.ch != 3 && s.ch != 2)) return RCV_ERR_UNSUPPORTED;
+    if (block != 2 || (s.ch != 3 && s.ch != 2 && s.ch != 1)) return RCV_ERR_UNSUPPORTED;
+    if (!mask && (!resp || s.ch != 1)) return RCV_ERR_UNSUPPORTED;   // response only: the gray-source cornerHarris
+    View m0 = s;          // (placeholder when there is no mask: never dereferenced by the kernel)
+    m0.p = nullptr;
+    const View& m = mask ? *mask : m0;
     if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8)) return RCV_ERR_UNSUPPORTED;
+    if (mask && ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8))) return RCV_ERR_UNSUPPORTED;
     if (resp && ((uintptr_t)resp->p % 16 || resp->step % 16 || (resp->n > 1 && resp->fstride % 16))) return RCV_ERR_UNSUPPORTED;
     HArgs a;
     a.src = s.p;
@@ -309,8 +323,8 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
         int& wpc = ctx->harris_wpc[resp ? 1 : 0];   // per context: contexts may be driven from different threads
         if (wpc == 0) {
             int nb = 0;
-            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, false>, 256, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false, false>, 256, 0);
+            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, 0>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false, 0>, 256, 0);
             wpc = (e == hipSuccess && nb > 0) ? 4 * nb : 8;
             (void)hipGetLastError();
         }
@@ -336,12 +350,16 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View& m, const View* res
     a.k = k;
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (s.ch == 2) {
-        if (resp) hipLaunchKernelGGL((k_harris_fused<true, true>), grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_harris_fused<false, true>), grid, dim3(256), 0, ctx->stream, a);
+    if (s.ch == 1) {
+        if (!mask) hipLaunchKernelGGL((k_harris_fused<true, 2, false>), grid, dim3(256), 0, ctx->stream, a);
+        else if (resp) hipLaunchKernelGGL((k_harris_fused<true, 2>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_harris_fused<false, 2>), grid, dim3(256), 0, ctx->stream, a);
+    } else if (s.ch == 2) {
+        if (resp) hipLaunchKernelGGL((k_harris_fused<true, 1>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_harris_fused<false, 1>), grid, dim3(256), 0, ctx->stream, a);
     } else {
-        if (resp) hipLaunchKernelGGL((k_harris_fused<true, false>), grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_harris_fused<false, false>), grid, dim3(256), 0, ctx->stream, a);
+        if (resp) hipLaunchKernelGGL((k_harris_fused<true, 0>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_harris_fused<false, 0>), grid, dim3(256), 0, ctx->stream, a);
     }
     return rcv_launch_check(ctx);
 }

@@ -10,7 +10,8 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
 int rcv_filter_i8_yuyv_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
 int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy);
 int rcv_filter_i16_gray(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift);   // rcv_filter_gray_dot4.hip
-int rcv_harris_fused(rcv_ctx* ctx, const View& bgr, const View& mask, const View* resp, int block, float k, float thr);
+// src: BGR (3 ch), packed YUYV (2 ch) or gray (1 ch); mask may be null (response only: needs resp)
+int rcv_harris_fused(rcv_ctx* ctx, const View& src, const View* mask, const View* resp, int block, float k, float thr);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
 // generic kernels restricted to the byte columns [xb_lo, xb_hi) of every row (edge fix-up of the streaming kernels)

@@ -1007,6 +1007,41 @@ def test_corner_harris(ctx, oracle, rng, rows, cols, block):
     assert np.array_equal(dst.to_array().view(np.uint32), want.view(np.uint32))  # bit-exact f32
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 8), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (7, 12)])
+def test_corner_harris_and_pipeline_from_gray(ctx, oracle, rows, cols):
+    """a one-channel source: cornerHarris (response only) and the pipeline (mask, mask + response) on the fused register-window
+    kernel where the shape allows (block 2, cols % 8 == 0), the generic kernels elsewhere; batch of 3, padded steps"""
+    n = 3
+    r = np.random.default_rng(rows * 7919 + cols + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 1), dtype=np.uint8)
+    frames[:, rows // 3: rows // 3 + 3, cols // 4: cols // 4 + 5] = 255      # a few real corners
+    src = device.DeviceBatch(ctx, n, rows, cols, 1, step=(cols + 15) // 16 * 16 + 16)
+    src.upload(frames)
+    resp = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F)
+    device.corner_harris(src, resp, 2, 0.04)
+    got = resp.download()
+    want = [oracle.corner_harris(frames[i, :, :, 0], 2, 0.04) for i in range(n)]
+    for i in range(n):
+        assert np.array_equal(got[i].view(np.uint32), want[i].view(np.uint32)), ("cornerHarris", i)
+    thr = 1e-5
+    for want_resp in (False, True):
+        mask = _canary_batch(ctx, n, rows, cols, 1, pad=8)
+        resp2 = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+        device.harris_pipeline(src, mask, resp2, 2, 0.04, thr)
+        gm = mask.download()
+        for i in range(n):
+            assert np.array_equal(gm[i], oracle.nms3x3(want[i], thr)), ("pipeline mask", want_resp, i)
+        if want_resp:
+            gr = resp2.download()
+            for i in range(n):
+                assert np.array_equal(gr[i].view(np.uint32), want[i].view(np.uint32))
+            resp2.free()
+        _assert_canaries(mask)
+        mask.free()
+    src.free()
+    resp.free()
+
+
 @pytest.mark.parametrize("rows,cols", SHAPES)
 def test_nms3x3(ctx, oracle, rng, rows, cols):
     resp = rng.standard_normal((rows, cols)).astype(np.float32)

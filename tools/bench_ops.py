@@ -203,6 +203,13 @@ def main():
     record("Harris pipeline from a YUYV source (config 5 [or YUYV])", "4K batch=64/GPU", yq.n, 3840 * 2160, 3,
            lambda: device.harris_pipeline(yq, m, None, 2, 0.04, 1e-4), note="2 B read + 1 B written per px; YUYV->BGR + pipeline as two launches moves 9")
     yq.free()
+    gq = B(64, 2160, 3840, 1)
+    device.synth(gq, 1, SEED + 5, 0)
+    record("Harris pipeline from a GRAY source", "4K batch=64/GPU", gq.n, 3840 * 2160, 2, lambda: device.harris_pipeline(gq, m, None, 2, 0.04, 1e-4))
+    rq = B(64, 2160, 3840, 1, _ffi.RCV_32F)
+    record("cornerHarris (gray -> f32 response)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5, lambda: device.corner_harris(gq, rq, 2, 0.04),
+           note="the fused kernel without its NMS stage; the generic three-kernel path takes ~9 ms")
+    gq.free(); rq.free()
     s.free(); d.free(); m.free()
 
     # ---- config 4: 8K warpAffine + resize -> 1080p, 32 frames per GPU ----------------------------------------
