@@ -78,6 +78,70 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3(View r, View m, float thr)
     }
 }
 
+// Streaming 3x3 NMS for 16-byte aligned f32 rows: one thread owns 4 adjacent pixels and walks down a row segment; every
+// response row is read once (one 16-byte load per lane, the two outer neighbours by DPP wave shifts), its 3-wide row maximum
+// serves the rows above and below, and the comparison `r >= all 8 neighbours` becomes r >= maximum(...).  The maxima are
+// v_maximum3_f32 (IEEE-754-2019 maximum: a NaN operand gives NaN), so a NaN neighbour makes `r >= m` false exactly as the
+// nine separate comparisons of k_nms3x3 / the oracle do; outside the image is -inf.
+__global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float thr, int seg_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = (blockIdx.x * kBlock + threadIdx.x) * 4;
+    const int ys = blockIdx.y * seg_rows, ye = min(r.rows, ys + seg_rows);
+    const uint8_t* rf = r.p + (size_t)blockIdx.z * r.fstride;
+    uint8_t* mf = m.p + (size_t)blockIdx.z * m.fstride;
+    const bool live = x < r.cols;
+    const int xc = min(x, r.cols - 4);
+    const float NEG = -INFINITY;
+    // the pixel outside the wave's 256: lane 0 needs x-1, lane 63 needs x+4 (every other lane reads one fixed cached address)
+    const int xe = lane == 0 ? x - 1 : x + 4;
+    const bool e_ok = (lane == 0 || lane == 63) && xe >= 0 && xe < r.cols;
+    const int xec = e_ok ? xe : 0;
+    struct Row { float4 q; float e; };
+    auto load = [&](int v) -> Row {
+        const int vr = min(max(v, 0), r.rows - 1);
+        const uint8_t* row = rf + (size_t)vr * r.step;
+        Row w;
+        w.q = *(const float4*)(row + (size_t)xc * 4);
+        w.e = *(const float*)(row + (size_t)xec * 4);
+        return w;
+    };
+    auto mx3 = [](float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); };
+    float rm3a[4], rm3b[4], lrb[4], rcb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rm3a[j] = rm3b[j] = lrb[j] = rcb[j] = NEG;
+    Row cur = load(ys - 1);
+    for (int v = ys - 1; v <= ye; ++v) {
+        const Row nxt = load(v + 1);   // (rows past the image re-read the last row and are replaced by -inf below)
+        const bool rowok = v >= 0 && v < r.rows;
+        float q[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w};
+        float e = cur.e;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = (rowok && live) ? q[j] : NEG;
+        e = (rowok && e_ok) ? e : NEG;
+        float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, q[3]), 0x138, 0xf, 0xf, true));   // lane-1's last pixel
+        float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, q[0]), 0x130, 0xf, 0xf, true));   // lane+1's first pixel
+        if (lane == 0) L = e;
+        if (lane == 63) R = e;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lf = j ? q[j - 1] : L, rt = j < 3 ? q[j + 1] : R;
+            const float rm3 = mx3(lf, q[j], rt), lr = __builtin_elementwise_maximum(lf, rt);
+            const float m8 = mx3(rm3a[j], lrb[j], rm3);            // the 8 neighbours of row v-1's pixel
+            const bool keep = rcb[j] > thr && rcb[j] >= m8;
+            bits |= keep ? (0xffu << (8 * j)) : 0u;
+            rm3a[j] = rm3b[j];
+            rm3b[j] = rm3;
+            lrb[j] = lr;
+            rcb[j] = q[j];
+        }
+        const int c = v - 1;
+        if (live && c >= ys && c < ye) *(uint32_t*)(mf + (size_t)c * m.step + x) = bits;
+        cur = nxt;
+    }
+}
+
 inline dim3 px_grid(const View& d)
 {
     unsigned gx = (unsigned)((d.cols + kBlock - 1) / kBlock);
@@ -137,6 +201,13 @@ extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* 
     if (m.rows != r.rows || m.cols != r.cols || m.n != r.n) return RCV_ERR_ARG;
     if (r.rows > 65535 || r.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (r.rows == 0 || r.cols == 0 || r.n == 0) return RCV_OK;
+    if (r.cols % 4 == 0 && r.cols >= 4 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
+        (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
+        const int seg = 64;
+        const dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
+        hipLaunchKernelGGL(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg);
+        return rcv_launch_check(ctx);
+    }
     hipLaunchKernelGGL(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
     return rcv_launch_check(ctx);
 }

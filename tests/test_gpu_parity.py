@@ -1042,6 +1042,30 @@ def test_corner_harris_and_pipeline_from_gray(ctx, oracle, rows, cols):
     resp.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 4), (2, 8), (5, 256), (70, 260), (130, 1024), (65, 1028), (33, 2052)])
+def test_nms3x3_streaming_kernel(ctx, oracle, rows, cols):
+    """the row-streaming NMS kernel (16-byte aligned f32 rows, cols % 4 == 0): wave and block seams, row-segment seams,
+    plateaus (ties are kept), +-inf, NaN (a NaN neighbour or centre is never kept), thresholds incl. NaN; batch of 2, padded steps"""
+    r = np.random.default_rng(rows * 131 + cols + _SOAK_SEED)
+    n = 2
+    resp = r.standard_normal((n, rows, cols)).astype(np.float32)
+    resp[r.random((n, rows, cols)) < 0.2] = 0.5
+    resp[r.random((n, rows, cols)) < 0.01] = np.nan
+    resp[r.random((n, rows, cols)) < 0.01] = np.inf
+    resp[r.random((n, rows, cols)) < 0.01] = -np.inf
+    src = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F, step=cols * 4 + 32)
+    src.upload(resp[..., None])
+    for thr in (0.0, 0.5, -np.inf, np.nan):
+        mask = _canary_batch(ctx, n, rows, cols, 1, pad=12)
+        device.nms3x3(src, mask, thr)
+        got = mask.download()
+        for i in range(n):
+            assert np.array_equal(got[i], oracle.nms3x3(resp[i], thr)), (thr, i)
+        _assert_canaries(mask)
+        mask.free()
+    src.free()
+
+
 @pytest.mark.parametrize("rows,cols", SHAPES)
 def test_nms3x3(ctx, oracle, rng, rows, cols):
     resp = rng.standard_normal((rows, cols)).astype(np.float32)

@@ -209,6 +209,7 @@ def main():
     rq = B(64, 2160, 3840, 1, _ffi.RCV_32F)
     record("cornerHarris (gray -> f32 response)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5, lambda: device.corner_harris(gq, rq, 2, 0.04),
            note="the fused kernel without its NMS stage; the generic three-kernel path takes ~9 ms")
+    record("NMS 3x3 (f32 response -> mask)", "4K batch=64/GPU", rq.n, 3840 * 2160, 5, lambda: device.nms3x3(rq, m, 1e-4))
     gq.free(); rq.free()
     s.free(); d.free(); m.free()
 
