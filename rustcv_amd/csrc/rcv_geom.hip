@@ -434,6 +434,67 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     }
 }
 
+// One-channel images: the scheme of k_warp_affine_bgr with 2-byte tap pairs.  One thread per output column and kWarpRows
+// rows; a wave whose taps all lie inside the source fetches each tap pair as the ALIGNED 8 bytes that contain it (one dwordx2
+// per source row: 16 tap loads in flight per lane), shifts it into place with v_alignbyte, lerps top and bottom rows as one
+// packed-f32 pair, and after a quad transpose every lane stores the 4 pixels of one row as a dword.  Waves that touch the
+// border run warp_px<1> per pixel (same f32 operations, same order).
+__global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Affine A)
+{
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0: quads never straddle the row end
+    const float fxx = (float)min(x, d.cols - 1);
+    const int ybase = blockIdx.y * kWarpRows;
+    const float fy0 = (float)min(ybase, d.rows - 1), fy1 = (float)min(ybase + kWarpRows - 1, d.rows - 1);
+    const float xa = fmaf(A.m[0], fxx, fmaf(A.m[1], fy0, A.m[2])), xb = fmaf(A.m[0], fxx, fmaf(A.m[1], fy1, A.m[2]));
+    const float ya = fmaf(A.m[3], fxx, fmaf(A.m[4], fy0, A.m[5])), yb = fmaf(A.m[3], fxx, fmaf(A.m[4], fy1, A.m[5]));
+    // (sx, sy are monotonic in the row index for a fixed lane: the first and the last row bound all eight; NaN -> false)
+    const bool inter = fminf(xa, xb) >= 0.0f && fmaxf(xa, xb) < (float)(s.cols - 7) && fminf(ya, yb) >= 0.0f && fmaxf(ya, yb) < (float)(s.rows - 1);
+    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    const int xq = x & ~3, yi = ybase + (lane & 3);
+    uint32_t px[kWarpRows];
+    if (small && __all(inter)) {
+        const unsigned sstep = (unsigned)s.step;
+        struct U2 { uint32_t a, b; };
+        U2 ta[kWarpRows], tb[kWarpRows];
+        f2 fxy[kWarpRows];
+        unsigned sh[kWarpRows];
+#pragma unroll
+        for (int r = 0; r < kWarpRows; ++r) {
+            const float fyy = (float)min(ybase + r, d.rows - 1);
+            const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
+            fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
+            const unsigned off = __umul24((unsigned)(int)sxy.y, sstep) + (unsigned)(int)sxy.x;
+            sh[r] = off & 3u;
+            ta[r] = *(const U2*)(sf + (off & ~3u));
+            tb[r] = *(const U2*)(sf + ((off & ~3u) + sstep));
+        }
+#pragma unroll
+        for (int r = 0; r < kWarpRows; ++r) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]);
+            // {top, bottom} as one packed pair: fma(fx, p01 - p00, p00), then v = fma(fy, bot - top, top), floor(v + 0.5)
+            const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
+            const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
+            px[r] = (uint32_t)(int)floorf(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // interior: an integer in [0, 255]
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < kWarpRows; ++r) {
+            uint8_t o1[1];
+            warp_px<1>(sf, s, A, fxx, (float)min(ybase + r, d.rows - 1), o1);
+            px[r] = o1[0];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < kWarpRows / 4; ++h) {
+        uint32_t t[4] = {px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]};
+        quad_transpose4(t, lane);
+        if (xq < d.cols && yi + 4 * h < d.rows) *(uint32_t*)(dfr + (size_t)(yi + 4 * h) * d.step + xq) = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+    }
+}
+
 // ---- bilinear resize, BGR, any scale: the register scheme of k_warp_affine_bgr ------------------------------------------
 // One thread per output column and kRszRows consecutive output rows: x0 and fx are computed once, every row costs two
 // aligned 12-byte tap windows (all in flight together), packed-f32 lerps, and four lanes share a 12-byte store.  A wave
@@ -644,6 +705,11 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
         const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
         hipLaunchKernelGGL(k_warp_affine_bgr, dim3(gx, (d.rows + band - 1) / band, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
+        return rcv_launch_check(ctx);
+    }
+    if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
+        hipLaunchKernelGGL(k_warp_affine_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0,
+                           ctx->stream, s, d, A);
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1) hipLaunchKernelGGL(k_warp_affine<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);

@@ -656,6 +656,31 @@ def test_geometry_kernels_random_maps(ctx, oracle):
         dst.free()
 
 
+def test_warp_affine_gray_random_maps(ctx, oracle):
+    """20 x RCV_SOAK seeded random affine maps through the one-channel warp kernel (output widths multiples of 4): interior waves
+    (aligned 8-byte tap windows), border waves (per-pixel path), footprints partly or wholly outside, padded steps, batch of 2"""
+    r = np.random.default_rng(0x6E0761 + _SOAK_SEED)
+    for case in range(20 * _SOAK):
+        sr, sc = int(r.integers(6, 260)), int(r.integers(8, 600))
+        dr, dc = int(r.integers(2, 150)), 4 * int(r.integers(1, 130))
+        img = r.integers(0, 256, size=(2, sr, sc, 1), dtype=np.uint8)
+        th, sx, sy = r.uniform(-3.2, 3.2), r.uniform(0.3, 3.0), r.uniform(0.3, 3.0)
+        if case % 3 == 0:     # near-identity maps keep most waves on the interior path
+            th, sx, sy = r.uniform(-0.2, 0.2), r.uniform(0.9, 1.1), r.uniform(0.9, 1.1)
+        M = np.array([sx * np.cos(th), -sy * np.sin(th) + r.uniform(-0.2, 0.2), r.uniform(-0.3 * sc, 0.3 * sc),
+                      sx * np.sin(th), sy * np.cos(th), r.uniform(-0.3 * sr, 0.3 * sr)], np.float32)
+        src = device.DeviceBatch(ctx, 2, sr, sc, 1, step=sc + int(r.choice([0, 3, 4, 13])))
+        src.upload(img)
+        dst = _canary_batch(ctx, 2, dr, dc, 1, pad=8)
+        device.warp_affine(src, dst, M)
+        got = dst.download()
+        for i in range(2):
+            assert np.array_equal(got[i], oracle.warp_affine(img[i, :, :, 0], M, dr, dc)), (case, i, sr, sc, dr, dc)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 def test_filter2d_i8_mfma_batch_4k_properties(ctx, oracle):
     """Full-size frames (BASELINE configs[2] shape, small batch): (1) rows of frame 0 against the oracle on
     slabs; (2) linearity: filter(K1) + filter(K2) == filter(K1+K2) where nothing saturates (shift 0 is not
