@@ -558,6 +558,60 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
     }
 }
 
+// One-channel images: k_resize_bgr's scheme with 2-byte tap pairs (one aligned dwordx2 per source row).
+__global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float scx, float scy)
+{
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0: quads never straddle the row end
+    const int xq = min(x, d.cols - 1);
+    const int ybase = blockIdx.y * kRszRows;
+    float sx = ((float)xq + 0.5f) * scx - 0.5f;
+    sx = sx < 0.0f ? 0.0f : sx;
+    sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
+    const float x0f = floorf(sx);
+    const int x0 = (int)x0f;
+    const float fx = sx - x0f;
+    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+                       (unsigned long long)s.rows * s.step < (1ull << 32);
+    if (small && __all(x0 <= s.cols - 8)) {   // the aligned 8-byte window [x0 & ~3, +8) ends inside the row
+        struct U2 { uint32_t a, b; };
+        U2 ta[kRszRows], tb[kRszRows];
+        float fy[kRszRows];
+        const unsigned sh = (unsigned)x0 & 3u, xa = (unsigned)x0 & ~3u;
+#pragma unroll
+        for (int r = 0; r < kRszRows; ++r) {
+            int y0, y1;
+            resize_row(s, scy, min(ybase + r, d.rows - 1), y0, y1, fy[r]);
+            ta[r] = *(const U2*)(sf + (__umul24((unsigned)y0, (unsigned)s.step) + xa));
+            tb[r] = *(const U2*)(sf + (__umul24((unsigned)y1, (unsigned)s.step) + xa));
+        }
+        uint32_t px[kRszRows];
+#pragma unroll
+        for (int r = 0; r < kRszRows; ++r) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh);
+            const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
+            const f2 tb2 = pk_fma_bc<0>(f2{fx, fy[r]}, p1 - p0, p0);          // {top, bottom}: fma(fx, p01 - p00, p00)
+            px[r] = (uint32_t)(int)floorf(fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f);   // an integer in [0, 255]
+        }
+        static_assert(kRszRows == 4, "one quad transpose per thread");
+        const int lane = threadIdx.x & 63, xs = x & ~3, yi = ybase + (lane & 3);
+        quad_transpose4(px, lane);
+        if (xs < d.cols && yi < d.rows) *(uint32_t*)(dfr + (size_t)yi * d.step + xs) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        return;
+    }
+#pragma unroll 1
+    for (int r = 0; r < kRszRows; ++r) {
+        if (x >= d.cols || ybase + r >= d.rows) continue;
+        int y0, y1;
+        float fy;
+        resize_row(s, scy, ybase + r, y0, y1, fy);
+        uint8_t o[1];
+        resize_px<1>(sf + (size_t)y0 * s.step, sf + (size_t)y1 * s.step, s, scx, fy, x, o);
+        dfr[(size_t)(ybase + r) * d.step + x] = o[0];
+    }
+}
+
 // ---- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR ("next" row f1) ---------------------
 // resize(warp_affine(src -> mid), dst) with mid = S * dst.  For an exact integer factor the bilinear resize reads only
 // the centre 2x2 of every SxS block of `mid` (k_resize_box above), so the fused kernel evaluates just those four warped
@@ -684,6 +738,11 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
     if (s.ch == 3 && s.cols >= 4 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 &&
         d.rows <= 65535 * kRszRows) {
         hipLaunchKernelGGL(k_resize_bgr, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
+                           dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
+        return rcv_launch_check(ctx);
+    }
+    if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 && d.rows <= 65535 * kRszRows) {
+        hipLaunchKernelGGL(k_resize_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);
     }

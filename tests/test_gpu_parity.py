@@ -657,7 +657,7 @@ def test_geometry_kernels_random_maps(ctx, oracle):
 
 
 def test_warp_affine_gray_random_maps(ctx, oracle):
-    """20 x RCV_SOAK seeded random affine maps through the one-channel warp kernel (output widths multiples of 4): interior waves
+    """(and random scales through the one-channel resize kernel)  20 x RCV_SOAK seeded random affine maps through the one-channel warp kernel (output widths multiples of 4): interior waves
     (aligned 8-byte tap windows), border waves (per-pixel path), footprints partly or wholly outside, padded steps, batch of 2"""
     r = np.random.default_rng(0x6E0761 + _SOAK_SEED)
     for case in range(20 * _SOAK):
@@ -676,6 +676,11 @@ def test_warp_affine_gray_random_maps(ctx, oracle):
         got = dst.download()
         for i in range(2):
             assert np.array_equal(got[i], oracle.warp_affine(img[i, :, :, 0], M, dr, dc)), (case, i, sr, sc, dr, dc)
+        _assert_canaries(dst)
+        device.resize(src, dst)          # the one-channel general resize kernel (any scale, up and down)
+        got = dst.download()
+        for i in range(2):
+            assert np.array_equal(got[i], oracle.resize(img[i, :, :, 0], dr, dc)), (case, "resize", i, sr, sc, dr, dc)
         _assert_canaries(dst)
         src.free()
         dst.free()
