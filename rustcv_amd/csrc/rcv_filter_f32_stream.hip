@@ -41,6 +41,8 @@ template <int KS, bool SEP>
 struct FWeights {
     f2 w2[((SEP ? KS : KS * KS) + 1) / 2];
     float delta;
+    float iscale;   // != 0: INTEGER filter on this kernel -- integer weights, exact integer sums (< 2^23), result = (sum + half) >> shift
+                    // formed as floor(sum * 2^-shift + 0.5) (iscale = 2^-shift; every step exact in f32), then saturated
 };
 
 // d = fma({w, w}, x, acc) with w = half HALF of the uniform pair `wp`
@@ -151,6 +153,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         const int y = r - RAD;
         // v_cvt_pk_u8_f32 itself rounds half to even (measured on gfx950: 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 254.5 -> 254),
         // saturates to [0, 255] (NaN -> 0) and packs: saturate(rint(v)) of the specification in one instruction per sample
+        if (W.iscale != 0.0f) {   // (uniform) integer mode: floor((sum + half) / 2^shift), exact
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                acc[done][j] = __builtin_elementwise_floor(__builtin_elementwise_fma(acc[done][j], f2{W.iscale, W.iscale}, f2{0.5f, 0.5f}));
+        }
         uint32_t o[BPT / 4];
 #pragma unroll
         for (int q = 0; q < BPT / 4; ++q) {
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
 }
 
 template <int KS, int CH, bool SEP, int BPT>
-int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta)
+int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta, float iscale)
 {
     constexpr int RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, NW = (LEADW + BPT + LEAD + 3) / 4;
     const int rowbytes = s.cols * CH;
@@ -194,6 +201,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     memset(&W, 0, sizeof(W));
     for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w2[i >> 1][i & 1] = w[i];
     W.delta = delta;
+    W.iscale = iscale;
     const unsigned gx = (unsigned)((rowbytes / BPT + kBlock - 1) / kBlock);
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
@@ -212,7 +220,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
 }
 
 template <bool SEP>
-int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksize, float delta)
+int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksize, float delta, float iscale = 0.0f)
 {
     if ((s.cols * s.ch) % 4 != 0) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4)) return RCV_ERR_UNSUPPORTED;
@@ -223,10 +231,10 @@ int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksi
 #define RCV_CASE(KS, CH)                                                                 \
     if (ksize == KS && s.ch == CH) {                                                     \
         if (wide) {                                                                      \
-            int rc = launch<KS, CH, SEP, 8>(ctx, s, d, w, delta);                        \
+            int rc = launch<KS, CH, SEP, 8>(ctx, s, d, w, delta, iscale);                \
             if (rc != RCV_ERR_UNSUPPORTED) return rc;                                    \
         }                                                                                \
-        return launch<KS, CH, SEP, 4>(ctx, s, d, w, delta);                              \
+        return launch<KS, CH, SEP, 4>(ctx, s, d, w, delta, iscale);                      \
     }
     RCV_CASE(3, 1) RCV_CASE(5, 1) RCV_CASE(7, 1) RCV_CASE(3, 3) RCV_CASE(5, 3) RCV_CASE(7, 3)
     if constexpr (SEP) { RCV_CASE(9, 1) RCV_CASE(11, 1) RCV_CASE(9, 3) RCV_CASE(11, 3) }
@@ -244,4 +252,35 @@ int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float*
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize)
 {
     return dispatch<true>(ctx, s, d, taps, ksize, 0.0f);
+}
+
+// Integer filter2D / integer GaussianBlur on the streaming kernel, for shapes the MFMA strip kernel does not take (rows that
+// are only 4-byte aligned, widths that are not a multiple of 16 -- a packed 1080-pixel-wide BGR image): integer weights and
+// u8 samples give integer partial sums, exact in f32 while sum(|k|) * 255 < 2^23, and the rounding shift is exact as well.
+int rcv_filter_i16_stream(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
+{
+    if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
+    long long mag = 0;
+    float w[49];
+    for (int i = 0; i < ksize * ksize; ++i) {
+        mag += k[i] < 0 ? -k[i] : k[i];
+        w[i] = (float)k[i];
+    }
+    if (mag * 255 >= (1 << 23) || shift < 0 || shift > 24) return RCV_ERR_UNSUPPORTED;
+    return dispatch<false>(ctx, s, d, w, ksize, 0.0f, ldexpf(1.0f, -shift));
+}
+
+// integer GaussianBlur: taps t (sum 2^(shift/2)) applied separably -- the exact integer sum of the 2-D kernel t x t
+int rcv_gauss_int_stream(rcv_ctx* ctx, const View& s, const View& d, const int* t, int ksize, int shift)
+{
+    if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
+    long long sum = 0;
+    float w[7];
+    for (int i = 0; i < ksize; ++i) {
+        if (t[i] < 0) return RCV_ERR_UNSUPPORTED;
+        sum += t[i];
+        w[i] = (float)t[i];
+    }
+    if (sum * sum * 255 >= (1 << 23)) return RCV_ERR_UNSUPPORTED;
+    return dispatch<true>(ctx, s, d, w, ksize, 0.0f, ldexpf(1.0f, -shift));
 }

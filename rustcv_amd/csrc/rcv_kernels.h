@@ -14,6 +14,9 @@ int rcv_filter_i16_gray(rcv_ctx* ctx, const View& s, const View& d, const int16_
 int rcv_harris_fused(rcv_ctx* ctx, const View& src, const View* mask, const View* resp, int block, float k, float thr);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
+// integer filters on the streaming f32 kernel (exact): shapes the strip kernel does not take
+int rcv_filter_i16_stream(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift);
+int rcv_gauss_int_stream(rcv_ctx* ctx, const View& s, const View& d, const int* taps, int ksize, int shift);
 // generic kernels restricted to the byte columns [xb_lo, xb_hi) of every row (edge fix-up of the streaming kernels)
 int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta, int xb_lo, int xb_hi);
 int rcv_gauss_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize, int xb_lo, int xb_hi);

@@ -163,6 +163,8 @@ extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_b
         tp.ksize = ksize;
         const int* t = ksize == 3 ? t3 : (ksize == 5 ? t5 : t7);
         tp.D = ksize == 3 ? 16 : (ksize == 5 ? 256 : 4096);
+        rc = rcv_gauss_int_stream(ctx, s, d, t, ksize, ksize == 3 ? 4 : (ksize == 5 ? 8 : 12));
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
         for (int i = 0; i < ksize; ++i) tp.t[i] = t[i];
         hipLaunchKernelGGL(k_gauss_int_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
     } else {
@@ -185,6 +187,12 @@ extern "C" int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
     int rc = rcv_filter_i8_fast(ctx, s, d, k, ksize, shift);
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    if (ksize <= 7 && (s.ch == 1 || s.ch == 3)) {   // rows only 4-byte aligned, odd widths: the streaming kernel in integer mode
+        int16_t k16[49];
+        for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+        rc = rcv_filter_i16_stream(ctx, s, d, k16, ksize, shift);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
     KernI8 kw;
     kw.ksize = ksize;
     kw.shift = shift;

@@ -62,12 +62,20 @@ def test_fast_kernels_are_dispatched(ctx):
         ("cvtColor BGR2GRAY", lambda: device.cvt_color(bgr, gray2, _ffi.RCV_BGR2GRAY), 0.25),
         ("cvtColor YUYV2BGR", lambda: device.cvt_color(yuyv, bgr2, _ffi.RCV_YUYV2BGR), 0.3),
     ]
+    # a packed 1080-pixel-wide (portrait) BGR batch: rows are only 4-byte aligned, so the strip kernel does not apply -- the
+    # integer filters must take the streaming kernel's exact integer mode, not the generic per-sample kernel (13x slower)
+    pw, pw2 = device.DeviceBatch(ctx, n, 1920, 1080, 3), device.DeviceBatch(ctx, n, 1920, 1080, 3)
+    device.synth(pw, 1, 10, 0)
+    cases += [
+        ("filter2D 7x7 i8, packed 1080-wide BGR (streaming kernel, integer mode)", lambda: device.filter2d(pw, pw2, k7, shift=6), 0.4),
+        ("GaussianBlur 5x5 int, packed 1080-wide BGR", lambda: device.gaussian_blur(pw, pw2, 5, 0.0), 0.25),
+    ]
     slow = []
     for name, fn, budget in cases:
         ms = _ms_per_call(ctx, fn)
         print(f"{name:52s} {ms:7.3f} ms  (budget {budget})")
         if ms > budget:
             slow.append((name, round(ms, 3), budget))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2):
         b.free()
     assert not slow, slow

@@ -574,6 +574,43 @@ def test_gray_filter_strip_kernel_4k_batch(ctx, oracle):
     dst.free()
 
 
+@pytest.mark.parametrize("ch", [1, 3])
+def test_integer_filters_on_the_streaming_kernel(ctx, oracle, ch):
+    """integer filter2D / GaussianBlur on shapes the MFMA strip kernel refuses (packed rows that are only 4-byte aligned, widths
+    that are not a multiple of 16 -- e.g. a packed 1080-pixel-wide BGR image): they run on the streaming f32 kernel in its
+    exact integer mode.  Full-range weights (negative sums, saturation at both ends), shifts 0..12, integer Gaussian 3/5/7."""
+    r = np.random.default_rng(0x51E4 + ch + _SOAK_SEED)
+    for case in range(8 * _SOAK):
+        cols = int(r.choice([20, 36, 100, 1080, 340, 52, 1364])) if ch == 3 else 4 * int(r.integers(3, 300)) + (0 if case % 2 else 4)
+        if ch == 3 and (cols * 3) % 4:
+            cols += 4 - cols % 4
+        rows = int(r.integers(1, 90))
+        n = int(r.integers(1, 3))
+        ksize = int(r.choice([3, 5, 7]))
+        frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+        if case % 5 == 0:
+            frames[:, :, : cols // 2] = 255
+        pad = 4 * int(r.integers(0, 3)) + (4 if (cols * ch) % 16 == 0 else 0)      # never a 16-byte aligned step
+        src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + pad)
+        dst = _canary_batch(ctx, n, rows, cols, ch, pad=4 * int(r.integers(1, 3)) + (0 if (cols * ch) % 16 else 0))
+        src.upload(frames)
+        fr = [frames[i] if ch == 3 else frames[i, :, :, 0] for i in range(n)]
+        if case % 3 == 2:
+            device.gaussian_blur(src, dst, ksize, 0.0)
+            want = [oracle.gaussian_blur(f, ksize, 0.0) for f in fr]
+        else:
+            k = r.integers(-128, 128, size=(ksize, ksize)).astype(np.int8)
+            shift = int(r.integers(0, 13))
+            device.filter2d(src, dst, k, shift=shift)
+            want = [oracle.filter2d_i8(f, k, shift) for f in fr]
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i].reshape(want[i].shape), want[i]), (case, rows, cols, ksize)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
 def test_register_window_kernels_random_shapes(ctx, oracle):
     """24 x RCV_SOAK seeded random shapes through the Sobel (gray and BGR source) and Harris (BGR and YUYV source) sliding-window kernels:
     widths 8..1600 (multiples of 8: one to four strips, partial last strip), heights 4..260 (several row segments), padded steps"""
