@@ -125,6 +125,16 @@ SIGNATURES = {
     "rcv_synth_batch": (_i, [_ctx, _bat, _i, _u64, _u64]),
 }
 
+# debug / calibration entry points (not part of include/rustcv_hip.h): used by tests, tools and bench.py's copy-ceiling leg
+DEBUG_SIGNATURES = {
+    "rcv__debug_set": (None, [_i]),
+    "rcv__debug_reload_knobs": (None, []),
+    "rcv__debug_kernels": (C.c_char_p, []),
+    "rcv__debug_kernels_reset": (None, []),
+    "rcv__debug_occupancy": (_i, []),
+    "rcv__membench": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz, _i, _i]),
+}
+
 _lib = None
 
 
@@ -137,7 +147,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C rustcv_amd/csrc`.  rustcv_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(l, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -9,6 +9,54 @@
 
 extern "C" int rcv_abi_version(void) { return RCV_ABI_VERSION; }
 
+// ---- environment knobs, read once ----
+static RcvKnobs g_knobs;
+static bool g_knobs_loaded = false;
+static int env_int(const char* name, int unset)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : unset;
+}
+static void load_knobs()
+{
+    g_knobs.f7_seg_rows = env_int("RCV_F7_SEG_ROWS", 0);
+    g_knobs.f7_tps = env_int("RCV_F7_TPS", 0);
+    g_knobs.f7_no_lat = getenv("RCV_F7_NO_LAT") != nullptr;
+    g_knobs.f7_no_gray = getenv("RCV_F7_NO_GRAY") != nullptr;
+    g_knobs.f7_dual_full = getenv("RCV_F7_DUAL_FULL") != nullptr;
+    g_knobs.f7_rows = env_int("RCV_F7_ROWS", -1);
+    g_knobs.fr_rounds = env_int("RCV_FR_ROUNDS", 0);
+    g_knobs.fr_wpc = env_int("RCV_FR_WPC", 0);
+    g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
+    g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
+    g_knobs_loaded = true;
+}
+const RcvKnobs& rcv_knobs()
+{
+    if (!g_knobs_loaded) load_knobs();   // (first use races only write the same values)
+    return g_knobs;
+}
+extern "C" void rcv__debug_reload_knobs(void) { load_knobs(); }
+
+// ---- per-thread log of launched kernels (tests: which kernel did this entry point dispatch?) ----
+static thread_local char t_kernels[1024];
+static thread_local size_t t_kernels_len = 0;
+void rcv_note_kernel(const char* name)
+{
+    const size_t n = strlen(name);
+    if (t_kernels_len + n + 2 >= sizeof(t_kernels)) return;   // full: keep the first ones
+    if (t_kernels_len) t_kernels[t_kernels_len++] = ';';
+    memcpy(t_kernels + t_kernels_len, name, n);
+    t_kernels_len += n;
+    t_kernels[t_kernels_len] = 0;
+}
+extern "C" const char* rcv__debug_kernels(void) { return t_kernels; }
+extern "C" void rcv__debug_kernels_reset(void)
+{
+    t_kernels_len = 0;
+    t_kernels[0] = 0;
+}
+
 extern "C" const char* rcv_strerror(int code)
 {
     switch (code) {

@@ -615,7 +615,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         const bool ok = d.ch == 1 && s.cols % 16 == 0 && s.cols >= 16 && s.rows >= 4 && (uintptr_t)s.p % 16 == 0 && s.step % 16 == 0 &&
                         (s.n <= 1 || s.fstride % 16 == 0) && (uintptr_t)d.p % 16 == 0 && d.step % 16 == 0 && (d.n <= 1 || d.fstride % 16 == 0) &&
                         s.step < (1u << 24) && d.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) &&
-                        (unsigned long long)s.rows * d.step < (1ull << 32) && !getenv("RCV_F7_NO_GRAY");
+                        (unsigned long long)s.rows * d.step < (1ull << 32) && !rcv_knobs().f7_no_gray;
         if (!ok) return rcv_filter_i16_gray(ctx, s, d, k, ksize, shift);
     } else {
         if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
@@ -637,7 +637,14 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         }
         ksum += k[i];
     }
-    const int mode = !dual ? 0 : ((centre && !getenv("RCV_F7_DUAL_FULL")) ? 2 : 1);   // (the knob keeps the full-table kernel testable)
+    const int mode = !dual ? 0 : ((centre && !rcv_knobs().f7_dual_full) ? 2 : 1);   // (the knob keeps the full-table kernel testable)
+    // BGR with weights inside i8, enough rows to fill the GPU: the row-streaming kernel (rcv_filter_rows_mfma.hip)
+    if (!gray && !src_yuyv && !dual) {
+        int8_t k8[49];
+        for (int i = 0; i < ksize * ksize; ++i) k8[i] = (int8_t)k[i];
+        const int rc = rcv_filter_i8_rows(ctx, s, d, k8, ksize, shift);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
 
     // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered).  While a graph is
     // being recorded the table goes into a buffer the graph owns, so that replays never depend on this cache.
@@ -675,12 +682,20 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     // strips of 256 px: line-aligned seams.  (240-px strips split widths such as 1920 evenly, but measured 3.5 % slower there
     // than 7 full strips + one half strip; the kernel still takes tps = 15 through the tuning knob below.)
     a.tps = gray ? kTilesG : kTiles;
-    if (const char* e = getenv("RCV_F7_TPS")) a.tps = gray ? a.tps : (atoi(e) == 15 ? 15 : 16);  // tuning knob (BGR strips)
+    if (rcv_knobs().f7_tps == 15 && !gray) a.tps = 15;  // tuning knob (BGR strips)
     a.nstrips = (a.ntiles_total + a.tps - 1) / a.tps;
     // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs), each
-    // segment a multiple of 16 rows (>= 32); the per-segment constant models the prologue (two synchronous blocks)
-    int seg_rows = (s.rows + 15) & ~15;
-    {
+    // segment a multiple of 16 rows (>= 32); the per-segment constant models the prologue (two synchronous blocks).
+    // The plan depends on the launch geometry only and is cached in the context (a 1080p frame is a 6-us launch).
+    int seg_rows;
+    bool lat = false;
+    const bool lat_ok = !src_yuyv && !dual && !rcv_knobs().f7_no_lat;
+    if (ctx->f7_plan_rows == s.rows && ctx->f7_plan_nstrips == a.nstrips && ctx->f7_plan_n == s.n && ctx->f7_plan_lat_ok == lat_ok &&
+        ctx->f7_plan_knob == rcv_knobs().f7_seg_rows) {
+        seg_rows = ctx->f7_plan_seg_rows;
+        lat = ctx->f7_plan_lat;
+    } else {
+        seg_rows = (s.rows + 15) & ~15;
         const long long slots = 3LL * ctx->cu_count;
         double best = 1e30;
         for (int ns = 1; ns <= 64; ++ns) {
@@ -693,18 +708,24 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
             double cost = (double)rounds * (sr + 6 + 40);
             if (cost < best) { best = cost; seg_rows = sr; }
         }
-    }
-    if (const char* e = getenv("RCV_F7_SEG_ROWS")) seg_rows = atoi(e) > 15 ? (atoi(e) + 15) / 16 * 16 : seg_rows;  // tuning knob
-    // small launches (everything resident in one round even with the shortest segments): the latency variant
-    bool lat = false;
-    if (!src_yuyv && !dual && !getenv("RCV_F7_NO_LAT")) {
-        for (int sr = 16; sr <= 32 && !lat; sr += 16) {
-            const long long tot = (long long)a.nstrips * ((s.rows + sr - 1) / sr) * s.n;
-            if (tot <= 3LL * ctx->cu_count) {
-                seg_rows = sr;
-                lat = true;
+        if (rcv_knobs().f7_seg_rows > 15) seg_rows = (rcv_knobs().f7_seg_rows + 15) / 16 * 16;   // tuning knob
+        // small launches (everything resident in one round even with the shortest segments): the latency variant
+        if (lat_ok) {
+            for (int sr = 16; sr <= 32 && !lat; sr += 16) {
+                const long long tot = (long long)a.nstrips * ((s.rows + sr - 1) / sr) * s.n;
+                if (tot <= 3LL * ctx->cu_count) {
+                    seg_rows = sr;
+                    lat = true;
+                }
             }
         }
+        ctx->f7_plan_rows = s.rows;
+        ctx->f7_plan_nstrips = a.nstrips;
+        ctx->f7_plan_n = s.n;
+        ctx->f7_plan_lat_ok = lat_ok;
+        ctx->f7_plan_knob = rcv_knobs().f7_seg_rows;
+        ctx->f7_plan_seg_rows = seg_rows;
+        ctx->f7_plan_lat = lat;
     }
     a.seg_rows = seg_rows;
     a.nsegs = (s.rows + seg_rows - 1) / seg_rows;
@@ -716,42 +737,42 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.wgs_per_xcd = (int)((total + 7) / 8);
     const dim3 grid((unsigned)(a.wgs_per_xcd * 8)), block(kThreads);
     if (gray) {
-        if (lat) hipLaunchKernelGGL((k_filter7_mfma<0, 0, 2, true>), grid, block, 0, ctx->stream, a);
-        else if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2, 2>), grid, block, 0, ctx->stream, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_filter7_mfma<0, 1, 2>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_filter7_mfma<0, 0, 2>), grid, block, 0, ctx->stream, a);
+        if (lat) RCV_LAUNCH((k_filter7_mfma<0, 0, 2, true>), grid, block, 0, ctx->stream, a);
+        else if (mode == 2) RCV_LAUNCH((k_filter7_mfma<0, 2, 2>), grid, block, 0, ctx->stream, a);
+        else if (mode == 1) RCV_LAUNCH((k_filter7_mfma<0, 1, 2>), grid, block, 0, ctx->stream, a);
+        else RCV_LAUNCH((k_filter7_mfma<0, 0, 2>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
     if (src_yuyv) {
         if (dual) return RCV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_filter7_mfma<0, 0, 1>), grid, block, 0, ctx->stream, a);
+        RCV_LAUNCH((k_filter7_mfma<0, 0, 1>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
     if (dual) {
-        if (mode == 2) hipLaunchKernelGGL((k_filter7_mfma<0, 2>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_filter7_mfma<0, 1>), grid, block, 0, ctx->stream, a);
+        if (mode == 2) RCV_LAUNCH((k_filter7_mfma<0, 2>), grid, block, 0, ctx->stream, a);
+        else RCV_LAUNCH((k_filter7_mfma<0, 1>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
     if (lat) {
-        hipLaunchKernelGGL((k_filter7_mfma<0, 0, 0, true>), grid, block, 0, ctx->stream, a);
+        RCV_LAUNCH((k_filter7_mfma<0, 0, 0, true>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
     switch (rcv_debug_flags & 31) {
-    case 8: hipLaunchKernelGGL((k_filter7_mfma<8, 0>), grid, block, 0, ctx->stream, a); break;
-    case 16: hipLaunchKernelGGL((k_filter7_mfma<16, 0>), grid, block, 0, ctx->stream, a); break;
-    case 24: hipLaunchKernelGGL((k_filter7_mfma<24, 0>), grid, block, 0, ctx->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_filter7_mfma<1, 0>), grid, block, 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_filter7_mfma<2, 0>), grid, block, 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((k_filter7_mfma<3, 0>), grid, block, 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_filter7_mfma<4, 0>), grid, block, 0, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL((k_filter7_mfma<5, 0>), grid, block, 0, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL((k_filter7_mfma<6, 0>), grid, block, 0, ctx->stream, a); break;
-    case 7: hipLaunchKernelGGL((k_filter7_mfma<7, 0>), grid, block, 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a); break;
+    case 8: RCV_LAUNCH((k_filter7_mfma<8, 0>), grid, block, 0, ctx->stream, a); break;
+    case 16: RCV_LAUNCH((k_filter7_mfma<16, 0>), grid, block, 0, ctx->stream, a); break;
+    case 24: RCV_LAUNCH((k_filter7_mfma<24, 0>), grid, block, 0, ctx->stream, a); break;
+    case 1: RCV_LAUNCH((k_filter7_mfma<1, 0>), grid, block, 0, ctx->stream, a); break;
+    case 2: RCV_LAUNCH((k_filter7_mfma<2, 0>), grid, block, 0, ctx->stream, a); break;
+    case 3: RCV_LAUNCH((k_filter7_mfma<3, 0>), grid, block, 0, ctx->stream, a); break;
+    case 4: RCV_LAUNCH((k_filter7_mfma<4, 0>), grid, block, 0, ctx->stream, a); break;
+    case 5: RCV_LAUNCH((k_filter7_mfma<5, 0>), grid, block, 0, ctx->stream, a); break;
+    case 6: RCV_LAUNCH((k_filter7_mfma<6, 0>), grid, block, 0, ctx->stream, a); break;
+    case 7: RCV_LAUNCH((k_filter7_mfma<7, 0>), grid, block, 0, ctx->stream, a); break;
+    default: RCV_LAUNCH((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a); break;
     }
 #else
-    hipLaunchKernelGGL((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a);
+    RCV_LAUNCH((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
 }

@@ -206,7 +206,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, false, BPT>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
     // threads whose window [xb0 - LEADW, xb0 - LEADW + 4 NW) left the row computed garbage: the first nl and the last nr of a
     // row -- redone by the EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
@@ -214,7 +214,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     const int hi_begin = (limit / BPT + 1) * BPT;
     const int nl = min((LEADW + BPT - 1) / BPT, rowbytes / BPT), nr = max(0, min((rowbytes - hi_begin) / BPT, rowbytes / BPT - nl));
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
-    hipLaunchKernelGGL((k_filter_f32_stream<KS, CH, SEP, true, BPT>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
+    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, true, BPT>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
                        dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr);
     return rcv_launch_check(ctx);
 }

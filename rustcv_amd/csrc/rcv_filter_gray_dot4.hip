@@ -160,12 +160,12 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int shi
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    hipLaunchKernelGGL((k_filter_gray_dot4<KS, DUAL, false>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, false>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
     // threads whose 12-byte window [xb0 - 4, xb0 + 8) leaves the row: the first one and the last one (xb0 = cols - 4)
     const int nl = 1, nr = s.cols / 4 - 1 >= 1 ? 1 : 0;
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
-    hipLaunchKernelGGL((k_filter_gray_dot4<KS, DUAL, true>), dim3(1, (unsigned)((s.rows + eseg - 1) / eseg), s.n), dim3(64), 0, ctx->stream, s, d, W,
+    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, true>), dim3(1, (unsigned)((s.rows + eseg - 1) / eseg), s.n), dim3(64), 0, ctx->stream, s, d, W,
                        eseg, nl, nr);
     return rcv_launch_check(ctx);
 }

@@ -1,0 +1,357 @@
+// rcv_filter_rows_mfma.hip -- filter2D with integer (i8) weights, ksize 3/5/7, u8 BGR -> u8 BGR, as a ROW-STREAMING stencil
+// on the i8 matrix cores whose data operands never leave the register file: no LDS, no barrier, nothing shared between waves.
+// (Round 2's north-star kernel; the round-1 strip kernel, rcv_filter7_mfma.hip, keeps the shapes this one does not take.)
+//
+// Why MFMA at all: 147 MACs per pixel against 6 bytes -- the vector ALU cannot keep the op HBM-bound.
+//
+// The matrix product.  Per colour plane a 16-pixel output tile needs a 22-pixel source window, so the 64-deep data operand of
+// v_mfma_i32_16x16x64_i8 holds the 32-pixel windows of TWO source rows:
+//
+//   D[m][n] += sum_k A[m][k] * B[k][n]
+//     n : one of the 16 WINDOWS of the wave's strip: window n = pixels [16n - 4, 16n + 28) of the strip, output tile = [16n, 16n + 16)
+//     k : (row half h = k >> 5, window pixel j = k & 31): plane[row 2i + h][16n - 4 + j]
+//     m : output pixel 16n + m
+//     A[m][32h + j] = K[ky(h)][j - 4 - m + r]   (banded, constant; lane l holds A[l & 15][16 (l >> 4) .. +15])
+//   lane (n, q = l >> 4) holds B[16q .. 16q + 15][n]: 16 consecutive pixels of ONE plane of row 2i + (q >> 1), chunk (q & 1) of
+//   the window -- i.e. a function of 48 consecutive SOURCE BYTES.  The lane loads those 48 bytes itself (three dword-aligned
+//   dwordx4; the half-waves q < 2 / q >= 2 fetch the two rows of a pair with one instruction), de-interleaves them with 24
+//   v_perm into the B, G and R operands and xors in the sign bit (u8 enters the signed MFMA as p ^ 0x80; the accumulator
+//   starts at 128 * sum(K) + round).  Every source byte is loaded by two lanes (window overlap): the second read is an L1 hit.
+//
+// Traversal.  A wave (= a 64-thread workgroup) owns a strip of 256 pixels = 768 bytes = six whole 128-byte lines per row and a
+// BAND of rows, and walks down it two rows at a time.  Source rows live in a register ring of row PAIRS (2i, 2i + 1); a step
+// needs NP = (ksize + 1) / 2 pairs and produces two output rows from them:
+//     even row 2u     : pairs u .. u + NP - 1 with kernel rows [K0 K1] [K2 K3] [K4 K5] [K6  0]
+//     odd  row 2u + 1 : the same pairs with                    [ 0 K0] [K1 K2] [K3 K4] [K5 K6]
+// = 2 * NP * 3 MFMAs per two rows of 256 pixels (4/7 of one-kernel-row-per-MFMA), accumulators chained through the C operand.
+// PP further pairs are in flight (requested PP steps ahead into the same ring; the loop is unrolled NP + PP times so that ring
+// slots are static registers).  The three planes' accumulators interleave directly into the lane's 12 output bytes (4 pixels x
+// BGR): v_ashr_pk_u8_i32 shift + saturate + pack, one non-temporal dwordx3 store per lane and row -- a wave instruction
+// writes 768 contiguous bytes.
+// BORDER_REFLECT_101: rows by reading the mirrored source row (scalar index math); columns in the first / last strip by
+// reading the chunk shifted into the row and repairing the planar registers (EDGE instantiation of the row loop, wave-uniform).
+//
+// Work split.  The batch's n * rows frame-rows are cut into equal bands; (band, strip) waves are dispatched so that each XCD
+// gets a contiguous run of bands and the strips of a band -- which share the 128-byte lines at their seams -- are neighbours
+// on one L2.  Occupancy is capped at 10 waves per CU through an (untouched) dynamic-LDS request: measured on 64 4K frames
+// 12 waves per CU 0.576-0.581 ms, 10 waves 0.557-0.563, 8 waves 0.566-0.573, 6 waves 0.583 -- with more streams in flight the
+// HBM read and write streams disturb each other more (the memory-only variant of the kernel moves the same way).
+//
+// What was tried on the way (DESIGN.md 4.1 has the numbers): byte-space operands straight from global memory with one kernel
+// row per MFMA (taps every 3rd byte; 7 MFMAs per tile, no VALU de-interleave) -- correct, but 1.75x the matrix work pulls the
+// clock from 2.25 to 1.95 GHz and the per-CU memory path with it; the same with v_smfmac_i32_16x16x128_i8 (the byte-space band
+// IS 2:4 sparse; layout probed with tools/probe_smfmac.hip) -- half the instructions, each twice as long.
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include "rcv_device_utils.h"
+#include <string.h>
+
+extern int rcv_debug_flags;
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v3i __attribute__((ext_vector_type(3)));
+
+struct FRArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    const uint4* wtab;   // 2 x NP tables x 64 lanes x 16 B (A operands), device memory
+    uint8_t* dump;       // 64 x 16 B scratch for masked-off lanes (EDGE path only)
+    size_t sstep, dstep, sfs, dfs;
+    int rows, rowbytes;
+    int nstrips, nframes;
+    int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
+    int shift, acc_init;
+};
+
+struct U3w { uint32_t a, b, c; };
+
+// 4 interleaved BGR pixels (3 dwords) -> planar B, G, R dwords
+__device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& pb, uint32_t& pg, uint32_t& pr)
+{
+    uint32_t t;
+    t = __builtin_amdgcn_perm(d1, d0, 0x00060300u);  // b0(d0.0) b1(d0.3) b2(d1.2) x
+    pb = __builtin_amdgcn_perm(d2, t, 0x05020100u);  // + b3(d2.1)
+    t = __builtin_amdgcn_perm(d1, d0, 0x00070401u);  // g0(d0.1) g1(d1.0) g2(d1.3) x
+    pg = __builtin_amdgcn_perm(d2, t, 0x06020100u);  // + g3(d2.2)
+    t = __builtin_amdgcn_perm(d1, d0, 0x00000502u);  // r0(d0.2) r1(d1.1) x x
+    pr = __builtin_amdgcn_perm(d2, t, 0x07040100u);  // + r2(d2.0) r3(d2.3)
+}
+
+// DBG (profiling builds, make EXTRA=-DRCV_ABLATE): 1 skip stores, 2 skip loads, 4 skip MFMAs, 8 plain instead of non-temporal stores
+template <int KS, int PP, bool EDGE, int DBG>
+__device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
+                                           uint8_t* dframe)
+{
+    constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
+    constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
+    const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
+    const int rb = a.rowbytes;
+
+    v4i A[2][NP];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
+            A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+        }
+
+    // the lane's 48 source bytes per pair: pixels [16n - 4 + 16c, +16) of row 2i + h.  Chunks that stick out of the row are read
+    // shifted into it and repaired after the de-interleave (EDGE); without EDGE the clamp is a no-op.
+    const int cb = X + 48 * n - 12 + 48 * c;
+    const unsigned cbo = (unsigned)min(max(cb, 0), rb - 48);
+    const bool fl = EDGE && cb < 0, fr = EDGE && cb == rb - 12;
+    const int so = X + 48 * n + 12 * q;   // the lane's 12 output bytes: pixels 16n + 4q .. +3
+    uint8_t* const dumpp = a.dump + lane * 16;
+
+    // accumulator start value as a resident register quad (opaque to the compiler, which would rebuild it before every chain)
+    v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+    asm volatile("" : "+v"(initv));
+
+    v4i W[RP][3];   // raw source bytes until prepare() turns them into the B, G, R operands
+    auto request = [&](int pr, v4i(&dst)[3]) {
+        // rows 2*pr (lanes h = 0) and 2*pr + 1 (lanes h = 1) of the segment's window, mirrored at the image border (scalar math);
+        // rows past the window re-read its last row (cache hits, never used)
+        const int y0 = min(ys - RAD + 2 * pr, ye - 1 + RAD), y1 = min(ys - RAD + 2 * pr + 1, ye - 1 + RAD);
+        const int s0 = y0 < 0 ? -y0 : (y0 >= a.rows ? 2 * a.rows - 2 - y0 : y0), s1 = y1 < 0 ? -y1 : (y1 >= a.rows ? 2 * a.rows - 2 - y1 : y1);
+        const unsigned o0 = (unsigned)s0 * (unsigned)a.sstep, o1 = (unsigned)s1 * (unsigned)a.sstep;   // < 2^32 (host check)
+        const unsigned off = (h ? o1 : o0) + cbo;
+        if (DBG & 2) {
+            dst[0] = dst[1] = dst[2] = v4i{(int)off, (int)cbo, s0, lane};
+            return;
+        }
+        dst[0] = *(const v4i*)(sframe + off);
+        dst[1] = *(const v4i*)(sframe + off + 16);
+        dst[2] = *(const v4i*)(sframe + off + 32);
+    };
+    auto prepare = [&](v4i(&w)[3]) {
+        uint32_t pb[4], pg[4], prr[4];
+        const uint32_t r[12] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
+                                (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
+        if (EDGE) {
+            // left border: the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
+            if (fl) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
+                    pp[3] = pp[2];
+                    pp[2] = pp[1];
+                    pp[1] = pp[0];
+                    pp[0] = __builtin_amdgcn_perm(pp[0], pp[0], 0x01020300u);   // [x, px3, px2, px1]
+                }
+            }
+            // right border: the lane read pixels cols-16..cols-1 instead of cols-4..cols+11; pixels cols..cols+2 mirror cols-2..cols-4
+            if (fr) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
+                    pp[0] = pp[3];
+                    pp[1] = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);   // [cols-2, cols-3, cols-4, x]
+                }
+            }
+        }
+        w[0] = v4i{(int)(pb[0] ^ 0x80808080u), (int)(pb[1] ^ 0x80808080u), (int)(pb[2] ^ 0x80808080u), (int)(pb[3] ^ 0x80808080u)};
+        w[1] = v4i{(int)(pg[0] ^ 0x80808080u), (int)(pg[1] ^ 0x80808080u), (int)(pg[2] ^ 0x80808080u), (int)(pg[3] ^ 0x80808080u)};
+        w[2] = v4i{(int)(prr[0] ^ 0x80808080u), (int)(prr[1] ^ 0x80808080u), (int)(prr[2] ^ 0x80808080u), (int)(prr[3] ^ 0x80808080u)};
+    };
+
+#pragma unroll
+    for (int i = 0; i < RP - 1; ++i) request(i, W[i]);
+#pragma unroll
+    for (int i = 0; i < NP - 1; ++i) prepare(W[i]);
+
+    const int nrows = ye - ys;
+    auto finish = [&](const v4i(&acc)[3], int y) {
+        // lane (q, n) holds pixels 16n + 4q .. +3 of the three planes: 12 interleaved output bytes
+        U3w o;
+        o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+        o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+        o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        uint8_t* drow = dframe + (size_t)y * a.dstep;
+        if (DBG & 1) {
+            if (o.a == 0x12345678u && o.b == 0x9abcdef0u) *(U3w*)dumpp = o;
+        } else if (EDGE) {
+            *(U3w*)(so < rb ? drow + so : dumpp) = o;   // windows past the row end (partial last strip) go to the dump line
+        } else if (DBG & 8) {
+            *(U3w*)(drow + so) = o;
+        } else {
+            // non-temporal: this launch never reads its output back, and the source lines that neighbouring strips share
+            // stay in L2 (measured -3 % end to end against plain stores)
+            __builtin_nontemporal_store(v3i{(int)o.a, (int)o.b, (int)o.c}, (v3i*)(drow + so));
+        }
+    };
+    const int nsteps = (nrows + 1) >> 1;
+    for (int u0 = 0; u0 < nsteps; u0 += RP) {
+#pragma unroll
+        for (int s = 0; s < RP; ++s) {
+            const int u = u0 + s;
+            if (u >= nsteps) break;
+            request(u + RP - 1, W[(s + RP - 1) % RP]);
+            prepare(W[(s + NP - 1) % RP]);
+            v4i acc[2][3];
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if (DBG & 4) acc[par][pl] = p == 0 ? W[(s + p) % RP][pl] : acc[par][pl] + W[(s + p) % RP][pl];
+                        else acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
+                    }
+            finish(acc[0], ys + 2 * u);
+            if (2 * u + 1 < nrows) finish(acc[1], ys + 2 * u + 1);
+        }
+    }
+}
+
+template <int KS, int PP, int DBG>
+__global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
+{
+    const int lane = threadIdx.x;
+    // XCD-aware order (speed only): hardware places block b on XCD b % 8; each XCD gets a contiguous run of bands, and the strips
+    // of one band -- which share the 128-B lines at their seams -- are neighbours in dispatch order on one L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int band = xcd * a.bands_per_xcd + slot / a.nstrips, strip = slot % a.nstrips;
+    if (band >= a.nbands) return;
+    const int X = strip * 768;
+    const bool edge = X == 0 || X + 804 > a.rowbytes;   // the last chunk a strip touches ends at X + 804
+    const long long G = (long long)a.nframes * a.rows;
+    long long g0 = G * band / a.nbands;
+    const long long g1 = G * (band + 1) / a.nbands;
+    while (g0 < g1) {   // (a band that crosses a frame boundary is two segments)
+        const int frame = (int)(g0 / a.rows), ys = (int)(g0 - (long long)frame * a.rows);
+        const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
+        const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
+        uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
+        if (edge) fr_segment<KS, PP, true, DBG>(a, lane, X, ys, ye, sframe, dframe);
+        else fr_segment<KS, PP, false, DBG>(a, lane, X, ys, ye, sframe, dframe);
+        g0 += ye - ys;
+    }
+}
+
+// host: A tables.  Table (parity, p): lane (m, qa) holds k = 16 qa + i: row half h = qa >> 1, window pixel j = 16 (qa & 1) + i
+// (the window starts 4 pixels left of the tile).  parity 0: pair p carries kernel rows 2p, 2p + 1; parity 1: 2p - 1, 2p.
+void build_rows_wtab(const int8_t* k, int ksize, int8_t* tab)
+{
+    const int rad = ksize / 2, np = (ksize + 1) / 2;
+    for (int par = 0; par < 2; ++par)
+        for (int p = 0; p < np; ++p)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i) {
+                    const int m = lane & 15, qa = lane >> 4, h = qa >> 1, j = 16 * (qa & 1) + i;
+                    const int ky = par == 0 ? 2 * p + h : 2 * p - 1 + h;
+                    const int t = j - 4 - m + rad;
+                    tab[(((par * np) + p) * 64 + lane) * 16 + i] = (int8_t)((ky >= 0 && ky < ksize && t >= 0 && t < ksize) ? k[ky * ksize + t] : 0);
+                }
+}
+
+template <int KS, int PP>
+void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t st)
+{
+#ifdef RCV_ABLATE
+    switch (rcv_debug_flags & 15) {
+    case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 1>), grid, dim3(64), lds, st, a); return;
+    case 2: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 2>), grid, dim3(64), lds, st, a); return;
+    case 3: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 3>), grid, dim3(64), lds, st, a); return;
+    case 4: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 4>), grid, dim3(64), lds, st, a); return;
+    case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 5>), grid, dim3(64), lds, st, a); return;
+    case 6: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 6>), grid, dim3(64), lds, st, a); return;
+    case 8: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 8>), grid, dim3(64), lds, st, a); return;
+    default: break;
+    }
+#endif
+    RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64), lds, st, a);
+}
+
+template <int KS>
+void launch_rows(const FRArgs& a, int pp, unsigned lds, hipStream_t st)
+{
+    const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
+#ifdef RCV_ABLATE   // profiling builds: prefetch depth selectable at run time (RCV_FR_PP)
+    if (KS == 7 && pp == 2) return launch_rows_dbg<7, 2>(a, grid, lds, st);
+    if (KS == 7 && pp == 4) return launch_rows_dbg<7, 4>(a, grid, lds, st);
+#endif
+    (void)pp;
+    launch_rows_dbg<KS, 3>(a, grid, lds, st);
+}
+
+} // namespace
+
+// Does this launch belong on the row-streaming kernel?  BGR, weights within i8, rows 16-byte aligned, width a multiple of 16
+// pixels; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
+// small launches keep the strip kernel's latency variant.
+int rcv_filter_i8_rows(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+{
+    const RcvKnobs& kn = rcv_knobs();
+    if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
+    if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
+    if (s.ch != 3 || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
+    const long long rb = (long long)s.cols * 3;
+    if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    // in-frame source offsets are 32-bit
+    if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
+    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
+    const int nstrips = (int)((rb + 767) / 768);
+    const long long G = (long long)s.n * s.rows;
+    if (kn.f7_rows < 0 && G * nstrips < 64LL * 10 * ctx->cu_count) return RCV_ERR_UNSUPPORTED;   // < 64 rows per wave slot
+
+    long long ksum = 0;
+    for (int i = 0; i < ksize * ksize; ++i) ksum += k[i];
+
+    if (!ctx->fr_valid || ctx->fr_ksize != ksize || memcmp(ctx->fr_k, k, (size_t)ksize * ksize) != 0) {
+        int8_t tab[2 * 4 * 64 * 16];
+        build_rows_wtab(k, ksize, tab);
+        ctx->fr_valid = false;
+        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)2 * ((ksize + 1) / 2) * 1024, 32768));
+        RCV_HIP(hipStreamSynchronize(ctx->stream));   // `tab` is on this stack frame
+        memcpy(ctx->fr_k, k, (size_t)ksize * ksize);
+        ctx->fr_ksize = ksize;
+        ctx->fr_valid = true;
+    }
+
+    FRArgs a;
+    a.src = s.p;
+    a.dst = d.p;
+    a.wtab = (const uint4*)(ctx->kconst + 32768);
+    a.dump = ctx->kconst + 61440;
+    a.sstep = s.step;
+    a.dstep = d.step;
+    a.sfs = s.fstride;
+    a.dfs = d.fstride;
+    a.rows = s.rows;
+    a.rowbytes = (int)rb;
+    a.nstrips = nstrips;
+    a.nframes = s.n;
+    // occupancy: the kernel's registers allow 12 waves per CU; 10 measured best (header).  The cap is a dynamic-LDS request that
+    // the kernel never touches: 160 KiB / 16 KiB = 10 workgroups per CU.
+    const int wpc = kn.fr_wpc > 0 ? (kn.fr_wpc > 12 ? 12 : kn.fr_wpc) : 10;
+    const unsigned lds = wpc >= 12 ? 0u : (unsigned)((163840 / wpc) & ~511);
+    // bands: the batch's frame-rows in equal parts, `rounds` x as many (band, strip) waves as the GPU holds (measured on 64 4K
+    // frames: 4..16 rounds within 1 %, one round -- a static partition -- +3 %: short waves balance the XCDs).  Each band
+    // boundary costs 2 * (ksize / 2) halo rows of re-reads.
+    {
+        const long long slots = (long long)wpc * ctx->cu_count;
+        const int rounds = kn.fr_rounds > 0 ? kn.fr_rounds : 8;
+        long long nb = slots / a.nstrips / 8 * 8;
+        nb = (nb < 8 ? 8 : nb) * rounds;
+        const long long most = (G + 31) / 32;          // at least 32 rows per band
+        if (nb > most) nb = most;
+        if (nb < 1) nb = 1;
+        a.nbands = (int)nb;
+        a.bands_per_xcd = (int)((nb + 7) / 8);
+    }
+    a.shift = shift;
+    a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
+    if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
+    const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
+    if (ksize == 7) launch_rows<7>(a, pp, lds, ctx->stream);
+    else if (ksize == 5) launch_rows<5>(a, pp, lds, ctx->stream);
+    else launch_rows<3>(a, pp, lds, ctx->stream);
+    return rcv_launch_check(ctx);
+}

@@ -729,26 +729,26 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
         if (s.ch == 3 && s.cols == S * d.cols && s.rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)s.p % 16 == 0 &&
             s.step % 16 == 0 && s.fstride % 16 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
             dim3 grid((unsigned)((d.cols / 4 + kBlock - 1) / kBlock), d.rows, d.n);
-            if (S == 2) hipLaunchKernelGGL(k_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d);
-            else hipLaunchKernelGGL(k_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d);
+            if (S == 2) RCV_LAUNCH(k_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d);
+            else RCV_LAUNCH(k_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d);
             return rcv_launch_check(ctx);
         }
     }
     float scx = (float)s.cols / (float)d.cols, scy = (float)s.rows / (float)d.rows;
     if (s.ch == 3 && s.cols >= 4 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 &&
         d.rows <= 65535 * kRszRows) {
-        hipLaunchKernelGGL(k_resize_bgr, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
+        RCV_LAUNCH(k_resize_bgr, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 && d.rows <= 65535 * kRszRows) {
-        hipLaunchKernelGGL(k_resize_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
+        RCV_LAUNCH(k_resize_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);
     }
-    if (s.ch == 1) hipLaunchKernelGGL(k_resize<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
-    else if (s.ch == 3) hipLaunchKernelGGL(k_resize<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
-    else hipLaunchKernelGGL(k_resize<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
+    if (s.ch == 1) RCV_LAUNCH(k_resize<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
+    else if (s.ch == 3) RCV_LAUNCH(k_resize<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
+    else RCV_LAUNCH(k_resize<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
     return rcv_launch_check(ctx);
 }
 
@@ -763,17 +763,17 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
     if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
         const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
-        hipLaunchKernelGGL(k_warp_affine_bgr, dim3(gx, (d.rows + band - 1) / band, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
+        RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, (d.rows + band - 1) / band, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
-        hipLaunchKernelGGL(k_warp_affine_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0,
+        RCV_LAUNCH(k_warp_affine_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0,
                            ctx->stream, s, d, A);
         return rcv_launch_check(ctx);
     }
-    if (s.ch == 1) hipLaunchKernelGGL(k_warp_affine<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
-    else if (s.ch == 3) hipLaunchKernelGGL(k_warp_affine<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
-    else hipLaunchKernelGGL(k_warp_affine<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
+    if (s.ch == 1) RCV_LAUNCH(k_warp_affine<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
+    else if (s.ch == 3) RCV_LAUNCH(k_warp_affine<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
+    else RCV_LAUNCH(k_warp_affine<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     return rcv_launch_check(ctx);
 }
 
@@ -793,8 +793,8 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
-            if (S == 2) hipLaunchKernelGGL(k_warp_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
-            else hipLaunchKernelGGL(k_warp_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
+            if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
+            else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
             return rcv_launch_check(ctx);
         }
     }

@@ -158,8 +158,8 @@ float harris_scale2(int block)
 // gray (device View) -> resp using two packed i16 planes carved from the workspace
 int harris_from_gray(rcv_ctx* ctx, const View& g, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
 {
-    hipLaunchKernelGGL(k_sobel_packed, px_grid(g), dim3(kBlock), 0, ctx->stream, g, (int16_t*)wix, (int16_t*)wiy);
-    hipLaunchKernelGGL(k_harris_resp, px_grid(r), dim3(kBlock), 0, ctx->stream, (const int16_t*)wix, (const int16_t*)wiy, r, block,
+    RCV_LAUNCH(k_sobel_packed, px_grid(g), dim3(kBlock), 0, ctx->stream, g, (int16_t*)wix, (int16_t*)wiy);
+    RCV_LAUNCH(k_harris_resp, px_grid(r), dim3(kBlock), 0, ctx->stream, (const int16_t*)wix, (const int16_t*)wiy, r, block,
                        harris_scale2(block), k);
     return rcv_launch_check(ctx);
 }
@@ -205,10 +205,10 @@ extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* 
         (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
         const int seg = 64;
         const dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
-        hipLaunchKernelGGL(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg);
+        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg);
         return rcv_launch_check(ctx);
     }
-    hipLaunchKernelGGL(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
+    RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
     return rcv_launch_check(ctx);
 }
 
@@ -283,7 +283,7 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
         r.esz = 4;
     }
     RCV_TRY(harris_from_gray(ctx, g, r, block, k, wix, wiy));
-    hipLaunchKernelGGL(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
+    RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
     return rcv_launch_check(ctx);
 }
 

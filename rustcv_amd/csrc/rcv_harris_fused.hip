@@ -339,7 +339,7 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
             if (cost < best) { best = cost; seg = sr; }
         }
     }
-    if (const char* e = getenv("RCV_HARRIS_SEG_ROWS")) seg = atoi(e) > 0 ? atoi(e) : seg;
+    if (rcv_knobs().harris_seg_rows > 0) seg = rcv_knobs().harris_seg_rows;
     a.seg_rows = seg;
     a.nsegs = (s.rows + seg - 1) / seg;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
@@ -351,15 +351,15 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
     dim3 grid((unsigned)((waves + 3) / 4));
     if (s.ch == 1) {
-        if (!mask) hipLaunchKernelGGL((k_harris_fused<true, 2, false>), grid, dim3(256), 0, ctx->stream, a);
-        else if (resp) hipLaunchKernelGGL((k_harris_fused<true, 2>), grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_harris_fused<false, 2>), grid, dim3(256), 0, ctx->stream, a);
+        if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(256), 0, ctx->stream, a);
+        else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(256), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 2>), grid, dim3(256), 0, ctx->stream, a);
     } else if (s.ch == 2) {
-        if (resp) hipLaunchKernelGGL((k_harris_fused<true, 1>), grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_harris_fused<false, 1>), grid, dim3(256), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 1>), grid, dim3(256), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 1>), grid, dim3(256), 0, ctx->stream, a);
     } else {
-        if (resp) hipLaunchKernelGGL((k_harris_fused<true, 0>), grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_harris_fused<false, 0>), grid, dim3(256), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 0>), grid, dim3(256), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 0>), grid, dim3(256), 0, ctx->stream, a);
     }
     return rcv_launch_check(ctx);
 }

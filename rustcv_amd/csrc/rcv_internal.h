@@ -27,6 +27,13 @@ struct rcv_ctx {
     int f7_ksize;
     int f7_mode;         // 0 one table, 1 K = 4Q + R, 2 K = K1 + 2*T2 (which tables the cache holds)
     int16_t f7_k[49];
+    // cached launch plan of the strip kernel (segment height, latency variant) for the last geometry
+    int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_knob, f7_plan_seg_rows;
+    bool f7_plan_lat_ok, f7_plan_lat;
+    // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), kconst[32768..40960)
+    bool fr_valid;
+    int fr_ksize;
+    int8_t fr_k[49];
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
     // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
     bool capturing;
@@ -39,6 +46,31 @@ struct rcv_ctx {
     hipEvent_t pin_ev;           // recorded after the H2D that reads `pin`
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
+
+// Environment knobs (tuning sweeps and tests only; nothing needs them in production).  Read ONCE per process -- a launch-bound
+// call (a single 1080p frame: 6 us) must not pay for getenv -- and again on rcv__debug_reload_knobs() (tests, after setenv).
+struct RcvKnobs {
+    int f7_seg_rows;      // RCV_F7_SEG_ROWS   row-segment height of the MFMA strip kernel (0 = cost model)
+    int f7_tps;           // RCV_F7_TPS        15: 240-pixel strips
+    int f7_no_lat;        // RCV_F7_NO_LAT     small launches take the pipelined strip kernel instead of its latency variant
+    int f7_no_gray;       // RCV_F7_NO_GRAY    one-channel images take the dot4 streaming kernel
+    int f7_dual_full;     // RCV_F7_DUAL_FULL  large-weight kernels use K = 4Q + R even where the centre split applies
+    int f7_rows;          // RCV_F7_ROWS       row-streaming MFMA kernel: 1 every eligible shape, 0 never, -1 (unset) by size
+    int fr_rounds;        // RCV_FR_ROUNDS     bands per wave slot of the row-streaming kernel (0 = 8)
+    int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
+    int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
+    int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS
+};
+const RcvKnobs& rcv_knobs();
+
+// Every kernel launch goes through RCV_LAUNCH, which logs the kernel's name in a per-thread list: tests assert WHICH kernel an
+// entry point dispatched (rcv__debug_kernels / rcv__debug_kernels_reset) instead of guessing it from timings.
+void rcv_note_kernel(const char* name);
+#define RCV_LAUNCH(kernelName, ...)                    \
+    do {                                               \
+        rcv_note_kernel(#kernelName);                  \
+        hipLaunchKernelGGL(kernelName, __VA_ARGS__);   \
+    } while (0)
 
 // Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the
 // shared 64-KiB kconst area at `offset`, uploaded stream-ordered.  During capture: a fresh device buffer owned by the

@@ -524,19 +524,19 @@ static int cvt_flat(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst
     hipStream_t st = ctx->stream;
     if (code == RCV_YUYV2BGR || code == RCV_YUYV2BGR_TWIN) {
         size_t groups = vec ? units / 8 : 0;
-        if (groups) hipLaunchKernelGGL(k_yuyv2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups) RCV_LAUNCH(k_yuyv2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
         if (groups * 8 < units)
-            hipLaunchKernelGGL(k_yuyv2bgr_scalar, dim3(grid1d(units - groups * 8), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 8, units);
+            RCV_LAUNCH(k_yuyv2bgr_scalar, dim3(grid1d(units - groups * 8), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 8, units);
     } else if (code == RCV_BGRA2BGR || code == RCV_BGRA2BGR_TWIN) {
         size_t groups = vec ? units / 16 : 0;
-        if (groups) hipLaunchKernelGGL(k_bgra2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups) RCV_LAUNCH(k_bgra2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
         if (groups * 16 < units)
-            hipLaunchKernelGGL(k_bgra2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
+            RCV_LAUNCH(k_bgra2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
     } else {
         size_t groups = vec ? units / 16 : 0;
-        if (groups) hipLaunchKernelGGL(k_rgb2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
+        if (groups) RCV_LAUNCH(k_rgb2bgr_vec, dim3(grid1d(groups), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups);
         if (groups * 16 < units)
-            hipLaunchKernelGGL(k_rgb2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
+            RCV_LAUNCH(k_rgb2bgr_scalar, dim3(grid1d(units - groups * 16), n), dim3(kBlock), 0, st, s, d, sfs, dfs, groups * 16, units);
     }
     return rcv_launch_check(ctx);
 }
@@ -554,12 +554,12 @@ static int cvt_gray(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst)
     int vec = ((uintptr_t)s.p % 4 == 0) && (s.step % 4 == 0) && (s.fstride % 4 == 0) &&
               ((uintptr_t)d.p % 4 == 0) && (d.step % 4 == 0) && (d.fstride % 4 == 0);
     if (s.cols % 16 == 0 && al(s.p, s.step, s.fstride, s.n, 16) && al(d.p, d.step, d.fstride, d.n, 16)) {
-        hipLaunchKernelGGL(k_bgr2gray16, dim3(grid1d((size_t)s.cols / 16), s.rows, s.n), dim3(kBlock), 0, ctx->stream, s.p, d.p, s.step, d.step,
+        RCV_LAUNCH(k_bgr2gray16, dim3(grid1d((size_t)s.cols / 16), s.rows, s.n), dim3(kBlock), 0, ctx->stream, s.p, d.p, s.step, d.step,
                            s.fstride, d.fstride, s.cols);
         return rcv_launch_check(ctx);
     }
     dim3 grid(grid1d((size_t)(s.cols + 3) / 4), s.rows, s.n);
-    hipLaunchKernelGGL(k_bgr2gray, grid, dim3(kBlock), 0, ctx->stream, s.p, d.p, s.step, d.step, s.fstride, d.fstride,
+    RCV_LAUNCH(k_bgr2gray, grid, dim3(kBlock), 0, ctx->stream, s.p, d.p, s.step, d.step, s.fstride, d.fstride,
                        s.rows, s.cols, vec);
     return rcv_launch_check(ctx);
 }
@@ -583,7 +583,7 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
         if (npx == 0 || n == 0) return RCV_OK;
         if (!dm->data || (nconv && !sm->data)) return RCV_ERR_ARG;
         const int vec = al(sm->data, 4, src->frame_stride, n, 4) && al(dm->data, 16, dst->frame_stride, n, 16);
-        hipLaunchKernelGGL(k_bgr2bgrx, dim3(grid1d((npx + 3) / 4), n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, (uint8_t*)dm->data,
+        RCV_LAUNCH(k_bgr2bgrx, dim3(grid1d((npx + 3) / 4), n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, (uint8_t*)dm->data,
                            src->frame_stride, dst->frame_stride, nconv, npx, vec);
         return rcv_launch_check(ctx);
     }
@@ -598,7 +598,7 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
         if (need == 0 || n == 0) return RCV_OK;
         if (!dm->data) return RCV_ERR_ARG;
         const int vec = al(s.p, s.step, s.fstride, n, 4) && al(dm->data, (size_t)s.cols * 3, dst->frame_stride, n, 4);
-        hipLaunchKernelGGL(k_bgr2rgb_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, (uint8_t*)dm->data, s.step,
+        RCV_LAUNCH(k_bgr2rgb_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, (uint8_t*)dm->data, s.step,
                            s.fstride, dst->frame_stride, s.cols, vec);
         return rcv_launch_check(ctx);
     }
@@ -615,7 +615,7 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
         if (d.rows == 0 || d.cols == 0 || n == 0) return RCV_OK;
         if (!sm->data) return RCV_ERR_ARG;
         const int vec = al(sm->data, sm->step, src->frame_stride, n, 4) && al(d.p, d.step, d.fstride, n, 4);
-        hipLaunchKernelGGL(k_nv12_rows, dim3(grid1d((size_t)(d.cols + 3) / 4), d.rows, n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, d.p,
+        RCV_LAUNCH(k_nv12_rows, dim3(grid1d((size_t)(d.cols + 3) / 4), d.rows, n), dim3(kBlock), 0, st, (const uint8_t*)sm->data, d.p,
                            sm->step, d.step, src->frame_stride, d.fstride, d.rows, d.cols, vec);
         return rcv_launch_check(ctx);
     }
@@ -625,7 +625,7 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
         if (s.ch != 4 || d.ch != 3 || s.rows != d.rows || s.cols != d.cols) return RCV_ERR_ARG;
         if (s.rows == 0 || s.cols == 0 || n == 0) return RCV_OK;
         const int vec = al(s.p, s.step, s.fstride, n, 16) && al(d.p, d.step, d.fstride, n, 4);
-        hipLaunchKernelGGL(k_bgra2bgr_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step,
+        RCV_LAUNCH(k_bgra2bgr_rows, dim3(grid1d((size_t)(s.cols + 3) / 4), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step,
                            s.fstride, d.fstride, s.cols, vec);
         return rcv_launch_check(ctx);
     }
@@ -633,7 +633,7 @@ static int cvt_next_rows(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch
     if (s.ch != 2 || d.ch != 3 || s.rows != d.rows || s.cols != d.cols) return RCV_ERR_ARG;
     if (s.rows == 0 || s.cols < 2 || n == 0) return RCV_OK;
     const int vec = al(s.p, s.step, s.fstride, n, 8) && al(d.p, d.step, d.fstride, n, 4);
-    hipLaunchKernelGGL(k_yuv422_rows, dim3(grid1d((size_t)(s.cols / 4 + 1)), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step, s.fstride,
+    RCV_LAUNCH(k_yuv422_rows, dim3(grid1d((size_t)(s.cols / 4 + 1)), s.rows, n), dim3(kBlock), 0, st, s.p, d.p, s.step, d.step, s.fstride,
                        d.fstride, s.cols, code == RCV_UYVY2BGR_STRIDED ? 1 : 0, vec);
     return rcv_launch_check(ctx);
 }
@@ -686,11 +686,11 @@ extern "C" int rcv_rectangle_batch(rcv_ctx* ctx, rcv_batch* mats, int32_t x, int
     bool in_range = (long long)y_min + thick <= m->rows && (long long)y_max - thick >= 0 &&
                     (long long)x_min + thick <= m->cols && (long long)x_max - thick >= 0;
     if (!in_range && m->step % 3 != 0) {
-        hipLaunchKernelGGL(k_rectangle_serial, dim3(mats->n), dim3(64), 0, ctx->stream, (uint8_t*)m->data, mats->frame_stride,
+        RCV_LAUNCH(k_rectangle_serial, dim3(mats->n), dim3(64), 0, ctx->stream, (uint8_t*)m->data, mats->frame_stride,
                            m->cap, m->step, x_min, y_min, x_max, y_max, thick, b, g, r);
         return rcv_launch_check(ctx);
     }
-    hipLaunchKernelGGL(k_rectangle, dim3(grid1d((size_t)total), mats->n), dim3(kBlock), 0, ctx->stream, (uint8_t*)m->data,
+    RCV_LAUNCH(k_rectangle, dim3(grid1d((size_t)total), mats->n), dim3(kBlock), 0, ctx->stream, (uint8_t*)m->data,
                        mats->frame_stride, m->cap, m->step, x_min, y_min, x_max, y_max, thick, b, g, r);
     return rcv_launch_check(ctx);
 }
@@ -719,7 +719,7 @@ extern "C" int rcv_synth_batch(rcv_ctx* ctx, rcv_batch* dst, int family, uint64_
     if (family != RCV_SYNTH_YUYV && d.ch != 1 && d.ch != 3 && d.ch != 4) return RCV_ERR_UNSUPPORTED;
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     dim3 grid(grid1d((size_t)d.cols), d.rows, d.n);
-    hipLaunchKernelGGL(k_synth, grid, dim3(kBlock), 0, ctx->stream, d.p, d.fstride, d.step, d.rows, d.cols, d.ch, family, seed,
+    RCV_LAUNCH(k_synth, grid, dim3(kBlock), 0, ctx->stream, d.p, d.fstride, d.step, d.rows, d.cols, d.ch, family, seed,
                        frame_base);
     return rcv_launch_check(ctx);
 }

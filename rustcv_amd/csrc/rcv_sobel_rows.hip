@@ -225,18 +225,18 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     a.total_waves = (int)waves;
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (s.ch == 3) {
-        hipLaunchKernelGGL((k_sobel_rows<0, true>), grid, dim3(256), 0, ctx->stream, a);
+        RCV_LAUNCH((k_sobel_rows<0, true>), grid, dim3(256), 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE
     switch (rcv_debug_flags & 3) {
-    case 1: hipLaunchKernelGGL((k_sobel_rows<1, false>), grid, dim3(256), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_sobel_rows<2, false>), grid, dim3(256), 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((k_sobel_rows<3, false>), grid, dim3(256), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    case 1: RCV_LAUNCH((k_sobel_rows<1, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: RCV_LAUNCH((k_sobel_rows<2, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    case 3: RCV_LAUNCH((k_sobel_rows<3, false>), grid, dim3(256), 0, ctx->stream, a); break;
+    default: RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a); break;
     }
 #else
-    hipLaunchKernelGGL((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a);
+    RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), 0, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
 }

@@ -166,14 +166,14 @@ extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_b
         rc = rcv_gauss_int_stream(ctx, s, d, t, ksize, ksize == 3 ? 4 : (ksize == 5 ? 8 : 12));
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
         for (int i = 0; i < ksize; ++i) tp.t[i] = t[i];
-        hipLaunchKernelGGL(k_gauss_int_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
+        RCV_LAUNCH(k_gauss_int_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp);
     } else {
         TapsF32 tp;
         tp.ksize = ksize;
         RCV_TRY(rcv_gaussian_taps_f32(ksize, sigma, tp.t));
         int rc = rcv_gauss_f32_fast(ctx, s, d, tp.t, ksize);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
-        hipLaunchKernelGGL(k_gauss_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp, 0, s.cols * s.ch);
+        RCV_LAUNCH(k_gauss_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, tp, 0, s.cols * s.ch);
     }
     return rcv_launch_check(ctx);
 }
@@ -197,7 +197,7 @@ extern "C" int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     kw.ksize = ksize;
     kw.shift = shift;
     for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
-    hipLaunchKernelGGL(k_filter_i8_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw);
+    RCV_LAUNCH(k_filter_i8_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw);
     return rcv_launch_check(ctx);
 }
 
@@ -242,7 +242,7 @@ extern "C" int rcv_filter2d_f32_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
     kw.ksize = ksize;
     kw.delta = delta;
     for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
-    hipLaunchKernelGGL(k_filter_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw, 0, s.cols * s.ch);
+    RCV_LAUNCH(k_filter_f32_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, d, kw, 0, s.cols * s.ch);
     return rcv_launch_check(ctx);
 }
 
@@ -276,7 +276,7 @@ extern "C" int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx
         RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, src, &tb));
         return rcv_sobel_batch(ctx, &tb, dx, dy);
     }
-    hipLaunchKernelGGL(k_sobel_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, vx, vy);
+    RCV_LAUNCH(k_sobel_generic, sample_grid(s), dim3(kBlock), 0, ctx->stream, s, vx, vy);
     return rcv_launch_check(ctx);
 }
 
@@ -288,7 +288,7 @@ int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, con
     kw.delta = delta;
     for (int i = 0; i < ksize * ksize; ++i) kw.k[i] = k[i];
     dim3 grid((unsigned)((xb_hi - xb_lo + kBlock - 1) / kBlock), s.rows, s.n);
-    hipLaunchKernelGGL(k_filter_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, kw, xb_lo, xb_hi);
+    RCV_LAUNCH(k_filter_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, kw, xb_lo, xb_hi);
     return rcv_launch_check(ctx);
 }
 
@@ -299,7 +299,7 @@ int rcv_gauss_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, cons
     tp.ksize = ksize;
     for (int i = 0; i < ksize; ++i) tp.t[i] = taps[i];
     dim3 grid((unsigned)((xb_hi - xb_lo + kBlock - 1) / kBlock), s.rows, s.n);
-    hipLaunchKernelGGL(k_gauss_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, tp, xb_lo, xb_hi);
+    RCV_LAUNCH(k_gauss_f32_generic, grid, dim3(kBlock), 0, ctx->stream, s, d, tp, xb_lo, xb_hi);
     return rcv_launch_check(ctx);
 }
 

@@ -149,7 +149,7 @@ extern "C" int rcv_blend_glyphs_batch(rcv_ctx* ctx, rcv_batch* mats, const rcv_g
             ux1 = x1 > ux1 ? x1 : ux1, uy1 = y1 > uy1 ? y1 : uy1;
         }
         const unsigned gy = (unsigned)(uy1 - uy0 < 65535 ? uy1 - uy0 : 65535), gz = (unsigned)(m.n < 65535 ? m.n : 65535);
-        hipLaunchKernelGGL(k_blend_glyphs, dim3(cdiv((size_t)(ux1 - ux0), kBlock), gy, gz), dim3(kBlock), 0, ctx->stream, m.p, m.fstride,
+        RCV_LAUNCH(k_blend_glyphs, dim3(cdiv((size_t)(ux1 - ux0), kBlock), gy, gz), dim3(kBlock), 0, ctx->stream, m.p, m.fstride,
                            m.step, m.n, dtbl + c0, cn, dcov, (int)ux0, (int)uy0, (int)ux1, (int)uy1, (float)b, (float)g, (float)r);
         RCV_TRY(rcv_launch_check(ctx));
     }

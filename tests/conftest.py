@@ -35,3 +35,24 @@ def ctx():
 @pytest.fixture
 def rng():
     return np.random.default_rng(0xC0FFEE)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_knobs(request):
+    """librustcv_hip.so reads its RCV_* environment knobs once per process; start every GPU test from the current environment
+    (the previous test's monkeypatch has been undone by now)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from rustcv_amd import _ffi
+        _ffi.lib().rcv__debug_reload_knobs()
+    yield
+
+
+@pytest.fixture
+def knob(monkeypatch):
+    """knob("RCV_F7_NO_LAT") sets an environment knob of the library for this test and makes the library re-read them."""
+    from rustcv_amd import _ffi
+
+    def _set(name, value="1"):
+        monkeypatch.setenv(name, str(value))
+        _ffi.lib().rcv__debug_reload_knobs()
+    return _set

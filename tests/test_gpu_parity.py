@@ -380,11 +380,14 @@ MFMA_SHAPES = [(4, 16), (5, 32), (16, 16), (17, 48), (33, 240), (40, 256), (19, 
 @pytest.mark.parametrize("rows,cols", MFMA_SHAPES)
 @pytest.mark.parametrize("ksize,shift", [(7, 6), (5, 3), (3, 0), (7, 0)])
 @pytest.mark.parametrize("pad", [0, 32])
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_filter2d_i8_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize, shift, pad, pipelined):
-    # small launches take the kernel's latency variant; RCV_F7_NO_LAT sends the same shapes through the pipelined one
-    if pipelined:
-        monkeypatch.setenv("RCV_F7_NO_LAT", "1")
+@pytest.mark.parametrize("pipelined", [False, True, "rows"])
+def test_filter2d_i8_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, shift, pad, pipelined):
+    # small launches take the strip kernel's latency variant; RCV_F7_NO_LAT sends the same shapes through the pipelined one,
+    # RCV_F7_ROWS=1 through the row-streaming kernel (which by default only takes launches that fill the GPU)
+    if pipelined == "rows":
+        knob("RCV_F7_ROWS")
+    elif pipelined:
+        knob("RCV_F7_NO_LAT")
     img = rand_img(rng, rows, cols, 3)
     k = rng.integers(-128, 128, size=(ksize, ksize), dtype=np.int8) if shift == 0 else rng.integers(-9, 10, size=(ksize, ksize)).astype(np.int8)
     src = Mat.from_array(img, step=cols * 3 + pad)
@@ -399,12 +402,14 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize,
 
 @pytest.mark.parametrize("rows,cols", [(4, 16), (33, 240), (19, 496), (300, 272)])
 @pytest.mark.parametrize("ksize", [3, 5, 7])
-@pytest.mark.parametrize("full_tables", [False, True])
-def test_gaussian_int_mfma_path(ctx, oracle, rng, monkeypatch, rows, cols, ksize, full_tables):
+@pytest.mark.parametrize("full_tables", [False, True, "rows"])
+def test_gaussian_int_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, full_tables):
     """integer GaussianBlur on the MFMA strip kernel.  ksize 7 has weights up to 324: two weight tables, by default the
     centre split K = K1 + 2*T2 (second table in kernel rows 2..4 only), with RCV_F7_DUAL_FULL the general K = 4Q + R"""
-    if full_tables:
-        monkeypatch.setenv("RCV_F7_DUAL_FULL", "1")
+    if full_tables == "rows":
+        knob("RCV_F7_ROWS")   # (ksize 3 / 5: weights inside i8 -> the row-streaming kernel; 7 stays on the two-table strip kernel)
+    elif full_tables:
+        knob("RCV_F7_DUAL_FULL")
     img = rand_img(rng, rows, cols, 3)
     img[: rows // 2] = 255  # saturating region: sums reach 255 * D exactly
     src, dst = Mat.from_array(img), Mat(rows, cols, 3)
@@ -434,13 +439,15 @@ def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
     dst.free()
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_filter2d_i8_mfma_random_shapes(ctx, oracle, monkeypatch, pipelined):
+@pytest.mark.parametrize("pipelined", [False, True, "rows"])
+def test_filter2d_i8_mfma_random_shapes(ctx, oracle, knob, pipelined):
     """(latency variant of the kernel for these small launches, and -- RCV_F7_NO_LAT -- the pipelined one)  40 x RCV_SOAK seeded random cases for the MFMA strip kernel: widths 16..1040 (multiples of 16: partial last strips, one to five strips),
     heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
     padded steps, batch 1..3, BGR and YUYV sources"""
-    if pipelined:
-        monkeypatch.setenv("RCV_F7_NO_LAT", "1")
+    if pipelined == "rows":
+        knob("RCV_F7_ROWS")   # (BGR sources: the row-streaming kernel; the YUYV cases keep the strip kernel)
+    elif pipelined:
+        knob("RCV_F7_NO_LAT")
     r = np.random.default_rng(0xF17E7 + _SOAK_SEED)
     for case in range(40 * _SOAK):
         cols = 16 * int(r.integers(1, 66))
@@ -510,7 +517,7 @@ GRAY_MFMA_COLS = [16, 32, 48, 64, 240, 752, 768, 784, 800, 816, 1520, 1536, 1552
 @pytest.mark.parametrize("cols", GRAY_MFMA_COLS)
 @pytest.mark.parametrize("dot4", [False, True])
 @pytest.mark.parametrize("pipelined", [False, True])
-def test_gray_filter_strip_kernel(ctx, oracle, monkeypatch, cols, dot4, pipelined):
+def test_gray_filter_strip_kernel(ctx, oracle, knob, cols, dot4, pipelined):
     """one-channel images on 16-byte aligned rows take the MFMA strip kernel's gray variant (768-pixel strips of 48 tiles):
     widths around the strip seams (one to three + strips; a last strip with 1, 2, 3, ... tiles -- every position ntiles % 3 of the
     right border inside a lane's 48-pixel chunk -- and full last strips, whose border sits in the halo piece), heights across
@@ -519,9 +526,9 @@ def test_gray_filter_strip_kernel(ctx, oracle, monkeypatch, cols, dot4, pipeline
     if dot4:
         if pipelined:
             pytest.skip("the dot4 kernel has one variant")
-        monkeypatch.setenv("RCV_F7_NO_GRAY", "1")
+        knob("RCV_F7_NO_GRAY")
     if pipelined:
-        monkeypatch.setenv("RCV_F7_NO_LAT", "1")   # (small launches would otherwise all take the strip kernel's latency variant)
+        knob("RCV_F7_NO_LAT")   # (small launches would otherwise all take the strip kernel's latency variant)
     r = np.random.default_rng(0x6A4700 + cols + _SOAK_SEED)
     for case in range(max(2, _SOAK // 2)):
         rows = int(r.integers(4, 120))
