@@ -246,7 +246,8 @@ int  rcv_ring_input(rcv_ring* ring, rcv_mat* host_in);
  * (the slot still has to be retired), RCV_ERR_BUSY if `depth` frames are already in flight */
 int  rcv_ring_submit(rcv_ring* ring, const rcv_mat* host_in, rcv_ring_op op, void* user);
 /* wait for the OLDEST frame; copy it to host_out (may be NULL) and/or describe the ring's own pinned output buffer in
- * *pinned_out (may be NULL; valid until `depth` further submits).  RCV_NOOP if nothing is in flight */
+ * *pinned_out (may be NULL).  The pinned view belongs to the slot just retired, which the NEXT rcv_ring_submit may reuse
+ * (always, when the ring was full): it is valid only until the next rcv_ring_submit.  RCV_NOOP if nothing is in flight */
 int  rcv_ring_retire(rcv_ring* ring, rcv_mat* host_out, rcv_mat* pinned_out);
 
 /* ---- launch graphs -------------------------------------------------------------------------------------------------
@@ -254,8 +255,11 @@ int  rcv_ring_retire(rcv_ring* ring, rcv_mat* host_out, rcv_mat* pinned_out);
  * one 1080p blur) are bound by launch latency.  rcv_graph_begin .. rcv_graph_end records the rcv_*_batch calls (and
  * single-Mat calls on RCV_DEVICE mats) made on `ctx` instead of executing them; rcv_graph_launch replays the chain as
  * one submission on the context stream.  Replays use the same device pointers -- refresh the buffers' contents between
- * launches.  Entry points that have to synchronise (host mats, rcv_sync, rcv_upload/rcv_download, timers, the ring,
- * workspace growth) return RCV_ERR_UNSUPPORTED while recording. */
+ * launches.  Entry points that have to synchronise (host mats, rcv_sync, rcv_free, rcv_upload/rcv_download, timers, the
+ * ring) return RCV_ERR_UNSUPPORTED while recording.  A graph owns every constant table and every workspace its ops used
+ * while they were recorded; it keeps its context alive (rcv_ctx_destroy on a context with live graphs or rings only drains
+ * the stream; the memory goes when the last of them is destroyed).  EXPERIMENTAL: on ROCm 7.2 a replay measured slower
+ * than the same calls made directly (profiles/graph_bench.json); nothing in the library uses graphs by itself. */
 typedef struct rcv_graph rcv_graph;
 int  rcv_graph_begin(rcv_ctx* ctx);
 int  rcv_graph_end(rcv_ctx* ctx, rcv_graph** out);

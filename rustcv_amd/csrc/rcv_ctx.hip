@@ -117,11 +117,34 @@ extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
     return RCV_OK;
 }
 
+// Graphs and staging rings keep a pointer to their context (device, stream).  Destroying the context first -- easy from a
+// garbage-collected host language -- must not leave them dangling: the context then only drains its stream and stays
+// allocated until its last child is destroyed.
+static void ctx_finalize(rcv_ctx* c);
+
 extern "C" void rcv_ctx_destroy(rcv_ctx* c)
 {
     if (!c) return;
+    if (c->children > 0) {
+        (void)hipSetDevice(c->device);
+        if (c->stream && !c->capturing) (void)hipStreamSynchronize(c->stream);
+        c->zombie = true;
+        return;
+    }
+    ctx_finalize(c);
+}
+
+void rcv_ctx_child_released(rcv_ctx* c)
+{
+    if (!c) return;
+    if (c->children > 0) c->children--;
+    if (c->zombie && c->children == 0) ctx_finalize(c);
+}
+
+static void ctx_finalize(rcv_ctx* c)
+{
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && !c->capturing) (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     if (c->tmp2) (void)hipFree(c->tmp2);
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
@@ -145,7 +168,7 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
 
 int rcv_bind(rcv_ctx* ctx)
 {
-    if (!ctx) return RCV_ERR_ARG;
+    if (!ctx || ctx->zombie) return RCV_ERR_ARG;
     RCV_HIP(hipSetDevice(ctx->device));
     return RCV_OK;
 }
@@ -181,6 +204,7 @@ extern "C" int rcv_free(rcv_ctx* ctx, void* p)
 {
     RCV_TRY(rcv_bind(ctx));
     if (!p) return RCV_OK;
+    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // would synchronise the recording stream
     RCV_HIP(hipStreamSynchronize(ctx->stream));
     RCV_HIP(hipFree(p));
     return RCV_OK;
@@ -271,24 +295,45 @@ extern "C" int rcv_gaussian_taps_f32(int ksize, double sigma, float* taps)
 // ---- workspace ------------------------------------------------------------------------------
 // Kernel-internal temporaries (unfused intermediates).  rcv_ws_reserve(total) first, then carve.
 
+// While a graph is being recorded a workspace is a FRESH allocation owned by that graph (like its constant tables): replays
+// must never depend on the context's grow-only buffers, which a later, larger call frees and re-allocates.
+static int graph_owned_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out)
+{
+    if (ctx->cap_nallocs >= 64) return RCV_ERR_UNSUPPORTED;
+    void* p = nullptr;
+    RCV_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    ctx->cap_allocs[ctx->cap_nallocs++] = p;
+    *out = (uint8_t*)p;
+    return RCV_OK;
+}
+
 int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
 {
     ctx->ws_off = 0;
-    if (total <= ctx->ws_cap) return RCV_OK;
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // growing means free + sync: run the op once before capturing
-    RCV_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->ws) RCV_HIP(hipFree(ctx->ws));
-    ctx->ws = nullptr;
-    ctx->ws_cap = 0;
-    RCV_HIP(hipMalloc((void**)&ctx->ws, total));
-    ctx->ws_cap = total;
+    if (ctx->capturing) {
+        ctx->ws_cur = nullptr;
+        ctx->ws_cur_cap = 0;
+        RCV_TRY(graph_owned_alloc(ctx, total, &ctx->ws_cur));
+        ctx->ws_cur_cap = total;
+        return RCV_OK;
+    }
+    if (total > ctx->ws_cap) {
+        RCV_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ws) RCV_HIP(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_cap = 0;
+        RCV_HIP(hipMalloc((void**)&ctx->ws, total));
+        ctx->ws_cap = total;
+    }
+    ctx->ws_cur = ctx->ws;
+    ctx->ws_cur_cap = ctx->ws_cap;
     return RCV_OK;
 }
 
 int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 {
+    if (ctx->capturing) return graph_owned_alloc(ctx, bytes, out);
     if (bytes > ctx->tmp2_cap) {
-        if (ctx->capturing) return RCV_ERR_UNSUPPORTED;
         RCV_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->tmp2) RCV_HIP(hipFree(ctx->tmp2));
         ctx->tmp2 = nullptr;
@@ -303,8 +348,8 @@ int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 {
     size_t off = (ctx->ws_off + 255) & ~(size_t)255;
-    if (off + bytes > ctx->ws_cap) return RCV_ERR_OOM;
-    *out = ctx->ws + off;
+    if (!ctx->ws_cur || off + bytes > ctx->ws_cur_cap) return RCV_ERR_OOM;
+    *out = ctx->ws_cur + off;
     ctx->ws_off = off + bytes;
     return RCV_OK;
 }

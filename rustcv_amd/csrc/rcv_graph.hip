@@ -8,9 +8,11 @@
 //
 // What a graph owns: per-call constant tables (the banded weight operand of the MFMA filter) are copied into device
 // buffers of the graph at record time, so a replay never depends on what later calls leave in the context's shared
-// constant cache.  What it does not own: the image buffers -- replays read and write the same device pointers, the
-// caller refreshes their contents between launches.  Entry points that must synchronise (host-Mat staging, rcv_sync,
-// rcv_upload/rcv_download, timers, the staging ring, workspace growth) return RCV_ERR_UNSUPPORTED while recording.
+// constant cache, and every workspace an op carves while it is being recorded (the intermediates of the unfused
+// fallbacks) is a fresh allocation of the graph -- never the context's grow-only workspace, which a later, larger call
+// would free under the graph's feet.  What it does not own: the image buffers -- replays read and write the same device
+// pointers, the caller refreshes their contents between launches.  Entry points that must synchronise (host-Mat staging,
+// rcv_sync, rcv_free, rcv_upload/rcv_download, timers, the staging ring) return RCV_ERR_UNSUPPORTED while recording.
 #include "rcv_internal.h"
 #include <string.h>
 #include <new>
@@ -61,6 +63,7 @@ extern "C" int rcv_graph_end(rcv_ctx* ctx, rcv_graph** out)
     r->nallocs = ctx->cap_nallocs;
     memcpy(r->allocs, ctx->cap_allocs, sizeof(void*) * r->nallocs);
     ctx->cap_nallocs = 0;
+    ctx->children++;   // the graph keeps using ctx's device and stream: rcv_ctx_destroy defers while it is alive
     *out = r;
     return RCV_OK;
 }
@@ -84,5 +87,7 @@ extern "C" void rcv_graph_destroy(rcv_graph* g)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     for (int i = 0; i < g->nallocs; ++i) (void)hipFree(g->allocs[i]);
+    rcv_ctx* owner = g->ctx;
     delete g;
+    if (owner) rcv_ctx_child_released(owner);
 }

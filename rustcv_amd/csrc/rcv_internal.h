@@ -17,6 +17,8 @@ struct rcv_ctx {
     // workspace for kernel-internal temporaries (reserve once per call, then carve)
     uint8_t* ws;
     size_t ws_cap, ws_off;
+    uint8_t* ws_cur;     // what rcv_ws_alloc carves: ws, or (while a graph is recorded) a buffer owned by that graph
+    size_t ws_cur_cap;
     uint8_t* tmp2;       // second grow-only temporary (an intermediate image of a two-stage fallback whose second stage uses ws)
     size_t tmp2_cap;
     // small device scratch for per-call constants (filter taps, weight tables)
@@ -44,6 +46,8 @@ struct rcv_ctx {
     uint8_t* pin;
     size_t pin_cap;
     hipEvent_t pin_ev;           // recorded after the H2D that reads `pin`
+    int children;                // live graphs / staging rings that use this context's device and stream
+    bool zombie;                 // rcv_ctx_destroy was called while children were alive: freed when the last one goes
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
@@ -104,6 +108,7 @@ struct View {
 static inline int rcv_elem_size(int depth) { return depth == RCV_8U ? 1 : (depth == RCV_16S ? 2 : (depth == RCV_32F ? 4 : 0)); }
 
 // ---- helpers implemented in rcv_ctx.hip -------------------------------------------------
+void rcv_ctx_child_released(rcv_ctx* ctx);                   // a graph / ring of this context was destroyed
 int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ctx->device)
 int rcv_launch_check(rcv_ctx* ctx);                           // hipGetLastError -> code
 int rcv_ws_reserve(rcv_ctx* ctx, size_t total);               // (re)size the workspace, reset the carve pointer

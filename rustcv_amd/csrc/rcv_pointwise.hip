@@ -517,6 +517,7 @@ static int cvt_flat(rcv_ctx* ctx, int code, const rcv_batch* src, rcv_batch* dst
     }
     if (units == 0 || n == 0) return RCV_OK;
     if (!sm->data || !dm->data) return RCV_ERR_ARG;
+    if (n > 65535) return RCV_ERR_UNSUPPORTED;   // frames ride on grid.y
     const uint8_t* s = (const uint8_t*)sm->data;
     uint8_t* d = (uint8_t*)dm->data;
     size_t sfs = src->frame_stride, dfs = dst->frame_stride;
@@ -551,6 +552,7 @@ static int cvt_gray(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst)
     if (s.ch != 3 || d.ch != 1) return RCV_ERR_UNSUPPORTED;
     if (s.rows != d.rows || s.cols != d.cols || s.n != d.n) return RCV_ERR_ARG;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;   // rows ride on grid.y, frames on grid.z
     int vec = ((uintptr_t)s.p % 4 == 0) && (s.step % 4 == 0) && (s.fstride % 4 == 0) &&
               ((uintptr_t)d.p % 4 == 0) && (d.step % 4 == 0) && (d.fstride % 4 == 0);
     if (s.cols % 16 == 0 && al(s.p, s.step, s.fstride, s.n, 16) && al(d.p, d.step, d.fstride, d.n, 16)) {

@@ -30,6 +30,7 @@ struct rcv_ring {
         hipEvent_t ev_in, ev_k, ev_out;
     }* slots;
     unsigned long long head, tail;  // submitted / retired frame counts
+    bool counted;                   // registered as a child of ctx (rcv_ctx_destroy defers while children are alive)
 };
 
 namespace {
@@ -104,6 +105,8 @@ extern "C" int rcv_ring_create(rcv_ctx* ctx, int depth, int in_rows, int in_cols
         rcv_ring_destroy(r);
         return RCV_ERR_OOM;
     }
+    ctx->children++;
+    r->counted = true;
     *out = r;
     return RCV_OK;
 }
@@ -128,7 +131,9 @@ extern "C" void rcv_ring_destroy(rcv_ring* r)
     delete[] r->slots;
     if (r->s_in) (void)hipStreamDestroy(r->s_in);
     if (r->s_out) (void)hipStreamDestroy(r->s_out);
+    rcv_ctx* owner = r->counted ? r->ctx : nullptr;
     delete r;
+    if (owner) rcv_ctx_child_released(owner);
 }
 
 extern "C" int rcv_ring_in_flight(const rcv_ring* r) { return r ? (int)(r->head - r->tail) : RCV_ERR_ARG; }
@@ -170,17 +175,24 @@ extern "C" int rcv_ring_submit(rcv_ring* r, const rcv_mat* host_in, rcv_ring_op 
     dout.data = s.dev_out;
     dout.device = RCV_DEVICE;
     const int rc = op(ctx, &din, &dout, user);
-    // the events are recorded even when the op failed, so that the slot can be retired and the ring stays consistent
-    RCV_HIP(hipEventRecord(s.ev_k, ctx->stream));
-    RCV_HIP(hipStreamWaitEvent(r->s_out, s.ev_k, 0));
-    RCV_HIP(hipMemcpyAsync(s.pin_out, s.dev_out, r->out_bytes, hipMemcpyDeviceToHost, r->s_out));
-    RCV_HIP(hipEventRecord(s.ev_out, r->s_out));
+    // Once the op has been invoked the frame is in flight: the slot's events are recorded and `head` advances even when the
+    // op or one of the calls below failed, so that the slot can be retired and the ring stays consistent.
+    hipError_t e = hipEventRecord(s.ev_k, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(r->s_out, s.ev_k, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.pin_out, s.dev_out, r->out_bytes, hipMemcpyDeviceToHost, r->s_out);
+    const hipError_t e2 = hipEventRecord(s.ev_out, r->s_out);   // (always: retire waits on this event)
     r->head++;
+    if (e != hipSuccess || e2 != hipSuccess) {
+        (void)hipGetLastError();
+        return rc < 0 ? rc : RCV_ERR_DEVICE;
+    }
     return rc < 0 ? rc : RCV_OK;
 }
 
 // Wait for the oldest frame in flight.  host_out may be NULL; *pinned_out (optional) receives a view of the ring's own
-// pinned output buffer, valid until `depth` further submits.  RCV_NOOP when nothing is in flight.
+// pinned output buffer.  That buffer belongs to the slot just retired, which is the slot the NEXT rcv_ring_submit may use
+// (always, when the ring was full): the view is valid only until the next rcv_ring_submit -- consume or copy it before
+// submitting again.  RCV_NOOP when nothing is in flight.
 extern "C" int rcv_ring_retire(rcv_ring* r, rcv_mat* host_out, rcv_mat* pinned_out)
 {
     if (!r) return RCV_ERR_ARG;

@@ -84,7 +84,9 @@ class StagingRing:
         _ffi.check(rc, "rcv_ring_submit")
 
     def retire(self, out=None, copy=True):
-        """wait for the oldest frame; returns it as an ndarray (a copy unless copy=False: then a view of the pinned buffer)"""
+        """wait for the oldest frame; returns it as an ndarray: a copy, or -- copy=False -- a view of the ring's pinned buffer of
+        the slot just retired.  That slot is the one the NEXT submit() may reuse (always, when the ring was full), so a view is
+        valid only until the next submit(): consume it first."""
         r, c, ch = self._out_shape
         dt = np.dtype(_NP[self._out_depth])
         if not copy:

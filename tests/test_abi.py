@@ -100,3 +100,95 @@ def test_cpp_facade_compiles_and_links(tmp_path):
                            "-o", str(exe), "-L", os.path.join(ROOT, "rustcv_amd"), "-lrustcv_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "rustcv_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+# ---- the Rust side of the boundary (rust/rustcv-backend-hip): never compiled here (no rustc), so it is held against the C
+# ---- header mechanically: names, arities, parameter kinds, struct fields in order, constants with their values ---------------
+RUST_FFI = os.path.join(ROOT, "rust", "rustcv-backend-hip", "src", "ffi.rs")
+
+
+def _c_kind(ctype):
+    """coarse, language-neutral description of a C type: (pointer depth, const-ness of the pointee, base)"""
+    t = " ".join(re.sub(r"/\*.*?\*/", "", ctype).split())
+    const = t.startswith("const ")
+    t = t[6:] if const else t
+    base = t.replace("*", "").strip()
+    base = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int8_t": "i8", "size_t": "usize",
+            "float": "f32", "double": "f64", "char": "c_char", "void": "void"}.get(base, base)
+    return (t.count("*"), const and t.count("*") > 0, base)
+
+
+def _rust_kind(rtype):
+    t = rtype.strip()
+    depth, const = 0, False
+    while t.startswith("*"):
+        depth += 1
+        if t.startswith("*const "):
+            t, const = t[7:], True
+        else:
+            t = t[5:]
+    base = {"c_int": "i32", "c_void": "void"}.get(t.strip(), t.strip())
+    return (depth, const, base)
+
+
+def _parse_header():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    funcs = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?\w+\s*\**)\s*(rcv_\w+)\s*\(([^;{]*?)\)\s*;", src, re.M | re.S):
+        params = [] if m.group(3).strip() in ("", "void") else [" ".join(p.split()) for p in m.group(3).split(",")]
+        funcs[m.group(2)] = (_c_kind(m.group(1)), [_c_kind(re.match(r"(.+?)\w+$", p).group(1)) for p in params])
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+\w+\s*\{(.*?)\}\s*(\w+)\s*;", src, re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                mm = re.match(r"((?:const\s+)?\w+\s*\**)\s*(.+)$", decl)
+                fields += [(n.strip().lstrip("*"), _c_kind(mm.group(1) + "*" * n.count("*"))) for n in mm.group(2).split(",")]
+        structs[m.group(2)] = fields
+    consts = {m.group(1): int(m.group(2).strip("() ")) for m in re.finditer(r"^#define\s+(RCV_\w+)\s+(\(?-?\d+\)?)\s*$", src, re.M)}
+    return funcs, structs, consts
+
+
+def _parse_rust():
+    src = open(RUST_FFI).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', src, re.S).group(1)
+    funcs = {}
+    for m in re.finditer(r"pub fn (\w+)\((.*?)\)(?: -> ([^;]+))?;", block):
+        params = [p.split(":", 1)[1] for p in m.group(2).split(", ")] if m.group(2).strip() else []
+        funcs[m.group(1)] = (_rust_kind(m.group(3)) if m.group(3) else (0, False, "void"), [_rust_kind(p) for p in params])
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\n(?:#\[derive\([^)]*\)\]\n)?pub struct (\w+) \{(.*?)\n\}", src, re.S):
+        fields = [(f.group(1).rstrip("_"), _rust_kind(f.group(2))) for f in re.finditer(r"pub (\w+): ([^,]+),", m.group(2))]
+        structs[m.group(1)] = fields
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (RCV_\w+): c_int = (-?\d+);", src)}
+    return funcs, structs, consts
+
+
+def test_rust_ffi_declares_the_whole_header():
+    """every function (name, arity, pointer depth / const-ness / base type of the result and of each parameter), every struct (fields
+    in order) and every constant of include/rustcv_hip.h is declared identically in the Rust crate's extern "C" block -- the
+    precedent declares the whole bridge (rustcv-camera/src/backend/macos/mod.rs:52-79 vs bridge.h:36-65)"""
+    hf, hs, hc = _parse_header()
+    rf, rs, rc = _parse_rust()
+    assert sorted(hf) == declared_symbols()                 # the parser sees every prototype of the header
+    assert sorted(rf) == sorted(hf), sorted(set(hf) ^ set(rf))
+    for name in hf:
+        assert rf[name] == hf[name], (name, rf[name], hf[name])
+    opaque = {k for k, v in rs.items() if not v}             # zero-sized handles (only a private field)
+    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph"}
+    for name, fields in hs.items():
+        assert rs[name] == fields, (name, rs[name], fields)
+    assert rc == hc and len(hc) >= 29
+
+
+def test_rust_ffi_is_up_to_date():
+    """rust/rustcv-backend-hip/src/ffi.rs is what tools/gen_rust_ffi.py derives from the header today"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(RUST_FFI).read() == gen.generate(), "stale: run python tools/gen_rust_ffi.py"
+    lib_rs = open(os.path.join(ROOT, "rust", "rustcv-backend-hip", "src", "lib.rs")).read()
+    assert "pub mod ffi;" in lib_rs and 'extern "C" {' not in lib_rs      # one declaration of the ABI, the generated one
+    assert "as i32, channels: 1" not in lib_rs                              # (flat-buffer views must not truncate lengths)

@@ -88,3 +88,65 @@ def test_graph_refuses_synchronising_calls(ctx, rng):
     g.close()
     d.free()
     d2.free()
+
+
+def test_graph_owns_its_workspace(ctx, oracle, rng):
+    """An op that goes through the context workspace (unfused Harris pipeline, block 3: gray + gradients + response through
+    `ws`) is recorded; afterwards a LARGER call of the same kind makes the context free and re-allocate its grow-only workspace.
+    The replay must not depend on that memory: a graph owns the workspace its ops used while they were recorded."""
+    rows, cols = 64, 96
+    src = device.DeviceBatch(ctx, 1, rows, cols, 3)
+    mask = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    frame = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+    src.upload(frame[None])
+    device.harris_pipeline(src, mask, None, 3, 0.04, 1e-6)            # run once: the context workspace exists at this size
+    with ctx.capture() as g:
+        device.harris_pipeline(src, mask, None, 3, 0.04, 1e-6)
+    want = oracle.harris_pipeline(frame, 3, 0.04, 1e-6)
+    for rounds in range(3):
+        big_s = device.DeviceBatch(ctx, 2, 300 + 200 * rounds, 512, 3)       # grows ws: free + hipMalloc of the context buffer
+        big_m = device.DeviceBatch(ctx, 2, 300 + 200 * rounds, 512, 1)
+        device.synth(big_s, 1, 5 + rounds, 0)
+        device.harris_pipeline(big_s, big_m, None, 3, 0.04, 1e-6)
+        mask.memset(7)
+        g.launch()
+        assert np.array_equal(mask.download()[0], want), rounds
+        big_s.free()
+        big_m.free()
+    g.close()
+    src.free()
+    mask.free()
+
+
+def test_graph_and_ring_outlive_their_context():
+    """rcv_ctx_destroy on a context with live graphs / rings only drains it; the children stay usable for destruction and the
+    context's memory goes with the last of them (Python: Context.close() is explicit, Graph / StagingRing finalisers run later)"""
+    c = rcv.Context(0)
+    a, b = device.DeviceBatch(c, 1, 32, 64, 3), device.DeviceBatch(c, 1, 32, 64, 1)
+    with c.capture() as g:
+        device.cvt_color(a, b, _ffi.RCV_BGR2GRAY)
+    g.launch()
+    c.sync()
+    ring = rcv.StagingRing(c, 2, (32, 64, 3), (32, 64, 1))
+    a.free()
+    b.free()
+    c.close()            # children alive: deferred
+    g.close()            # must not touch freed memory
+    ring.close()         # last child: the context is finalised here
+    c2 = rcv.Context(0)  # the device is still usable
+    c2.sync()
+    c2.close()
+
+
+def test_free_is_refused_while_recording(ctx):
+    L = _ffi.lib()
+    d = device.DeviceBatch(ctx, 1, 16, 32, 3)
+    d2 = device.DeviceBatch(ctx, 1, 16, 32, 3)
+    with ctx.capture() as g:
+        assert L.rcv_free(ctx.handle, d.ptr) == _ffi.RCV_ERR_UNSUPPORTED     # would synchronise the recording stream
+        device.gaussian_blur(d, d2, 3, 0.0)
+    g.launch()
+    ctx.sync()
+    g.close()
+    d.free()
+    d2.free()
