@@ -13,6 +13,12 @@
 // is used.  Rows are prefetched a group of 8 ahead into registers; all loads and stores are unconditional
 // (clamped addresses / dump line) so the compiler can keep counted vmcnt waits.  BORDER_REFLECT_101: rows by
 // index reflection, the single reflected column at each image edge by a byte move inside the edge lane.
+// RAG instantiation: ANY width >= 8 and ANY alignment (the reference's Mat::new gives step = cols * channels,
+// rustcv/src/core/mat.rs:18-29, so odd widths mean byte-aligned rows): the same window on unaligned 8-byte loads and
+// 16-byte stores (one wave instruction then costs ~45 instead of ~16 cycles of the address path -- still far from the
+// generic per-sample kernels these shapes used to fall to), the lane that holds the last, partial run of a row rebuilds
+// its 8 logical pixels -- the valid ones and their mirror images -- from the clamped load with one byte permute per
+// dword, and stores only its valid samples.
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
@@ -51,11 +57,16 @@ __device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b)  // a + 2*b
 }
 
 struct U2 { uint32_t lo, hi; };
+struct __attribute__((packed, aligned(1))) U2u { uint32_t lo, hi; };          // unaligned views (RAG)
+struct __attribute__((packed, aligned(1))) U1u { uint32_t v; };
+struct __attribute__((packed, aligned(2))) U4u { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(2))) U2h { uint32_t a, b; };
+struct __attribute__((packed, aligned(2))) U1h { uint32_t a; };
 
 // DBG (profiling builds, -DRCV_ABLATE): 1 skip global stores, 2 skip global loads
 // BGR = true: the source is a BGR image and the gradient is taken of its gray conversion (the fixed-point BT.601 of
 // RCV_BGR2GRAY, two v_dot4 per pixel) -- cvtColor + Sobel in one launch, 7 instead of 9 bytes per pixel and no gray image.
-template <int DBG, bool BGR>
+template <int DBG, bool BGR, bool RAG = false>
 __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -70,6 +81,21 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     const int xc = min(x, a.cols - 8);                         // clamped load position
     const bool edgeR = x == a.cols;                            // lane right of the image: supplies the mirrored column cols-2
     const bool live = x < a.cols;
+    // RAG: the lane's 8 logical pixels x .. x+7 (beyond the image: their mirror images) as byte selectors into the 8 bytes it
+    // loads from the clamped position xc; identity for every lane whose run lies inside the image
+    uint32_t sel_lo = 0x03020100u, sel_hi = 0x07060504u;
+    int nvalid = 8;
+    if (RAG) {
+        nvalid = min(max(a.cols - x, 0), 8);
+        sel_lo = sel_hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = x + j, pr = p < a.cols ? p : 2 * a.cols - 2 - p;
+            const uint32_t idx = (uint32_t)min(max(pr - xc, 0), 7);
+            if (j < 4) sel_lo |= idx << (8 * j);
+            else sel_hi |= idx << (8 * (j - 4));
+        }
+    }
     // the pixel outside the wave: lane 0 needs x-1 (mirror: 1), lane 63 needs x+8 (mirror: cols-2); other lanes load
     // a harmless in-row byte so that the load stays unconditional
     const int xe = lane == 0 ? (x == 0 ? 1 : x - 1) : min(x + 8 >= a.cols ? a.cols - 2 : x + 8, a.cols - 1);
@@ -101,6 +127,22 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
             return w;
         }
         const uint8_t* row = sf + (size_t)r * a.sstep;
+        if constexpr (RAG) {
+            const U2u q0 = *(const U2u*)row;
+            w.d[0] = q0.lo; w.d[1] = q0.hi;
+            if constexpr (BGR) {
+                const U2u q1 = *(const U2u*)(row + 8), q2 = *(const U2u*)(row + 16);
+                w.d[2] = q1.lo; w.d[3] = q1.hi; w.d[4] = q2.lo; w.d[5] = q2.hi;
+                // edge pixel: the (unaligned) dword at its first byte, clamped so that it ends inside the row
+                const unsigned ec = min(eoff, (unsigned)(3 * a.cols - 4));
+                w.e0 = (*(const U1u*)(se + (size_t)r * a.sstep + ec)).v >> (8 * (eoff - ec));
+                w.e1 = 0;
+            } else {
+                w.e0 = se[(size_t)r * a.sstep + eoff];
+                w.e1 = 0;
+            }
+            return w;
+        }
         const U2 q0 = *(const U2*)row;
         w.d[0] = q0.lo; w.d[1] = q0.hi;
         if constexpr (BGR) {
@@ -126,7 +168,7 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
                 const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;
                 g[j] = gray_of(sh == 0 ? w.d[w0] : __builtin_amdgcn_alignbyte(w.d[w0 + 1 < 6 ? w0 + 1 : 5], w.d[w0], sh));
             }
-            const uint32_t ge = gray_of(__builtin_amdgcn_alignbyte(w.e1, w.e0, eoff & 3u));
+            const uint32_t ge = gray_of(RAG ? w.e0 : __builtin_amdgcn_alignbyte(w.e1, w.e0, eoff & 3u));
             return Row{U2{g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24)}, ge};
         }
     };
@@ -138,7 +180,8 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     auto feed = [&](const Row& rw, int r) {  // r = index of the row just loaded; emits output row r-1 when r-1 >= ys
         U2 v = rw.v;
         // x = cols mirrors cols-2: the lane just right of the image holds cols-8..cols-1 after clamping -> its byte 0 := byte 6
-        if (edgeR) v.lo = pk(v.hi, v.lo, 0x03020106u);
+        if (RAG) v = U2{pk(v.hi, v.lo, sel_lo), pk(v.hi, v.lo, sel_hi)};
+        else if (edgeR) v.lo = pk(v.hi, v.lo, 0x03020106u);
         uint32_t lf = __builtin_amdgcn_update_dpp(0u, v.hi, 0x138, 0xf, 0xf, true);  // wave_shr:1 -> lane-1's hi dword
         uint32_t rt = __builtin_amdgcn_update_dpp(0u, v.lo, 0x130, 0xf, 0xf, true);  // wave_shl:1 -> lane+1's lo dword
         if (lane == 0) lf = rw.e << 24;   // byte 3 of "lane -1's hi dword"
@@ -172,6 +215,33 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
             if (ox[0] == 0x12345678u && oy[1] == 0x9abcdef0u) *(uint4*)dump = make_uint4(ox[0], ox[1], oy[2], oy[3]);
             return;
         }
+        if constexpr (RAG) {
+            uint8_t* px = dxp + (size_t)y * a.xstep;
+            uint8_t* py = dyp + (size_t)y * a.ystep;
+            if (st && nvalid == 8) {
+                *(U4u*)px = U4u{ox[0], ox[1], ox[2], ox[3]};
+                *(U4u*)py = U4u{oy[0], oy[1], oy[2], oy[3]};
+            } else if (st) {   // the row's last, partial run: 4 + 2 + 1 samples as its length says
+                int j = 0;
+                if (nvalid & 4) {
+                    *(U2h*)px = U2h{ox[0], ox[1]};
+                    *(U2h*)py = U2h{oy[0], oy[1]};
+                    j = 2;
+                }
+                const uint32_t bx = j ? ox[2] : ox[0], by = j ? oy[2] : oy[0], cx = j ? ox[3] : ox[1], cy = j ? oy[3] : oy[1];
+                if (nvalid & 2) {
+                    *(U1h*)(px + 4 * j) = U1h{bx};
+                    *(U1h*)(py + 4 * j) = U1h{by};
+                }
+                if (nvalid & 1) {
+                    const uint32_t lx = (nvalid & 2) ? cx : bx, ly = (nvalid & 2) ? cy : by;
+                    const int o = 4 * j + ((nvalid & 2) ? 4 : 0);
+                    *(uint16_t*)(px + o) = (uint16_t)lx;
+                    *(uint16_t*)(py + o) = (uint16_t)ly;
+                }
+            }
+            return;
+        }
         *(uint4*)(st ? dxp + (size_t)y * a.xstep : dump) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
         *(uint4*)(st ? dyp + (size_t)y * a.ystep : dump) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
     };
@@ -197,10 +267,12 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
 {
     if (s.ch != 1 && s.ch != 3) return RCV_ERR_UNSUPPORTED;
-    if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 2) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)dx.p % 16 || dx.step % 16 || (dx.n > 1 && dx.fstride % 16)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)dy.p % 16 || dy.step % 16 || (dy.n > 1 && dy.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    if (s.cols < 8 || s.rows < 2) return RCV_ERR_UNSUPPORTED;
+    // widths that are not a multiple of 8 and rows that are not 8 / 16-byte aligned: the RAG instantiation (i16 outputs are
+    // at least 2-byte aligned by construction of rcv_mat)
+    const bool rag = s.cols % 8 != 0 || (uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8) || (uintptr_t)dx.p % 16 || dx.step % 16 ||
+                     (dx.n > 1 && dx.fstride % 16) || (uintptr_t)dy.p % 16 || dy.step % 16 || (dy.n > 1 && dy.fstride % 16);
+    if (rag && ((uintptr_t)dx.p % 2 || dx.step % 2 || dx.fstride % 2 || (uintptr_t)dy.p % 2 || dy.step % 2 || dy.fstride % 2)) return RCV_ERR_UNSUPPORTED;
     SobelArgs a;
     a.src = s.p;
     a.dx = dx.p;
@@ -224,6 +296,11 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const dim3 grid((unsigned)((waves + 3) / 4));
+    if (rag) {
+        if (s.ch == 3) RCV_LAUNCH((k_sobel_rows<0, true, true>), grid, dim3(256), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_sobel_rows<0, false, true>), grid, dim3(256), 0, ctx->stream, a);
+        return rcv_launch_check(ctx);
+    }
     if (s.ch == 3) {
         RCV_LAUNCH((k_sobel_rows<0, true>), grid, dim3(256), 0, ctx->stream, a);
         return rcv_launch_check(ctx);

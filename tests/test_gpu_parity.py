@@ -1691,3 +1691,35 @@ def test_no_out_of_bounds_writes(ctx, oracle, rows, cols):
     odd = _canary_batch(ctx, n, rows // 3 + 1, cols // 3 + 1, 3)
     device.resize(src, odd)
     _assert_canaries(odd)
+
+
+def test_sobel_ragged_and_unaligned_shapes(ctx, oracle):
+    """the register-window Sobel on the shapes real callers produce (Mat::new: step = cols * channels, rustcv/src/core/mat.rs:18-29):
+    25 x RCV_SOAK seeded cases, widths 8..1100 that are mostly NOT multiples of 8, odd steps (byte-aligned rows), i16 outputs on
+    2-byte-aligned rows with canaries in the padding, gray and BGR sources, batches of 1..3 -- and the kernel that ran is the
+    row kernel's RAG instantiation, not a generic per-sample kernel"""
+    L = _ffi.lib()
+    r = np.random.default_rng(0x50BE1 + _SOAK_SEED)
+    for case in range(25 * _SOAK):
+        cols = int(r.integers(8, 1101))
+        rows = int(r.integers(2, 90))
+        ch = 3 if case % 3 == 2 else 1
+        n = int(r.integers(1, 4))
+        sp = int(r.integers(0, 4)) if case % 4 else 0            # source row padding: odd steps
+        op = 2 * int(r.integers(0, 9))                            # i16 output padding: rows stay 2-byte aligned, rarely 16
+        src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + sp, frame_stride=rows * (cols * ch + sp) + int(r.integers(0, 7)))
+        dx = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=op)
+        dy = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=op)
+        frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+        src.upload(frames)
+        L.rcv__debug_kernels_reset()
+        device.sobel(src, dx, dy)
+        gx, gy = dx.download(), dy.download()
+        assert "k_sobel_rows<" in L.rcv__debug_kernels().decode(), (rows, cols, ch, L.rcv__debug_kernels().decode())
+        for i in range(n):
+            wx, wy = oracle.sobel(oracle.bgr2gray(frames[i]) if ch == 3 else frames[i][..., 0])
+            assert np.array_equal(gx[i], wx) and np.array_equal(gy[i], wy), (case, rows, cols, ch, n, sp, op)
+        _assert_canaries(dx)
+        _assert_canaries(dy)
+        for b in (src, dx, dy):
+            b.free()
