@@ -14,6 +14,10 @@
 // is negated on the mirrored row (a mirrored Sobel flips the sign of dy); the left border P(-1) := P(1) is a lane
 // fix-up; response values outside the image are -inf for the NMS.  f32 ops follow the oracle's order exactly
 // (six separate IEEE ops, -ffp-contract=off).
+// RAG instantiation: any width >= 8 and any alignment (Mat::new gives step = cols * channels: odd widths mean byte-aligned
+// rows): unaligned vector loads / stores, the lane with the row's last, partial run rebuilds its 8 logical gray pixels --
+// the valid ones and their mirror images -- with one byte permute per dword, sets the responses right of the image to -inf
+// for the NMS and stores only its valid samples (same scheme as rcv_sobel_rows.hip).
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
@@ -54,13 +58,19 @@ typedef RCV_GLOBAL uint8_t* gptr;
 typedef const RCV_GLOBAL uint8_t* cgptr;
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+// unaligned views (RAG)
+typedef uint32_t U2m __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t U1m __attribute__((aligned(1)));
+typedef uint16_t H1m __attribute__((aligned(1)));
+typedef float F4m __attribute__((ext_vector_type(4), aligned(4)));
+typedef float F2m __attribute__((ext_vector_type(2), aligned(4)));
 
 // YUYV = true: the source is packed YUYV (2 B/px, SURVEY.md 8(d) config 5 "[or YUYV]"); each macropixel goes through the
 // reference's BT.601 conversion (rustcv/src/videoio/mod.rs:356-363, saturated to u8) and then the same gray formula, so the
 // result equals harris_pipeline(yuyv_to_bgr(.)) bit for bit with 3 instead of 4 algorithmic bytes per pixel.
 // SRCK: 0 = BGR, 1 = packed YUYV, 2 = one-channel gray (cornerHarris' own input: the window starts at the Sobel stage).
 // WANT_MASK = false: response only (rcv_corner_harris): no NMS stage, no mask store.
-template <bool WANT_RESP, int SRCK, bool WANT_MASK = true>
+template <bool WANT_RESP, int SRCK, bool WANT_MASK = true, bool RAG = false>
 __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -77,6 +87,22 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const int xc = min(max(x, 0), a.cols - 8);
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    // RAG: the lane's 8 logical pixels x .. x+7 (right of the image: their mirror images) as byte selectors into the gray run it
+    // gets from the clamped position xc; identity wherever the run lies inside the image (and for the left halo lane, which
+    // keeps its own fix-up below)
+    uint32_t sel_lo = 0x03020100u, sel_hi = 0x07060504u;
+    int nvalid = 8;
+    if (RAG && x >= 0) {
+        nvalid = min(max(a.cols - x, 0), 8);
+        sel_lo = sel_hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = x + j, pr = p < a.cols ? p : 2 * a.cols - 2 - p;
+            const uint32_t idx = (uint32_t)min(max(pr - xc, 0), 7);
+            if (j < 4) sel_lo |= idx << (8 * j);
+            else sel_hi |= idx << (8 * (j - 4));
+        }
+    }
     // uniform frame bases + 32-bit per-lane offsets: the loads and stores take the scalar-base + vector-offset form
     const uint8_t* const sf = a.src + (size_t)frame * a.sfs;
     uint8_t* const mf = a.mask + (size_t)frame * a.mfs;
@@ -90,6 +116,14 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
         cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
         asm("" : "+s"(p));   // the row base stays in SGPRs: loads take the saddr + 32-bit voffset form, no VALU address math
+        if constexpr (RAG) {
+            const U2m q0 = *(const RCV_GLOBAL U2m*)(p + sx);
+            if constexpr (GRAY) return Row6{{q0.x, q0.y, 0u, 0u, 0u, 0u}};
+            const U2m q1 = *(const RCV_GLOBAL U2m*)(p + sx + 8);
+            if constexpr (YUYV) return Row6{{q0.x, q0.y, q1.x, q1.y, 0u, 0u}};
+            const U2m q2 = *(const RCV_GLOBAL U2m*)(p + sx + 16);
+            return Row6{{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y}};
+        }
         if constexpr (GRAY) {
             const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx);
             return Row6{{q0.x, q0.y, 0u, 0u, 0u, 0u}};
@@ -146,7 +180,13 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         }
         uint32_t lo = GRAY ? q.d[0] : g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = GRAY ? q.d[1] : g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
         if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
-        if (edgeR) lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+        if (RAG) {
+            const uint32_t l2 = pk(hi, lo, sel_lo), h2 = pk(hi, lo, sel_hi);
+            lo = l2;
+            hi = h2;
+        } else if (edgeR) {
+            lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+        }
         const uint32_t lf = shr1(hi), rt = shl1(lo);
         // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
         uint32_t L[5], Cc[4];
@@ -230,8 +270,26 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
                 gptr orow = (gptr)(rf + (size_t)u * a.rstep);
                 asm("" : "+s"(orow));
                 gptr o = orow + 4 * mx;
-                *(RCV_GLOBAL f4v*)o = f4v{r[0], r[1], r[2], r[3]};
-                *(RCV_GLOBAL f4v*)(o + 16) = f4v{r[4], r[5], r[6], r[7]};
+                if constexpr (RAG) {
+                    if (nvalid == 8) {
+                        *(RCV_GLOBAL F4m*)o = F4m{r[0], r[1], r[2], r[3]};
+                        *(RCV_GLOBAL F4m*)(o + 16) = F4m{r[4], r[5], r[6], r[7]};
+                    } else {   // the row's last, partial run: 4 + 2 + 1 samples as its length says
+                        int j = 0;
+                        if (nvalid & 4) {
+                            *(RCV_GLOBAL F4m*)o = F4m{r[0], r[1], r[2], r[3]};
+                            j = 4;
+                        }
+                        if (nvalid & 2) {
+                            *(RCV_GLOBAL F2m*)(o + 4 * j) = j ? F2m{r[4], r[5]} : F2m{r[0], r[1]};
+                            j += 2;
+                        }
+                        if (nvalid & 1) *(RCV_GLOBAL float*)(o + 4 * j) = j == 0 ? r[0] : (j == 2 ? r[2] : (j == 4 ? r[4] : r[6]));
+                    }
+                } else {
+                    *(RCV_GLOBAL f4v*)o = f4v{r[0], r[1], r[2], r[3]};
+                    *(RCV_GLOBAL f4v*)(o + 16) = f4v{r[4], r[5], r[6], r[7]};
+                }
             }
         }
         if constexpr (!WANT_MASK) return;
@@ -242,6 +300,11 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         if (u < 0 || u >= a.rows) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] = NEG_INF;
+        }
+        if (RAG) {   // columns right of the image inside the row's last, partial run
+#pragma unroll
+            for (int j = 1; j < 8; ++j)
+                if (j >= nvalid) r[j] = NEG_INF;
         }
         const float rl = shr1f(edgeL ? NEG_INF : r[7]);              // r[x-1] of the lane's first pixel
         const float rr = shl1f(x >= a.cols ? NEG_INF : r[0]);        // r[x+8]
@@ -267,7 +330,22 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         if (live && w >= ys && w < ye) {
             gptr mrow = (gptr)(mf + (size_t)w * a.mstep);
             asm("" : "+s"(mrow));
-            *(RCV_GLOBAL u2v*)(mrow + mx) = u2v{mbits[0], mbits[1]};
+            if constexpr (RAG) {
+                if (nvalid == 8) {
+                    *(RCV_GLOBAL U2m*)(mrow + mx) = U2m{mbits[0], mbits[1]};
+                } else {
+                    int j = 0;
+                    if (nvalid & 4) {
+                        *(RCV_GLOBAL U1m*)(mrow + mx) = mbits[0];
+                        j = 4;
+                    }
+                    const uint32_t rest = j ? mbits[1] : mbits[0];
+                    if (nvalid & 2) *(RCV_GLOBAL H1m*)(mrow + mx + j) = (uint16_t)rest;
+                    if (nvalid & 1) *(mrow + mx + j + (nvalid & 2)) = (uint8_t)((nvalid & 2) ? rest >> 16 : rest);
+                }
+            } else {
+                *(RCV_GLOBAL u2v*)(mrow + mx) = u2v{mbits[0], mbits[1]};
+            }
         }
     };
 
@@ -299,10 +377,12 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     View m0 = s;          // (placeholder when there is no mask: never dereferenced by the kernel)
     m0.p = nullptr;
     const View& m = mask ? *mask : m0;
-    if (s.cols % 8 != 0 || s.cols < 8 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
-    if (mask && ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8))) return RCV_ERR_UNSUPPORTED;
-    if (resp && ((uintptr_t)resp->p % 16 || resp->step % 16 || (resp->n > 1 && resp->fstride % 16))) return RCV_ERR_UNSUPPORTED;
+    if (s.cols < 8 || s.rows < 4 || (s.ch == 2 && (s.cols & 1))) return RCV_ERR_UNSUPPORTED;
+    // widths that are not a multiple of 8 and rows that are not 8 / 16-byte aligned: the RAG instantiations
+    const bool rag = s.cols % 8 != 0 || (uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8) ||
+                     (mask && ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8))) ||
+                     (resp && ((uintptr_t)resp->p % 16 || resp->step % 16 || (resp->n > 1 && resp->fstride % 16)));
+    if (rag && resp && ((uintptr_t)resp->p % 4 || resp->step % 4 || resp->fstride % 4)) return RCV_ERR_UNSUPPORTED;
     HArgs a;
     a.src = s.p;
     a.mask = m.p;
@@ -350,6 +430,20 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     a.k = k;
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
     dim3 grid((unsigned)((waves + 3) / 4));
+    if (rag) {
+        if (s.ch == 1) {
+            if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false, true>), grid, dim3(256), 0, ctx->stream, a);
+            else if (resp) RCV_LAUNCH((k_harris_fused<true, 2, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 2, true, true>), grid, dim3(256), 0, ctx->stream, a);
+        } else if (s.ch == 2) {
+            if (resp) RCV_LAUNCH((k_harris_fused<true, 1, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 1, true, true>), grid, dim3(256), 0, ctx->stream, a);
+        } else {
+            if (resp) RCV_LAUNCH((k_harris_fused<true, 0, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 0, true, true>), grid, dim3(256), 0, ctx->stream, a);
+        }
+        return rcv_launch_check(ctx);
+    }
     if (s.ch == 1) {
         if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(256), 0, ctx->stream, a);
         else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(256), 0, ctx->stream, a);

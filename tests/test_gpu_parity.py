@@ -1723,3 +1723,58 @@ def test_sobel_ragged_and_unaligned_shapes(ctx, oracle):
         _assert_canaries(dy)
         for b in (src, dx, dy):
             b.free()
+
+
+def test_harris_ragged_and_unaligned_shapes(ctx, oracle):
+    """the fused Harris kernel on widths that are not multiples of 8 and on byte-aligned rows (Mat::new: step = cols * channels):
+    20 x RCV_SOAK seeded cases, BGR / YUYV / gray sources, mask only / mask + response / response only (cornerHarris), batches of
+    1..3, canaries around the outputs -- mask and f32 response bit for bit, and the kernel that ran is the fused one"""
+    L = _ffi.lib()
+    r = np.random.default_rng(0x4A221 + _SOAK_SEED)
+    for case in range(20 * _SOAK):
+        kind = case % 4                                         # 0 BGR, 1 YUYV, 2 gray pipeline, 3 cornerHarris (gray -> response)
+        cols = int(r.integers(8, 1050))
+        if kind == 1:
+            cols += cols & 1                                    # YUYV: whole macropixels
+        rows = int(r.integers(4, 70))
+        n = int(r.integers(1, 4))
+        ch = (3, 2, 1, 1)[kind]
+        sp = int(r.integers(0, 4)) if case % 5 else 0
+        want_resp = kind == 3 or bool(case & 8)
+        src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + sp, frame_stride=rows * (cols * ch + sp) + int(r.integers(0, 5)))
+        mask = _canary_batch(ctx, n, rows, cols, 1, pad=int(r.integers(0, 6))) if kind != 3 else None
+        resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=4 * int(r.integers(0, 5))) if want_resp else None
+        frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+        frames[:, rows // 3: rows // 3 + 3, cols // 4: cols // 4 + 5] = 255      # a few real corners
+        frames[:, :, -2:] = 0                                                    # structure right at the ragged edge
+        src.upload(frames)
+        thr = 1e-5
+        L.rcv__debug_kernels_reset()
+        if kind == 3:
+            device.corner_harris(src, resp, 2, 0.04)
+        else:
+            device.harris_pipeline(src, mask, resp, 2, 0.04, thr)
+        gm = mask.download() if mask is not None else None
+        gr = resp.download() if resp is not None else None
+        assert "k_harris_fused<" in L.rcv__debug_kernels().decode(), (kind, rows, cols, L.rcv__debug_kernels().decode())
+        for i in range(n):
+            if kind == 0:
+                bgr = frames[i]
+            elif kind == 1:
+                flat = np.zeros(rows * cols * 3, np.uint8)
+                oracle.yuv422_to_bgr_strided(frames[i].reshape(-1), cols * 2, rows, cols, False, flat)
+                bgr = flat.reshape(rows, cols, 3)
+            if kind in (0, 1):
+                wm, wr = oracle.harris_pipeline(bgr, 2, 0.04, thr, want_resp=True)
+            else:
+                wr = oracle.corner_harris(frames[i][..., 0], 2, 0.04)
+                wm = oracle.nms3x3(wr, thr)
+            if gm is not None:
+                assert np.array_equal(gm[i], wm), (case, kind, rows, cols, n, sp)
+            if gr is not None:
+                assert np.array_equal(gr[i].view(np.uint32), wr.view(np.uint32)), (case, kind, rows, cols, n, sp)
+        for b in (mask, resp):
+            if b is not None:
+                _assert_canaries(b)
+                b.free()
+        src.free()
