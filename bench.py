@@ -193,7 +193,9 @@ def run_rank(a, rank, world, device, ctx, fence, torch):
         nbytes = n * ROWS * COLS * CH
         best, best_name = 0.0, None
         for variant, grid, name in ((0, 1, "hipMemcpyAsync D2D"), (1, 1024, "sweep g=1024"), (1, 2048, "sweep g=2048"), (3, 512, "sweep nt g=512"),
-                                    (3, 2048, "sweep nt g=2048"), (2, 1024, "block g=1024"), (5, 2048, "block nt g=2048"), (5, 512, "block nt g=512")):
+                                    (3, 2048, "sweep nt g=2048"), (2, 1024, "block g=1024"), (5, 2048, "block nt g=2048"), (5, 512, "block nt g=512"),
+                                    (8, 1024, "XCD-local sweep g=1024"), (8, 2048, "XCD-local sweep g=2048"), (9, 1024, "XCD-local sweep nt g=1024"),
+                                    (9, 2048, "XCD-local sweep nt g=2048")):
             def cp():
                 rc = L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid)
                 if rc != 0:

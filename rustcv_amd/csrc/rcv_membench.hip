@@ -50,6 +50,16 @@ __global__ __launch_bounds__(kT) void k_copy_block(const uint4* __restrict__ s, 
     for (size_t i = b0 + threadIdx.x; i < b1; i += 4 * kT) cp4<NTL, NTS>(s, d, i, kT, b1);
 }
 
+// XCD-local sweep: hardware places block b on XCD b % 8; XCD x sweeps its own contiguous eighth of the buffer (what one XCD has
+// in flight stays a compact address range -- the layout the filter kernel uses, so the ceiling it is held against gets it too)
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(kT) void k_copy_xcd(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n)
+{
+    const size_t per = (n + 7) / 8, b0 = per * (blockIdx.x & 7), b1 = b0 + per < n ? b0 + per : n;
+    const size_t stride = (size_t)(gridDim.x >> 3) * kT;
+    for (size_t i = b0 + (size_t)(blockIdx.x >> 3) * kT + threadIdx.x; i < b1; i += 4 * stride) cp4<NTL, NTS>(s, d, i, stride, b1);
+}
+
 __global__ __launch_bounds__(kT) void k_read_sweep(const uint4* __restrict__ s, uint4* __restrict__ dump, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * kT;
@@ -74,7 +84,8 @@ __global__ __launch_bounds__(kT) void k_write_sweep(uint4* __restrict__ d, size_
 } // namespace
 
 // variant: 0 hipMemcpyAsync D2D | 1 sweep | 2 block-contiguous | 3 sweep, nt loads + nt stores | 4 sweep, nt stores |
-//          5 block-contiguous, nt loads + nt stores | 6 read only | 7 write only.   Asynchronous on the context's stream.
+//          5 block-contiguous, nt loads + nt stores | 6 read only | 7 write only | 8 XCD-local sweep | 9 XCD-local sweep, nt / nt
+//          (grid a multiple of 8).   Asynchronous on the context's stream.
 extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t bytes, int variant, int grid)
 {
     RCV_TRY(rcv_bind(ctx));
@@ -92,6 +103,14 @@ extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t by
     case 5: hipLaunchKernelGGL((k_copy_block<true, true>), g, b, 0, ctx->stream, s, d, n); break;
     case 6: hipLaunchKernelGGL(k_read_sweep, g, b, 0, ctx->stream, s, (uint4*)(ctx->kconst + 49152), n); break;
     case 7: hipLaunchKernelGGL(k_write_sweep, g, b, 0, ctx->stream, d, n, 0x5EEDu); break;
+    case 8:
+        if (grid % 8) return RCV_ERR_ARG;
+        hipLaunchKernelGGL((k_copy_xcd<false, false>), g, b, 0, ctx->stream, s, d, n);
+        break;
+    case 9:
+        if (grid % 8) return RCV_ERR_ARG;
+        hipLaunchKernelGGL((k_copy_xcd<true, true>), g, b, 0, ctx->stream, s, d, n);
+        break;
     default: return RCV_ERR_ARG;
     }
     return rcv_launch_check(ctx);

@@ -22,7 +22,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
-KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP")
+KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP", "RCV_FR_ORDER")
 
 
 def setenv(env):
@@ -64,6 +64,7 @@ def main():
     nbytes = n * rows * cols * 3
     flt = lambda: device.filter2d(src, dst, k, shift=6)   # noqa: E731
     variants = [("strip kernel (round 1)", {"RCV_F7_ROWS": 0}, 0, flt), ("row-streaming kernel (default: 10 waves/CU, 8 rounds, PP=3)", {}, 0, flt)]
+    variants.append(("rows, bands dealt round-robin to the XCDs", {"RCV_FR_ORDER": 1}, 0, flt))
     for wpc in (8, 12):
         variants.append((f"rows {wpc} waves/CU", {"RCV_FR_WPC": wpc}, 0, flt))
     for r in (1, 4, 16):
@@ -74,8 +75,9 @@ def main():
         for flags, nm in ((8, "plain stores"), (1, "no stores"), (2, "no loads"), (3, "compute only"), (4, "no MFMA"), (5, "loads only"), (6, "stores only")):
             variants.append((f"rows, {nm}", {}, flags, flt))
     if a.copies:
-        names = {0: "hipMemcpy D2D", 1: "copy sweep", 2: "copy block-contiguous", 3: "copy sweep nt", 5: "copy block nt", 6: "read only", 7: "write only"}
-        for variant, grid in ((0, 1), (1, 1024), (1, 2048), (2, 1024), (3, 512), (3, 2048), (5, 512), (5, 2048), (6, 2048), (7, 32768)):
+        names = {0: "hipMemcpy D2D", 1: "copy sweep", 2: "copy block-contiguous", 3: "copy sweep nt", 5: "copy block nt", 6: "read only", 7: "write only",
+                 8: "copy XCD-local sweep", 9: "copy XCD-local sweep nt"}
+        for variant, grid in ((0, 1), (1, 1024), (1, 2048), (2, 1024), (3, 512), (3, 2048), (5, 512), (5, 2048), (8, 1024), (8, 2048), (8, 4096), (9, 1024), (9, 2048), (9, 4096), (6, 2048), (7, 32768)):
             def cp(variant=variant, grid=grid):
                 assert L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid) == 0
             variants.append((f"{names[variant]} g={grid}", {}, 0, cp))
