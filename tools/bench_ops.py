@@ -213,6 +213,19 @@ def main():
     gq.free(); rq.free()
     s.free(); d.free(); m.free()
 
+    # ---- the shapes real callers produce (Mat::new: step = cols * channels): odd widths, byte-aligned rows, next to the aligned
+    # ---- shape of the same size -- the register-window kernels' RAG instantiations against their aligned ones ----------------
+    for (rr, cc, tag) in ((1080, 1920, "1920x1080 (aligned)"), (1079, 1919, "1919x1079 packed (odd width, byte-aligned rows)")):
+        nb = 64
+        gg, bb = B(nb, rr, cc, 1), B(nb, rr, cc, 3)
+        ddx, ddy, mm = B(nb, rr, cc, 1, _ffi.RCV_16S), B(nb, rr, cc, 1, _ffi.RCV_16S), B(nb, rr, cc, 1)
+        device.synth(gg, 1, SEED + 7, 0)
+        device.synth(bb, 1, SEED + 7, 0)
+        record("Sobel 3x3 -> dx,dy i16", tag, gg.n, rr * cc, 5, lambda: device.sobel(gg, ddx, ddy))
+        record("Harris pipeline (BGR->mask)", tag, bb.n, rr * cc, 4, lambda: device.harris_pipeline(bb, mm, None, 2, 0.04, 1e-4))
+        for x in (gg, bb, ddx, ddy, mm):
+            x.free()
+
     # ---- config 4: 8K warpAffine + resize -> 1080p, 32 frames per GPU ----------------------------------------
     s, d = B(32, 4320, 7680, 3), B(32, 4320, 7680, 3)
     device.synth(s, 0, SEED + 4, 0)

@@ -7,12 +7,28 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "ops_bench.json")
 d = json.load(open(src))
-out = ["| op | config | frames | ms / launch | Gpix/s | algorithmic TB/s | % of 8 TB/s | CPU oracle Mpix/s (cores) |", "|---|---|---|---|---|---|---|---|"]
+# what bounds each op: ops whose fixed arithmetic exceeds what the vector ALU can issue at HBM rate are VALU-bound by
+# construction; for those the HBM percentage is information, not the target (rocprofv3 issue-slot figures: profiles/r02_op_*.txt)
+BOUND = [("filter2D 7x7 f32", "VALU (49 dependent fmaf per sample)"), ("sigma=1.5", "VALU (14 fmaf per sample)"),
+         ("Harris pipeline", "VALU (34 instr/px: 86 % of issue slots)"), ("cornerHarris", "VALU / stores"),
+         ("warpAffine + resize", "VALU + over-fetch x2.2"), ("warpAffine", "VALU 72 % of issue slots + tap gathers"),
+         ("rectangle", "launch latency"), ("text blend", "launch latency"), ("batch=1", "launch latency (L3-resident)"),
+         ("640x480", "launch latency"), ("resize 8K -> 1080p", "HBM (line granularity: 56 MB/frame must be fetched for 31 MB used)")]
+
+
+def bound_of(r):
+    for key, b in BOUND:
+        if key in r["op"] or key in r["config"]:
+            return b
+    return "HBM"
+
+
+out = ["| op | config | frames | ms / launch | Gpix/s | algorithmic TB/s | % of 8 TB/s | bound | CPU oracle Mpix/s (cores) |", "|---|---|---|---|---|---|---|---|---|"]
 for r in d["rows"]:
     cpu = r.get("cpu")
     cpu_s = f"{cpu['mpix_s']:.0f} ({cpu['cores']})" if cpu else ""
     hbm = f"{r['alg_gb_s'] / 1e3:.2f} | {r['frac_hbm_peak'] * 100:.1f}" if r["alg_bytes_per_px"] else "– | –"
-    out.append(f"| {r['op']} | {r['config']} | {r['frames']} | {r['ms_per_launch']:.4f} | {r['mpix_s'] / 1e3:.0f} | {hbm} | {cpu_s} |")
+    out.append(f"| {r['op']} | {r['config']} | {r['frames']} | {r['ms_per_launch']:.4f} | {r['mpix_s'] / 1e3:.0f} | {hbm} | {bound_of(r)} | {cpu_s} |")
 text = "\n".join(out) + "\n"
 sys.stdout.write(text)
 if len(sys.argv) <= 1:
