@@ -29,6 +29,7 @@ static void load_knobs()
     g_knobs.fr_wpc = env_int("RCV_FR_WPC", 0);
     g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
+    g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
     g_knobs_loaded = true;
 }

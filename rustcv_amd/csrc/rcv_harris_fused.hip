@@ -36,6 +36,7 @@ struct HArgs {
     uint8_t *mask, *resp;
     size_t sstep, mstep, rstep, sfs, mfs, rfs;
     int rows, cols, nstrips, seg_rows, nsegs, total_waves;
+    int blocks_per_xcd;   // > 0: XCD-contiguous block order (as rcv_sobel_rows.hip)
     float s2, k, thr_up;   // thr_up: smallest float > thr (+inf for a NaN threshold: nothing is kept, as `rc > NaN` is never true)
 };
 
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const int lane = threadIdx.x & 63;
     // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are
     // then SALU work (as VALU work the 64-bit row multiplies alone were ~100 quarter-rate slots per four rows)
-    int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
     if (wid >= a.total_waves) return;
     const int strip = wid % a.nstrips;
     wid /= a.nstrips;
@@ -429,7 +431,9 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     a.s2 = (float)(sc * sc);
     a.k = k;
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
-    dim3 grid((unsigned)((waves + 3) / 4));
+    const long long nblocks = (waves + 3) / 4;
+    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     if (rag) {
         if (s.ch == 1) {
             if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false, true>), grid, dim3(256), 0, ctx->stream, a);

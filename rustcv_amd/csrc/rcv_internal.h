@@ -64,6 +64,7 @@ struct RcvKnobs {
     int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
     int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
+    int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)
     int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS
 };
 const RcvKnobs& rcv_knobs();

@@ -28,6 +28,7 @@ extern int rcv_debug_flags;
 namespace {
 
 typedef short s2v __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 constexpr int kRowsAhead = 8;
 constexpr int kStripPx = 64 * 8;
@@ -37,6 +38,7 @@ struct SobelArgs {
     uint8_t *dx, *dy, *dump;
     size_t sstep, xstep, ystep, sfs, xfs, yfs;
     int rows, cols, nstrips, seg_rows, nsegs, total_waves;
+    int blocks_per_xcd;   // > 0: XCD-contiguous block order (see the kernel)
 };
 
 __device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -70,7 +72,11 @@ template <int DBG, bool BGR, bool RAG = false>
 __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 {
     const int lane = threadIdx.x & 63;
-    int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row indices and row bases on the SALU
+    // Block order (speed only): hardware places block b on XCD b % 8.  Each XCD works through its own contiguous eighth of the
+    // (frame, segment, strip) list, so that what ONE XCD has in flight is a compact address range (measured on the filter
+    // kernel: -9 % against dealing neighbouring work round-robin to the XCDs)
+    const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));   // scalar: row indices and row bases on the SALU
     if (wid >= a.total_waves) return;
     const int strip = wid % a.nstrips;
     wid /= a.nstrips;
@@ -242,8 +248,14 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
             }
             return;
         }
-        *(uint4*)(st ? dxp + (size_t)y * a.xstep : dump) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
-        *(uint4*)(st ? dyp + (size_t)y * a.ystep : dump) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+        if (DBG & 4) {   // ablation: plain stores
+            *(uint4*)(st ? dxp + (size_t)y * a.xstep : dump) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+            *(uint4*)(st ? dyp + (size_t)y * a.ystep : dump) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+            return;
+        }
+        // non-temporal: the gradients are never read back by this launch
+        __builtin_nontemporal_store(v4u{ox[0], ox[1], ox[2], ox[3]}, (v4u*)(st ? dxp + (size_t)y * a.xstep : dump));
+        __builtin_nontemporal_store(v4u{oy[0], oy[1], oy[2], oy[3]}, (v4u*)(st ? dyp + (size_t)y * a.ystep : dump));
     };
 
     // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kRowsAhead, next group in flight while this one computes
@@ -295,7 +307,9 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
-    const dim3 grid((unsigned)((waves + 3) / 4));
+    const long long nblocks = (waves + 3) / 4;
+    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     if (rag) {
         if (s.ch == 3) RCV_LAUNCH((k_sobel_rows<0, true, true>), grid, dim3(256), 0, ctx->stream, a);
         else RCV_LAUNCH((k_sobel_rows<0, false, true>), grid, dim3(256), 0, ctx->stream, a);
@@ -306,7 +320,8 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
         return rcv_launch_check(ctx);
     }
 #ifdef RCV_ABLATE
-    switch (rcv_debug_flags & 3) {
+    switch (rcv_debug_flags & 7) {
+    case 4: RCV_LAUNCH((k_sobel_rows<4, false>), grid, dim3(256), 0, ctx->stream, a); break;
     case 1: RCV_LAUNCH((k_sobel_rows<1, false>), grid, dim3(256), 0, ctx->stream, a); break;
     case 2: RCV_LAUNCH((k_sobel_rows<2, false>), grid, dim3(256), 0, ctx->stream, a); break;
     case 3: RCV_LAUNCH((k_sobel_rows<3, false>), grid, dim3(256), 0, ctx->stream, a); break;
