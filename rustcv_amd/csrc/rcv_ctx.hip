@@ -30,6 +30,8 @@ static void load_knobs()
     g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
+    g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
+    g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
     g_knobs_loaded = true;
 }

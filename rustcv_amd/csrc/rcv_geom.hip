@@ -793,8 +793,11 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
-            if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
-            else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), 0, ctx->stream, s, d, A);
+            // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
+            // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)
+            constexpr unsigned kLds = 27136;
+            if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A);
+            else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A);
             return rcv_launch_check(ctx);
         }
     }

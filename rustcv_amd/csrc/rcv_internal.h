@@ -64,6 +64,8 @@ struct RcvKnobs {
     int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
     int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
+    int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
+    int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
     int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)
     int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS
 };
@@ -72,10 +74,10 @@ const RcvKnobs& rcv_knobs();
 // Every kernel launch goes through RCV_LAUNCH, which logs the kernel's name in a per-thread list: tests assert WHICH kernel an
 // entry point dispatched (rcv__debug_kernels / rcv__debug_kernels_reset) instead of guessing it from timings.
 void rcv_note_kernel(const char* name);
-#define RCV_LAUNCH(kernelName, ...)                    \
-    do {                                               \
-        rcv_note_kernel(#kernelName);                  \
-        hipLaunchKernelGGL(kernelName, __VA_ARGS__);   \
+#define RCV_LAUNCH(kernelName, grid_, block_, lds_, ...)                                                   \
+    do {                                                                                                   \
+        rcv_note_kernel(#kernelName);                                                                      \
+        hipLaunchKernelGGL(kernelName, grid_, block_, (lds_) + (unsigned)rcv_knobs().extra_lds, __VA_ARGS__); \
     } while (0)
 
 // Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the

@@ -17,7 +17,7 @@ L = _ffi.lib()
 
 
 def setenv(env):
-    for k in ("RCV_XCD_ORDER", "RCV_HARRIS_SEG_ROWS"):
+    for k in ("RCV_XCD_ORDER", "RCV_HARRIS_SEG_ROWS", "RCV_SOBEL_WGS"):
         os.environ.pop(k, None)
     for k, v in env.items():
         os.environ[k] = str(v)
@@ -56,6 +56,9 @@ def main():
     for name, fn, bpp in ops:
         variants.append((name + " | XCD-contiguous (default)", {}, 0, fn, bpp))
         variants.append((name + " | plain block order", {"RCV_XCD_ORDER": 0}, 0, fn, bpp))
+    for w in (2, 3, 4, 5):
+        variants.append((f"Sobel gray | {w} workgroups per CU", {"RCV_SOBEL_WGS": w}, 0, ops[0][1], 5))
+        variants.append((f"Sobel of BGR | {w} workgroups per CU", {"RCV_SOBEL_WGS": w}, 0, ops[1][1], 7))
     if "--ablate" in sys.argv:
         variants.append(("Sobel gray | plain stores", {}, 4, ops[0][1], 5))
     res = {v[0]: [] for v in variants}
