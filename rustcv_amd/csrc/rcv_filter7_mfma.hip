@@ -638,11 +638,9 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
     const int mode = !dual ? 0 : ((centre && !rcv_knobs().f7_dual_full) ? 2 : 1);   // (the knob keeps the full-table kernel testable)
-    // BGR with weights inside i8, enough rows to fill the GPU: the row-streaming kernel (rcv_filter_rows_mfma.hip)
-    if (!gray && !src_yuyv && !dual) {
-        int8_t k8[49];
-        for (int i = 0; i < ksize * ksize; ++i) k8[i] = (int8_t)k[i];
-        const int rc = rcv_filter_i8_rows(ctx, s, d, k8, ksize, shift);
+    // BGR, enough rows to fill the GPU: the row-streaming kernel (rcv_filter_rows_mfma.hip), one or two weight tables
+    if (!gray && !src_yuyv) {
+        const int rc = rcv_filter_i16_rows(ctx, s, d, k, ksize, shift);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
 

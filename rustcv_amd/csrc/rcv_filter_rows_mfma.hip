@@ -33,9 +33,10 @@
 //
 // Work split.  The batch's n * rows frame-rows are cut into equal bands; (band, strip) waves are dispatched so that each XCD
 // gets a contiguous run of bands and the strips of a band -- which share the 128-byte lines at their seams -- are neighbours
-// on one L2.  Occupancy is capped at 10 waves per CU through an (untouched) dynamic-LDS request: measured on 64 4K frames
-// 12 waves per CU 0.576-0.581 ms, 10 waves 0.557-0.563, 8 waves 0.566-0.573, 6 waves 0.583 -- with more streams in flight the
-// HBM read and write streams disturb each other more (the memory-only variant of the kernel moves the same way).
+// on one L2.  Occupancy: with 2 row pairs in flight the kernel needs 162 VGPRs (12 waves per CU), with 3 pairs 174 (8 waves per
+// CU).  Measured on 64 4K frames: 2 pairs at 12 / 10 / 8 waves per CU (capped with an untouched dynamic-LDS request) 0.581 /
+// 0.563 / 0.573 ms; 3 pairs (8 waves) 0.557-0.566; 6 / 4 waves 0.583 / 0.62 -- more streams in flight do not help on this
+// memory system, deeper streams do (the memory-only variant of the kernel moves the same way).  Default: 3 pairs.
 //
 // What was tried on the way (DESIGN.md 4.1 has the numbers): byte-space operands straight from global memory with one kernel
 // row per MFMA (taps every 3rd byte; 7 MFMAs per tile, no VALU de-interleave) -- correct, but 1.75x the matrix work pulls the
@@ -64,6 +65,7 @@ struct FRArgs {
     int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
     int shift, acc_init;
+    int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
 };
 
 struct U3w { uint32_t a, b, c; };
@@ -81,7 +83,11 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 }
 
 // DBG (profiling builds, make EXTRA=-DRCV_ABLATE): 1 skip stores, 2 skip loads, 4 skip MFMAs, 8 plain instead of non-temporal stores
-template <int KS, int PP, bool EDGE, int DBG>
+// DMASK: weights beyond the i8 range are split K = M + (S << dual_shift) with M, S inside i8 (integer GaussianBlur 7x7: taps up to
+// 324 = K1 + 2 * T2 with T2 confined to the centre rows; any |w| <= 511 as 4Q + R).  The same data operand feeds a second MFMA
+// with the S table into a second accumulator set; bit (parity * NP + p) of DMASK says which row pairs have a non-zero S table
+// (compile time, so that the accumulator chains stay static): matrix work +5/8 for the Gaussian, memory traffic unchanged.
+template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
                                            uint8_t* dframe)
 {
@@ -98,6 +104,17 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
             A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
         }
+    v4i A2[2][NP];
+    if constexpr (DMASK != 0) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if ((DMASK >> (par * NP + p)) & 1) {
+                    const uint4 w = a.wtab[(2 * NP + par * NP + p) * 64 + lane];
+                    A2[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+                }
+    }
 
     // the lane's 48 source bytes per pair: pixels [16n - 4 + 16c, +16) of row 2i + h.  Chunks that stick out of the row are read
     // shifted into it and repaired after the de-interleave (EDGE); without EDGE the clamp is a no-op.
@@ -166,7 +183,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     for (int i = 0; i < NP - 1; ++i) prepare(W[i]);
 
     const int nrows = ye - ys;
-    auto finish = [&](const v4i(&acc)[3], int y) {
+    auto finish = [&](v4i(&acc)[3], const v4i(&acc2)[3], int y) {
+        if constexpr (DMASK != 0) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
+        }
         // lane (q, n) holds pixels 16n + 4q .. +3 of the three planes: 12 interleaved output bytes
         U3w o;
         o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
@@ -193,7 +214,8 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             if (u >= nsteps) break;
             request(u + RP - 1, W[(s + RP - 1) % RP]);
             prepare(W[(s + NP - 1) % RP]);
-            v4i acc[2][3];
+            v4i acc[2][3], acc2[2][3];
+            const v4i zerov = v4i{0, 0, 0, 0};
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -202,14 +224,21 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                     for (int pl = 0; pl < 3; ++pl) {
                         if (DBG & 4) acc[par][pl] = p == 0 ? W[(s + p) % RP][pl] : acc[par][pl] + W[(s + p) % RP][pl];
                         else acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
+                        if constexpr (DMASK != 0) {
+                            const int bits = (DMASK >> (par * NP)) & ((1 << NP) - 1);   // this parity's pairs (constant after unrolling)
+                            if ((bits >> p) & 1) {
+                                const bool first = (bits & ((1 << p) - 1)) == 0;   // no earlier pair of this parity has an S table
+                                acc2[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[par][p], W[(s + p) % RP][pl], first ? zerov : acc2[par][pl], 0, 0, 0);
+                            }
+                        }
                     }
-            finish(acc[0], ys + 2 * u);
-            if (2 * u + 1 < nrows) finish(acc[1], ys + 2 * u + 1);
+            finish(acc[0], acc2[0], ys + 2 * u);
+            if (2 * u + 1 < nrows) finish(acc[1], acc2[1], ys + 2 * u + 1);
         }
     }
 }
 
-template <int KS, int PP, int DBG>
+template <int KS, int PP, int DBG, int DMASK = 0>
 __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
 {
     const int lane = threadIdx.x;
@@ -235,8 +264,8 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
         const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
         const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
         uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
-        if (edge) fr_segment<KS, PP, true, DBG>(a, lane, X, ys, ye, sframe, dframe);
-        else fr_segment<KS, PP, false, DBG>(a, lane, X, ys, ye, sframe, dframe);
+        if (edge) fr_segment<KS, PP, true, DBG, DMASK>(a, lane, X, ys, ye, sframe, dframe);
+        else fr_segment<KS, PP, false, DBG, DMASK>(a, lane, X, ys, ye, sframe, dframe);
         g0 += ye - ys;
     }
 }
@@ -275,10 +304,31 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64), lds, st, a);
 }
 
+// which row pairs of which parity carry kernel rows [lo, hi]: the DMASK of a second table confined to those rows
+constexpr int rows_dmask(int ksize, int lo, int hi)
+{
+    const int np = (ksize + 1) / 2;
+    int m = 0;
+    for (int par = 0; par < 2; ++par)
+        for (int p = 0; p < np; ++p)
+            for (int h = 0; h < 2; ++h) {
+                const int ky = par == 0 ? 2 * p + h : 2 * p - 1 + h;
+                if (ky >= lo && ky <= hi) m |= 1 << (par * np + p);
+            }
+    return m;
+}
+constexpr int kCentre7 = rows_dmask(7, 2, 4);   // second table in kernel rows 2..4 (the integer 7x7 Gaussian): 2 of 4 pairs per parity
+
 template <int KS>
-void launch_rows(const FRArgs& a, int pp, unsigned lds, hipStream_t st)
+void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, hipStream_t st)
 {
     const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
+    constexpr int kAll = (1 << (2 * ((KS + 1) / 2))) - 1;
+    if (dmask != 0) {   // two weight tables
+        if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>), grid, dim3(64), lds, st, a);
+        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll>), grid, dim3(64), lds, st, a);
+        return;
+    }
 #ifdef RCV_ABLATE   // profiling builds: prefetch depth selectable at run time (RCV_FR_PP)
     if (KS == 7 && pp == 2) return launch_rows_dbg<7, 2>(a, grid, lds, st);
     if (KS == 7 && pp == 4) return launch_rows_dbg<7, 4>(a, grid, lds, st);
@@ -289,10 +339,10 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, hipStream_t st)
 
 } // namespace
 
-// Does this launch belong on the row-streaming kernel?  BGR, weights within i8, rows 16-byte aligned, width a multiple of 16
+// Does this launch belong on the row-streaming kernel?  BGR, |weights| <= 511, rows 16-byte aligned, width a multiple of 16
 // pixels; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
 // small launches keep the strip kernel's latency variant.
-int rcv_filter_i8_rows(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
 {
     const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
@@ -309,19 +359,46 @@ int rcv_filter_i8_rows(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     const long long G = (long long)s.n * s.rows;
     if (kn.f7_rows < 0 && G * nstrips < 64LL * 10 * ctx->cu_count) return RCV_ERR_UNSUPPORTED;   // < 64 rows per wave slot
 
+    // weights beyond i8: K = M + 2 * S when every weight fits that split (|w| <= 381; the integer Gaussian), else K = 4Q + R
+    const int nk = ksize * ksize, np = (ksize + 1) / 2;
     long long ksum = 0;
-    for (int i = 0; i < ksize * ksize; ++i) ksum += k[i];
+    bool dual = false, split2 = true;
+    for (int i = 0; i < nk; ++i) {
+        if (k[i] < -512 || k[i] > 511) return RCV_ERR_UNSUPPORTED;
+        if (k[i] < -128 || k[i] > 127) dual = true;
+        if (k[i] > 127 + 2 * 127 || k[i] < -128 - 2 * 128) split2 = false;
+        ksum += k[i];
+    }
+    if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
 
-    if (!ctx->fr_valid || ctx->fr_ksize != ksize || memcmp(ctx->fr_k, k, (size_t)ksize * ksize) != 0) {
-        int8_t tab[2 * 4 * 64 * 16];
-        build_rows_wtab(k, ksize, tab);
+    if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
+        int8_t m8[49], s8[49];
+        int dmask = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int w = k[i];
+            int sv = 0;
+            if (dual) sv = split2 ? (w > 127 ? (w - 127 + 1) / 2 : (w < -128 ? -((-w - 128 + 1) / 2) : 0)) : (w >> 2);
+            m8[i] = (int8_t)(dual ? (split2 ? w - 2 * sv : w - 4 * sv) : w);
+            s8[i] = (int8_t)sv;
+        }
+        int8_t tab[2 * 2 * 4 * 64 * 16];
+        build_rows_wtab(m8, ksize, tab);
+        if (dual) {
+            build_rows_wtab(s8, ksize, tab + (size_t)2 * np * 1024);
+            for (int t = 0; t < 2 * np; ++t)
+                for (int i = 0; i < 1024; ++i)
+                    if (tab[(size_t)(2 * np + t) * 1024 + i]) { dmask |= 1 << t; break; }
+        }
         ctx->fr_valid = false;
-        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)2 * ((ksize + 1) / 2) * 1024, 32768));
+        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)(dual ? 4 : 2) * np * 1024, 32768));
         RCV_HIP(hipStreamSynchronize(ctx->stream));   // `tab` is on this stack frame
-        memcpy(ctx->fr_k, k, (size_t)ksize * ksize);
+        memcpy(ctx->fr_k, k, (size_t)nk * sizeof(int16_t));
         ctx->fr_ksize = ksize;
+        ctx->fr_split2 = split2;
+        ctx->fr_dmask = dmask;
         ctx->fr_valid = true;
     }
+    const int dmask = ctx->fr_dmask;
 
     FRArgs a;
     a.src = s.p;
@@ -336,13 +413,15 @@ int rcv_filter_i8_rows(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.rowbytes = (int)rb;
     a.nstrips = nstrips;
     a.nframes = s.n;
-    // occupancy: the kernel's registers allow 12 waves per CU; 10 measured best (header).  The cap is a dynamic-LDS request that
-    // the kernel never touches: 160 KiB / 16 KiB = 10 workgroups per CU.
+    a.dual_shift = split2 ? 1 : 2;
+    // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
+    // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob
+    // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).
     const int wpc = kn.fr_wpc > 0 ? (kn.fr_wpc > 12 ? 12 : kn.fr_wpc) : 10;
-    const unsigned lds = wpc >= 12 ? 0u : (unsigned)((163840 / wpc) & ~511);
+    const unsigned lds = kn.fr_wpc > 0 && wpc < 12 ? (unsigned)((163840 / wpc) & ~511) : 0u;
     // bands: the batch's frame-rows in equal parts, `rounds` x as many (band, strip) waves as the GPU holds (measured on 64 4K
-    // frames: 4..16 rounds within 1 %, one round -- a static partition -- +3 %: short waves balance the XCDs).  Each band
-    // boundary costs 2 * (ksize / 2) halo rows of re-reads.
+    // frames: 4..16 rounds within 1-2 %, one round -- a static partition -- +20 %).  Each band boundary costs 2 * (ksize / 2)
+    // halo rows of re-reads.
     {
         const long long slots = (long long)wpc * ctx->cu_count;
         const int rounds = kn.fr_rounds > 0 ? kn.fr_rounds : 8;
@@ -359,8 +438,8 @@ int rcv_filter_i8_rows(rcv_ctx* ctx, const View& s, const View& d, const int8_t*
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
-    if (ksize == 7) launch_rows<7>(a, pp, lds, ctx->stream);
-    else if (ksize == 5) launch_rows<5>(a, pp, lds, ctx->stream);
-    else launch_rows<3>(a, pp, lds, ctx->stream);
+    if (ksize == 7) launch_rows<7>(a, pp, lds, dmask, ctx->stream);
+    else if (ksize == 5) launch_rows<5>(a, pp, lds, dmask, ctx->stream);
+    else launch_rows<3>(a, pp, lds, dmask, ctx->stream);
     return rcv_launch_check(ctx);
 }

@@ -33,9 +33,9 @@ struct rcv_ctx {
     int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_knob, f7_plan_seg_rows;
     bool f7_plan_lat_ok, f7_plan_lat;
     // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), kconst[32768..40960)
-    bool fr_valid;
-    int fr_ksize;
-    int8_t fr_k[49];
+    bool fr_valid, fr_split2;
+    int fr_ksize, fr_dmask;
+    int16_t fr_k[49];
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
     // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
     bool capturing;
