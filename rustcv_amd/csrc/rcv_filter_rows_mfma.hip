@@ -60,7 +60,7 @@ struct FRArgs {
     const uint4* wtab;   // 2 x NP tables x 64 lanes x 16 B (A operands), device memory
     uint8_t* dump;       // 64 x 16 B scratch for masked-off lanes (EDGE path only)
     size_t sstep, dstep, sfs, dfs;
-    int rows, rowbytes;
+    int rows, cols;
     int nstrips, nframes;
     int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
@@ -87,14 +87,18 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 // 324 = K1 + 2 * T2 with T2 confined to the centre rows; any |w| <= 511 as 4Q + R).  The same data operand feeds a second MFMA
 // with the S table into a second accumulator set; bit (parity * NP + p) of DMASK says which row pairs have a non-zero S table
 // (compile time, so that the accumulator chains stay static): matrix work +5/8 for the Gaussian, memory traffic unchanged.
-template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0>
+// SRC = 1: the source is packed YUYV (2 B/px): the lane's 16 pixels are 8 macropixels = 32 consecutive bytes, converted with the
+// reference's BT.601 integer formula (rustcv/src/videoio/mod.rs:356-363) straight into the three planar operands -- the capture
+// chain YUYV -> BGR -> filter2D in one launch, 5 instead of 11 algorithmic bytes per pixel and no BGR intermediate.
+template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
                                            uint8_t* dframe)
 {
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
     const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
-    const int rb = a.rowbytes;
+    constexpr int SB = SRC == 1 ? 2 : 3, CB = 16 * SB;   // source bytes per pixel / per 16-pixel chunk
+    const int rb = a.cols * 3, rbs = a.cols * SB;        // destination / source row bytes
 
     v4i A[2][NP];
 #pragma unroll
@@ -118,9 +122,9 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 
     // the lane's 48 source bytes per pair: pixels [16n - 4 + 16c, +16) of row 2i + h.  Chunks that stick out of the row are read
     // shifted into it and repaired after the de-interleave (EDGE); without EDGE the clamp is a no-op.
-    const int cb = X + 48 * n - 12 + 48 * c;
-    const unsigned cbo = (unsigned)min(max(cb, 0), rb - 48);
-    const bool fl = EDGE && cb < 0, fr = EDGE && cb == rb - 12;
+    const int cb = (X / 3) * SB + CB * n - 4 * SB + CB * c;
+    const unsigned cbo = (unsigned)min(max(cb, 0), rbs - CB);
+    const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - 4 * SB;
     const int so = X + 48 * n + 12 * q;   // the lane's 12 output bytes: pixels 16n + 4q .. +3
     uint8_t* const dumpp = a.dump + lane * 16;
 
@@ -142,14 +146,35 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         }
         dst[0] = *(const v4i*)(sframe + off);
         dst[1] = *(const v4i*)(sframe + off + 16);
-        dst[2] = *(const v4i*)(sframe + off + 32);
+        if constexpr (SRC == 0) dst[2] = *(const v4i*)(sframe + off + 32);
     };
     auto prepare = [&](v4i(&w)[3]) {
         uint32_t pb[4], pg[4], prr[4];
-        const uint32_t r[12] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
-                                (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
+        if constexpr (SRC == 1) {
+            // 8 macropixels [Y0 U Y1 V] -> the six pre-shift BT.601 sums of their two pixels; >> 8, saturate and pack four pixels
+            // of a plane per dword (v_ashr_pk_u8_i32)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
+            for (int i = 0; i < 4; ++i) {
+                int sb[4], sg[4], sr[4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint32_t mp = (uint32_t)w[i >> 1][2 * (i & 1) + m];
+                    const int y0 = (int)(mp & 0xff), u = (int)((mp >> 8) & 0xff) - 128, y1 = (int)((mp >> 16) & 0xff), v = (int)(mp >> 24) - 128;
+                    const int c0 = 298 * (y0 - 16) + 128, c1 = 298 * (y1 - 16) + 128;
+                    const int db = 516 * u, dg = -100 * u - 208 * v, dr = 409 * v;
+                    sb[2 * m] = c0 + db; sg[2 * m] = c0 + dg; sr[2 * m] = c0 + dr;
+                    sb[2 * m + 1] = c1 + db; sg[2 * m + 1] = c1 + dg; sr[2 * m + 1] = c1 + dr;
+                }
+                pb[i] = rcv_ashr_sat_pk4(sb[0], sb[1], sb[2], sb[3], 8);
+                pg[i] = rcv_ashr_sat_pk4(sg[0], sg[1], sg[2], sg[3], 8);
+                prr[i] = rcv_ashr_sat_pk4(sr[0], sr[1], sr[2], sr[3], 8);
+            }
+        } else {
+            const uint32_t r[12] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
+                                    (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
+        }
         if (EDGE) {
             // left border: the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
             if (fl) {
@@ -238,7 +263,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     }
 }
 
-template <int KS, int PP, int DBG, int DMASK = 0>
+template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0>
 __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
 {
     const int lane = threadIdx.x;
@@ -255,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (band >= a.nbands) return;
     const int X = strip * 768;
-    const bool edge = X == 0 || X + 804 > a.rowbytes;   // the last chunk a strip touches ends at X + 804
+    const bool edge = X == 0 || X + 804 > a.cols * 3;   // the last chunk a strip touches ends at pixel X/3 + 268
     const long long G = (long long)a.nframes * a.rows;
     long long g0 = G * band / a.nbands;
     const long long g1 = G * (band + 1) / a.nbands;
@@ -264,8 +289,8 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
         const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
         const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
         uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
-        if (edge) fr_segment<KS, PP, true, DBG, DMASK>(a, lane, X, ys, ye, sframe, dframe);
-        else fr_segment<KS, PP, false, DBG, DMASK>(a, lane, X, ys, ye, sframe, dframe);
+        if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
+        else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
         g0 += ye - ys;
     }
 }
@@ -320,9 +345,13 @@ constexpr int rows_dmask(int ksize, int lo, int hi)
 constexpr int kCentre7 = rows_dmask(7, 2, 4);   // second table in kernel rows 2..4 (the integer 7x7 Gaussian): 2 of 4 pairs per parity
 
 template <int KS>
-void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, hipStream_t st)
+void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st)
 {
     const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
+    if (src_yuyv) {   // (one weight table only: the caller checked)
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 1>), grid, dim3(64), lds, st, a);
+        return;
+    }
     constexpr int kAll = (1 << (2 * ((KS + 1) / 2))) - 1;
     if (dmask != 0) {   // two weight tables
         if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>), grid, dim3(64), lds, st, a);
@@ -342,12 +371,12 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, hipStream_t s
 // Does this launch belong on the row-streaming kernel?  BGR, |weights| <= 511, rows 16-byte aligned, width a multiple of 16
 // pixels; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
 // small launches keep the strip kernel's latency variant.
-int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
+int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv)
 {
     const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
-    if (s.ch != 3 || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     const long long rb = (long long)s.cols * 3;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
@@ -370,6 +399,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
     if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
+    if (dual && src_yuyv) return RCV_ERR_UNSUPPORTED;
 
     if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
         int8_t m8[49], s8[49];
@@ -410,7 +440,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.sfs = s.fstride;
     a.dfs = d.fstride;
     a.rows = s.rows;
-    a.rowbytes = (int)rb;
+    a.cols = s.cols;
     a.nstrips = nstrips;
     a.nframes = s.n;
     a.dual_shift = split2 ? 1 : 2;
@@ -438,8 +468,8 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
-    if (ksize == 7) launch_rows<7>(a, pp, lds, dmask, ctx->stream);
-    else if (ksize == 5) launch_rows<5>(a, pp, lds, dmask, ctx->stream);
-    else launch_rows<3>(a, pp, lds, dmask, ctx->stream);
+    if (ksize == 7) launch_rows<7>(a, pp, lds, dmask, src_yuyv, ctx->stream);
+    else if (ksize == 5) launch_rows<5>(a, pp, lds, dmask, src_yuyv, ctx->stream);
+    else launch_rows<3>(a, pp, lds, dmask, src_yuyv, ctx->stream);
     return rcv_launch_check(ctx);
 }

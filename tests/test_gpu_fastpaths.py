@@ -57,7 +57,7 @@ def test_fast_kernels_are_dispatched(ctx):
         ("filter2D 7x7 gray (strip kernel, gray variant)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter7_mfma<0, 0, 2>"),
         ("GaussianBlur 7x7 int BGR, 8 x 4K (row-streaming kernel, two weight tables)", lambda: device.gaussian_blur(bgr, bgr2, 7, 0.0), "k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>"),
         ("GaussianBlur 7x7 int BGR, one 1080p frame (two-table strip kernel)", lambda: device.gaussian_blur(one, one2, 7, 0.0), "k_filter7_mfma<0, 2>"),
-        ("fused YUYV -> filter2D", lambda: device.filter2d_yuyv(yuyv, bgr2, k7, shift=6), "k_filter7_mfma<0, 0, 1>"),
+        ("fused YUYV -> filter2D, 8 x 4K (row-streaming kernel, conversion in registers)", lambda: device.filter2d_yuyv(yuyv, bgr2, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 1>"),
         ("filter2D 7x7 f32 BGR (stream kernel)", lambda: device.filter2d(bgr, bgr2, kf), "k_filter_f32_stream<"),
         ("GaussianBlur sigma BGR (separable stream kernel)", lambda: device.gaussian_blur(bgr, bgr2, 7, 1.5), "k_filter_f32_stream<"),
         ("Sobel gray", lambda: device.sobel(gray, dx, dy), "k_sobel_rows<"),

@@ -419,9 +419,13 @@ def test_gaussian_int_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, full_
 
 @pytest.mark.parametrize("rows,cols", [(4, 16), (5, 32), (33, 240), (40, 256), (19, 496), (70, 512), (300, 272), (9, 10), (6, 770)])
 @pytest.mark.parametrize("ksize,shift", [(7, 6), (3, 0), (5, 4)])
-def test_fused_yuyv_filter(ctx, oracle, rng, rows, cols, ksize, shift):
-    """f1: YUYV -> BGR -> filter2D in one launch == the two-step oracle composition (fused MFMA path when cols % 16 == 0,
-    unfused HIP path otherwise), batch of 2 with padded steps"""
+@pytest.mark.parametrize("kernel", ["strip", "rows"])
+def test_fused_yuyv_filter(ctx, oracle, rng, knob, rows, cols, ksize, shift, kernel):
+    """f1: YUYV -> BGR -> filter2D in one launch == the two-step oracle composition (fused MFMA path when cols % 16 == 0 -- the
+    strip kernel for these small launches, the row-streaming kernel with RCV_F7_ROWS=1 -- the unfused HIP path otherwise), batch
+    of 2 with padded steps"""
+    if kernel == "rows":
+        knob("RCV_F7_ROWS")
     n = 2
     k = rng.integers(-9, 10, size=(ksize, ksize)).astype(np.int8)
     src = device.DeviceBatch(ctx, n, rows, cols, 2, step=cols * 2 + 16)
@@ -445,7 +449,7 @@ def test_filter2d_i8_mfma_random_shapes(ctx, oracle, knob, pipelined):
     heights 4..150 (one to several 16-row steps, ragged last step), ksize 3/5/7, weights over the full i8 range, shifts 0..12,
     padded steps, batch 1..3, BGR and YUYV sources"""
     if pipelined == "rows":
-        knob("RCV_F7_ROWS")   # (BGR sources: the row-streaming kernel; the YUYV cases keep the strip kernel)
+        knob("RCV_F7_ROWS")   # (BGR and YUYV sources on the row-streaming kernel)
     elif pipelined:
         knob("RCV_F7_NO_LAT")
     r = np.random.default_rng(0xF17E7 + _SOAK_SEED)
