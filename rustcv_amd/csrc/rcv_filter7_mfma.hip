@@ -639,8 +639,8 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     }
     const int mode = !dual ? 0 : ((centre && !rcv_knobs().f7_dual_full) ? 2 : 1);   // (the knob keeps the full-table kernel testable)
     // BGR, enough rows to fill the GPU: the row-streaming kernel (rcv_filter_rows_mfma.hip), one or two weight tables
-    if (!gray) {
-        const int rc = rcv_filter_i16_rows(ctx, s, d, k, ksize, shift, src_yuyv);
+    {
+        const int rc = rcv_filter_i16_rows(ctx, s, d, k, ksize, shift, gray ? 2 : src_yuyv);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
 

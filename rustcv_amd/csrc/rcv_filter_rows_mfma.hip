@@ -70,6 +70,20 @@ struct FRArgs {
 
 struct U3w { uint32_t a, b, c; };
 
+// swap the odd 16-lane rows of x with the even rows of y / the upper 32 lanes of x with the lower 32 of y
+__device__ __forceinline__ void sw16(uint32_t& x, uint32_t& y)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+__device__ __forceinline__ void sw32(uint32_t& x, uint32_t& y)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
 // 4 interleaved BGR pixels (3 dwords) -> planar B, G, R dwords
 __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& pb, uint32_t& pg, uint32_t& pr)
 {
@@ -90,6 +104,10 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 // SRC = 1: the source is packed YUYV (2 B/px): the lane's 16 pixels are 8 macropixels = 32 consecutive bytes, converted with the
 // reference's BT.601 integer formula (rustcv/src/videoio/mod.rs:356-363) straight into the three planar operands -- the capture
 // chain YUYV -> BGR -> filter2D in one launch, 5 instead of 11 algorithmic bytes per pixel and no BGR intermediate.
+// SRC = 2: ONE-channel (gray) source and destination.  A strip is 768 PIXELS = three neighbouring blocks of 256; what the BGR
+// kernel calls the three planes of a window are the same window in the three blocks, loaded as one dwordx4 each -- no
+// de-interleave at all.  The lane's four output pixels of the three blocks are three dwords 256 bytes apart: a 4 x 4 dword
+// transpose across the four 16-lane rows (2 v_permlane16_swap + 2 v_permlane32_swap) turns them into 16 consecutive bytes per lane.
 template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
                                            uint8_t* dframe)
@@ -97,8 +115,9 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
     const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
-    constexpr int SB = SRC == 1 ? 2 : 3, CB = 16 * SB;   // source bytes per pixel / per 16-pixel chunk
-    const int rb = a.cols * 3, rbs = a.cols * SB;        // destination / source row bytes
+    constexpr bool GRAY = SRC == 2;
+    constexpr int SB = GRAY ? 1 : (SRC == 1 ? 2 : 3), CB = 16 * SB;   // source bytes per pixel / per 16-pixel chunk
+    const int rb = a.cols * (GRAY ? 1 : 3), rbs = a.cols * SB;        // destination / source row bytes
 
     v4i A[2][NP];
 #pragma unroll
@@ -122,10 +141,20 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 
     // the lane's 48 source bytes per pair: pixels [16n - 4 + 16c, +16) of row 2i + h.  Chunks that stick out of the row are read
     // shifted into it and repaired after the de-interleave (EDGE); without EDGE the clamp is a no-op.
-    const int cb = (X / 3) * SB + CB * n - 4 * SB + CB * c;
+    // (gray: X counts pixels = bytes, and the chunk of block pl starts 256 * pl further)
+    const int cb = (GRAY ? X : (X / 3) * SB) + CB * n - 4 * SB + CB * c;
     const unsigned cbo = (unsigned)min(max(cb, 0), rbs - CB);
     const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - 4 * SB;
-    const int so = X + 48 * n + 12 * q;   // the lane's 12 output bytes: pixels 16n + 4q .. +3
+    unsigned cbo1 = 0, cbo2 = 0;
+    bool fr1 = false, fr2 = false;
+    if constexpr (GRAY) {
+        cbo1 = (unsigned)min(cb + 256, rbs - CB);
+        cbo2 = (unsigned)min(cb + 512, rbs - CB);
+        fr1 = EDGE && cb + 256 == rbs - 4;
+        fr2 = EDGE && cb + 512 == rbs - 4;
+    }
+    // the lane's output bytes: BGR: 12 bytes = pixels 16n + 4q .. +3; gray (after the transpose): 16 bytes = window n of block q
+    const int so = GRAY ? X + 256 * min(q, 2) + 16 * n : X + 48 * n + 12 * q;
     uint8_t* const dumpp = a.dump + lane * 16;
 
     // accumulator start value as a resident register quad (opaque to the compiler, which would rebuild it before every chain)
@@ -144,13 +173,27 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             dst[0] = dst[1] = dst[2] = v4i{(int)off, (int)cbo, s0, lane};
             return;
         }
+        if constexpr (GRAY) {
+            const unsigned ro = h ? o1 : o0;
+            dst[0] = *(const v4i*)(sframe + ro + cbo);
+            dst[1] = *(const v4i*)(sframe + ro + cbo1);
+            dst[2] = *(const v4i*)(sframe + ro + cbo2);
+            return;
+        }
         dst[0] = *(const v4i*)(sframe + off);
         dst[1] = *(const v4i*)(sframe + off + 16);
         if constexpr (SRC == 0) dst[2] = *(const v4i*)(sframe + off + 32);
     };
     auto prepare = [&](v4i(&w)[3]) {
         uint32_t pb[4], pg[4], prr[4];
-        if constexpr (SRC == 1) {
+        if constexpr (GRAY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pb[i] = (uint32_t)w[0][i];
+                pg[i] = (uint32_t)w[1][i];
+                prr[i] = (uint32_t)w[2][i];
+            }
+        } else if constexpr (SRC == 1) {
             // 8 macropixels [Y0 U Y1 V] -> the six pre-shift BT.601 sums of their two pixels; >> 8, saturate and pack four pixels
             // of a plane per dword (v_ashr_pk_u8_i32)
 #pragma unroll
@@ -179,7 +222,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             // left border: the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
             if (fl) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < (GRAY ? 1 : 3); ++pl) {
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
                     pp[3] = pp[2];
                     pp[2] = pp[1];
@@ -188,9 +231,10 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                 }
             }
             // right border: the lane read pixels cols-16..cols-1 instead of cols-4..cols+11; pixels cols..cols+2 mirror cols-2..cols-4
-            if (fr) {
+            if (GRAY ? (fr || fr1 || fr2) : fr) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
+                    if (GRAY && !(pl == 0 ? fr : (pl == 1 ? fr1 : fr2))) continue;
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
                     pp[0] = pp[3];
                     pp[1] = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);   // [cols-2, cols-3, cols-4, x]
@@ -212,6 +256,26 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         if constexpr (DMASK != 0) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
+        }
+        if constexpr (GRAY) {
+            // lane (q, n): four consecutive pixels of window n in each of the three blocks -> transpose -> window n of block q
+            uint32_t D[4];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) D[pl] = rcv_ashr_sat_pk4(acc[pl][0], acc[pl][1], acc[pl][2], acc[pl][3], a.shift);
+            D[3] = D[2];
+            sw16(D[0], D[1]);
+            sw16(D[2], D[3]);
+            sw32(D[0], D[2]);
+            sw32(D[1], D[3]);
+            uint8_t* drow = dframe + (size_t)y * a.dstep;
+            if (DBG & 1) {
+                if (D[0] == 0x12345678u && D[1] == 0x9abcdef0u) *(uint4*)dumpp = make_uint4(D[0], D[1], D[2], D[3]);
+            } else if (EDGE) {
+                *(uint4*)(so < rb ? drow + so : dumpp) = make_uint4(D[0], D[1], D[2], D[3]);
+            } else {
+                __builtin_nontemporal_store(v4i{(int)D[0], (int)D[1], (int)D[2], (int)D[3]}, (v4i*)(drow + so));
+            }
+            return;
         }
         // lane (q, n) holds pixels 16n + 4q .. +3 of the three planes: 12 interleaved output bytes
         U3w o;
@@ -279,8 +343,9 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
     // at one time, the slower its memory path (translation reach per XCD is the likely cause).  RCV_FR_ORDER keeps it measurable.
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (band >= a.nbands) return;
-    const int X = strip * 768;
-    const bool edge = X == 0 || X + 804 > a.cols * 3;   // the last chunk a strip touches ends at pixel X/3 + 268
+    const int X = strip * 768;   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset)
+    // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
+    const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
     long long g0 = G * band / a.nbands;
     const long long g1 = G * (band + 1) / a.nbands;
@@ -348,8 +413,12 @@ template <int KS>
 void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st)
 {
     const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
-    if (src_yuyv) {   // (one weight table only: the caller checked)
+    if (src_yuyv == 1) {   // (one weight table only: the caller checked)
         RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 1>), grid, dim3(64), lds, st, a);
+        return;
+    }
+    if (src_yuyv == 2) {   // one-channel images
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 2>), grid, dim3(64), lds, st, a);
         return;
     }
     constexpr int kAll = (1 << (2 * ((KS + 1) / 2))) - 1;
@@ -376,9 +445,11 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
-    if (s.ch != (src_yuyv ? 2 : 3) || d.ch != 3) return RCV_ERR_UNSUPPORTED;
+    // src_yuyv: 0 BGR, 1 packed YUYV source, 2 one-channel (gray) source and destination
+    const bool gray = src_yuyv == 2;
+    if (s.ch != (gray ? 1 : (src_yuyv ? 2 : 3)) || d.ch != (gray ? 1 : 3)) return RCV_ERR_UNSUPPORTED;
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
-    const long long rb = (long long)s.cols * 3;
+    const long long rb = (long long)s.cols * (gray ? 1 : 3);
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     // in-frame source offsets are 32-bit
@@ -399,7 +470,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
     if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
-    if (dual && src_yuyv) return RCV_ERR_UNSUPPORTED;
+    if (dual && src_yuyv) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR only)
 
     if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
         int8_t m8[49], s8[49];

@@ -40,6 +40,8 @@ def test_fast_kernels_are_dispatched(ctx):
     bgr, bgr2, gray, gray2, yuyv = B(3), B(3), B(1), B(1), B(2)
     dx, dy, resp, mask = B(1, _ffi.RCV_16S), B(1, _ffi.RCV_16S), B(1, _ffi.RCV_32F), B(1)
     small = B(3, r=540, c=960)
+    gray16, gray16b = device.DeviceBatch(ctx, 16, rows, cols, 1), device.DeviceBatch(ctx, 16, rows, cols, 1)
+    device.synth(gray16, 1, 12, 0)
     one = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
     one2 = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
     device.synth(bgr, 1, 7, 0)
@@ -54,7 +56,9 @@ def test_fast_kernels_are_dispatched(ctx):
         ("filter2D 7x7 BGR, 8 x 4K (row-streaming MFMA kernel)", lambda: device.filter2d(bgr, bgr2, k7, shift=6), "k_filter_rows_mfma<"),
         ("GaussianBlur 5x5 int BGR, 8 x 4K (row-streaming MFMA kernel)", lambda: device.gaussian_blur(bgr, bgr2, 5, 0.0), "k_filter_rows_mfma<"),
         ("filter2D 7x7 BGR, one 1080p frame (strip kernel, latency variant)", lambda: device.filter2d(one, one2, k7, shift=6), "k_filter7_mfma<0, 0, 0, true>"),
-        ("filter2D 7x7 gray (strip kernel, gray variant)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter7_mfma<0, 0, 2>"),
+        ("filter2D 7x7 gray, 16 x 4K (row-streaming kernel, gray variant)", lambda: device.filter2d(gray16, gray16b, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 2>"),
+        ("filter2D 7x7 gray, 8 x 4K (fewer than 64 rows per wave slot: strip kernel, gray variant)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter7_mfma<0, 0, 2>"),
+        ("GaussianBlur 7x7 int gray (strip kernel, gray variant, two tables)", lambda: device.gaussian_blur(gray, gray2, 7, 0.0), "k_filter7_mfma<0, 2, 2>"),
         ("GaussianBlur 7x7 int BGR, 8 x 4K (row-streaming kernel, two weight tables)", lambda: device.gaussian_blur(bgr, bgr2, 7, 0.0), "k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>"),
         ("GaussianBlur 7x7 int BGR, one 1080p frame (two-table strip kernel)", lambda: device.gaussian_blur(one, one2, 7, 0.0), "k_filter7_mfma<0, 2>"),
         ("fused YUYV -> filter2D, 8 x 4K (row-streaming kernel, conversion in registers)", lambda: device.filter2d_yuyv(yuyv, bgr2, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 1>"),
@@ -89,7 +93,7 @@ def test_fast_kernels_are_dispatched(ctx):
         print(f"{name:72s} {ms:7.3f} ms   {launched}")
         if want not in launched or "generic" in launched:
             wrong.append((name, want, launched))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b):
         b.free()
     assert not wrong, wrong
 

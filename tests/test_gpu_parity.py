@@ -520,7 +520,7 @@ GRAY_MFMA_COLS = [16, 32, 48, 64, 240, 752, 768, 784, 800, 816, 1520, 1536, 1552
 
 @pytest.mark.parametrize("cols", GRAY_MFMA_COLS)
 @pytest.mark.parametrize("dot4", [False, True])
-@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("pipelined", [False, True, "rows"])
 def test_gray_filter_strip_kernel(ctx, oracle, knob, cols, dot4, pipelined):
     """one-channel images on 16-byte aligned rows take the MFMA strip kernel's gray variant (768-pixel strips of 48 tiles):
     widths around the strip seams (one to three + strips; a last strip with 1, 2, 3, ... tiles -- every position ntiles % 3 of the
@@ -531,7 +531,9 @@ def test_gray_filter_strip_kernel(ctx, oracle, knob, cols, dot4, pipelined):
         if pipelined:
             pytest.skip("the dot4 kernel has one variant")
         knob("RCV_F7_NO_GRAY")
-    if pipelined:
+    if pipelined == "rows":
+        knob("RCV_F7_ROWS")     # the row-streaming kernel's gray variant (three 256-pixel blocks per strip; two-table weights: strip kernel)
+    elif pipelined:
         knob("RCV_F7_NO_LAT")   # (small launches would otherwise all take the strip kernel's latency variant)
     r = np.random.default_rng(0x6A4700 + cols + _SOAK_SEED)
     for case in range(max(2, _SOAK // 2)):
