@@ -250,6 +250,16 @@ int  rcv_ring_submit(rcv_ring* ring, const rcv_mat* host_in, rcv_ring_op op, voi
  * (always, when the ring was full): it is valid only until the next rcv_ring_submit.  RCV_NOOP if nothing is in flight */
 int  rcv_ring_retire(rcv_ring* ring, rcv_mat* host_out, rcv_mat* pinned_out);
 
+/* ---- zero-copy import of a DMA-BUF capture buffer ----------------------------------------------------------------------
+ * The consuming side of the reference's declared-but-unimplemented hand-over `AsDmaBuf::as_dmabuf_fd(&self) -> Option<RawFd>`
+ * (rustcv-core/src/frame.rs:58-65: "feed the fd to CUDA/Vulkan; do not close it, ownership belongs to the backend").  The fd is
+ * duplicated -- the caller keeps and later closes its own -- imported as external memory, and bytes [offset, offset + bytes) of
+ * it (a plane's data offset) are mapped on the context's device; *dev_ptr is then ordinary RCV_DEVICE memory of `bytes` bytes for every entry point (rcv_mat.data, device = RCV_DEVICE), valid
+ * until rcv_import_release.  RCV_ERR_DEVICE when the runtime cannot import the buffer. */
+typedef struct rcv_import rcv_import;
+int  rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, size_t bytes, rcv_import** out, void** dev_ptr);
+void rcv_import_release(rcv_import* imp);
+
 /* ---- launch graphs -------------------------------------------------------------------------------------------------
  * The small configurations of the path (the reference's 640x480 convert + rectangle loop, examples/camera_demo.rs:50-76;
  * one 1080p blur) are bound by launch latency.  rcv_graph_begin .. rcv_graph_end records the rcv_*_batch calls (and

@@ -44,6 +44,26 @@ pub fn frame_range(n_frames: usize, rank: usize, world: usize) -> (usize, usize)
     (rank * n_frames / world, (rank + 1) * n_frames / world)
 }
 
+/// A capture buffer that lives in a DMA-BUF, mapped on the GPU without a copy: the consuming side of
+/// `rustcv_core::frame::AsDmaBuf::as_dmabuf_fd` (rustcv-core/src/frame.rs:58-65).  The backend keeps its fd (the import works on a
+/// duplicate); `ptr` is device memory for `rcv_mat { data: ptr, device: RCV_DEVICE, .. }` until the value is dropped.
+pub struct DmaBufImport {
+    raw: *mut rcv_import,
+    pub ptr: *mut c_void,
+    pub len: usize,
+}
+unsafe impl Send for DmaBufImport {}
+impl DmaBufImport {
+    pub fn new(ctx: &HipContext, fd: std::os::unix::io::RawFd, offset: usize, len: usize) -> Result<Self, i32> {
+        let (mut raw, mut ptr) = (std::ptr::null_mut(), std::ptr::null_mut());
+        let rc = unsafe { rcv_import_dmabuf(ctx.raw, fd, offset, len, &mut raw, &mut ptr) };
+        if rc != RCV_OK { Err(rc) } else { Ok(Self { raw, ptr, len }) }
+    }
+}
+impl Drop for DmaBufImport {
+    fn drop(&mut self) { unsafe { rcv_import_release(self.raw) } }
+}
+
 /// View of a `rustcv::core::mat::Mat { data, rows, cols, step, channels }` (host memory, u8).
 pub fn mat_view(data: &mut [u8], rows: i32, cols: i32, step: usize, channels: u8) -> rcv_mat {
     rcv_mat { data: data.as_mut_ptr() as *mut c_void, cap: data.len(), step, rows, cols, channels, depth: RCV_8U as u8, device: RCV_HOST as u8, reserved: 0 }

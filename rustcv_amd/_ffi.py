@@ -77,6 +77,8 @@ SIGNATURES = {
     "rcv_ring_input": (_i, [_ring, _mat]),
     "rcv_ring_submit": (_i, [_ring, _mat, RING_OP, C.c_void_p]),
     "rcv_ring_retire": (_i, [_ring, _mat, _mat]),
+    "rcv_import_dmabuf": (_i, [_ctx, _i, _sz, _sz, _P(C.c_void_p), _P(C.c_void_p)]),
+    "rcv_import_release": (None, [C.c_void_p]),
     "rcv_abi_version": (_i, []),
     "rcv_strerror": (C.c_char_p, [_i]),
     "rcv_device_count": (_i, [_P(_i)]),

@@ -78,6 +78,44 @@ class DeviceBatch:
             pass
 
 
+class ImportedBuffer:
+    """A DMA-BUF mapped into the context's device address space without a copy (`rcv_import_dmabuf`; the consuming side of the
+    reference's `AsDmaBuf::as_dmabuf_fd`, rustcv-core/src/frame.rs:58-65).  `.ptr` is device memory for `DeviceBatch`-style views;
+    the caller keeps ownership of its fd."""
+
+    def __init__(self, ctx: Context, fd: int, nbytes: int, offset: int = 0):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        h, p = C.c_void_p(), C.c_void_p()
+        _ffi.check(_ffi.lib().rcv_import_dmabuf(ctx.handle, int(fd), int(offset), self.nbytes, C.byref(h), C.byref(p)), "rcv_import_dmabuf")
+        self._h, self.ptr = h, p
+
+    def as_batch(self, n, rows, cols, channels, depth=_ffi.RCV_8U, step=None, frame_stride=None):
+        """view the imported bytes as n frames (no allocation: the view does not own the memory)"""
+        b = DeviceBatch.__new__(DeviceBatch)
+        b.ctx, b.n, b.rows, b.cols, b.channels, b.depth = self.ctx, int(n), int(rows), int(cols), int(channels), depth
+        rowb = b.cols * b.channels * _ESZ[depth]
+        b.step = int(step) if step is not None else rowb
+        b.frame_cap = b.rows * b.step
+        b.frame_stride = int(frame_stride) if frame_stride is not None else b.frame_cap
+        b.nbytes = max(b.n, 1) * b.frame_stride
+        if b.nbytes > self.nbytes:
+            raise ValueError("view larger than the imported buffer")
+        b.ptr = self.ptr
+        b.free = lambda: None     # the import owns the mapping
+        return b
+
+    def release(self):
+        if self._h is not None:
+            _ffi.lib().rcv_import_release(self._h)
+            self._h, self.ptr = None, None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def _h(b):
     return b.ctx.handle
 

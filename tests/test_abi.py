@@ -176,7 +176,7 @@ def test_rust_ffi_declares_the_whole_header():
     for name in hf:
         assert rf[name] == hf[name], (name, rf[name], hf[name])
     opaque = {k for k, v in rs.items() if not v}             # zero-sized handles (only a private field)
-    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph"}
+    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph", "rcv_import"}
     for name, fields in hs.items():
         assert rs[name] == fields, (name, rs[name], fields)
     assert rc == hc and len(hc) >= 29
