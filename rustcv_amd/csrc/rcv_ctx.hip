@@ -29,6 +29,7 @@ static void load_knobs()
     g_knobs.fr_wpc = env_int("RCV_FR_WPC", 0);
     g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
+    g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
     g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);

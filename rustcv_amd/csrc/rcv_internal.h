@@ -63,6 +63,7 @@ struct RcvKnobs {
     int fr_rounds;        // RCV_FR_ROUNDS     bands per wave slot of the row-streaming kernel (0 = 8)
     int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
     int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
+    int fr_bpf;           // RCV_FR_BPF        bands per frame (batches of >= 8 frames; 0 = from RCV_FR_ROUNDS)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)

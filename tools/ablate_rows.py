@@ -22,7 +22,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
-KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP", "RCV_FR_ORDER")
+KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP", "RCV_FR_ORDER", "RCV_FR_BPF")
 
 
 def setenv(env):
@@ -51,6 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ablate", action="store_true", help="profiling build: add the no-stores / no-loads / no-MFMA variants")
     ap.add_argument("--copies", action="store_true", help="add plain device copies / reads / writes of the same bytes")
+    ap.add_argument("--fine", action="store_true", help="finer sweep of the bands-per-slot knob")
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
     from bench import bench_kernel7
@@ -69,6 +70,9 @@ def main():
         variants.append((f"rows {wpc} waves/CU", {"RCV_FR_WPC": wpc}, 0, flt))
     for r in (1, 4, 16):
         variants.append((f"rows rounds={r}", {"RCV_FR_ROUNDS": r}, 0, flt))
+    if "--fine" in sys.argv:
+        for b in (10, 12, 14, 15, 16, 18, 20, 21, 22, 24, 27, 30, 32, 36, 40, 43, 45, 48, 54, 60):
+            variants.append((f"rows, {b} bands per frame ({2160 / b:.1f} rows)", {"RCV_FR_BPF": b}, 0, flt))
     if a.ablate:
         for pp in (2, 4):
             variants.append((f"rows PP={pp}", {"RCV_FR_PP": pp}, 0, flt))
