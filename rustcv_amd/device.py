@@ -63,6 +63,16 @@ class DeviceBatch:
         a = np.ascontiguousarray(v).view(_DT[self.depth]).reshape(self.n, self.rows, self.cols, self.channels)
         return a[..., 0] if self.channels == 1 else a
 
+    def download_frame(self, i):
+        """one frame of the batch as [rows, cols(, ch)] (the other frames stay on the device)"""
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        raw = np.empty(self.rows * self.step, dtype=np.uint8)
+        _ffi.check(_ffi.lib().rcv_download(self.ctx.handle, raw.ctypes.data, self.ptr.value + i * self.frame_stride, raw.size), "rcv_download")
+        rowb = self.cols * self.channels * _ESZ[self.depth]
+        a = np.ascontiguousarray(raw.reshape(self.rows, self.step)[:, :rowb]).view(_DT[self.depth]).reshape(self.rows, self.cols, self.channels)
+        return a[..., 0] if self.channels == 1 else a
+
     def memset(self, value=0):
         _ffi.check(_ffi.lib().rcv_memset(self.ctx.handle, self.ptr, value, self.nbytes), "rcv_memset")
 

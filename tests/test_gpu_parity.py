@@ -1271,6 +1271,53 @@ def test_baseline_configs_at_full_size(ctx, oracle):
         x.free()
 
 
+def test_baseline_batch_geometries(ctx, oracle):
+    """the launch geometries the benchmark and the driver time: the whole batches BASELINE.json's configs 3, 4 and 5 name per
+    GPU (64 x 4K, 32 x 8K, 64 x 4K), first / middle / last frame of each result bit for bit against the oracle.  (One-frame and
+    few-frame launches of the same shapes run different band / segment partitions.)"""
+    k7 = (np.arange(49, dtype=np.int8).reshape(7, 7) * 5 % 23 - 11).astype(np.int8)
+    # config 3: 64 x 4K BGR, 7x7 integer filter2D; gray + Sobel of the same batch
+    n, rows, cols = 64, 2160, 3840
+    s, d = device.DeviceBatch(ctx, n, rows, cols, 3), device.DeviceBatch(ctx, n, rows, cols, 3)
+    g = device.DeviceBatch(ctx, n, rows, cols, 1)
+    dx, dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+    m = device.DeviceBatch(ctx, n, rows, cols, 1)
+    device.synth(s, 1, 0x5EED0003, 0)
+    device.filter2d(s, d, k7, shift=6)
+    device.cvt_color(s, g, _ffi.RCV_BGR2GRAY)
+    device.sobel(g, dx, dy)
+    device.harris_pipeline(s, m, None, 2, 0.04, 1e-4)          # config 5
+    for i in (0, n // 2 - 1, n - 1):
+        frame = s.download_frame(i)
+        assert np.array_equal(frame, oracle.synth_frame(rows, cols, 3, 1, 0x5EED0003, i))
+        assert np.array_equal(d.download_frame(i), oracle.filter2d_i8(frame, k7, 6)), ("filter2D", i)
+        gray = oracle.bgr2gray(frame)
+        assert np.array_equal(g.download_frame(i), gray), ("gray", i)
+        wx, wy = oracle.sobel(gray)
+        assert np.array_equal(dx.download_frame(i), wx) and np.array_equal(dy.download_frame(i), wy), ("sobel", i)
+        wm = oracle.harris_pipeline(frame, 2, 0.04, 1e-4)
+        assert np.array_equal(m.download_frame(i), wm) and wm.any(), ("harris", i)
+    for x in (s, d, g, dx, dy, m):
+        x.free()
+    # config 4: 32 x 8K BGR, warpAffine (rotate 7 degrees) and resize to 1080p, and the fused form
+    n, rows, cols = 32, 4320, 7680
+    s, w = device.DeviceBatch(ctx, n, rows, cols, 3), device.DeviceBatch(ctx, n, rows, cols, 3)
+    small, fused = device.DeviceBatch(ctx, n, 1080, 1920, 3), device.DeviceBatch(ctx, n, 1080, 1920, 3)
+    device.synth(s, 1, 0x5EED0004, 0)
+    M = _rot(7.0, cols / 2, rows / 2, 13.25, -8.5)
+    device.warp_affine(s, w, M)
+    device.resize(w, small)
+    device.warp_affine_resize(s, fused, M, rows, cols)
+    for i in (0, n // 2, n - 1):
+        warped = oracle.warp_affine(s.download_frame(i), M, rows, cols)
+        assert np.array_equal(w.download_frame(i), warped), ("warp", i)
+        want = oracle.resize(warped, 1080, 1920)
+        assert np.array_equal(small.download_frame(i), want), ("resize", i)
+        assert np.array_equal(fused.download_frame(i), want), ("fused", i)
+    for x in (s, w, small, fused):
+        x.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(4, 8), (9, 496), (40, 504), (33, 1000), (130, 3840), (21, 10), (7, 6)])
 @pytest.mark.parametrize("want_resp", [False, True])
 def test_harris_pipeline_from_yuyv(ctx, oracle, rows, cols, want_resp):
