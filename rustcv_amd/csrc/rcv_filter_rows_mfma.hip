@@ -154,7 +154,8 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         fr2 = EDGE && cb + 512 == rbs - 4;
     }
     // the lane's output bytes: BGR: 12 bytes = pixels 16n + 4q .. +3; gray (after the transpose): 16 bytes = window n of block q
-    const int so = GRAY ? X + 256 * min(q, 2) + 16 * n : X + 48 * n + 12 * q;
+    const int so = GRAY ? X + 256 * min(q, 2) + 16 * n : ((DBG & 16) ? X + 12 * lane : X + 48 * n + 12 * q);
+    const int ordl = ((lane >> 2) + 16 * (lane & 3)) << 2;   // (DBG & 16) lane-ordered stores: lane l takes the 12 bytes of lane (n = l >> 2, q = l & 3)
     uint8_t* const dumpp = a.dump + lane * 16;
 
     // accumulator start value as a resident register quad (opaque to the compiler, which would rebuild it before every chain)
@@ -165,7 +166,8 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     auto request = [&](int pr, v4i(&dst)[3]) {
         // rows 2*pr (lanes h = 0) and 2*pr + 1 (lanes h = 1) of the segment's window, mirrored at the image border (scalar math);
         // rows past the window re-read its last row (cache hits, never used)
-        const int y0 = min(ys - RAD + 2 * pr, ye - 1 + RAD), y1 = min(ys - RAD + 2 * pr + 1, ye - 1 + RAD);
+        const int XR = (DBG & 128) ? 0 : RAD;   // (experiment: no halo rows)
+        const int y0 = min(ys - XR + 2 * pr, ye - 1 + XR), y1 = min(ys - XR + 2 * pr + 1, ye - 1 + XR);
         const int s0 = y0 < 0 ? -y0 : (y0 >= a.rows ? 2 * a.rows - 2 - y0 : y0), s1 = y1 < 0 ? -y1 : (y1 >= a.rows ? 2 * a.rows - 2 - y1 : y1);
         const unsigned o0 = (unsigned)s0 * (unsigned)a.sstep, o1 = (unsigned)s1 * (unsigned)a.sstep;   // < 2^32 (host check)
         const unsigned off = (h ? o1 : o0) + cbo;
@@ -178,6 +180,23 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             dst[0] = *(const v4i*)(sframe + ro + cbo);
             dst[1] = *(const v4i*)(sframe + ro + cbo1);
             dst[2] = *(const v4i*)(sframe + ro + cbo2);
+            return;
+        }
+        if constexpr ((DBG & 32) != 0) {   // (experiment: every source byte loaded by exactly one lane: 24 bytes per lane)
+            const unsigned xo = (h ? o1 : o0) + (unsigned)(X + 48 * n + 24 * c);
+            typedef int v2i_ __attribute__((ext_vector_type(2)));
+            v4i t0;
+            v2i_ t1;
+            if (DBG & 64) {
+                t0 = __builtin_nontemporal_load((const v4i*)(sframe + xo));
+                t1 = __builtin_nontemporal_load((const v2i_*)(sframe + xo + 16));
+            } else {
+                t0 = *(const v4i*)(sframe + xo);
+                t1 = *(const v2i_*)(sframe + xo + 16);
+            }
+            dst[0] = t0;
+            dst[1] = v4i{t1.x, t1.y, t0.x, t0.y};
+            dst[2] = t0;
             return;
         }
         dst[0] = *(const v4i*)(sframe + off);
@@ -282,6 +301,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
         o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
         o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        if (DBG & 16) {
+            o.a = (uint32_t)__builtin_amdgcn_ds_bpermute(ordl, (int)o.a);
+            o.b = (uint32_t)__builtin_amdgcn_ds_bpermute(ordl, (int)o.b);
+            o.c = (uint32_t)__builtin_amdgcn_ds_bpermute(ordl, (int)o.c);
+        }
         uint8_t* drow = dframe + (size_t)y * a.dstep;
         if (DBG & 1) {
             if (o.a == 0x12345678u && o.b == 0x9abcdef0u) *(U3w*)dumpp = o;
@@ -380,7 +404,18 @@ template <int KS, int PP>
 void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t st)
 {
 #ifdef RCV_ABLATE
-    switch (rcv_debug_flags & 15) {
+    switch (rcv_debug_flags & 255) {
+    case 32: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 32>), grid, dim3(64), lds, st, a); return;
+    case 96: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 96>), grid, dim3(64), lds, st, a); return;
+    case 128: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 128>), grid, dim3(64), lds, st, a); return;
+    case 224: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 224>), grid, dim3(64), lds, st, a); return;
+    case 36: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 36>), grid, dim3(64), lds, st, a); return;
+    case 100: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 100>), grid, dim3(64), lds, st, a); return;
+    case 132: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 132>), grid, dim3(64), lds, st, a); return;
+    case 228: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 228>), grid, dim3(64), lds, st, a); return;
+    case 37: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 37>), grid, dim3(64), lds, st, a); return;
+    case 101: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 101>), grid, dim3(64), lds, st, a); return;
+    case 229: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 229>), grid, dim3(64), lds, st, a); return;
     case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 1>), grid, dim3(64), lds, st, a); return;
     case 2: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 2>), grid, dim3(64), lds, st, a); return;
     case 3: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 3>), grid, dim3(64), lds, st, a); return;
@@ -388,6 +423,8 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 5>), grid, dim3(64), lds, st, a); return;
     case 6: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 6>), grid, dim3(64), lds, st, a); return;
     case 8: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 8>), grid, dim3(64), lds, st, a); return;
+    case 16: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 16>), grid, dim3(64), lds, st, a); return;
+    case 18: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 18>), grid, dim3(64), lds, st, a); return;
     default: break;
     }
 #endif

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="profiling build: add the no-stores / no-loads / no-MFMA variants")
     ap.add_argument("--copies", action="store_true", help="add plain device copies / reads / writes of the same bytes")
     ap.add_argument("--fine", action="store_true", help="finer sweep of the bands-per-slot knob")
+    ap.add_argument("--rounds", action="store_true", help="sweep of the band height (rounds of bands per wave slot)")
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
     from bench import bench_kernel7
@@ -73,10 +74,18 @@ def main():
     if "--fine" in sys.argv:
         for b in (10, 12, 14, 15, 16, 18, 20, 21, 22, 24, 27, 30, 32, 36, 40, 43, 45, 48, 54, 60):
             variants.append((f"rows, {b} bands per frame ({2160 / b:.1f} rows)", {"RCV_FR_BPF": b}, 0, flt))
+    if a.rounds:
+        for r in (12, 16, 20, 24, 32, 40, 48, 64, 96, 128):
+            variants.append((f"rows rounds={r}", {"RCV_FR_ROUNDS": r}, 0, flt))
     if a.ablate:
         for pp in (2, 4):
             variants.append((f"rows PP={pp}", {"RCV_FR_PP": pp}, 0, flt))
-        for flags, nm in ((8, "plain stores"), (1, "no stores"), (2, "no loads"), (3, "compute only"), (4, "no MFMA"), (5, "loads only"), (6, "stores only")):
+        for flags, nm in ((8, "plain stores"), (1, "no stores"), (2, "no loads"), (3, "compute only"), (4, "no MFMA"), (5, "loads only"), (6, "stores only"),
+                          (16, "lane-ordered stores (bpermute)"), (18, "lane-ordered stores only"),
+                          (32, "exclusive loads (24 B per lane; wrong data)"), (96, "exclusive nt loads"), (128, "no halo rows (wrong data)"),
+                          (224, "exclusive nt loads, no halo rows"), (36, "no MFMA, exclusive loads"), (100, "no MFMA, exclusive nt loads"),
+                          (132, "no MFMA, no halo rows"), (228, "no MFMA, exclusive nt loads, no halo rows"),
+                          (37, "loads only, exclusive"), (101, "loads only, exclusive nt"), (229, "loads only, exclusive nt, no halo")):
             variants.append((f"rows, {nm}", {}, flags, flt))
     if a.copies:
         names = {0: "hipMemcpy D2D", 1: "copy sweep", 2: "copy block-contiguous", 3: "copy sweep nt", 5: "copy block nt", 6: "read only", 7: "write only",
