@@ -282,44 +282,43 @@ __device__ __forceinline__ void quad_transpose4(uint32_t (&a)[4], int lane)
     a[3] = hi ? b3 : y1;
 }
 
-// Two phases per thread so that all 16 tap loads of its 8 rows are in flight together: the loads are unconditional
-// (clamped tap windows) -- a branch around them would make the compiler wait vmcnt(0) row by row.
-__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A)
+// One wave's share of k_warp_affine_bgr / of the tiles k_warp_affine_bgr_lds cannot stage: column x, rows ybase .. ybase + 7 of
+// frames f0 .. f1 - 1.  The map is the same for every frame of a batch, so the source coordinates, tap offsets and lerp weights
+// of the thread's 8 pixels -- a quarter of the interior path's arithmetic -- are computed once and reused for every frame.
+// The tap loads are unconditional (clamped tap windows): a branch around them would make the compiler wait vmcnt(0) row by row.
+__device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, const Affine& A, int f0, int f1, int x, int ybase)
 {
-    // (an XCD-aware block order that keeps vertically neighbouring bands on one L2 was measured: no gain, the kernel is bound
-    //  by the per-lane tap gathers and the arithmetic, not by the 1.4x source re-reads)
-    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
-    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
     const int rowbytes = s.cols * 3;
-    // lane -> pixel: a wave covers kWarpWW columns x (64 / kWarpWW) bands of kWarpRows rows, a workgroup kWarpTW columns
-    // (squarer source patches than one 256-pixel row band: more of every fetched line is used before it leaves L1 / L2)
-    const int wlane = threadIdx.x & 63, wwave = threadIdx.x >> 6;
-    const int x = blockIdx.x * kWarpTW + (wwave % (kWarpTW / kWarpWW)) * kWarpWW + (wlane % kWarpWW);   // d.cols % 4 == 0: quads never straddle the row end
     const float fxx = (float)min(x, d.cols - 1);
-    const int ybase = ((int)blockIdx.y * (kBlock / kWarpTW) + (wwave / (kWarpTW / kWarpWW)) * (64 / kWarpWW) + wlane / kWarpWW) * kWarpRows;
 
     // ---- interior fast path (wave-uniform) ----
     // The border version below spends ~160 VALU ops per pixel and two unaligned 8-byte loads per row.  sx and sy are
     // monotonic in the row index for a fixed lane (fmaf rounds monotonically), so testing the first and the last row of the
     // thread bounds all eight.  If every lane of the wave keeps all four taps and the whole 12-byte aligned tap window
     // inside the source (0 <= sx < cols-3, 0 <= sy < rows-1) the validity masks, the clamps, the funnel shifts and the final
-    // saturation are all no-ops: 59 VALU ops per pixel, same f32 operations in the same order.
+    // saturation are all no-ops: 54 VALU ops per pixel for the first frame of a group and 41 for the others, same f32
+    // operations in the same order.
     {
         const float fy0 = (float)min(ybase, d.rows - 1), fy1 = (float)min(ybase + kWarpRows - 1, d.rows - 1);
         const float xa = fmaf(A.m[0], fxx, fmaf(A.m[1], fy0, A.m[2])), xb = fmaf(A.m[0], fxx, fmaf(A.m[1], fy1, A.m[2]));
         const float ya = fmaf(A.m[3], fxx, fmaf(A.m[4], fy0, A.m[5])), yb = fmaf(A.m[3], fxx, fmaf(A.m[4], fy1, A.m[5]));
         const float xl = (float)(s.cols - 3), yl = (float)(s.rows - 1);   // x0 <= cols-4: the 12-byte window below ends inside the row
         const bool inter = fminf(xa, xb) >= 0.0f && fmaxf(xa, xb) < xl && fminf(ya, yb) >= 0.0f && fmaxf(ya, yb) < yl;   // NaN -> false
-        const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) &&
-                           d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
+        // (every frame of the batch 4-byte aligned: base and frame stride)
+        const bool small = ((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+                           (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) && d.rows < (1 << 24) &&
+                           (unsigned long long)d.rows * d.step < (1ull << 32);
         // all eight rows of every lane outside the source on the same side: constant border, nothing to load
         const bool outside = !(fmaxf(xa, xb) > -1.0f) || !(fminf(xa, xb) < (float)s.cols) || !(fmaxf(ya, yb) > -1.0f) || !(fminf(ya, yb) < (float)s.rows);
         if (__all(outside)) {
             if ((threadIdx.x & 3) == 0 && x < d.cols) {
                 struct U3 { uint32_t a, b, c; };
+                for (int f = f0; f < f1; ++f) {
+                    uint8_t* dfr = d.p + (size_t)f * d.fstride;
 #pragma unroll
-                for (int r = 0; r < kWarpRows; ++r)
-                    if (ybase + r < d.rows) *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{0u, 0u, 0u};
+                    for (int r = 0; r < kWarpRows; ++r)
+                        if (ybase + r < d.rows) *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{0u, 0u, 0u};
+                }
             }
             return;
         }
@@ -329,9 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
             // (the address path serialises misaligned lanes; measured, same for ds_read_b64), so the taps are fetched as
             // the three ALIGNED dwords that contain them and shifted into place with v_alignbyte.
             struct U3 { uint32_t a, b, c; };
-            U3 ta[kWarpRows], tb[kWarpRows];
             f2 fxy[kWarpRows];
-            unsigned sh[kWarpRows];
+            unsigned sh[kWarpRows], oa[kWarpRows];
 #pragma unroll
             for (int r = 0; r < kWarpRows; ++r) {
                 const float fyy = (float)min(ybase + r, d.rows - 1);
@@ -344,33 +342,74 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
                 const unsigned x0 = (unsigned)(int)sxy.x, y0 = (unsigned)(int)sxy.y;
                 const unsigned off = __umul24(y0, sstep) + 3u * x0;   // rows start 4-byte aligned (checked by the caller)
                 sh[r] = off & 3u;
-                ta[r] = *(const U3*)(sf + (off & ~3u));
-                tb[r] = *(const U3*)(sf + ((off & ~3u) + sstep));
+                oa[r] = off & ~3u;
             }
-            uint32_t px[kWarpRows];
-#pragma unroll
-            for (int r = 0; r < kWarpRows; ++r) {
-                const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh[r]);
-                const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh[r]);
-                px[r] = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[r]);
-            }
-            // four rows at a time: quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
             const int lane = threadIdx.x & 63;
             const int xq = x & ~3, yi = ybase + (lane & 3);
+            unsigned so[kWarpRows / 4];
 #pragma unroll
-            for (int h = 0; h < kWarpRows / 4; ++h) {
-                uint32_t t[4] = {px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]};
+            for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq;
+            // Frames are software-pipelined in halves of four rows: while one half's 12 lerps run, the other half's eight
+            // tap loads and the next frame's are in flight (the tap registers are reloaded right after their last use), so
+            // a wave always has 8-16 loads outstanding instead of alternating between waiting and computing.
+            typedef const __attribute__((address_space(1))) uint8_t* cgp;
+            typedef __attribute__((address_space(1))) uint8_t* gp;
+            typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+            typedef __attribute__((address_space(1))) u3v gU3;
+            u3v ta[kWarpRows], tb[kWarpRows];
+            auto load_half = [&](int h, int f) {
+                // uniform frame base pinned to SGPRs: the loads take the scalar-base + 32-bit-offset form
+                cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
+                asm("" : "+s"(sf));
+#pragma unroll
+                for (int r = 4 * h; r < 4 * h + 4; ++r) {
+                    // (the offsets are made opaque here so that their zero-extension is not hoisted out of the frame loop as
+                    //  64-bit values -- instruction selection then no longer sees base + zext(offset) and builds 64-bit
+                    //  vector addresses with one v_lshl_add_u64 per load)
+                    unsigned o0 = oa[r], o1 = oa[r] + sstep;
+                    asm("" : "+v"(o0), "+v"(o1));
+                    ta[r] = *(const gU3*)(sf + o0);
+                    tb[r] = *(const gU3*)(sf + o1);
+                }
+            };
+            auto finish_half = [&](int h, int f) {
+                gp dfr = (gp)(d.p + (size_t)f * d.fstride);
+                asm("" : "+s"(dfr));
+                uint32_t t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * h + i;
+                    const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].y, ta[r].x, sh[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].z, ta[r].y, sh[r]);
+                    const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].y, tb[r].x, sh[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].z, tb[r].y, sh[r]);
+                    t[i] = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[r]);
+                }
+                // quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
                 quad_transpose4(t, lane);
                 if (xq < d.cols && yi + 4 * h < d.rows) {
+                    unsigned o = so[h];
+                    asm("" : "+v"(o));
                     // 4 x {b g r 0} -> 12 bytes with three byte permutes
-                    *(U3*)(dfr + (__umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq)) =
-                        U3{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+                    *(gU3*)(dfr + o) =
+                        u3v{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
                 }
+            };
+            load_half(0, f0);
+            load_half(1, f0);
+            for (int f = f0; f < f1 - 1; ++f) {
+                finish_half(0, f);
+                load_half(0, f + 1);
+                finish_half(1, f);
+                load_half(1, f + 1);
             }
+            finish_half(0, f1 - 1);
+            finish_half(1, f1 - 1);
             return;
         }
     }
 
+    for (int f = f0; f < f1; ++f) {
+    const uint8_t* sf = s.p + (size_t)f * s.fstride;
+    uint8_t* dfr = d.p + (size_t)f * d.fstride;
     uint2 ta[kWarpRows], tb[kWarpRows];
     float fx[kWarpRows], fy[kWarpRows];
     int sh[kWarpRows];          // bit shift that puts the tap pair at bit 0 of the 8-byte window
@@ -432,6 +471,19 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
             *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
         }
     }
+    }
+}
+
+// blockIdx.z = a GROUP of fpg consecutive frames (see warp_bgr_wave).
+// (Two tile orders that keep vertically neighbouring tiles on one XCD's L2 were measured against the plain order: 1-10 % slower.)
+__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affine A, int fpg)
+{
+    // lane -> pixel: a wave covers kWarpWW columns x (64 / kWarpWW) bands of kWarpRows rows, a workgroup kWarpTW columns
+    const int wlane = threadIdx.x & 63, wwave = threadIdx.x >> 6;
+    const int x = blockIdx.x * kWarpTW + (wwave % (kWarpTW / kWarpWW)) * kWarpWW + (wlane % kWarpWW);   // d.cols % 4 == 0: quads never straddle the row end
+    const int ybase = ((int)blockIdx.y * (kBlock / kWarpTW) + (wwave / (kWarpTW / kWarpWW)) * (64 / kWarpWW) + wlane / kWarpWW) * kWarpRows;
+    const int f0 = (int)blockIdx.z * fpg;
+    warp_bgr_wave(s, d, A, f0, min(f0 + fpg, d.n), x, ybase);
 }
 
 // One-channel images: the scheme of k_warp_affine_bgr with 2-byte tap pairs.  One thread per output column and kWarpRows
@@ -763,7 +815,13 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
     if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
         const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
-        RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, (d.rows + band - 1) / band, d.n), dim3(kBlock), 0, ctx->stream, s, d, A);
+        const unsigned gy = (unsigned)((d.rows + band - 1) / band);
+        // frames per workgroup (the coordinate arithmetic is shared inside a group): as many of 8 / 4 / 2 as still leave >= 8192 workgroups
+        const unsigned long long wgs = (unsigned long long)gx * gy * d.n;
+        int fpg = wgs / 8 >= 8192 ? 8 : (wgs / 4 >= 8192 ? 4 : (wgs / 2 >= 8192 ? 2 : 1));
+        if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
+        const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
+        RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, gy, gz), dim3(kBlock), 0, ctx->stream, s, d, A, fpg);
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
