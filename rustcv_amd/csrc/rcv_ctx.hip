@@ -32,6 +32,7 @@ static void load_knobs()
     g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
+    g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
     g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);

@@ -2,6 +2,7 @@
 // (SURVEY.md F1); semantics SURVEY.md 8-A == oracle/rcv_oracle.c orc_resize / orc_warp_affine.
 // f32 evaluation order is fixed and spelled out op by op; built with -ffp-contract=off.
 #include "rcv_internal.h"
+#include <math.h>
 
 namespace {
 
@@ -368,8 +369,24 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
                     //  vector addresses with one v_lshl_add_u64 per load)
                     unsigned o0 = oa[r], o1 = oa[r] + sstep;
                     asm("" : "+v"(o0), "+v"(o1));
+#if defined(RCV_WARP_EXP) && RCV_WARP_EXP == 2     // (experiment, wrong results: 8-byte tap loads)
+                    typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
+                    const u2v_ e0 = *(const __attribute__((address_space(1))) u2v_*)(sf + o0), e1 = *(const __attribute__((address_space(1))) u2v_*)(sf + o1);
+                    ta[r] = u3v{e0.x, e0.y, e0.x};
+                    tb[r] = u3v{e1.x, e1.y, e1.x};
+#elif defined(RCV_WARP_EXP) && RCV_WARP_EXP == 1   // (experiment, wrong results: 4-byte tap loads)
+                    const uint32_t e0 = *(const __attribute__((address_space(1))) uint32_t*)(sf + o0), e1 = *(const __attribute__((address_space(1))) uint32_t*)(sf + o1);
+                    ta[r] = u3v{e0, e0, e0};
+                    tb[r] = u3v{e1, e1, e1};
+#elif defined(RCV_WARP_EXP) && RCV_WARP_EXP == 4   // (experiment, wrong results: 16-byte tap loads)
+                    typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
+                    const u4v_ e0 = *(const __attribute__((address_space(1))) u4v_*)(sf + (o0 & ~15u)), e1 = *(const __attribute__((address_space(1))) u4v_*)(sf + (o1 & ~15u));
+                    ta[r] = u3v{e0.x, e0.y, e0.z ^ e0.w};
+                    tb[r] = u3v{e1.x, e1.y, e1.z ^ e1.w};
+#else
                     ta[r] = *(const gU3*)(sf + o0);
                     tb[r] = *(const gU3*)(sf + o1);
+#endif
                 }
             };
             auto finish_half = [&](int h, int f) {
@@ -484,6 +501,167 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
     const int ybase = ((int)blockIdx.y * (kBlock / kWarpTW) + (wwave / (kWarpTW / kWarpWW)) * (64 / kWarpWW) + wlane / kWarpWW) * kWarpRows;
     const int f0 = (int)blockIdx.z * fpg;
     warp_bgr_wave(s, d, A, f0, min(f0 + fpg, d.n), x, ybase);
+}
+
+// ---- warpAffine BGR through an LDS-staged source patch ------------------------------------------------------------------
+// k_warp_affine_bgr is bound by its tap gathers: every pixel costs two 12-byte vector loads whose 64 lanes spread over many
+// cache lines, and the texture-address path spends ~32 cycles on each such wave instruction whatever its width (4 / 8 / 12 /
+// 16-byte tap loads time the same) -- 512 of them per wave and frame against ~330 cycles of arithmetic.  Here a
+// workgroup (4 waves, an output tile of 64 columns x 32 rows: near-square, so the rotated source patch is only ~1.4x the
+// tile) copies the patch into LDS with coalesced 12-byte loads of 4 pixels each -- about four per thread and frame instead of
+// sixteen gathers -- unpacked to one dword per pixel {b g r x}: a pixel's two taps of a row are then two consecutive dwords
+// (one ds_read2_b32, no byte alignment work), and with a row pitch chosen by the host for the matrix (warp_lds_plan) the 32
+// lanes of a read land on 32 different banks.  Two LDS buffers: the next frame's patch is in flight while this frame's 8
+// pixels per thread are computed, one barrier per frame.  pitch / prow / cpr: bytes per staged row (a multiple of 16), staged
+// rows and 4-pixel chunks per row; a tile whose patch does not fit, touches the source border or lies outside runs
+// warp_bgr_wave (direct gathers) instead.  Same f32 operations in the same order as every other path.
+constexpr int kWlTW = 64, kWlTH = 32, kWlMaxG = 6;
+
+// bilerp_bgr on unpacked pixels: p00, p01 = {b g r x} of the upper tap pair, p10, p11 of the lower
+__device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, f2 fxy)
+{
+    const f2 a0 = {ub<0>(p00), ub<1>(p00)}, a1 = {ub<0>(p01), ub<1>(p01)};
+    const f2 b0 = {ub<0>(p10), ub<1>(p10)}, b1 = {ub<0>(p11), ub<1>(p11)};
+    const f2 c0 = {ub<2>(p00), ub<2>(p10)}, c1 = {ub<2>(p01), ub<2>(p11)};
+    const f2 half2 = {0.5f, 0.5f};
+    const f2 top = pk_fma_bc<0>(fxy, a1 - a0, a0);
+    const f2 bot = pk_fma_bc<0>(fxy, b1 - b0, b0);
+    const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
+    const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
+    const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
+    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+}
+
+__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
+                                                                int tiles_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wl_lds[];
+    // Tile order: hardware places block b on XCD b % 8.  With tiles_per_xcd > 0 every XCD works through its own contiguous run
+    // of the (frame group, tile row, tile column) list in raster order: the patches of neighbouring tiles overlap (the bounding
+    // box of a rotated tile is ~1.5x the tile), and only tiles that run on the same XCD shortly after one another find the
+    // shared source rows in its L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_per_xcd > 0) {
+        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
+        if (t >= ntiles) return;
+        bz = t / (gx * gy);
+        const int rem = t - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
+    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
+    // the tile's source patch: sx and sy are monotonic in x and in y (fmaf rounds monotonically), so the four corners of the
+    // (clamped) tile bound every lane's coordinates
+    const float cx0 = (float)min(bx * kWlTW, d.cols - 1), cx1 = (float)min(bx * kWlTW + kWlTW - 1, d.cols - 1);
+    const float cy0 = (float)min(by * kWlTH, d.rows - 1), cy1 = (float)min(by * kWlTH + kWlTH - 1, d.rows - 1);
+    const float t0 = fmaf(A.m[1], cy0, A.m[2]), t1 = fmaf(A.m[1], cy1, A.m[2]), u0 = fmaf(A.m[4], cy0, A.m[5]), u1 = fmaf(A.m[4], cy1, A.m[5]);
+    const float xa = fmaf(A.m[0], cx0, t0), xb = fmaf(A.m[0], cx1, t0), xc = fmaf(A.m[0], cx0, t1), xd = fmaf(A.m[0], cx1, t1);
+    const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
+    const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+    const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+    // every tap of the tile inside the source, one more row of slack below (the last 12-byte chunk of a patch row may read past
+    // the row's end into the next row), 32-bit in-frame offsets, 4-byte aligned rows in every frame
+    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
+              ((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0 && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+              (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
+    int ix0 = 0, iy0 = 0;
+    if (ok) {
+        ix0 = (int)xmin & ~3;   // patch columns start at a multiple of 4 pixels = 12 bytes: 4-byte aligned chunk loads
+        iy0 = (int)ymin;
+        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) {   // (the same value in every lane of the workgroup)
+        warp_bgr_wave(s, d, A, f0, f1, x, ybase);
+        return;
+    }
+    ix0 = __builtin_amdgcn_readfirstlane(ix0);
+    iy0 = __builtin_amdgcn_readfirstlane(iy0);
+
+    // ---- frame-invariant per-thread state: lerp weights and the LDS offset of each pixel's upper-left tap ----
+    const float fxx = (float)min(x, d.cols - 1);
+    f2 fxy[kWarpRows];
+    unsigned la[kWarpRows];
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        const float fyy = (float)min(ybase + r, d.rows - 1);
+        const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
+        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
+        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+    }
+    const int xq = x & ~3, yi = ybase + (lane & 3);
+    unsigned so[kWarpRows / 4];
+#pragma unroll
+    for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq;
+    // ---- staging plan: chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ... ----
+    const int nchunks = prow * cpr;             // <= kWlMaxG * 256 (host)
+    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - 12u;
+    unsigned goff[kWlMaxG], loff[kWlMaxG];
+    bool gval[kWlMaxG];
+#pragma unroll
+    for (int g = 0; g < kWlMaxG; ++g) {
+        const int c = (int)threadIdx.x + kBlock * g;
+        gval[g] = c < nchunks;
+        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
+        // rows below the source and a chunk past the frame's end are read from a clamped position: no tap lies in them
+        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(3 * (ix0 + 4 * col)), frame_lim);
+        loff[g] = (unsigned)(row * pitch + 16 * col);
+    }
+    const int ng = (nchunks + kBlock - 1) / kBlock;
+    typedef const __attribute__((address_space(1))) uint8_t* cgp;
+    typedef __attribute__((address_space(1))) uint8_t* gp;
+    typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) u3v gU3;
+    u3v G[kWlMaxG];
+    auto gload = [&](int f) {
+        cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
+        asm("" : "+s"(sf));
+#pragma unroll
+        for (int g = 0; g < kWlMaxG; ++g)
+            if (g < ng) {   // uniform
+                unsigned o = goff[g];
+                asm("" : "+v"(o));
+                G[g] = *(const gU3*)(sf + o);
+            }
+    };
+    const unsigned bufbytes = (unsigned)(pitch * prow);
+    gload(f0);
+    for (int f = f0; f < f1; ++f) {
+        uint8_t* buf = wl_lds + ((f - f0) & 1) * bufbytes;
+#pragma unroll
+        for (int g = 0; g < kWlMaxG; ++g)
+            if (gval[g])   // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
+                *(u4v*)(buf + loff[g]) = u4v{G[g].x, __builtin_amdgcn_alignbyte(G[g].y, G[g].x, 3), __builtin_amdgcn_alignbyte(G[g].z, G[g].y, 2), G[g].z >> 8};
+        __syncthreads();
+        if (f + 1 < f1) gload(f + 1);
+        gp dfr = (gp)(d.p + (size_t)f * d.fstride);
+        asm("" : "+s"(dfr));
+#pragma unroll
+        for (int h = 0; h < kWarpRows / 4; ++h) {
+            uint32_t t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * h + i;
+                const uint32_t* pa = (const uint32_t*)(buf + la[r]);
+                const uint32_t* pb = (const uint32_t*)(buf + la[r] + pitch);
+                t[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[r]);
+            }
+            // quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
+            // (the same transpose through LDS -- four dword writes and one ds_read_b128 per wave instead of 16 VALU
+            //  instructions -- timed the same: 1.655 against 1.645 ms)
+            quad_transpose4(t, lane);
+            if (xq < d.cols && yi + 4 * h < d.rows) {
+                unsigned o = so[h];
+                asm("" : "+v"(o));
+                *(gU3*)(dfr + o) =
+                    u3v{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+            }
+        }
+    }
 }
 
 // One-channel images: the scheme of k_warp_affine_bgr with 2-byte tap pairs.  One thread per output column and kWarpRows
@@ -804,6 +982,60 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
     return rcv_launch_check(ctx);
 }
 
+// Patch geometry of k_warp_affine_bgr_lds for the map M: staged rows, 4-pixel chunks per row and the LDS row pitch.  Extents
+// from the matrix with slack for the floor, the right / lower tap and the 4-pixel alignment of the patch's first column.  The
+// pitch is the one -- of the multiples of 16 bytes that keep both buffers within 64 KB -- for which the 32 lanes of a tap read
+// (ds_read_b32 groups, bank = dword index mod 32) collide least: the lanes of a wave walk along a source row and step to the
+// next row every 1 / |m3| pixels, so the best row pitch depends on the matrix.  A model of the first wave of two tiles decides.
+static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cpr_out)
+{
+    for (int i = 0; i < 6; ++i)
+        if (!(fabsf(M[i]) <= 3.0e38f)) return false;   // NaN, inf
+    const double wx = fabs((double)M[0]) * (kWlTW - 1) + fabs((double)M[1]) * (kWlTH - 1);
+    const double wy = fabs((double)M[3]) * (kWlTW - 1) + fabs((double)M[4]) * (kWlTH - 1);
+    if (!(wx < 2048.0 && wy < 2048.0)) return false;
+    const int cpr = ((int)ceil(wx) + 3 + 3 + 3) / 4;     // pixels: extent + floor slack + right tap, + up to 3 for the aligned start
+    const int prow = (int)ceil(wy) + 3;
+    if ((long long)cpr * prow > (long long)kWlMaxG * kBlock) return false;
+    int best = 0;
+    long long best_cost = -1;
+    for (int pitch = 16 * cpr; pitch <= 16 * cpr + 512; pitch += 16) {
+        if (2LL * pitch * prow > 65536) break;
+        long long cost = 0;
+        for (int tile = 0; tile < 2; ++tile) {
+            const double ox = tile ? 7.0 * kWlTW : 0.0, oy = tile ? 3.0 * kWlTH : 0.0;
+            for (int r = 0; r < kWarpRows; ++r)
+                for (int half = 0; half < 2; ++half) {
+                    int cnt[32] = {0}, seen[32][8];
+                    for (int l = 32 * half; l < 32 * half + 32; ++l) {
+                        const double sx = M[0] * (ox + l) + M[1] * (oy + r) + (M[2] - floor(M[2])) + 4096.0;
+                        const double sy = M[3] * (ox + l) + M[4] * (oy + r) + (M[5] - floor(M[5])) + 4096.0;
+                        const long long dw = (long long)floor(sy) * (pitch / 4) + (long long)floor(sx);   // dword index up to a constant
+                        const int bank = (int)(((dw % 32) + 32) % 32);
+                        bool dup = false;
+                        for (int k = 0; k < cnt[bank] && k < 8; ++k) dup = dup || seen[bank][k] == (int)(dw & 0x7fffffff);
+                        if (!dup) {
+                            if (cnt[bank] < 8) seen[bank][cnt[bank]] = (int)(dw & 0x7fffffff);
+                            ++cnt[bank];
+                        }
+                    }
+                    int worst = 1;
+                    for (int b = 0; b < 32; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+                    cost += worst;
+                }
+        }
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = pitch;
+        }
+    }
+    if (best == 0) return false;
+    *pitch_out = best;
+    *prow_out = prow;
+    *cpr_out = cpr;
+    return true;
+}
+
 extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M)
 {
     RCV_TRY(rcv_bind(ctx));
@@ -821,6 +1053,20 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         int fpg = wgs / 8 >= 8192 ? 8 : (wgs / 4 >= 8192 ? 4 : (wgs / 2 >= 8192 ? 2 : 1));
         if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
         const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
+        // the LDS-staged kernel when the source patch of a 64 x 32 tile is small enough (rotations, shears and scales near 1)
+        int pitch = 0, prow = 0, cpr = 0;
+        if (rcv_knobs().warp_lds != 0 && s.cols >= 8 && s.rows >= 4 && warp_lds_plan(M, &pitch, &prow, &cpr)) {
+            const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
+            const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
+            const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;
+            if (rcv_knobs().xcd_order != 0 && tiles < (1ull << 30)) {
+                const int tpx = (int)((tiles + 7) / 8);
+                RCV_LAUNCH(k_warp_affine_bgr_lds, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+            } else {
+                RCV_LAUNCH(k_warp_affine_bgr_lds, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
+            }
+            return rcv_launch_check(ctx);
+        }
         RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, gy, gz), dim3(kBlock), 0, ctx->stream, s, d, A, fpg);
         return rcv_launch_check(ctx);
     }

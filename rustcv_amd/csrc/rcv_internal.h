@@ -67,6 +67,7 @@ struct RcvKnobs {
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
+    int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)
     int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)
     int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS

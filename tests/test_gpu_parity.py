@@ -1057,6 +1057,80 @@ def test_warp_affine_bgr_kernel_degenerate_matrices(ctx, oracle, rng, M):
         b.free()
 
 
+def _kernels_launched(ctx, fn):
+    L = _ffi.lib()
+    L.rcv__debug_kernels_reset()
+    fn()
+    ctx.sync()
+    return L.rcv__debug_kernels().decode()
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case):
+    """the LDS-staged BGR warp (source patch of a 64 x 32 tile copied to LDS, taps from LDS) on maps whose patch fits --
+    rotations of any angle, scales, shears, translations -- over images with interior tiles, border tiles and tiles wholly
+    outside the source; batches split into frame groups of 1 / 2 / 3 / 8 frames (incomplete last group); same bytes as the
+    oracle and as the gather kernel (RCV_WARP_LDS=0)"""
+    rng = np.random.default_rng(0xC0FFEE + case)
+    sr, sc = int(rng.integers(150, 420)), int(rng.integers(200, 640))
+    dr, dc = int(rng.integers(100, 400)), 4 * int(rng.integers(40, 150))
+    n = int(rng.integers(1, 6))
+    kind = case % 7
+    if kind == 0:
+        M = _rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20)))
+    elif kind == 1:
+        M = _rot(float(rng.choice([7.0, 45.0, 90.0, -90.0, 180.0, 0.1])), sc / 2, sr / 2, 13.25, -8.5)
+    elif kind == 2:
+        M = np.array([1, 0, float(rng.uniform(-5, 5)), 0, 1, float(rng.uniform(-5, 5))], np.float32)
+    elif kind == 3:
+        sx, sy = float(rng.uniform(0.6, 1.5)), float(rng.uniform(0.6, 1.5))
+        M = np.array([sx, 0, float(rng.uniform(0, 9)), 0, sy, float(rng.uniform(0, 9))], np.float32)
+    elif kind == 4:
+        M = np.array([1, float(rng.uniform(-0.5, 0.5)), 3.5, float(rng.uniform(-0.5, 0.5)), 1, 2.25], np.float32)
+    elif kind == 5:   # mirror + rotation
+        M = _rot(float(rng.uniform(-30, 30)), sc / 2, sr / 2, 0.0, 0.0) * np.array([-1, 1, 1, -1, 1, 1], np.float32) + np.array([0, 0, sc - 3, 0, 0, 0], np.float32)
+    else:             # general affine near the identity
+        M = (np.array([1, 0, 0, 0, 1, 0]) + rng.uniform(-0.25, 0.25, 6) * np.array([1, 1, 40, 1, 1, 40])).astype(np.float32)
+    M = np.asarray(M, np.float32)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src, dst = device.DeviceBatch(ctx, n, sr, sc, 3), device.DeviceBatch(ctx, n, dr, dc, 3, step=dc * 3 + 4 * int(rng.integers(0, 3)))
+    src.upload(frames)
+    want = [oracle.warp_affine(frames[i], M, dr, dc) for i in range(n)]
+    for fpg in (0, 1, 2, 3, 8):
+        if fpg:
+            knob("RCV_WARP_FPG", fpg)
+        dst.memset(0xAB)
+        launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
+        assert "k_warp_affine_bgr_lds" in launched, (launched, M)
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (case, fpg, i, M.tolist(), (sr, sc, dr, dc))
+    knob("RCV_WARP_LDS", 0)
+    dst.memset(0xCD)
+    launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
+    assert launched.split(";") == ["k_warp_affine_bgr"], launched
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), (case, "gather", i)
+    src.free()
+    dst.free()
+
+
+def test_warp_affine_bgr_large_patch_takes_the_gather_kernel(ctx, oracle, rng):
+    """a map whose source patch per tile exceeds the LDS budget (4x down-scale) stays on the gather kernel"""
+    M = np.array([4.0, 0.3, 1.5, -0.2, 4.0, 2.5], np.float32)
+    frames = rng.integers(0, 256, size=(2, 300, 400, 3), dtype=np.uint8)
+    src, dst = device.DeviceBatch(ctx, 2, 300, 400, 3), device.DeviceBatch(ctx, 2, 64, 96, 3)
+    src.upload(frames)
+    launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
+    assert launched.split(";") == ["k_warp_affine_bgr"], launched
+    got = dst.download()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.warp_affine(frames[i], M, 64, 96))
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("ch,mid,dshape", [(3, (50, 70), (20, 28)), (1, (48, 64), (24, 32)), (3, (48, 66), (24, 33)), (4, (40, 40), (10, 10))])
 def test_warp_affine_resize_unfused_shapes(ctx, oracle, rng, ch, mid, dshape):
     """shapes the fused kernel does not take (non-integer factor, 1/4 channels, width not a multiple of 4) run warp then resize"""

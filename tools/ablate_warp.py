@@ -14,7 +14,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
-KNOBS = ("RCV_XCD_ORDER", "RCV_WARP_FPG")
+KNOBS = ("RCV_XCD_ORDER", "RCV_WARP_FPG", "RCV_WARP_LDS")
 
 
 def setenv(env):
@@ -59,15 +59,26 @@ def main():
     Mid = np.array([1, 0, 0.3, 0, 1, 0.7], np.float32)
     w = lambda M: (lambda: device.warp_affine(src, dst, M))   # noqa: E731
     variants = [("warp 7 deg (default)", {}, w(M7))]
-    variants += [("warp 7 deg, plain tile order", {"RCV_XCD_ORDER": 0}, w(M7))]
+    variants += [("warp 7 deg, gather kernel (no LDS staging)", {"RCV_WARP_LDS": 0}, w(M7)), ("warp 7 deg, plain tile order", {"RCV_XCD_ORDER": 0}, w(M7))]
     for f in (1, 2, 4, 8, 16):
         variants.append((f"warp 7 deg, {f} frames per workgroup", {"RCV_WARP_FPG": f}, w(M7)))
-        variants.append((f"warp 7 deg, {f} frames per workgroup, plain order", {"RCV_WARP_FPG": f, "RCV_XCD_ORDER": 0}, w(M7)))
-    variants += [("warp translation (0.3, 0.7)", {}, w(Mid)), ("warp 1 deg", {}, w(M1)), ("warp 45 deg", {}, w(M45)),
-                 ("warp 45 deg, plain order", {"RCV_XCD_ORDER": 0}, w(M45)),
+        variants.append((f"warp 7 deg, {f} frames per workgroup, gather kernel", {"RCV_WARP_FPG": f, "RCV_WARP_LDS": 0}, w(M7)))
+    variants += [("warp translation (0.3, 0.7)", {}, w(Mid)), ("warp translation, gather kernel", {"RCV_WARP_LDS": 0}, w(Mid)),
+                 ("warp 1 deg", {}, w(M1)), ("warp 1 deg, gather kernel", {"RCV_WARP_LDS": 0}, w(M1)),
+                 ("warp 45 deg", {}, w(M45)), ("warp 45 deg, gather kernel", {"RCV_WARP_LDS": 0}, w(M45)), ("warp 45 deg, plain tile order", {"RCV_XCD_ORDER": 0}, w(M45)),
+                 ("warp 90 deg", {}, w(rot(90.0, cols / 2, rows / 2, 0.0, 0.0))), ("warp 90 deg, gather kernel", {"RCV_WARP_LDS": 0}, w(rot(90.0, cols / 2, rows / 2, 0.0, 0.0))),
+                 ("warp translation (13.25, -8.5)", {}, w(np.array([1, 0, 13.25, 0, 1, -8.5], np.float32))),
+                 ("warp translation (100.5, 0)", {}, w(np.array([1, 0, 100.5, 0, 1, 0], np.float32))),
+                 ("warp translation (0, 100.5)", {}, w(np.array([1, 0, 0, 0, 1, 100.5], np.float32))),
+                 ("warp 0.1 deg", {}, w(rot(0.1, cols / 2, rows / 2, 0.0, 0.0))),
+                 ("warp scale 0.9", {}, w(np.array([0.9, 0, 10, 0, 0.9, 10], np.float32))),
+                 ("warp scale 1.1", {}, w(np.array([1.1, 0, 10, 0, 1.1, 10], np.float32))),
+                 ("warp shear x", {}, w(np.array([1, 0.2, 0, 0, 1, 0], np.float32))),
                  ("warp gray 7 deg", {}, lambda: device.warp_affine(gsrc, gdst, M7)),
                  ("fused warp + 4x down-scale", {}, lambda: device.warp_affine_resize(src, small, M7, rows, cols)),
-                 ("fused warp + 4x down-scale, plain order", {"RCV_XCD_ORDER": 0}, lambda: device.warp_affine_resize(src, small, M7, rows, cols))]
+                 ]
+    if "--quick" in sys.argv:
+        variants = [variants[0], [v for v in variants if v[0].startswith("warp translation")][0]]
     res = {v[0]: [] for v in variants}
     for rep in range(3):
         for tag, env, fn in variants:
