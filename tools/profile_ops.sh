@@ -12,7 +12,7 @@ run_op() {  # tag, --only pattern, kernel substring, algorithmic bytes per launc
   local OUT=/tmp/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
   local CMD="python $REPO/tools/bench_ops.py --steps 5 --warmup 2 --only $PAT --out $OUT/bench.json"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
-  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE"; do
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"; do
     name=$(echo $set | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
   done
@@ -23,7 +23,7 @@ PX4K=$((64*2160*3840)); PX8K=$((32*4320*7680))
 run_op bgr2gray_4k "BGR2GRAY" "k_bgr2gray16" $((PX4K*4))
 run_op sobel_4k "Sobel_3x3" "k_sobel_rows<0, false>" $((PX4K*5))
 run_op harris_4k "Harris_pipeline_(BGR" "k_harris_fused<false, 0," $((PX4K*4))
-run_op warp_8k "warpAffine_bilinear" "k_warp_affine_bgr" $((PX8K*6))
+run_op warp_8k "warpAffine_bilinear_(rot_7deg)" "k_warp_affine_bgr_lds" $((PX8K*6))
 PXO=$((32*1080*1920))
 run_op warp_resize_fused "warpAffine_+_resize" "k_warp_resize_box" $((PXO*30))
 run_op resize_5k "resize_8K_->_5K" "k_resize_bgr" $((32*2880*5120*975/100))
