@@ -3,6 +3,7 @@
 // f32 evaluation order is fixed and spelled out op by op; built with -ffp-contract=off.
 #include "rcv_internal.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -999,7 +1000,7 @@ static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cp
     if ((long long)cpr * prow > (long long)kWlMaxG * kBlock) return false;
     int best = 0;
     long long best_cost = -1;
-    for (int pitch = 16 * cpr; pitch <= 16 * cpr + 512; pitch += 16) {
+    for (int pitch = 16 * cpr; pitch < 16 * cpr + 128; pitch += 16) {   // (the bank pattern repeats every 128 bytes of pitch)
         if (2LL * pitch * prow > 65536) break;
         long long cost = 0;
         for (int tile = 0; tile < 2; ++tile) {
@@ -1055,7 +1056,13 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
         // the LDS-staged kernel when the source patch of a 64 x 32 tile is small enough (rotations, shears and scales near 1)
         int pitch = 0, prow = 0, cpr = 0;
-        if (rcv_knobs().warp_lds != 0 && s.cols >= 8 && s.rows >= 4 && warp_lds_plan(M, &pitch, &prow, &cpr)) {
+        if (!ctx->wl_valid || memcmp(ctx->wl_M, M, sizeof(ctx->wl_M)) != 0) {   // (the plan depends on the matrix only: kept for the next call)
+            ctx->wl_ok = warp_lds_plan(M, &ctx->wl_pitch, &ctx->wl_prow, &ctx->wl_cpr);
+            memcpy(ctx->wl_M, M, sizeof(ctx->wl_M));
+            ctx->wl_valid = true;
+        }
+        pitch = ctx->wl_pitch; prow = ctx->wl_prow; cpr = ctx->wl_cpr;
+        if (rcv_knobs().warp_lds != 0 && s.cols >= 8 && s.rows >= 4 && ctx->wl_ok) {
             const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
             const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
             const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;

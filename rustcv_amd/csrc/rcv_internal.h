@@ -34,6 +34,10 @@ struct rcv_ctx {
     bool f7_plan_lat_ok, f7_plan_lat;
     // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), kconst[32768..40960)
     bool fr_valid, fr_split2;
+    // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
+    bool wl_valid = false, wl_ok = false;
+    float wl_M[6] = {0, 0, 0, 0, 0, 0};
+    int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
     int fr_ksize, fr_dmask;
     int16_t fr_k[49];
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
