@@ -370,24 +370,8 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
                     //  vector addresses with one v_lshl_add_u64 per load)
                     unsigned o0 = oa[r], o1 = oa[r] + sstep;
                     asm("" : "+v"(o0), "+v"(o1));
-#if defined(RCV_WARP_EXP) && RCV_WARP_EXP == 2     // (experiment, wrong results: 8-byte tap loads)
-                    typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
-                    const u2v_ e0 = *(const __attribute__((address_space(1))) u2v_*)(sf + o0), e1 = *(const __attribute__((address_space(1))) u2v_*)(sf + o1);
-                    ta[r] = u3v{e0.x, e0.y, e0.x};
-                    tb[r] = u3v{e1.x, e1.y, e1.x};
-#elif defined(RCV_WARP_EXP) && RCV_WARP_EXP == 1   // (experiment, wrong results: 4-byte tap loads)
-                    const uint32_t e0 = *(const __attribute__((address_space(1))) uint32_t*)(sf + o0), e1 = *(const __attribute__((address_space(1))) uint32_t*)(sf + o1);
-                    ta[r] = u3v{e0, e0, e0};
-                    tb[r] = u3v{e1, e1, e1};
-#elif defined(RCV_WARP_EXP) && RCV_WARP_EXP == 4   // (experiment, wrong results: 16-byte tap loads)
-                    typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
-                    const u4v_ e0 = *(const __attribute__((address_space(1))) u4v_*)(sf + (o0 & ~15u)), e1 = *(const __attribute__((address_space(1))) u4v_*)(sf + (o1 & ~15u));
-                    ta[r] = u3v{e0.x, e0.y, e0.z ^ e0.w};
-                    tb[r] = u3v{e1.x, e1.y, e1.z ^ e1.w};
-#else
                     ta[r] = *(const gU3*)(sf + o0);
                     tb[r] = *(const gU3*)(sf + o1);
-#endif
                 }
             };
             auto finish_half = [&](int h, int f) {
