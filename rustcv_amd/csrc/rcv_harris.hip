@@ -83,13 +83,25 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3(View r, View m, float thr)
 // serves the rows above and below, and the comparison `r >= all 8 neighbours` becomes r >= maximum(...).  The maxima are
 // v_maximum3_f32 (IEEE-754-2019 maximum: a NaN operand gives NaN), so a NaN neighbour makes `r >= m` false exactly as the
 // nine separate comparisons of k_nms3x3 / the oracle do; outside the image is -inf.
-__global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float thr, int seg_rows)
+__global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float thr, int seg_rows, int gx, int gy, int nblocks, int blocks_per_xcd)
 {
     const int lane = threadIdx.x & 63;
-    const int x = (blockIdx.x * kBlock + threadIdx.x) * 4;
-    const int ys = blockIdx.y * seg_rows, ye = min(r.rows, ys + seg_rows);
-    const uint8_t* rf = r.p + (size_t)blockIdx.z * r.fstride;
-    uint8_t* mf = m.p + (size_t)blockIdx.z * m.fstride;
+    // Block order (speed only): hardware places block b on XCD b % 8; with blocks_per_xcd > 0 each XCD works through its own
+    // contiguous eighth of the (frame, row segment, column block) list, so that what ONE XCD has in flight is a compact address
+    // range
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (blocks_per_xcd > 0) {
+        const int t = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);
+        if (t >= nblocks) return;
+        bz = t / (gx * gy);
+        const int rem = t - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    const int x = (bx * kBlock + (int)threadIdx.x) * 4;
+    const int ys = by * seg_rows, ye = min(r.rows, ys + seg_rows);
+    const uint8_t* rf = r.p + (size_t)bz * r.fstride;
+    uint8_t* mf = m.p + (size_t)bz * m.fstride;
     const bool live = x < r.cols;
     const int xc = min(x, r.cols - 4);
     const float NEG = -INFINITY;
@@ -204,8 +216,15 @@ extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* 
     if (r.cols % 4 == 0 && r.cols >= 4 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
         (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
         const int seg = 64;
-        const dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
-        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg);
+        dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
+        const int gx = (int)grid.x, gy = (int)grid.y;
+        const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
+        int bpx = 0;
+        if (rcv_knobs().xcd_order != 0 && nb < (1ull << 30)) {
+            bpx = (int)((nb + 7) / 8);
+            grid = dim3((unsigned)bpx * 8);
+        }
+        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
         return rcv_launch_check(ctx);
     }
     RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
