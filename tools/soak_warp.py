@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""tools/soak_warp.py [N] -- N seeded random (shape, map, batch, frames-per-workgroup) cases of the BGR warpAffine against the oracle,
+run from the repo root on a GPU box; prints how many launches took the LDS-staged kernel and the number of mismatches (round 2: 400 cases,
+676 launches on the LDS kernel, 0 mismatches)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import rustcv_amd as rcv
+from rustcv_amd import _ffi, device
+from oracle import pyoracle as oracle
+
+def rot(deg, cx, cy, tx, ty):
+    t = np.deg2rad(deg); c, s = np.cos(t), np.sin(t)
+    return np.array([c, -s, cx - c * cx + s * cy + tx, s, c, cy - s * cx - c * cy + ty], np.float32)
+
+ctx = rcv.Context(0)
+L = _ffi.lib()
+bad = 0
+nlds = 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for case in range(N):
+    rng = np.random.default_rng(0xABCD00 + case)
+    sr, sc = int(rng.integers(40, 700)), int(rng.integers(40, 900))
+    dr, dc = int(rng.integers(8, 600)), 4 * int(rng.integers(2, 220))
+    n = int(rng.integers(1, 10))
+    kind = case % 8
+    if kind == 0: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)))
+    elif kind == 1: M = rot(float(rng.choice([7.0, 45.0, 90.0, -90.0, 180.0, 0.1, 0.0])), sc / 2, sr / 2, 13.25, -8.5)
+    elif kind == 2: M = np.array([1, 0, float(rng.uniform(-5, 5)), 0, 1, float(rng.uniform(-5, 5))], np.float32)
+    elif kind == 3:
+        sx, sy = float(rng.uniform(0.3, 2.5)), float(rng.uniform(0.3, 2.5))
+        M = np.array([sx, 0, float(rng.uniform(0, 9)), 0, sy, float(rng.uniform(0, 9))], np.float32)
+    elif kind == 4: M = np.array([1, float(rng.uniform(-1, 1)), 3.5, float(rng.uniform(-1, 1)), 1, 2.25], np.float32)
+    elif kind == 5: M = (np.array([1, 0, 0, 0, 1, 0]) + rng.uniform(-0.5, 0.5, 6) * np.array([1, 1, 80, 1, 1, 80])).astype(np.float32)
+    elif kind == 6: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, 0, 0) * np.float32(rng.uniform(0.5, 1.6))
+    else: M = np.array([float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 800)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 600))], np.float32)
+    M = np.asarray(M, np.float32)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, sr, sc, 3)
+    dst = device.DeviceBatch(ctx, n, dr, dc, 3)
+    src.upload(frames)
+    for fpg in (0, int(rng.integers(1, 9))):
+        os.environ.pop("RCV_WARP_FPG", None)
+        if fpg: os.environ["RCV_WARP_FPG"] = str(fpg)
+        L.rcv__debug_reload_knobs()
+        dst.memset(0x5A)
+        L.rcv__debug_kernels_reset()
+        device.warp_affine(src, dst, M)
+        ctx.sync()
+        k = L.rcv__debug_kernels().decode()
+        nlds += "lds" in k
+        got = dst.download()
+        for i in range(n):
+            want = oracle.warp_affine(frames[i], M, dr, dc)
+            if not np.array_equal(got[i], want):
+                bad += 1
+                print("MISMATCH", case, fpg, i, k, M.tolist(), (sr, sc, dr, dc, n), int((got[i] != want).sum()), flush=True)
+                break
+    src.free(); dst.free()
+print(f"soak: {N} cases, {nlds} launches on the LDS kernel, {bad} mismatches")
