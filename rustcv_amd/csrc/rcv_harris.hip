@@ -167,6 +167,51 @@ float harris_scale2(int block)
     return (float)(s * s);
 }
 
+// Sobel planes of `src` (gray or BGR: the gradient of its gray conversion) as i16 images with 16-byte aligned rows in the two
+// workspace buffers, then the register-window response kernel for any block size.  RCV_ERR_UNSUPPORTED when either kernel does
+// not take the shape (the caller then runs the per-sample kernels on the same buffers).
+size_t plane_step(int cols) { return ((size_t)cols * 2 + 15) & ~(size_t)15; }
+int harris_fast_planes(rcv_ctx* ctx, const View& src, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
+{
+    if (!rcv_harris_resp_rows_ok(r, block) || src.rows > 65535 || (src.ch != 1 && src.ch != 3)) return RCV_ERR_UNSUPPORTED;
+    View vx;
+    vx.p = wix;
+    vx.step = plane_step(r.cols);
+    vx.fstride = vx.step * r.rows;
+    vx.cap = vx.fstride;
+    vx.rows = r.rows;
+    vx.cols = r.cols;
+    vx.ch = 1;
+    vx.esz = 2;
+    vx.n = r.n;
+    View vy = vx;
+    vy.p = wiy;
+    const int rc = rcv_sobel_tiled(ctx, src, vx, vy);
+    if (rc != RCV_OK) return rc;
+    return rcv_harris_resp_rows(ctx, vx, vy, r, block, k);
+}
+
+// 3x3 NMS: the streaming kernel for 16-byte aligned response rows, the per-sample kernel otherwise
+int nms_launch(rcv_ctx* ctx, const View& r, const View& m, float thr)
+{
+    if (r.cols % 4 == 0 && r.cols >= 4 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
+        (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
+        const int seg = 64;
+        dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
+        const int gx = (int)grid.x, gy = (int)grid.y;
+        const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
+        int bpx = 0;
+        if (rcv_knobs().xcd_order != 0 && nb < (1ull << 30)) {
+            bpx = (int)((nb + 7) / 8);
+            grid = dim3((unsigned)bpx * 8);
+        }
+        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
+        return rcv_launch_check(ctx);
+    }
+    RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
+    return rcv_launch_check(ctx);
+}
+
 // gray (device View) -> resp using two packed i16 planes carved from the workspace
 int harris_from_gray(rcv_ctx* ctx, const View& g, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
 {
@@ -194,11 +239,15 @@ extern "C" int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_
         const int rc = rcv_harris_fused(ctx, g, nullptr, &r, block, k, 0.0f);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
-    size_t plane = (size_t)g.n * g.rows * g.cols * 2;
+    size_t plane = (size_t)g.n * g.rows * plane_step(g.cols);   // (>= the packed layout of the per-sample kernels)
     RCV_TRY(rcv_ws_reserve(ctx, 2 * (plane + 256)));
     uint8_t *wix, *wiy;
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wix));
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wiy));
+    {   // other block sizes: streaming Sobel into aligned planes + the register-window response kernel
+        const int rc = harris_fast_planes(ctx, g, r, block, k, wix, wiy);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
     return harris_from_gray(ctx, g, r, block, k, wix, wiy);
 }
 
@@ -213,22 +262,7 @@ extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* 
     if (m.rows != r.rows || m.cols != r.cols || m.n != r.n) return RCV_ERR_ARG;
     if (r.rows > 65535 || r.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (r.rows == 0 || r.cols == 0 || r.n == 0) return RCV_OK;
-    if (r.cols % 4 == 0 && r.cols >= 4 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
-        (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
-        const int seg = 64;
-        dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
-        const int gx = (int)grid.x, gy = (int)grid.y;
-        const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
-        int bpx = 0;
-        if (rcv_knobs().xcd_order != 0 && nb < (1ull << 30)) {
-            bpx = (int)((nb + 7) / 8);
-            grid = dim3((unsigned)bpx * 8);
-        }
-        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
-        return rcv_launch_check(ctx);
-    }
-    RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
-    return rcv_launch_check(ctx);
+    return nms_launch(ctx, r, m, thr);
 }
 
 extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mask, rcv_batch* resp,
@@ -267,43 +301,53 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
         RCV_TRY(rcv_cvt_color_batch(ctx, RCV_YUYV2BGR_STRIDED, bgr, &tb));
         return rcv_harris_pipeline_batch(ctx, &tb, mask, resp, block, k, thr);
     }
-    // generic: gray, Ix, Iy (and the response when the caller does not want it) live in the workspace
-    size_t npx = (size_t)s.n * s.rows * s.cols;
-    RCV_TRY(rcv_ws_reserve(ctx, npx * (1 + 2 + 2 + (resp ? 0 : 4)) + 4 * 256));
+    // other shapes / block sizes: Ix, Iy (and the response when the caller does not want it, and the gray image for the
+    // per-sample kernels) live in the workspace
+    const size_t npx = (size_t)s.n * s.rows * s.cols;
+    const size_t plane = (size_t)s.n * s.rows * plane_step(s.cols);        // i16 plane with 16-byte aligned rows (>= the packed layout)
+    const size_t rstep = ((size_t)s.cols * 4 + 15) & ~(size_t)15;          // response rows likewise
+    RCV_TRY(rcv_ws_reserve(ctx, npx + 2 * plane + (resp ? 0 : rstep * s.rows * s.n) + 5 * 256));
     uint8_t *wg, *wix, *wiy, *wr = nullptr;
-    RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));   // (unused for a gray source)
-    RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wix));
-    RCV_TRY(rcv_ws_alloc(ctx, npx * 2, &wiy));
-    if (!resp) RCV_TRY(rcv_ws_alloc(ctx, npx * 4, &wr));
-    rcv_batch gb;
-    gb.frame0.data = wg;
-    gb.frame0.cap = (size_t)s.rows * s.cols;
-    gb.frame0.step = (size_t)s.cols;
-    gb.frame0.rows = s.rows;
-    gb.frame0.cols = s.cols;
-    gb.frame0.channels = 1;
-    gb.frame0.depth = RCV_8U;
-    gb.frame0.device = RCV_DEVICE;
-    gb.frame0.reserved = 0;
-    gb.frame_stride = (size_t)s.rows * s.cols;
-    gb.n = s.n;
-    gb.reserved = 0;
-    View g;
-    if (s.ch == 1) g = s;   // the source is the gray image
-    else {
-        RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
-        RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
-    }
+    RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));   // (only the per-sample path of a BGR source uses it)
+    RCV_TRY(rcv_ws_alloc(ctx, plane, &wix));
+    RCV_TRY(rcv_ws_alloc(ctx, plane, &wiy));
     if (!resp) {
-        r = g;
+        RCV_TRY(rcv_ws_alloc(ctx, rstep * s.rows * s.n, &wr));
+        r = s;
         r.p = wr;
-        r.step = (size_t)s.cols * 4;
-        r.fstride = (size_t)s.rows * s.cols * 4;
+        r.step = rstep;
+        r.fstride = rstep * s.rows;
+        r.cap = r.fstride;
+        r.ch = 1;
         r.esz = 4;
     }
-    RCV_TRY(harris_from_gray(ctx, g, r, block, k, wix, wiy));
-    RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);
-    return rcv_launch_check(ctx);
+    // streaming kernels: Sobel straight from the source (a BGR source: the gradient of its gray conversion, no gray image),
+    // the register-window response for any block size, the streaming NMS
+    int rc2 = harris_fast_planes(ctx, s, r, block, k, wix, wiy);
+    if (rc2 == RCV_ERR_UNSUPPORTED) {
+        rcv_batch gb;
+        gb.frame0.data = wg;
+        gb.frame0.cap = (size_t)s.rows * s.cols;
+        gb.frame0.step = (size_t)s.cols;
+        gb.frame0.rows = s.rows;
+        gb.frame0.cols = s.cols;
+        gb.frame0.channels = 1;
+        gb.frame0.depth = RCV_8U;
+        gb.frame0.device = RCV_DEVICE;
+        gb.frame0.reserved = 0;
+        gb.frame_stride = (size_t)s.rows * s.cols;
+        gb.n = s.n;
+        gb.reserved = 0;
+        View g;
+        if (s.ch == 1) g = s;   // the source is the gray image
+        else {
+            RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
+            RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
+        }
+        rc2 = harris_from_gray(ctx, g, r, block, k, wix, wiy);
+    }
+    RCV_TRY(rc2);
+    return nms_launch(ctx, r, m, thr);
 }
 
 // ---- single-Mat forms -----------------------------------------------------------------------------

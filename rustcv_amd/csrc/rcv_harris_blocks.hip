@@ -1,0 +1,226 @@
+// rcv_harris_blocks.hip -- cornerHarris response for ANY blockSize 1..7 from the Sobel planes Ix, Iy (i16), as a register
+// sliding window down the image.  (blockSize 2 on aligned shapes runs the fully fused kernel of rcv_harris_fused.hip; this
+// is what every other block size runs instead of the per-sample kernel k_harris_resp -- 6.4 ms against 0.66 ms on 64 4K frames
+// before this kernel existed.)  Not in the reference; semantics SURVEY.md 8-A == oracle/rcv_oracle.c:
+// Sxx, Sxy, Syy = exact i32 sums of the products over the block (anchor block/2, BORDER_REFLECT_101 of the product image),
+// one (float) cast each, then the six separate IEEE f32 operations of the response.
+//
+// One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 / 63 carry halo only) and walks down a row segment, as the fused
+// kernel does.  State per lane: the VERTICAL window sums V = sum over the block's rows of Ix^2, IxIy, Iy^2 for its 8 pixels
+// (24 registers, i32).  Moving down one row adds the products of the row that enters the window and subtracts those of the
+// row that leaves it -- both are loaded (the leaving row a second time: it was read `block` rows earlier and comes from L2),
+// so no ring of rows lives in registers and the cost per row does not depend on the block size: v_mad_i32_i24 on the
+// sign-extended i16 values, exact.  The HORIZONTAL sums are sliding sums over V with the up to 3 pixels either side taken
+// from the neighbouring lanes by DPP wave shifts.  Reflection: rows by reflected row index (scalar); at the image's left and
+// right edge the halo lane builds its 8 mirrored pixels of Ix, Iy from two aligned loads and four byte permutes per plane
+// (P(-j) = P(j) is a function of Ix(j), Iy(j), so mirroring the planes mirrors the products) -- only in the waves of the first
+// and the last strip (a wave-uniform branch).
+#include "rcv_internal.h"
+#include "rcv_kernels.h"
+#include <math.h>
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int kStripPx = 62 * 8;
+
+struct HBArgs {
+    const uint8_t *ix, *iy;   // i16 planes
+    uint8_t* resp;
+    size_t pstep, pfs, rstep, rfs;   // plane row step / frame stride (bytes), response likewise
+    int rows, cols, nstrips, seg_rows, nsegs, total_waves, blocks_per_xcd;
+    float s2, k;
+};
+
+__device__ __forceinline__ int shr1i(int v) { return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x138, 0xf, 0xf, true); }   // from lane-1
+__device__ __forceinline__ int shl1i(int v) { return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x130, 0xf, 0xf, true); }   // from lane+1
+
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }   // v_mad_i32_i24: |Ix|, |Iy| <= 1020
+
+struct Raw2 { u4v a, b; };   // a: the lane's 8 pixels (16 bytes); b: second load of the mirroring edge lanes
+
+template <int B>
+__global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
+{
+    constexpr int AN = B / 2, RT = B - 1 - AN;   // window offsets -AN .. +RT
+    const int lane = threadIdx.x & 63;
+    const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+    if (wid >= a.total_waves) return;
+    const int strip = wid % a.nstrips;
+    wid /= a.nstrips;
+    const int seg = wid % a.nsegs;
+    const int frame = wid / a.nsegs;
+    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    const int x = strip * kStripPx + 8 * (lane - 1);
+    const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    // mirroring halo lanes (cols % 8 == 0, cols >= 16): x == -8 mirrors pixels 8..1, x == cols mirrors cols-2 .. cols-9
+    const bool isL = x == -8, isR = x == a.cols;
+    const bool edge_wave = strip == 0 || strip == a.nstrips - 1;   // wave-uniform
+    // byte offsets in a plane row: the lane's own 8 pixels (clamped: lanes beyond the image read a harmless place), and for the
+    // mirroring lanes the two aligned runs that hold their source pixels
+    const int xc = min(max(x, 0), a.cols - 8);
+    const unsigned o1 = 2u * (unsigned)(isL ? 0 : (isR ? a.cols - 16 : xc));
+    const unsigned o2 = 2u * (unsigned)(isL ? 8 : (isR ? a.cols - 8 : xc));
+    const uint8_t* const fx = a.ix + (size_t)frame * a.pfs;
+    const uint8_t* const fy = a.iy + (size_t)frame * a.pfs;
+    uint8_t* const rf = a.resp + (size_t)frame * a.rfs;
+
+    auto refl = [&](int v) { return v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v); };   // (rows >= block: one reflection is enough)
+    struct RowRaw { Raw2 x, y; };
+    auto load_row = [&](int v) -> RowRaw {   // virtual row -> reflected plane row
+        const size_t ro = (size_t)refl(min(max(v, -AN - 1), a.rows + RT)) * a.pstep;
+        RowRaw w;
+        w.x.a = *(const u4v*)(fx + ro + o1);
+        w.y.a = *(const u4v*)(fy + ro + o1);
+        if (edge_wave) {
+            w.x.b = *(const u4v*)(fx + ro + o2);
+            w.y.b = *(const u4v*)(fy + ro + o2);
+        } else {
+            w.x.b = w.x.a;
+            w.y.b = w.y.a;
+        }
+        return w;
+    };
+    // the 8 pixels of a plane as four dwords of i16 pairs; mirroring lanes reverse their source run
+    auto pixels = [&](const Raw2& q) -> u4v {
+        if (!edge_wave) return q.a;
+        // S = the five dwords that hold the 8 source pixels + one: L: pixels 0..9 = a.x a.y a.z a.w b.x;  R: cols-10 .. cols-1 = a.w b.x b.y b.z b.w
+        const uint32_t s0 = isL ? q.a.x : q.a.w, s1 = isL ? q.a.y : q.b.x, s2 = isL ? q.a.z : q.b.y, s3 = isL ? q.a.w : q.b.z, s4 = isL ? q.b.x : q.b.w;
+        const u4v rev = {__builtin_amdgcn_perm(s3, s4, 0x07060100u), __builtin_amdgcn_perm(s2, s3, 0x07060100u), __builtin_amdgcn_perm(s1, s2, 0x07060100u),
+                         __builtin_amdgcn_perm(s0, s1, 0x07060100u)};
+        return (isL || isR) ? rev : q.a;
+    };
+
+    int vxx[8], vxy[8], vyy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vxx[j] = vxy[j] = vyy[j] = 0;
+    // leave = false: the row enters the window (+products), true: it leaves (-products)
+    auto accumulate = [&](const RowRaw& w, bool leave) {
+        const u4v px = pixels(w.x), py = pixels(w.y);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int gx0 = (int)(short)(px[d] & 0xffff), gx1 = (int)px[d] >> 16, gy0 = (int)(short)(py[d] & 0xffff), gy1 = (int)py[d] >> 16;
+            const int nx0 = leave ? -gx0 : gx0, nx1 = leave ? -gx1 : gx1, ny0 = leave ? -gy0 : gy0, ny1 = leave ? -gy1 : gy1;
+            vxx[2 * d] = mad24(nx0, gx0, vxx[2 * d]);
+            vxy[2 * d] = mad24(nx0, gy0, vxy[2 * d]);
+            vyy[2 * d] = mad24(ny0, gy0, vyy[2 * d]);
+            vxx[2 * d + 1] = mad24(nx1, gx1, vxx[2 * d + 1]);
+            vxy[2 * d + 1] = mad24(nx1, gy1, vxy[2 * d + 1]);
+            vyy[2 * d + 1] = mad24(ny1, gy1, vyy[2 * d + 1]);
+        }
+    };
+    // horizontal sums of one plane: h[x] = sum of e[x - AN .. x + RT], e = the lane's 8 values with the neighbours' either side
+    auto hsum = [&](const int (&v)[8], int (&h)[8]) {
+        int e[8 + AN + RT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[AN + j] = v[j];
+#pragma unroll
+        for (int j = 1; j <= AN; ++j) e[AN - j] = shr1i(v[8 - j]);
+#pragma unroll
+        for (int j = 1; j <= RT; ++j) e[AN + 7 + j] = shl1i(v[j - 1]);
+        int s = e[0];
+#pragma unroll
+        for (int i = 1; i < B; ++i) s += e[i];
+        h[0] = s;
+#pragma unroll
+        for (int xx = 1; xx < 8; ++xx) {
+            s += e[xx + B - 1] - e[xx - 1];
+            h[xx] = s;
+        }
+    };
+
+    // the window of output row ys: virtual rows ys-AN .. ys+RT
+#pragma unroll 1
+    for (int i = 0; i < B; ++i) accumulate(load_row(ys - AN + i), false);
+    RowRaw ent = load_row(ys + RT + 1), lea = load_row(ys - AN);
+    for (int y = ys; y < ye; ++y) {
+        // the rows that move the window to y+2 are in flight while row y is computed and the window moves to y+1
+        const RowRaw ent2 = load_row(y + RT + 2), lea2 = load_row(y - AN + 1);
+        int hxx[8], hxy[8], hyy[8];
+        hsum(vxx, hxx);
+        hsum(vxy, hxy);
+        hsum(vyy, hyy);
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // packed pairs {pixel j, pixel j+4}: two IEEE operations per instruction, same bits as the scalar ops
+            const f2 fa = f2{(float)hxx[j], (float)hxx[j + 4]} * a.s2, fb = f2{(float)hxy[j], (float)hxy[j + 4]} * a.s2, fc = f2{(float)hyy[j], (float)hyy[j + 4]} * a.s2;
+            const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+            const f2 t4 = a.k * t3;
+            const f2 t5 = t4 * t3;
+            const f2 rr = (t1 - t2) - t5;
+            r[j] = rr.x;
+            r[j + 4] = rr.y;
+        }
+        if (live) {
+            uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
+            __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
+            __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+        }
+        accumulate(ent, false);
+        accumulate(lea, true);
+        ent = ent2;
+        lea = lea2;
+    }
+}
+
+template <int B>
+void launch_resp(const HBArgs& a, dim3 grid, hipStream_t st)
+{
+    RCV_LAUNCH((k_harris_resp_rows<B>), grid, dim3(256), 0, st, a);
+}
+
+} // namespace
+
+// Does k_harris_resp_rows take this response image?  Widths that are a multiple of 8 (>= 16), at least `block` rows, 16-byte
+// aligned rows.
+bool rcv_harris_resp_rows_ok(const View& r, int block)
+{
+    if (block < 1 || block > 7) return false;
+    if (r.cols % 8 != 0 || r.cols < 16 || r.rows < block || r.rows < 2) return false;
+    return !((uintptr_t)r.p % 16 || r.step % 16 || (r.n > 1 && r.fstride % 16));
+}
+
+// Response from the Sobel planes (i16, rows 16-byte aligned, same step for both) for any block 1..7; RCV_ERR_UNSUPPORTED for
+// shapes it does not take (generic kernel).
+int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k)
+{
+    if (!rcv_harris_resp_rows_ok(r, block)) return RCV_ERR_UNSUPPORTED;
+    if (ix.step != iy.step || ix.fstride != iy.fstride || ix.step % 16 || (uintptr_t)ix.p % 16 || (uintptr_t)iy.p % 16 || (ix.n > 1 && ix.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    HBArgs a;
+    a.ix = ix.p;
+    a.iy = iy.p;
+    a.resp = r.p;
+    a.pstep = ix.step;
+    a.pfs = ix.fstride;
+    a.rstep = r.step;
+    a.rfs = r.fstride;
+    a.rows = r.rows;
+    a.cols = r.cols;
+    a.nstrips = (r.cols + kStripPx - 1) / kStripPx;
+    int seg = r.rows;
+    while ((long long)a.nstrips * ((r.rows + seg - 1) / seg) * r.n < 8192 && seg > 48) seg = (seg + 1) / 2;
+    a.seg_rows = seg;
+    a.nsegs = (r.rows + seg - 1) / seg;
+    const long long waves = (long long)a.nstrips * a.nsegs * r.n;
+    if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
+    a.total_waves = (int)waves;
+    const long long nblocks = (waves + 3) / 4;
+    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
+    const double s = 1.0 / (4.0 * (double)block * 255.0);   // 2^(aperture-1) * blockSize * 255, aperture = 3
+    a.s2 = (float)(s * s);
+    a.k = k;
+    switch (block) {
+    case 1: launch_resp<1>(a, grid, ctx->stream); break;
+    case 2: launch_resp<2>(a, grid, ctx->stream); break;
+    case 3: launch_resp<3>(a, grid, ctx->stream); break;
+    case 4: launch_resp<4>(a, grid, ctx->stream); break;
+    case 5: launch_resp<5>(a, grid, ctx->stream); break;
+    case 6: launch_resp<6>(a, grid, ctx->stream); break;
+    default: launch_resp<7>(a, grid, ctx->stream); break;
+    }
+    return rcv_launch_check(ctx);
+}

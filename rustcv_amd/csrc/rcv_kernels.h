@@ -13,6 +13,9 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
 int rcv_filter_i16_gray(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift);   // rcv_filter_gray_dot4.hip
 // src: BGR (3 ch), packed YUYV (2 ch) or gray (1 ch); mask may be null (response only: needs resp)
 int rcv_harris_fused(rcv_ctx* ctx, const View& src, const View* mask, const View* resp, int block, float k, float thr);
+// cornerHarris response for any block 1..7 from i16 Sobel planes (rcv_harris_blocks.hip)
+bool rcv_harris_resp_rows_ok(const View& r, int block);
+int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
 // integer filters on the streaming f32 kernel (exact): shapes the strip kernel does not take
