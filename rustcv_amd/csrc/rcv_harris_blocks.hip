@@ -8,9 +8,11 @@
 // One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 / 63 carry halo only) and walks down a row segment, as the fused
 // kernel does.  State per lane: the VERTICAL window sums V = sum over the block's rows of Ix^2, IxIy, Iy^2 for its 8 pixels
 // (24 registers, i32).  Moving down one row adds the products of the row that enters the window and subtracts those of the
-// row that leaves it -- both are loaded (the leaving row a second time: it was read `block` rows earlier and comes from L2),
-// so no ring of rows lives in registers and the cost per row does not depend on the block size: v_mad_i32_i24 on the
-// sign-extended i16 values, exact.  The HORIZONTAL sums are sliding sums over V with the up to 3 pixels either side taken
+// row that leaves it, so the arithmetic per row does not depend on the block size (24-bit multiplies on the sign-extended i16
+// values, exact).  The block's rows of Ix, Iy stay in a register ring (8 registers per row; the row loop is unrolled by the
+// block size, so the ring slots are static): the first version re-loaded the leaving row instead, and since `block` rows of
+// every wave's strip do not survive in L2 next to the response stream that doubled the plane reads (rocprofv3: 4.2 GB for
+// 2.1 GB of planes).  The HORIZONTAL sums are sliding sums over V with the up to 3 pixels either side taken
 // from the neighbouring lanes by DPP wave shifts.  Reflection: rows by reflected row index (scalar); at the image's left and
 // right edge the halo lane builds its 8 mirrored pixels of Ix, Iy from two aligned loads and four byte permutes per plane
 // (P(-j) = P(j) is a function of Ix(j), Iy(j), so mirroring the planes mirrors the products) -- only in the waves of the first
@@ -97,12 +99,12 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
     int vxx[8], vxy[8], vyy[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) vxx[j] = vxy[j] = vyy[j] = 0;
+    struct RowPix { u4v x, y; };   // the lane's 8 pixels of Ix and of Iy (mirrored in the edge lanes)
     // leave = false: the row enters the window (+products), true: it leaves (-products)
-    auto accumulate = [&](const RowRaw& w, bool leave) {
-        const u4v px = pixels(w.x), py = pixels(w.y);
+    auto accumulate = [&](const RowPix& w, bool leave) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int gx0 = (int)(short)(px[d] & 0xffff), gx1 = (int)px[d] >> 16, gy0 = (int)(short)(py[d] & 0xffff), gy1 = (int)py[d] >> 16;
+            const int gx0 = (int)(short)(w.x[d] & 0xffff), gx1 = (int)w.x[d] >> 16, gy0 = (int)(short)(w.y[d] & 0xffff), gy1 = (int)w.y[d] >> 16;
             const int nx0 = leave ? -gx0 : gx0, nx1 = leave ? -gx1 : gx1, ny0 = leave ? -gy0 : gy0, ny1 = leave ? -gy1 : gy1;
             vxx[2 * d] = mad24(nx0, gx0, vxx[2 * d]);
             vxy[2 * d] = mad24(nx0, gy0, vxy[2 * d]);
@@ -132,37 +134,52 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
         }
     };
 
-    // the window of output row ys: virtual rows ys-AN .. ys+RT
-#pragma unroll 1
-    for (int i = 0; i < B; ++i) accumulate(load_row(ys - AN + i), false);
-    RowRaw ent = load_row(ys + RT + 1), lea = load_row(ys - AN);
-    for (int y = ys; y < ye; ++y) {
-        // the rows that move the window to y+2 are in flight while row y is computed and the window moves to y+1
-        const RowRaw ent2 = load_row(y + RT + 2), lea2 = load_row(y - AN + 1);
-        int hxx[8], hxy[8], hyy[8];
-        hsum(vxx, hxx);
-        hsum(vxy, hxy);
-        hsum(vyy, hyy);
-        float r[8];
+    // the window of output row ys: virtual rows ys-AN .. ys+RT in ring slots 0 .. B-1 (virtual row v lives in slot (v - ys + AN) % B)
+    RowPix ring[B];
+    {
+        RowRaw first[B];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // packed pairs {pixel j, pixel j+4}: two IEEE operations per instruction, same bits as the scalar ops
-            const f2 fa = f2{(float)hxx[j], (float)hxx[j + 4]} * a.s2, fb = f2{(float)hxy[j], (float)hxy[j + 4]} * a.s2, fc = f2{(float)hyy[j], (float)hyy[j + 4]} * a.s2;
-            const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
-            const f2 t4 = a.k * t3;
-            const f2 t5 = t4 * t3;
-            const f2 rr = (t1 - t2) - t5;
-            r[j] = rr.x;
-            r[j + 4] = rr.y;
+        for (int i = 0; i < B; ++i) first[i] = load_row(ys - AN + i);
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            ring[i] = RowPix{pixels(first[i].x), pixels(first[i].y)};
+            accumulate(ring[i], false);
         }
-        if (live) {
-            uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
-            __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
-            __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+    }
+    RowRaw ent = load_row(ys + RT + 1);
+    for (int y0 = ys; y0 < ye; y0 += B) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int y = y0 + i;
+            if (y >= ye) break;
+            // the row that moves the window to y+2 is in flight while row y is computed and the window moves to y+1
+            const RowRaw ent2 = load_row(y + RT + 2);
+            int hxx[8], hxy[8], hyy[8];
+            hsum(vxx, hxx);
+            hsum(vxy, hxy);
+            hsum(vyy, hyy);
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // packed pairs {pixel j, pixel j+4}: two IEEE operations per instruction, same bits as the scalar ops
+                const f2 fa = f2{(float)hxx[j], (float)hxx[j + 4]} * a.s2, fb = f2{(float)hxy[j], (float)hxy[j + 4]} * a.s2, fc = f2{(float)hyy[j], (float)hyy[j + 4]} * a.s2;
+                const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+                const f2 t4 = a.k * t3;
+                const f2 t5 = t4 * t3;
+                const f2 rr = (t1 - t2) - t5;
+                r[j] = rr.x;
+                r[j + 4] = rr.y;
+            }
+            if (live) {
+                uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
+                __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
+                __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+            }
+            // row y-AN (slot i) leaves, row y+RT+1 takes its slot
+            accumulate(ring[i], true);
+            ring[i] = RowPix{pixels(ent.x), pixels(ent.y)};
+            accumulate(ring[i], false);
+            ent = ent2;
         }
-        accumulate(ent, false);
-        accumulate(lea, true);
-        ent = ent2;
-        lea = lea2;
     }
 }
 
