@@ -60,7 +60,11 @@ __device__ __forceinline__ f2 pk_fma_w(int half, f2 wp, f2 x, f2 acc)
 // run the identical accumulation code -- so the border columns are bit-identical by construction and cost microseconds
 // (a second launch of the generic per-sample kernel over those columns used to take as long as the main kernel).
 // BPT = owned bytes per thread (4 or 8): with 8 the 2*LEAD halo conversions are shared by twice as many samples.
-template <int KS, int CH, bool SEP, bool EDGE, int BPT>
+// RAG = true (BPT = 4): rows of ANY alignment and length (the reference's Mat::new gives step = cols * channels, so an odd
+// width means byte-aligned rows): a row's misalignment is the same for every thread, so the window is fetched as the NW + 1
+// ALIGNED dwords that contain it and shifted into place with v_alignbyte (unaligned per-lane loads would serialise in the
+// address path); results go out as unaligned dword stores, the row's last partial dword byte by byte (EDGE instantiation).
+template <int KS, int CH, bool SEP, bool EDGE, int BPT, bool RAG = false>
 __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows, int edge_nl, int edge_nr)
 {
     constexpr int RAD = KS / 2;
@@ -70,15 +74,16 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     constexpr int NW = (LEADW + BPT + LEAD + 3) / 4; // window dwords
     constexpr int NB = 2 * LEAD + BPT;               // window bytes
     constexpr int NP = BPT / 2;                      // packed sample pairs per thread
-    constexpr int NR = EDGE ? NB : NW;             // registers per staged row
+    constexpr int NR = EDGE ? NB : (RAG ? NW + 2 : NW);   // registers per staged row (RAG: NW + 1 aligned dwords and the byte shift)
     const int rowbytes = s.cols * CH;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (EDGE) {
         if (t >= edge_nl + edge_nr) return;
-        if (t >= edge_nl) t = rowbytes / BPT - edge_nr + (t - edge_nl);
+        if (t >= edge_nl) t = (rowbytes + BPT - 1) / BPT - edge_nr + (t - edge_nl);
     }
     const int xb0 = BPT * t;
     if (xb0 >= rowbytes) return;
+    if (RAG && !EDGE && xb0 + BPT > rowbytes) return;   // the row's last, partial dword belongs to the EDGE launch
     const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride + xb0;
@@ -102,6 +107,13 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         if constexpr (EDGE) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) w[b] = row[goff[b]];
+        } else if constexpr (RAG) {
+            const unsigned mis = (unsigned)((uintptr_t)row & 3);
+            const uint32_t* base = (const uint32_t*)(row - mis);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = base[i];
+            w[NW] = base[mis ? NW : NW - 1];   // (an aligned row needs no further dword: never read past the window then)
+            w[NW + 1] = mis;
         } else {
 #pragma unroll
             for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
@@ -122,8 +134,16 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     auto feed = [&](const uint32_t (&w)[NR], int r, auto rho_tag) __attribute__((always_inline)) {
         constexpr int RHO = decltype(rho_tag)::value;
         float p[NB];
+        uint32_t wa[EDGE ? 1 : NW];   // the window's dwords
+        if constexpr (!EDGE) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) p[b] = EDGE ? (float)w[b] : (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
+            for (int i = 0; i < NW; ++i) {
+                if constexpr (RAG) wa[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], w[NW + 1]);
+                else wa[i] = w[i];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) p[b] = EDGE ? (float)w[b] : (float)((wa[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
         f2 h[NP];
         if (SEP) {
 #pragma unroll
@@ -170,7 +190,15 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
         for (int j = 0; j < NP; ++j) acc[done][j] = SEP ? f2{0.0f, 0.0f} : f2{W.delta, W.delta};
         if (y >= ys && y < ye) {
             if constexpr (BPT == 8) *(uint2*)(df + (size_t)y * d.step) = make_uint2(o[0], o[1]);
-            else *(uint32_t*)(df + (size_t)y * d.step) = o[0];
+            else if constexpr (RAG) {
+                uint8_t* q = df + (size_t)y * d.step;
+                if (xb0 + 4 <= rowbytes) {
+                    typedef uint32_t u1m __attribute__((aligned(1)));
+                    *(u1m*)q = o[0];
+                } else {   // the row's last 1..3 bytes (EDGE launch only)
+                    for (int b = 0; b < rowbytes - xb0; ++b) q[b] = (uint8_t)(o[0] >> (8 * b));
+                }
+            } else *(uint32_t*)(df + (size_t)y * d.step) = o[0];
         }
     };
 
@@ -191,30 +219,31 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     }
 }
 
-template <int KS, int CH, bool SEP, int BPT>
+template <int KS, int CH, bool SEP, int BPT, bool RAG = false>
 int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta, float iscale)
 {
     constexpr int RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, NW = (LEADW + BPT + LEAD + 3) / 4;
     const int rowbytes = s.cols * CH;
-    if (rowbytes < 4 * NW || rowbytes % BPT != 0) return RCV_ERR_UNSUPPORTED;
+    if (rowbytes < 4 * NW + 4 || (!RAG && rowbytes % BPT != 0)) return RCV_ERR_UNSUPPORTED;
+    const int nthreads = (rowbytes + BPT - 1) / BPT;   // threads per row (RAG: the last one may own fewer than BPT bytes)
     FWeights<KS, SEP> W;
     memset(&W, 0, sizeof(W));
     for (int i = 0; i < (SEP ? KS : KS * KS); ++i) W.w2[i >> 1][i & 1] = w[i];
     W.delta = delta;
     W.iscale = iscale;
-    const unsigned gx = (unsigned)((rowbytes / BPT + kBlock - 1) / kBlock);
+    const unsigned gx = (unsigned)((nthreads + kBlock - 1) / kBlock);
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
     // threads whose window [xb0 - LEADW, xb0 - LEADW + 4 NW) left the row computed garbage: the first nl and the last nr of a
     // row -- redone by the EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
     const int limit = rowbytes - 4 * NW + LEADW;                  // last xb0 whose window still fits
     const int hi_begin = (limit / BPT + 1) * BPT;
-    const int nl = min((LEADW + BPT - 1) / BPT, rowbytes / BPT), nr = max(0, min((rowbytes - hi_begin) / BPT, rowbytes / BPT - nl));
+    const int nl = min((LEADW + BPT - 1) / BPT, nthreads), nr = max(0, min(nthreads - hi_begin / BPT, nthreads - nl));
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
-    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, true, BPT>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
+    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, true, BPT, RAG>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
                        dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr);
     return rcv_launch_check(ctx);
 }
@@ -222,9 +251,16 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
 template <bool SEP>
 int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksize, float delta, float iscale = 0.0f)
 {
-    if ((s.cols * s.ch) % 4 != 0) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)d.p % 4 || d.step % 4 || (d.n > 1 && d.fstride % 4)) return RCV_ERR_UNSUPPORTED;
+    // rows that are not 4-byte aligned or whose length is not a multiple of 4 (odd widths of packed images): RAG instantiation
+    const bool rag = (s.cols * s.ch) % 4 != 0 || (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4) || (uintptr_t)d.p % 4 || d.step % 4 ||
+                     (d.n > 1 && d.fstride % 4);
+    if (rag) {
+#define RCV_CASE_RAG(KS, CH) \
+    if (ksize == KS && s.ch == CH) return launch<KS, CH, SEP, 4, true>(ctx, s, d, w, delta, iscale);
+        RCV_CASE_RAG(3, 1) RCV_CASE_RAG(5, 1) RCV_CASE_RAG(7, 1) RCV_CASE_RAG(3, 3) RCV_CASE_RAG(5, 3) RCV_CASE_RAG(7, 3)
+#undef RCV_CASE_RAG
+        return RCV_ERR_UNSUPPORTED;
+    }
     // 8 bytes per thread where rows and row ends are 8-byte aligned (the halo conversions are shared by twice the samples)
     const bool wide = (s.cols * s.ch) % 8 == 0 && (uintptr_t)s.p % 8 == 0 && s.step % 8 == 0 && (s.n <= 1 || s.fstride % 8 == 0) &&
                       (uintptr_t)d.p % 8 == 0 && d.step % 8 == 0 && (d.n <= 1 || d.fstride % 8 == 0);

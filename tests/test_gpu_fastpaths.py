@@ -86,6 +86,28 @@ def test_fast_kernels_are_dispatched(ctx):
         ("filter2D 7x7 i8, packed 1080-wide BGR (streaming kernel, integer mode)", lambda: device.filter2d(pw, pw2, k7, shift=6), "k_filter_f32_stream<"),
         ("GaussianBlur 5x5 int, packed 1080-wide BGR", lambda: device.gaussian_blur(pw, pw2, 5, 0.0), "k_filter_f32_stream<"),
     ]
+    # odd widths of packed images (the reference's Mat::new gives step = cols * channels: rows are then only byte-aligned): the
+    # streaming kernel's unaligned instantiation, the register-window kernels' ragged instantiations -- never the per-sample kernels
+    ow, ow2 = device.DeviceBatch(ctx, n, 1079, 1919, 3), device.DeviceBatch(ctx, n, 1079, 1919, 3)
+    og, og2 = device.DeviceBatch(ctx, n, 1079, 1919, 1), device.DeviceBatch(ctx, n, 1079, 1919, 1)
+    odx, ody, om = device.DeviceBatch(ctx, n, 1079, 1919, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, 1079, 1919, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, 1079, 1919, 1)
+    device.synth(ow, 1, 13, 0)
+    device.synth(og, 1, 14, 0)
+    kf5 = np.full((5, 5), 1 / 25, np.float32)
+    cases += [
+        ("filter2D 7x7 i8, packed 1919-wide BGR (odd width)", lambda: device.filter2d(ow, ow2, k7, shift=6), "k_filter_f32_stream<"),
+        ("GaussianBlur 5x5 int, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 5, 0.0), "k_filter_f32_stream<"),
+        ("GaussianBlur 7x7 sigma 1.5, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 7, 1.5), "k_filter_f32_stream<"),
+        ("filter2D 5x5 f32, packed 1919-wide BGR", lambda: device.filter2d(ow, ow2, kf5), "k_filter_f32_stream<"),
+        ("filter2D 7x7 i8, packed 1919-wide gray", lambda: device.filter2d(og, og2, k7, shift=6), "k_filter_f32_stream<"),
+        ("Sobel, packed 1919-wide gray", lambda: device.sobel(og, odx, ody), "k_sobel_rows<0, false, true>"),
+        ("Harris pipeline, packed 1919-wide BGR", lambda: device.harris_pipeline(ow, om, None, 2, 0.04, 1e-4), "k_harris_fused<false, 0, true, true>"),
+    ]
+    # block sizes other than 2: streaming Sobel + the register-window response kernel + streaming NMS
+    cases += [
+        ("cornerHarris blockSize 3 (gray)", lambda: device.corner_harris(gray, resp, 3, 0.04), "k_harris_resp_rows<"),
+        ("Harris pipeline blockSize 5 (BGR)", lambda: device.harris_pipeline(bgr, mask, None, 5, 0.04, 1e-4), "k_harris_resp_rows<"),
+    ]
     wrong = []
     for name, fn, want in cases:
         launched = _kernels_of(ctx, fn)
@@ -93,7 +115,7 @@ def test_fast_kernels_are_dispatched(ctx):
         print(f"{name:72s} {ms:7.3f} ms   {launched}")
         if want not in launched or "generic" in launched:
             wrong.append((name, want, launched))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om):
         b.free()
     assert not wrong, wrong
 

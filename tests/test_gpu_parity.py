@@ -1057,6 +1057,44 @@ def test_warp_affine_bgr_kernel_degenerate_matrices(ctx, oracle, rng, M):
         b.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 41), (64, 333), (129, 1919), (30, 1021), (200, 47)])
+@pytest.mark.parametrize("ch", [1, 3])
+def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
+    """odd widths of packed images (step = cols * channels: rows start at any byte, frames too): integer filter2D 3/5/7, integer
+    GaussianBlur, GaussianBlur sigma > 0 and f32 filter2D all run the streaming kernel's unaligned instantiation (window fetched
+    as aligned dwords + one v_alignbyte shift per row, unaligned dword stores, the row's last 1-3 bytes by the edge launch) --
+    bit for bit against the oracle, padding between frames untouched, and never the per-sample kernels"""
+    n = 3
+    r = np.random.default_rng(rows * 4099 + cols * 7 + ch + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+    fs = rows * cols * ch + int(r.integers(1, 4)) * 2 + 1          # odd frame stride: every frame starts at another alignment
+    src = device.DeviceBatch(ctx, n, rows, cols, ch, frame_stride=fs)
+    src.upload(frames)
+    img = lambda i: frames[i] if ch == 3 else frames[i, :, :, 0]   # noqa: E731
+
+    def check(tag, fn, ref):
+        dst = device.DeviceBatch(ctx, n, rows, cols, ch, frame_stride=fs + 2)
+        dst.memset(0xCD)
+        launched = _kernels_launched(ctx, lambda: fn(dst))
+        assert "k_filter_f32_stream<" in launched and "generic" not in launched, (tag, launched)
+        raw = dst.download_bytes()[: n * dst.frame_stride].reshape(n, dst.frame_stride)
+        for i in range(n):
+            got = raw[i, : rows * cols * ch].reshape(rows, cols, ch)
+            want = ref(img(i))
+            assert np.array_equal(got if ch == 3 else got[:, :, 0], want), (tag, i)
+        assert (raw[:, rows * cols * ch:] == 0xCD).all(), (tag, "gap between frames overwritten")
+        dst.free()
+
+    for ks in (3, 5, 7):
+        k = r.integers(-9, 10, size=(ks, ks)).astype(np.int8)
+        check(f"filter2D i8 {ks}", lambda d, k=k: device.filter2d(src, d, k, shift=5), lambda a, k=k: oracle.filter2d_i8(a, k, 5))
+        check(f"Gaussian int {ks}", lambda d, ks=ks: device.gaussian_blur(src, d, ks, 0.0), lambda a, ks=ks: oracle.gaussian_blur(a, ks, 0.0))
+        check(f"Gaussian sigma {ks}", lambda d, ks=ks: device.gaussian_blur(src, d, ks, 1.3), lambda a, ks=ks: oracle.gaussian_blur(a, ks, 1.3))
+        kf = (r.standard_normal((ks, ks)) / ks).astype(np.float32)
+        check(f"filter2D f32 {ks}", lambda d, kf=kf: device.filter2d(src, d, kf, delta=1.5), lambda a, kf=kf: oracle.filter2d_f32(a, kf, 1.5))
+    src.free()
+
+
 def _kernels_launched(ctx, fn):
     L = _ffi.lib()
     L.rcv__debug_kernels_reset()
