@@ -83,6 +83,10 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3(View r, View m, float thr)
 // serves the rows above and below, and the comparison `r >= all 8 neighbours` becomes r >= maximum(...).  The maxima are
 // v_maximum3_f32 (IEEE-754-2019 maximum: a NaN operand gives NaN), so a NaN neighbour makes `r >= m` false exactly as the
 // nine separate comparisons of k_nms3x3 / the oracle do; outside the image is -inf.
+// RAG instantiation: any width >= 4 and response rows that are only 4-byte aligned (an odd width of a packed f32 image), mask
+// rows of any alignment: dword-aligned 16-byte loads (same cost as aligned ones), the lane that holds the row's last, partial
+// group takes its pixels from the clamped load by a per-lane shift and stores only its valid bytes; unaligned dword stores.
+template <bool RAG>
 __global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float thr, int seg_rows, int gx, int gy, int nblocks, int blocks_per_xcd)
 {
     const int lane = threadIdx.x & 63;
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float th
     uint8_t* mf = m.p + (size_t)bz * m.fstride;
     const bool live = x < r.cols;
     const int xc = min(x, r.cols - 4);
+    const int shift = RAG ? max(x - xc, 0) : 0, nvalid = RAG ? min(max(r.cols - x, 0), 4) : 4;   // (RAG) the row's last group: `nvalid` pixels at offset `shift` of the load
     const float NEG = -INFINITY;
     // the pixel outside the wave's 256: lane 0 needs x-1, lane 63 needs x+4 (every other lane reads one fixed cached address)
     const int xe = lane == 0 ? x - 1 : x + 4;
@@ -114,7 +119,13 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float th
         const int vr = min(max(v, 0), r.rows - 1);
         const uint8_t* row = rf + (size_t)vr * r.step;
         Row w;
-        w.q = *(const float4*)(row + (size_t)xc * 4);
+        if constexpr (RAG) {
+            typedef float f4m __attribute__((ext_vector_type(4), aligned(4)));
+            const f4m t = *(const f4m*)(row + (size_t)xc * 4);
+            w.q = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            w.q = *(const float4*)(row + (size_t)xc * 4);
+        }
         w.e = *(const float*)(row + (size_t)xec * 4);
         return w;
     };
@@ -128,6 +139,14 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float th
         const bool rowok = v >= 0 && v < r.rows;
         float q[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w};
         float e = cur.e;
+        if (RAG) {   // logical pixel j of the lane = loaded pixel j + shift; beyond the row: -inf
+            const float l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3];
+            q[0] = shift == 0 ? l0 : (shift == 1 ? l1 : (shift == 2 ? l2 : l3));
+            q[1] = shift == 0 ? l1 : (shift == 1 ? l2 : l3);
+            q[2] = shift == 0 ? l2 : l3;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) q[j] = j < nvalid ? q[j] : NEG;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) q[j] = (rowok && live) ? q[j] : NEG;
         e = (rowok && e_ok) ? e : NEG;
@@ -149,7 +168,17 @@ __global__ __launch_bounds__(kBlock) void k_nms3x3_rows(View r, View m, float th
             rcb[j] = q[j];
         }
         const int c = v - 1;
-        if (live && c >= ys && c < ye) *(uint32_t*)(mf + (size_t)c * m.step + x) = bits;
+        if (live && c >= ys && c < ye) {
+            uint8_t* o = mf + (size_t)c * m.step + x;
+            if constexpr (RAG) {
+                typedef uint32_t u1m __attribute__((aligned(1)));
+                if (nvalid == 4) *(u1m*)o = bits;
+                else
+                    for (int j = 0; j < nvalid; ++j) o[j] = (uint8_t)(bits >> (8 * j));
+            } else {
+                *(uint32_t*)o = bits;
+            }
+        }
         cur = nxt;
     }
 }
@@ -170,12 +199,12 @@ float harris_scale2(int block)
 // Sobel planes of `src` (gray or BGR: the gradient of its gray conversion) as i16 images with 16-byte aligned rows in the two
 // workspace buffers, then the register-window response kernel for any block size.  RCV_ERR_UNSUPPORTED when either kernel does
 // not take the shape (the caller then runs the per-sample kernels on the same buffers).
-size_t plane_step(int cols) { return ((size_t)cols * 2 + 15) & ~(size_t)15; }
+size_t plane_step(int cols) { return rcv_harris_plane_step(cols); }
 int harris_fast_planes(rcv_ctx* ctx, const View& src, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
 {
     if (!rcv_harris_resp_rows_ok(r, block) || src.rows > 65535 || (src.ch != 1 && src.ch != 3)) return RCV_ERR_UNSUPPORTED;
     View vx;
-    vx.p = wix;
+    vx.p = wix + rcv_harris_plane_margin();   // column 0 (the kernel's margins lie either side of the row)
     vx.step = plane_step(r.cols);
     vx.fstride = vx.step * r.rows;
     vx.cap = vx.fstride;
@@ -185,7 +214,7 @@ int harris_fast_planes(rcv_ctx* ctx, const View& src, const View& r, int block, 
     vx.esz = 2;
     vx.n = r.n;
     View vy = vx;
-    vy.p = wiy;
+    vy.p = wiy + rcv_harris_plane_margin();
     const int rc = rcv_sobel_tiled(ctx, src, vx, vy);
     if (rc != RCV_OK) return rc;
     return rcv_harris_resp_rows(ctx, vx, vy, r, block, k);
@@ -194,10 +223,11 @@ int harris_fast_planes(rcv_ctx* ctx, const View& src, const View& r, int block, 
 // 3x3 NMS: the streaming kernel for 16-byte aligned response rows, the per-sample kernel otherwise
 int nms_launch(rcv_ctx* ctx, const View& r, const View& m, float thr)
 {
-    if (r.cols % 4 == 0 && r.cols >= 4 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
-        (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0)) {
+    if (r.cols >= 4 && (uintptr_t)r.p % 4 == 0 && r.step % 4 == 0 && (r.n <= 1 || r.fstride % 4 == 0)) {
+        const bool aligned = r.cols % 4 == 0 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
+                             (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0);
         const int seg = 64;
-        dim3 grid((unsigned)((r.cols / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
+        dim3 grid((unsigned)(((r.cols + 3) / 4 + kBlock - 1) / kBlock), (unsigned)((r.rows + seg - 1) / seg), r.n);
         const int gx = (int)grid.x, gy = (int)grid.y;
         const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
         int bpx = 0;
@@ -205,7 +235,8 @@ int nms_launch(rcv_ctx* ctx, const View& r, const View& m, float thr)
             bpx = (int)((nb + 7) / 8);
             grid = dim3((unsigned)bpx * 8);
         }
-        RCV_LAUNCH(k_nms3x3_rows, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
+        if (aligned) RCV_LAUNCH(k_nms3x3_rows<false>, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
+        else RCV_LAUNCH(k_nms3x3_rows<true>, grid, dim3(kBlock), 0, ctx->stream, r, m, thr, seg, gx, gy, (int)nb, bpx);
         return rcv_launch_check(ctx);
     }
     RCV_LAUNCH(k_nms3x3, px_grid(r), dim3(kBlock), 0, ctx->stream, r, m, thr);

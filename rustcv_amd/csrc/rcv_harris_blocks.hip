@@ -13,10 +13,12 @@
 // block size, so the ring slots are static): the first version re-loaded the leaving row instead, and since `block` rows of
 // every wave's strip do not survive in L2 next to the response stream that doubled the plane reads (rocprofv3: 4.2 GB for
 // 2.1 GB of planes).  The HORIZONTAL sums are sliding sums over V with the up to 3 pixels either side taken
-// from the neighbouring lanes by DPP wave shifts.  Reflection: rows by reflected row index (scalar); at the image's left and
-// right edge the halo lane builds its 8 mirrored pixels of Ix, Iy from two aligned loads and four byte permutes per plane
-// (P(-j) = P(j) is a function of Ix(j), Iy(j), so mirroring the planes mirrors the products) -- only in the waves of the first
-// and the last strip (a wave-uniform branch).
+// from the neighbouring lanes by DPP wave shifts.  Reflection: rows by reflected row index (scalar); columns through MARGINS of
+// the planes -- the planes are this library's own workspace images, laid out with a margin either side of every row, and a tiny
+// launch (k_mirror_margins) copies Ix, Iy of columns 1..3 to -1..-3 and of cols-2..cols-4 to cols..cols+2 (P(-j) = P(j) is a
+// function of Ix(j), Iy(j), so mirroring the planes mirrors the products).  The window kernel then needs no edge cases at all:
+// lanes left and right of the image read the margins, and a width that is not a multiple of 8 only shortens the last lane's
+// store.
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include <math.h>
@@ -41,9 +43,25 @@ __device__ __forceinline__ int shl1i(int v) { return (int)__builtin_amdgcn_updat
 
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }   // v_mad_i32_i24: |Ix|, |Iy| <= 1020
 
-struct Raw2 { u4v a, b; };   // a: the lane's 8 pixels (16 bytes); b: second load of the mirroring edge lanes
+// columns -1..-3 := 1..3 and cols..cols+2 := cols-2..cols-4 of both planes (BORDER_REFLECT_101 of the product image, see above);
+// one thread per (row, frame)
+__global__ __launch_bounds__(256) void k_mirror_margins(uint8_t* ix, uint8_t* iy, size_t pstep, size_t pfs, int rows, int cols, int nrows_total)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nrows_total) return;
+    const int frame = t / rows, y = t - frame * rows;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        int16_t* row = (int16_t*)((pl ? iy : ix) + (size_t)frame * pfs + (size_t)y * pstep);
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) {
+            row[-j] = row[min(j, cols - 1)];
+            row[cols - 1 + j] = row[max(cols - 1 - j, 0)];
+        }
+    }
+}
 
-template <int B>
+template <int B, bool RAG>
 __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 {
     constexpr int AN = B / 2, RT = B - 1 - AN;   // window offsets -AN .. +RT
@@ -58,48 +76,25 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
     const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
     const int x = strip * kStripPx + 8 * (lane - 1);
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
-    // mirroring halo lanes (cols % 8 == 0, cols >= 16): x == -8 mirrors pixels 8..1, x == cols mirrors cols-2 .. cols-9
-    const bool isL = x == -8, isR = x == a.cols;
-    const bool edge_wave = strip == 0 || strip == a.nstrips - 1;   // wave-uniform
-    // byte offsets in a plane row: the lane's own 8 pixels (clamped: lanes beyond the image read a harmless place), and for the
-    // mirroring lanes the two aligned runs that hold their source pixels
-    const int xc = min(max(x, 0), a.cols - 8);
-    const unsigned o1 = 2u * (unsigned)(isL ? 0 : (isR ? a.cols - 16 : xc));
-    const unsigned o2 = 2u * (unsigned)(isL ? 8 : (isR ? a.cols - 8 : xc));
+    const int nvalid = min(max(a.cols - x, 0), 8);   // < 8 only in the lane that holds the row's last, partial run
+    // byte offset of the lane's 8 pixels in a plane row (the row pointer is column 0; the margins -- 8 pixels left, 16 right --
+    // make -8 and the first multiple of 8 at or beyond cols valid places; lanes further right re-read that place: their values
+    // feed no stored pixel)
+    const int o1 = 2 * min(x, (a.cols + 7) & ~7);
     const uint8_t* const fx = a.ix + (size_t)frame * a.pfs;
     const uint8_t* const fy = a.iy + (size_t)frame * a.pfs;
     uint8_t* const rf = a.resp + (size_t)frame * a.rfs;
 
     auto refl = [&](int v) { return v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v); };   // (rows >= block: one reflection is enough)
-    struct RowRaw { Raw2 x, y; };
-    auto load_row = [&](int v) -> RowRaw {   // virtual row -> reflected plane row
-        const size_t ro = (size_t)refl(min(max(v, -AN - 1), a.rows + RT)) * a.pstep;
-        RowRaw w;
-        w.x.a = *(const u4v*)(fx + ro + o1);
-        w.y.a = *(const u4v*)(fy + ro + o1);
-        if (edge_wave) {
-            w.x.b = *(const u4v*)(fx + ro + o2);
-            w.y.b = *(const u4v*)(fy + ro + o2);
-        } else {
-            w.x.b = w.x.a;
-            w.y.b = w.y.a;
-        }
-        return w;
-    };
-    // the 8 pixels of a plane as four dwords of i16 pairs; mirroring lanes reverse their source run
-    auto pixels = [&](const Raw2& q) -> u4v {
-        if (!edge_wave) return q.a;
-        // S = the five dwords that hold the 8 source pixels + one: L: pixels 0..9 = a.x a.y a.z a.w b.x;  R: cols-10 .. cols-1 = a.w b.x b.y b.z b.w
-        const uint32_t s0 = isL ? q.a.x : q.a.w, s1 = isL ? q.a.y : q.b.x, s2 = isL ? q.a.z : q.b.y, s3 = isL ? q.a.w : q.b.z, s4 = isL ? q.b.x : q.b.w;
-        const u4v rev = {__builtin_amdgcn_perm(s3, s4, 0x07060100u), __builtin_amdgcn_perm(s2, s3, 0x07060100u), __builtin_amdgcn_perm(s1, s2, 0x07060100u),
-                         __builtin_amdgcn_perm(s0, s1, 0x07060100u)};
-        return (isL || isR) ? rev : q.a;
+    struct RowPix { u4v x, y; };   // the lane's 8 pixels of Ix and of Iy
+    auto load_row = [&](int v) -> RowPix {   // virtual row -> reflected plane row
+        const ptrdiff_t ro = (ptrdiff_t)refl(min(max(v, -AN - 1), a.rows + RT)) * (ptrdiff_t)a.pstep + o1;
+        return RowPix{*(const u4v*)(fx + ro), *(const u4v*)(fy + ro)};
     };
 
     int vxx[8], vxy[8], vyy[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) vxx[j] = vxy[j] = vyy[j] = 0;
-    struct RowPix { u4v x, y; };   // the lane's 8 pixels of Ix and of Iy (mirrored in the edge lanes)
     // leave = false: the row enters the window (+products), true: it leaves (-products)
     auto accumulate = [&](const RowPix& w, bool leave) {
 #pragma unroll
@@ -136,24 +131,18 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 
     // the window of output row ys: virtual rows ys-AN .. ys+RT in ring slots 0 .. B-1 (virtual row v lives in slot (v - ys + AN) % B)
     RowPix ring[B];
-    {
-        RowRaw first[B];
 #pragma unroll
-        for (int i = 0; i < B; ++i) first[i] = load_row(ys - AN + i);
+    for (int i = 0; i < B; ++i) ring[i] = load_row(ys - AN + i);
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
-            ring[i] = RowPix{pixels(first[i].x), pixels(first[i].y)};
-            accumulate(ring[i], false);
-        }
-    }
-    RowRaw ent = load_row(ys + RT + 1);
+    for (int i = 0; i < B; ++i) accumulate(ring[i], false);
+    RowPix ent = load_row(ys + RT + 1);
     for (int y0 = ys; y0 < ye; y0 += B) {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             const int y = y0 + i;
             if (y >= ye) break;
             // the row that moves the window to y+2 is in flight while row y is computed and the window moves to y+1
-            const RowRaw ent2 = load_row(y + RT + 2);
+            const RowPix ent2 = load_row(y + RT + 2);
             int hxx[8], hxy[8], hyy[8];
             hsum(vxx, hxx);
             hsum(vxy, hxy);
@@ -171,12 +160,22 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
             }
             if (live) {
                 uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
-                __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
-                __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+                if constexpr (RAG) {   // response rows that are only 4-byte aligned; the row's last, partial run
+                    typedef float f4m __attribute__((ext_vector_type(4), aligned(4)));
+                    if (nvalid == 8) {
+                        *(f4m*)o = f4m{r[0], r[1], r[2], r[3]};
+                        *(f4m*)(o + 16) = f4m{r[4], r[5], r[6], r[7]};
+                    } else {
+                        for (int j = 0; j < nvalid; ++j) ((float*)o)[j] = r[j];
+                    }
+                } else {
+                    __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
+                    __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+                }
             }
             // row y-AN (slot i) leaves, row y+RT+1 takes its slot
             accumulate(ring[i], true);
-            ring[i] = RowPix{pixels(ent.x), pixels(ent.y)};
+            ring[i] = ent;
             accumulate(ring[i], false);
             ent = ent2;
         }
@@ -184,28 +183,38 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 }
 
 template <int B>
-void launch_resp(const HBArgs& a, dim3 grid, hipStream_t st)
+void launch_resp(const HBArgs& a, dim3 grid, bool rag, hipStream_t st)
 {
-    RCV_LAUNCH((k_harris_resp_rows<B>), grid, dim3(256), 0, st, a);
+    if (rag) RCV_LAUNCH((k_harris_resp_rows<B, true>), grid, dim3(256), 0, st, a);
+    else RCV_LAUNCH((k_harris_resp_rows<B, false>), grid, dim3(256), 0, st, a);
 }
 
 } // namespace
 
-// Does k_harris_resp_rows take this response image?  Widths that are a multiple of 8 (>= 16), at least `block` rows, 16-byte
-// aligned rows.
+// Layout of the Sobel planes this kernel reads: 8 pixels of margin left and 16 right of every row, rows 16-byte aligned.
+size_t rcv_harris_plane_step(int cols) { return ((size_t)(cols + 24) * 2 + 15) & ~(size_t)15; }
+size_t rcv_harris_plane_margin() { return 16; }   // bytes in front of column 0
+
+// Does k_harris_resp_rows take this response image?  Any width >= 8, at least `block` rows, 4-byte aligned rows.
 bool rcv_harris_resp_rows_ok(const View& r, int block)
 {
     if (block < 1 || block > 7) return false;
-    if (r.cols % 8 != 0 || r.cols < 16 || r.rows < block || r.rows < 2) return false;
-    return !((uintptr_t)r.p % 16 || r.step % 16 || (r.n > 1 && r.fstride % 16));
+    if (r.cols < 8 || r.rows < block || r.rows < 2) return false;
+    return !((uintptr_t)r.p % 4 || r.step % 4 || (r.n > 1 && r.fstride % 4));
 }
 
-// Response from the Sobel planes (i16, rows 16-byte aligned, same step for both) for any block 1..7; RCV_ERR_UNSUPPORTED for
-// shapes it does not take (generic kernel).
+// Response from the Sobel planes for any block 1..7.  ix / iy: views of column 0 of planes laid out as above (the margins are
+// filled here); RCV_ERR_UNSUPPORTED for shapes it does not take (per-sample kernels).
 int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k)
 {
     if (!rcv_harris_resp_rows_ok(r, block)) return RCV_ERR_UNSUPPORTED;
     if (ix.step != iy.step || ix.fstride != iy.fstride || ix.step % 16 || (uintptr_t)ix.p % 16 || (uintptr_t)iy.p % 16 || (ix.n > 1 && ix.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    if (ix.step < rcv_harris_plane_step(r.cols) || (long long)r.rows * r.n > 0x7fffffff) return RCV_ERR_UNSUPPORTED;
+    {
+        const int total = r.rows * r.n;
+        RCV_LAUNCH(k_mirror_margins, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ix.p, iy.p, ix.step, ix.fstride, r.rows, r.cols, total);
+    }
+    const bool rag = r.cols % 8 != 0 || (uintptr_t)r.p % 16 || r.step % 16 || (r.n > 1 && r.fstride % 16);
     HBArgs a;
     a.ix = ix.p;
     a.iy = iy.p;
@@ -231,13 +240,13 @@ int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const Vie
     a.s2 = (float)(s * s);
     a.k = k;
     switch (block) {
-    case 1: launch_resp<1>(a, grid, ctx->stream); break;
-    case 2: launch_resp<2>(a, grid, ctx->stream); break;
-    case 3: launch_resp<3>(a, grid, ctx->stream); break;
-    case 4: launch_resp<4>(a, grid, ctx->stream); break;
-    case 5: launch_resp<5>(a, grid, ctx->stream); break;
-    case 6: launch_resp<6>(a, grid, ctx->stream); break;
-    default: launch_resp<7>(a, grid, ctx->stream); break;
+    case 1: launch_resp<1>(a, grid, rag, ctx->stream); break;
+    case 2: launch_resp<2>(a, grid, rag, ctx->stream); break;
+    case 3: launch_resp<3>(a, grid, rag, ctx->stream); break;
+    case 4: launch_resp<4>(a, grid, rag, ctx->stream); break;
+    case 5: launch_resp<5>(a, grid, rag, ctx->stream); break;
+    case 6: launch_resp<6>(a, grid, rag, ctx->stream); break;
+    default: launch_resp<7>(a, grid, rag, ctx->stream); break;
     }
     return rcv_launch_check(ctx);
 }

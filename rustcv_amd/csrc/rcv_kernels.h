@@ -14,6 +14,8 @@ int rcv_filter_i16_gray(rcv_ctx* ctx, const View& s, const View& d, const int16_
 // src: BGR (3 ch), packed YUYV (2 ch) or gray (1 ch); mask may be null (response only: needs resp)
 int rcv_harris_fused(rcv_ctx* ctx, const View& src, const View* mask, const View* resp, int block, float k, float thr);
 // cornerHarris response for any block 1..7 from i16 Sobel planes (rcv_harris_blocks.hip)
+size_t rcv_harris_plane_step(int cols);   // row step of the i16 planes the kernel reads (8 pixels of margin left, 16 right)
+size_t rcv_harris_plane_margin();         // bytes in front of column 0
 bool rcv_harris_resp_rows_ok(const View& r, int block);
 int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);

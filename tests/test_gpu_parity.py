@@ -1199,20 +1199,21 @@ def test_corner_harris(ctx, oracle, rng, rows, cols, block):
     assert np.array_equal(dst.to_array().view(np.uint32), want.view(np.uint32))  # bit-exact f32
 
 
-@pytest.mark.parametrize("rows,cols", [(7, 16), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (8, 24)])
+@pytest.mark.parametrize("rows,cols", [(7, 16), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (8, 24), (45, 497), (64, 1919), (23, 9), (31, 503)])
 @pytest.mark.parametrize("block", [1, 3, 4, 5, 6, 7])
 def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, block):
-    """block sizes other than 2 on widths that are a multiple of 8: streaming Sobel into aligned i16 planes + the register-window
-    response kernel (vertical running sums, horizontal sliding sums with DPP halos, mirrored halo lanes at the image edges,
-    row segments) -- cornerHarris from gray and the pipeline from BGR (mask, mask + response; streaming NMS) -- bit for bit
-    against the oracle; batch of 3, padded steps.  Images with fewer rows than the block stay on the per-sample kernels."""
+    """block sizes other than 2 on any width >= 8 (multiples of 8 and ragged ones, byte-aligned rows): streaming Sobel into i16
+    planes with mirrored margins + the register-window response kernel (vertical running sums in a register ring, horizontal
+    sliding sums with DPP halos, row segments) -- cornerHarris from gray and the pipeline from BGR (mask, mask + response;
+    streaming NMS) -- bit for bit against the oracle; batch of 3, padded steps.  Images with fewer rows than the block stay on
+    the per-sample kernels."""
     n = 3
     r = np.random.default_rng(rows * 7919 + cols * 31 + block + _SOAK_SEED)
     gray = r.integers(0, 256, size=(n, rows, cols, 1), dtype=np.uint8)
     gray[:, rows // 3: rows // 3 + 3, cols // 4: cols // 4 + 5] = 255      # a few real corners
-    src = device.DeviceBatch(ctx, n, rows, cols, 1, step=(cols + 15) // 16 * 16 + 16)
+    src = device.DeviceBatch(ctx, n, rows, cols, 1, step=(cols + 15) // 16 * 16 + 16) if cols % 8 == 0 else device.DeviceBatch(ctx, n, rows, cols, 1)
     src.upload(gray)
-    resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=32)
+    resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=32 if cols % 8 == 0 else 4)
     launched = _kernels_launched(ctx, lambda: device.corner_harris(src, resp, block, 0.04))
     streaming = rows >= block
     assert ("k_harris_resp_rows" in launched) == streaming and ("k_sobel_rows" in launched) == streaming, launched
@@ -1230,7 +1231,7 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
         resp2 = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
         launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, resp2, block, 0.04, thr))
         assert ("k_harris_resp_rows" in launched) == streaming, launched
-        assert "k_nms3x3_rows" in launched if cols % 4 == 0 else True, launched
+        assert "k_nms3x3_rows" in launched, launched
         gm = mask.download()
         for i in range(n):
             wm, wr = oracle.harris_pipeline(bgr[i], block, 0.04, thr, True)
