@@ -284,6 +284,21 @@ __device__ __forceinline__ void quad_transpose4(uint32_t (&a)[4], int lane)
     a[3] = hi ? b3 : y1;
 }
 
+// The 12 bytes {a, b, c} of a quad of BGR pixels to a RAGGED destination: rows that are not 4-byte aligned (an odd width of a
+// packed image: step = cols * 3) and the row's last quad, which holds npx < 4 pixels when the width is not a multiple of 4.
+__device__ __forceinline__ void store_quad_ragged(uint8_t* q, uint32_t a, uint32_t b, uint32_t c, int npx)
+{
+    if (npx >= 4) {
+        typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+        *(u3m*)q = u3m{a, b, c};
+    } else {
+        const uint32_t w[3] = {a, b, c};
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i < 3 * npx) q[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
 // One wave's share of k_warp_affine_bgr / of the tiles k_warp_affine_bgr_lds cannot stage: column x, rows ybase .. ybase + 7 of
 // frames f0 .. f1 - 1.  The map is the same for every frame of a batch, so the source coordinates, tap offsets and lerp weights
 // of the thread's 8 pixels -- a quarter of the interior path's arithmetic -- are computed once and reused for every frame.
@@ -292,6 +307,7 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
 {
     const int rowbytes = s.cols * 3;
     const float fxx = (float)min(x, d.cols - 1);
+    const bool ragd = (d.cols & 3) || ((uintptr_t)d.p & 3) || (d.step & 3) || (d.fstride & 3);   // ragged destination (uniform)
 
     // ---- interior fast path (wave-uniform) ----
     // The border version below spends ~160 VALU ops per pixel and two unaligned 8-byte loads per row.  sx and sy are
@@ -319,7 +335,11 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
                     uint8_t* dfr = d.p + (size_t)f * d.fstride;
 #pragma unroll
                     for (int r = 0; r < kWarpRows; ++r)
-                        if (ybase + r < d.rows) *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{0u, 0u, 0u};
+                        if (ybase + r < d.rows) {
+                            uint8_t* q = dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3;
+                            if (ragd) store_quad_ragged(q, 0u, 0u, 0u, d.cols - x);
+                            else *(U3*)q = U3{0u, 0u, 0u};
+                        }
                 }
             }
             return;
@@ -391,8 +411,9 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
                     unsigned o = so[h];
                     asm("" : "+v"(o));
                     // 4 x {b g r 0} -> 12 bytes with three byte permutes
-                    *(gU3*)(dfr + o) =
-                        u3v{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+                    const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+                    if (ragd) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
+                    else *(gU3*)(dfr + o) = val;
                 }
             };
             load_half(0, f0);
@@ -470,7 +491,9 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
         // (stores may be conditional here: no load is outstanding any more)
         if ((threadIdx.x & 3) == 0 && x < d.cols && ybase + r < d.rows) {
             struct U3 { uint32_t a, b, c; };
-            *(U3*)(dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3) = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+            uint8_t* q = dfr + (size_t)(ybase + r) * d.step + (size_t)x * 3;
+            if (ragd) store_quad_ragged(q, px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8), d.cols - x);
+            else *(U3*)q = U3{px | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
         }
     }
     }
@@ -567,6 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     iy0 = __builtin_amdgcn_readfirstlane(iy0);
 
     // ---- frame-invariant per-thread state: lerp weights and the LDS offset of each pixel's upper-left tap ----
+    const bool ragd = (d.cols & 3) || ((uintptr_t)d.p & 3) || (d.step & 3) || (d.fstride & 3);   // ragged destination (uniform)
     const float fxx = (float)min(x, d.cols - 1);
     f2 fxy[kWarpRows];
     unsigned la[kWarpRows];
@@ -642,8 +666,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
             if (xq < d.cols && yi + 4 * h < d.rows) {
                 unsigned o = so[h];
                 asm("" : "+v"(o));
-                *(gU3*)(dfr + o) =
-                    u3v{__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+                const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+                if (ragd) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
+                else *(gU3*)(dfr + o) = val;
             }
         }
     }
@@ -1030,7 +1055,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     Affine A;
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
-    if (s.ch == 3 && s.cols >= 3 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
+    if (s.ch == 3 && s.cols >= 3) {   // (any destination width / alignment: ragged destinations store their quads piecewise)
         const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
         const unsigned gy = (unsigned)((d.rows + band - 1) / band);
         // frames per workgroup (the coordinate arithmetic is shared inside a group): as many of 8 / 4 / 2 as still leave >= 8192 workgroups

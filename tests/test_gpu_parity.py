@@ -1111,7 +1111,7 @@ def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case):
     oracle and as the gather kernel (RCV_WARP_LDS=0)"""
     rng = np.random.default_rng(0xC0FFEE + case)
     sr, sc = int(rng.integers(150, 420)), int(rng.integers(200, 640))
-    dr, dc = int(rng.integers(100, 400)), 4 * int(rng.integers(40, 150))
+    dr, dc = int(rng.integers(100, 400)), (4 * int(rng.integers(40, 150)) if case % 2 == 0 else int(rng.integers(160, 600)))   # odd cases: any width
     n = int(rng.integers(1, 6))
     kind = case % 7
     if kind == 0:
@@ -1131,7 +1131,7 @@ def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case):
         M = (np.array([1, 0, 0, 0, 1, 0]) + rng.uniform(-0.25, 0.25, 6) * np.array([1, 1, 40, 1, 1, 40])).astype(np.float32)
     M = np.asarray(M, np.float32)
     frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
-    src, dst = device.DeviceBatch(ctx, n, sr, sc, 3), device.DeviceBatch(ctx, n, dr, dc, 3, step=dc * 3 + 4 * int(rng.integers(0, 3)))
+    src, dst = device.DeviceBatch(ctx, n, sr, sc, 3), device.DeviceBatch(ctx, n, dr, dc, 3, step=dc * 3 + (4 if case % 2 == 0 else 1) * int(rng.integers(0, 3)))
     src.upload(frames)
     want = [oracle.warp_affine(frames[i], M, dr, dc) for i in range(n)]
     for fpg in (0, 1, 2, 3, 8):

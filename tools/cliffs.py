@@ -25,6 +25,7 @@ for (rows, cols) in ((2160, 3840), (2159, 3839), (2160, 3838), (2160, 3836)):
     bgr, bgr2, gray, gray2 = B(3), B(3), B(1), B(1)
     dx, dy, resp, mask = B(1, _ffi.RCV_16S), B(1, _ffi.RCV_16S), B(1, _ffi.RCV_32F), B(1)
     half = device.DeviceBatch(ctx, n, rows // 2, cols // 2, 3)
+    bgra = B(4)
     odd = device.DeviceBatch(ctx, n, 1441, 2561, 3)
     device.synth(bgr, 1, 7, 0); device.synth(gray, 1, 8, 0)
     ops = [("filter2D 7x7 i8", lambda: device.filter2d(bgr, bgr2, k7, shift=6)), ("Gaussian 5x5 int", lambda: device.gaussian_blur(bgr, bgr2, 5, 0.0)),
@@ -34,8 +35,11 @@ for (rows, cols) in ((2160, 3840), (2159, 3839), (2160, 3838), (2160, 3836)):
            ("cornerHarris b2", lambda: device.corner_harris(gray, resp, 2, 0.04)), ("NMS", lambda: device.nms3x3(resp, mask, 1e-4)),
            ("warpAffine", lambda: device.warp_affine(bgr, bgr2, M)), ("warp gray", lambda: device.warp_affine(gray, gray2, M)),
            ("resize to half", lambda: device.resize(bgr, half)), ("resize to 2561x1441", lambda: device.resize(bgr, odd)),
-           ("gray filter 7x7", lambda: device.filter2d(gray, gray2, k7, shift=6))]
+           ("gray filter 7x7", lambda: device.filter2d(gray, gray2, k7, shift=6)),
+           ("BGRA -> BGR", lambda: device.cvt_color(bgra, bgr2, _ffi.RCV_BGRA2BGR)), ("BGR -> RGB", lambda: device.cvt_color(bgr, bgr2, _ffi.RCV_BGR2RGB)),
+           ("BGR -> BGRX", lambda: device.cvt_color(bgr, bgra, _ffi.RCV_BGR2BGRX)),
+           ("Sobel of BGR", lambda: device.sobel(bgr, dx, dy)), ("fused warp + 2x down-scale", lambda: device.warp_affine_resize(bgr, half, M, 2 * (rows // 2), 2 * (cols // 2)))]
     print(f"---- {cols} x {rows}, {n} frames")
     for name, fn in ops:
         print(f"{name:24s} {t(fn):8.3f} ms   {kern(fn)}", flush=True)
-    for b in (bgr, bgr2, gray, gray2, dx, dy, resp, mask, half, odd): b.free()
+    for b in (bgr, bgr2, gray, gray2, dx, dy, resp, mask, half, odd, bgra): b.free()

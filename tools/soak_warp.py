@@ -22,7 +22,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for case in range(N):
     rng = np.random.default_rng(0xABCD00 + case)
     sr, sc = int(rng.integers(40, 700)), int(rng.integers(40, 900))
-    dr, dc = int(rng.integers(8, 600)), 4 * int(rng.integers(2, 220))
+    dr, dc = int(rng.integers(8, 600)), (4 * int(rng.integers(2, 220)) if case % 3 else int(rng.integers(5, 880)))   # every third case: any width
     n = int(rng.integers(1, 10))
     kind = case % 8
     if kind == 0: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)))
