@@ -144,7 +144,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // (gray: X counts pixels = bytes, and the chunk of block pl starts 256 * pl further)
     const int cb = (GRAY ? X : (X / 3) * SB) + CB * n - 4 * SB + CB * c;
     const unsigned cbo = (unsigned)min(max(cb, 0), rbs - CB);
-    const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - 4 * SB;
+    // The chunk that holds pixel `cols` (the first one past the row) has `rv` valid pixels in front of it: 4 when the width is a
+    // multiple of 16; BGR also takes widths that are a multiple of 4 (a 1080-pixel portrait frame): rv = 0, 8, 12 then (the same in
+    // every such lane of the launch: a scalar)
+    const int rv = (SRC == 0) ? ((a.cols & 15) + 4) & 15 : 4;
+    const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - rv * SB;
     unsigned cbo1 = 0, cbo2 = 0;
     bool fr1 = false, fr2 = false;
     if constexpr (GRAY) {
@@ -249,14 +253,29 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                     pp[0] = __builtin_amdgcn_perm(pp[0], pp[0], 0x01020300u);   // [x, px3, px2, px1]
                 }
             }
-            // right border: the lane read pixels cols-16..cols-1 instead of cols-4..cols+11; pixels cols..cols+2 mirror cols-2..cols-4
+            // right border: the lane read pixels cols-16..cols-1 instead of cols-rv..cols-rv+15: its rv valid pixels move down to
+            // the front, pixels cols..cols+2 mirror cols-2..cols-4
             if (GRAY ? (fr || fr1 || fr2) : fr) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     if (GRAY && !(pl == 0 ? fr : (pl == 1 ? fr1 : fr2))) continue;
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
-                    pp[0] = pp[3];
-                    pp[1] = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);   // [cols-2, cols-3, cols-4, x]
+                    const uint32_t mir = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);   // [cols-2, cols-3, cols-4, x]
+                    if (SRC != 0 || rv == 4) {
+                        pp[0] = pp[3];
+                        pp[1] = mir;
+                    } else if (rv == 8) {
+                        pp[0] = pp[2];
+                        pp[1] = pp[3];
+                        pp[2] = mir;
+                    } else if (rv == 12) {
+                        pp[0] = pp[1];
+                        pp[1] = pp[2];
+                        pp[2] = pp[3];
+                        pp[3] = mir;
+                    } else {   // rv == 0: the chunk starts at pixel cols
+                        pp[0] = mir;
+                    }
                 }
             }
         }
@@ -474,8 +493,8 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 
 } // namespace
 
-// Does this launch belong on the row-streaming kernel?  BGR, |weights| <= 511, rows 16-byte aligned, width a multiple of 16
-// pixels; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
+// Does this launch belong on the row-streaming kernel?  |weights| <= 511; BGR: rows 4-byte aligned, width a multiple of 4 pixels;
+// YUYV / gray sources: rows 16-byte aligned, width a multiple of 16; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
 // small launches keep the strip kernel's latency variant.
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv)
 {
@@ -485,10 +504,14 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     // src_yuyv: 0 BGR, 1 packed YUYV source, 2 one-channel (gray) source and destination
     const bool gray = src_yuyv == 2;
     if (s.ch != (gray ? 1 : (src_yuyv ? 2 : 3)) || d.ch != (gray ? 1 : 3)) return RCV_ERR_UNSUPPORTED;
-    if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
+    // widths: a multiple of 16 pixels; BGR -> BGR also any multiple of 4 (the right-border repair knows the four residues) with
+    // rows that are only 4-byte aligned (a packed 1080-pixel-wide portrait frame: step = 3240): its loads and stores are dword-
+    // aligned dwordx4 / dwordx3, which cost the same as 16-byte aligned ones
+    const int wq = src_yuyv == 0 ? 4 : 16, al = src_yuyv == 0 ? 4 : 16;
+    if (s.cols % wq != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     const long long rb = (long long)s.cols * (gray ? 1 : 3);
-    if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)s.p % al || s.step % al || (s.n > 1 && s.fstride % al)) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)d.p % al || d.step % al || (d.n > 1 && d.fstride % al)) return RCV_ERR_UNSUPPORTED;
     // in-frame source offsets are 32-bit
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)

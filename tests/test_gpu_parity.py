@@ -1057,6 +1057,37 @@ def test_warp_affine_bgr_kernel_degenerate_matrices(ctx, oracle, rng, M):
         b.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(40, 20), (33, 36), (64, 1080), (50, 1084), (37, 1088), (29, 1092), (45, 252), (31, 260), (70, 264), (19, 268), (23, 772),
+                                       (41, 1548), (16, 16), (90, 28)])
+def test_row_streaming_kernel_on_widths_that_are_multiples_of_4(ctx, oracle, knob, rows, cols):
+    """the row-streaming MFMA kernel on BGR widths with every residue mod 16 (a packed 1080-pixel-wide frame: rows only 4-byte
+    aligned, the right-border chunk holds 0 / 4 / 8 / 12 valid pixels, partial last windows and strips): filter2D 3 / 5 / 7 and
+    the integer GaussianBlur (two weight tables at 7) against the oracle; frames 4-byte aligned only"""
+    knob("RCV_F7_ROWS", 1)
+    n = 3
+    for ks in (3, 5, 7):
+        rng = np.random.default_rng(1000 * rows + 7 * cols + ks + _SOAK_SEED)
+        frames = rng.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+        k = rng.integers(-20, 21, size=(ks, ks)).astype(np.int8)
+        src = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + 4 * int(rng.integers(0, 3)))
+        dst = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + 4 * int(rng.integers(1, 3)))
+        src.upload(frames)
+        dst.memset(0xEE)
+        launched = _kernels_launched(ctx, lambda: device.filter2d(src, dst, k, shift=6))
+        assert "k_filter_rows_mfma<" in launched, launched
+        raw = dst.download_bytes()[: n * dst.frame_stride].reshape(n, dst.frame_stride)
+        for i in range(n):
+            assert np.array_equal(raw[i, : rows * cols * 3].reshape(rows, cols, 3), oracle.filter2d_i8(frames[i], k, 6)), (ks, i)
+        assert (raw[:, rows * cols * 3:] == 0xEE).all(), "gap between frames overwritten"
+        launched = _kernels_launched(ctx, lambda: device.gaussian_blur(src, dst, ks, 0.0))
+        assert "k_filter_rows_mfma<" in launched, launched
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i], oracle.gaussian_blur(frames[i], ks, 0.0)), ("gauss", ks, i)
+        src.free()
+        dst.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(37, 41), (64, 333), (129, 1919), (30, 1021), (200, 47)])
 @pytest.mark.parametrize("ch", [1, 3])
 def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
