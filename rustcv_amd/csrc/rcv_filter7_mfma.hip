@@ -623,8 +623,9 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     if (!gray && !src_yuyv && (s.cols % 16 != 0 || (uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16) || (uintptr_t)d.p % 16 || d.step % 16 ||
                                (d.n > 1 && d.fstride % 16)))
         // BGR widths that are a multiple of 4 with 4-byte aligned rows (a packed 1080-pixel-wide frame): the row-streaming kernel
-        // takes them when the launch fills the GPU; this strip kernel does not
-        return rcv_filter_i16_rows(ctx, s, d, k, ksize, shift, 0);
+        // takes them whatever the size of the launch (one 1080 x 1920 frame: 0.015 ms against 0.088 ms on the streaming VALU
+        // kernel); this strip kernel does not
+        return rcv_filter_i16_rows(ctx, s, d, k, ksize, shift, 0, true);
     if (s.cols % 16 != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)s.p % 16 || s.step % 16 || (s.n > 1 && s.fstride % 16)) return RCV_ERR_UNSUPPORTED;
     if ((uintptr_t)d.p % 16 || d.step % 16 || (d.n > 1 && d.fstride % 16)) return RCV_ERR_UNSUPPORTED;

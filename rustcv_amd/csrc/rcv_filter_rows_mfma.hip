@@ -496,7 +496,7 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 // Does this launch belong on the row-streaming kernel?  |weights| <= 511; BGR: rows 4-byte aligned, width a multiple of 4 pixels;
 // YUYV / gray sources: rows 16-byte aligned, width a multiple of 16; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
 // small launches keep the strip kernel's latency variant.
-int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv)
+int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size)
 {
     const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
@@ -517,7 +517,9 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
     const int nstrips = (int)((rb + 767) / 768);
     const long long G = (long long)s.n * s.rows;
-    if (kn.f7_rows < 0 && G * nstrips < 64LL * 10 * ctx->cu_count) return RCV_ERR_UNSUPPORTED;   // < 64 rows per wave slot
+    // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
+    //  streaming VALU kernel: 4-7x slower even on one frame)
+    if (kn.f7_rows < 0 && !any_size && G * nstrips < 64LL * 10 * ctx->cu_count) return RCV_ERR_UNSUPPORTED;   // < 64 rows per wave slot
 
     // weights beyond i8: K = M + 2 * S when every weight fits that split (|w| <= 381; the integer Gaussian), else K = 4Q + R
     const int nk = ksize * ksize, np = (ksize + 1) / 2;

@@ -78,13 +78,17 @@ def test_fast_kernels_are_dispatched(ctx):
         ("cvtColor BGR2GRAY", lambda: device.cvt_color(bgr, gray2, _ffi.RCV_BGR2GRAY), "k_bgr2gray16"),
         ("cvtColor YUYV2BGR", lambda: device.cvt_color(yuyv, bgr2, _ffi.RCV_YUYV2BGR), "k_yuyv2bgr_vec"),
     ]
-    # a packed 1080-pixel-wide (portrait) BGR batch: rows are only 4-byte aligned, so the MFMA kernels do not apply -- the
-    # integer filters must take the streaming kernel's exact integer mode, not the generic per-sample kernel (13x slower)
+    # a packed 1080-pixel-wide (portrait) BGR batch: rows are only 4-byte aligned and the width is not a multiple of 16 -- the
+    # row-streaming MFMA kernel takes widths that are a multiple of 4 (whatever the size of the launch: the strip kernel does not
+    # apply); a one-channel 1084-wide image takes the streaming kernel's exact integer mode, never the per-sample kernel
     pw, pw2 = device.DeviceBatch(ctx, n, 1920, 1080, 3), device.DeviceBatch(ctx, n, 1920, 1080, 3)
+    pg, pg2 = device.DeviceBatch(ctx, n, 1920, 1084, 1), device.DeviceBatch(ctx, n, 1920, 1084, 1)
     device.synth(pw, 1, 10, 0)
+    device.synth(pg, 1, 15, 0)
     cases += [
-        ("filter2D 7x7 i8, packed 1080-wide BGR (streaming kernel, integer mode)", lambda: device.filter2d(pw, pw2, k7, shift=6), "k_filter_f32_stream<"),
-        ("GaussianBlur 5x5 int, packed 1080-wide BGR", lambda: device.gaussian_blur(pw, pw2, 5, 0.0), "k_filter_f32_stream<"),
+        ("filter2D 7x7 i8, packed 1080-wide BGR (row-streaming MFMA kernel)", lambda: device.filter2d(pw, pw2, k7, shift=6), "k_filter_rows_mfma<"),
+        ("GaussianBlur 5x5 int, packed 1080-wide BGR", lambda: device.gaussian_blur(pw, pw2, 5, 0.0), "k_filter_rows_mfma<"),
+        ("filter2D 7x7 i8, packed 1084-wide gray", lambda: device.filter2d(pg, pg2, k7, shift=6), "k_filter_"),
     ]
     # odd widths of packed images (the reference's Mat::new gives step = cols * channels: rows are then only byte-aligned): the
     # streaming kernel's unaligned instantiation, the register-window kernels' ragged instantiations -- never the per-sample kernels
@@ -115,7 +119,7 @@ def test_fast_kernels_are_dispatched(ctx):
         print(f"{name:72s} {ms:7.3f} ms   {launched}")
         if want not in launched or "generic" in launched:
             wrong.append((name, want, launched))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om, pg, pg2):
         b.free()
     assert not wrong, wrong
 
