@@ -200,24 +200,27 @@ float harris_scale2(int block)
 // workspace buffers, then the register-window response kernel for any block size.  RCV_ERR_UNSUPPORTED when either kernel does
 // not take the shape (the caller then runs the per-sample kernels on the same buffers).
 size_t plane_step(int cols) { return rcv_harris_plane_step(cols); }
-int harris_fast_planes(rcv_ctx* ctx, const View& src, const View& r, int block, float k, uint8_t* wix, uint8_t* wiy)
+int harris_fast_planes(rcv_ctx* ctx, const View& src, const View* r, const View* m, int block, float k, float thr, uint8_t* wix, uint8_t* wiy)
 {
-    if (!rcv_harris_resp_rows_ok(r, block) || src.rows > 65535 || (src.ch != 1 && src.ch != 3)) return RCV_ERR_UNSUPPORTED;
+    const View& o = r ? *r : *m;
+    if ((r && !rcv_harris_resp_rows_ok(*r, block, true)) || (m && !rcv_harris_resp_rows_ok(*m, block, false)) || src.rows > 65535 ||
+        (src.ch != 1 && src.ch != 3))
+        return RCV_ERR_UNSUPPORTED;
     View vx;
     vx.p = wix + rcv_harris_plane_margin();   // column 0 (the kernel's margins lie either side of the row)
-    vx.step = plane_step(r.cols);
-    vx.fstride = vx.step * r.rows;
+    vx.step = plane_step(o.cols);
+    vx.fstride = vx.step * o.rows;
     vx.cap = vx.fstride;
-    vx.rows = r.rows;
-    vx.cols = r.cols;
+    vx.rows = o.rows;
+    vx.cols = o.cols;
     vx.ch = 1;
     vx.esz = 2;
-    vx.n = r.n;
+    vx.n = o.n;
     View vy = vx;
     vy.p = wiy + rcv_harris_plane_margin();
     const int rc = rcv_sobel_tiled(ctx, src, vx, vy);
     if (rc != RCV_OK) return rc;
-    return rcv_harris_resp_rows(ctx, vx, vy, r, block, k);
+    return rcv_harris_resp_rows(ctx, vx, vy, r, m, block, k, thr);
 }
 
 // 3x3 NMS: the streaming kernel for 16-byte aligned response rows, the per-sample kernel otherwise
@@ -276,7 +279,7 @@ extern "C" int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wix));
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wiy));
     {   // other block sizes: streaming Sobel into aligned planes + the register-window response kernel
-        const int rc = harris_fast_planes(ctx, g, r, block, k, wix, wiy);
+        const int rc = harris_fast_planes(ctx, g, &r, nullptr, block, k, 0.0f, wix, wiy);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
     return harris_from_gray(ctx, g, r, block, k, wix, wiy);
@@ -335,13 +338,19 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     // other shapes / block sizes: Ix, Iy (and the response when the caller does not want it, and the gray image for the
     // per-sample kernels) live in the workspace
     const size_t npx = (size_t)s.n * s.rows * s.cols;
-    const size_t plane = (size_t)s.n * s.rows * plane_step(s.cols);        // i16 plane with 16-byte aligned rows (>= the packed layout)
+    const size_t plane = (size_t)s.n * s.rows * plane_step(s.cols);        // i16 plane with margins and 16-byte aligned rows (>= the packed layout)
     const size_t rstep = ((size_t)s.cols * 4 + 15) & ~(size_t)15;          // response rows likewise
     RCV_TRY(rcv_ws_reserve(ctx, npx + 2 * plane + (resp ? 0 : rstep * s.rows * s.n) + 5 * 256));
     uint8_t *wg, *wix, *wiy, *wr = nullptr;
     RCV_TRY(rcv_ws_alloc(ctx, npx, &wg));   // (only the per-sample path of a BGR source uses it)
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wix));
     RCV_TRY(rcv_ws_alloc(ctx, plane, &wiy));
+    // streaming kernels: Sobel straight from the source (a BGR source: the gradient of its gray conversion, no gray image), then
+    // ONE register-window kernel for the response of any block size and its 3x3 NMS (no response image unless the caller wants it)
+    {
+        const int rc2 = harris_fast_planes(ctx, s, resp ? &r : nullptr, &m, block, k, thr, wix, wiy);
+        if (rc2 != RCV_ERR_UNSUPPORTED) return rc2;
+    }
     if (!resp) {
         RCV_TRY(rcv_ws_alloc(ctx, rstep * s.rows * s.n, &wr));
         r = s;
@@ -352,32 +361,26 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
         r.ch = 1;
         r.esz = 4;
     }
-    // streaming kernels: Sobel straight from the source (a BGR source: the gradient of its gray conversion, no gray image),
-    // the register-window response for any block size, the streaming NMS
-    int rc2 = harris_fast_planes(ctx, s, r, block, k, wix, wiy);
-    if (rc2 == RCV_ERR_UNSUPPORTED) {
-        rcv_batch gb;
-        gb.frame0.data = wg;
-        gb.frame0.cap = (size_t)s.rows * s.cols;
-        gb.frame0.step = (size_t)s.cols;
-        gb.frame0.rows = s.rows;
-        gb.frame0.cols = s.cols;
-        gb.frame0.channels = 1;
-        gb.frame0.depth = RCV_8U;
-        gb.frame0.device = RCV_DEVICE;
-        gb.frame0.reserved = 0;
-        gb.frame_stride = (size_t)s.rows * s.cols;
-        gb.n = s.n;
-        gb.reserved = 0;
-        View g;
-        if (s.ch == 1) g = s;   // the source is the gray image
-        else {
-            RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
-            RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
-        }
-        rc2 = harris_from_gray(ctx, g, r, block, k, wix, wiy);
+    rcv_batch gb;
+    gb.frame0.data = wg;
+    gb.frame0.cap = (size_t)s.rows * s.cols;
+    gb.frame0.step = (size_t)s.cols;
+    gb.frame0.rows = s.rows;
+    gb.frame0.cols = s.cols;
+    gb.frame0.channels = 1;
+    gb.frame0.depth = RCV_8U;
+    gb.frame0.device = RCV_DEVICE;
+    gb.frame0.reserved = 0;
+    gb.frame_stride = (size_t)s.rows * s.cols;
+    gb.n = s.n;
+    gb.reserved = 0;
+    View g;
+    if (s.ch == 1) g = s;   // the source is the gray image
+    else {
+        RCV_TRY(rcv_cvt_color_batch(ctx, RCV_BGR2GRAY, bgr, &gb));
+        RCV_TRY(rcv_view_batch(&gb, RCV_8U, &g));
     }
-    RCV_TRY(rc2);
+    RCV_TRY(harris_from_gray(ctx, g, r, block, k, wix, wiy));
     return nms_launch(ctx, r, m, thr);
 }
 

@@ -32,14 +32,17 @@ constexpr int kStripPx = 62 * 8;
 
 struct HBArgs {
     const uint8_t *ix, *iy;   // i16 planes
-    uint8_t* resp;
-    size_t pstep, pfs, rstep, rfs;   // plane row step / frame stride (bytes), response likewise
+    uint8_t *resp, *mask;     // either may be null (MODE)
+    size_t pstep, pfs, rstep, rfs, mstep, mfs;   // plane row step / frame stride (bytes), response and mask likewise
     int rows, cols, nstrips, seg_rows, nsegs, total_waves, blocks_per_xcd;
-    float s2, k;
+    float s2, k, thr_up;      // thr_up: smallest float > thr (+inf for a NaN threshold), as in rcv_harris_fused.hip
 };
 
 __device__ __forceinline__ int shr1i(int v) { return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x138, 0xf, 0xf, true); }   // from lane-1
 __device__ __forceinline__ int shl1i(int v) { return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x130, 0xf, 0xf, true); }   // from lane+1
+
+__device__ __forceinline__ float shr1f(float v) { return __builtin_bit_cast(float, shr1i(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(float, shl1i(__builtin_bit_cast(int, v))); }
 
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }   // v_mad_i32_i24: |Ix|, |Iy| <= 1020
 
@@ -61,10 +64,14 @@ __global__ __launch_bounds__(256) void k_mirror_margins(uint8_t* ix, uint8_t* iy
     }
 }
 
-template <int B, bool RAG>
+// MODE: 0 response only (cornerHarris), 1 mask only, 2 both (the Harris pipeline: the 3x3 NMS of rcv_harris_fused.hip on the
+// response rows as they are formed -- the response of row y completes the mask of row y-1, so a segment computes the responses of
+// rows ys-1 .. ye; responses outside the image are -inf)
+template <int B, bool RAG, int MODE>
 __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 {
     constexpr int AN = B / 2, RT = B - 1 - AN;   // window offsets -AN .. +RT
+    constexpr bool WANT_RESP = MODE != 1, WANT_MASK = MODE != 0;
     const int lane = threadIdx.x & 63;
     const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
@@ -83,12 +90,14 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
     const int o1 = 2 * min(x, (a.cols + 7) & ~7);
     const uint8_t* const fx = a.ix + (size_t)frame * a.pfs;
     const uint8_t* const fy = a.iy + (size_t)frame * a.pfs;
-    uint8_t* const rf = a.resp + (size_t)frame * a.rfs;
+    uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
+    uint8_t* const mf = WANT_MASK ? a.mask + (size_t)frame * a.mfs : nullptr;
+    const float NEG_INF = -INFINITY;
 
     auto refl = [&](int v) { return v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v); };   // (rows >= block: one reflection is enough)
     struct RowPix { u4v x, y; };   // the lane's 8 pixels of Ix and of Iy
     auto load_row = [&](int v) -> RowPix {   // virtual row -> reflected plane row
-        const ptrdiff_t ro = (ptrdiff_t)refl(min(max(v, -AN - 1), a.rows + RT)) * (ptrdiff_t)a.pstep + o1;
+        const ptrdiff_t ro = (ptrdiff_t)refl(min(max(v, -AN - 2), a.rows + RT + 1)) * (ptrdiff_t)a.pstep + o1;   // (rows >= block >= ... see host: one reflection)
         return RowPix{*(const u4v*)(fx + ro), *(const u4v*)(fy + ro)};
     };
 
@@ -129,18 +138,25 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
         }
     };
 
-    // the window of output row ys: virtual rows ys-AN .. ys+RT in ring slots 0 .. B-1 (virtual row v lives in slot (v - ys + AN) % B)
+    // NMS state: rowmax3 of response rows u-2, u-1; response and left/right max of row u-1 (as rcv_harris_fused.hip)
+    float m3a[8], m3b[8], rc[8], mlr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m3a[j] = m3b[j] = rc[j] = mlr[j] = NEG_INF;
+
+    // first / last response row of the segment (the mask needs one more either side)
+    const int yf = WANT_MASK ? ys - 1 : ys, yl = WANT_MASK ? ye : ye - 1;
+    // the window of response row yf: virtual rows yf-AN .. yf+RT in ring slots 0 .. B-1 (virtual row v lives in slot (v - yf + AN) % B)
     RowPix ring[B];
 #pragma unroll
-    for (int i = 0; i < B; ++i) ring[i] = load_row(ys - AN + i);
+    for (int i = 0; i < B; ++i) ring[i] = load_row(yf - AN + i);
 #pragma unroll
     for (int i = 0; i < B; ++i) accumulate(ring[i], false);
-    RowPix ent = load_row(ys + RT + 1);
-    for (int y0 = ys; y0 < ye; y0 += B) {
+    RowPix ent = load_row(yf + RT + 1);
+    for (int y0 = yf; y0 <= yl; y0 += B) {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             const int y = y0 + i;
-            if (y >= ye) break;
+            if (y > yl) break;
             // the row that moves the window to y+2 is in flight while row y is computed and the window moves to y+1
             const RowPix ent2 = load_row(y + RT + 2);
             int hxx[8], hxy[8], hyy[8];
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
                 r[j] = rr.x;
                 r[j + 4] = rr.y;
             }
-            if (live) {
+            if (WANT_RESP && live && y >= ys && y < ye) {
                 uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
                 if constexpr (RAG) {   // response rows that are only 4-byte aligned; the row's last, partial run
                     typedef float f4m __attribute__((ext_vector_type(4), aligned(4)));
@@ -173,6 +189,41 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
                     __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
                 }
             }
+            if constexpr (WANT_MASK) {
+                // responses outside the image are -inf: rows (scalar condition), columns left of 0 / right of cols-1 (per lane)
+                const bool rowout = y < 0 || y >= a.rows;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (rowout || x + j < 0 || x + j >= a.cols) ? NEG_INF : r[j];
+                const float rl = shr1f(r[7]), rr = shl1f(r[0]);   // r[x-1] of the lane's first pixel, r[x+8]
+                uint32_t mbits[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float left = j ? r[j - 1] : rl, right = j < 7 ? r[j + 1] : rr;
+                    // the threshold rides in the neighbour maxima: rc > thr <=> rc >= thr_up, keep = rc >= max(8 neighbours, thr_up)
+                    const float lrmax = fmaxf(fmaxf(left, right), a.thr_up);
+                    const float m3 = fmaxf(lrmax, r[j]);
+                    const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);   // mask row y-1: rowmax3(y-2), left/right of y-1, rowmax3(y)
+                    const bool keep = rc[j] >= m8;
+                    mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                    m3a[j] = m3b[j];
+                    m3b[j] = m3;
+                    rc[j] = r[j];
+                    mlr[j] = lrmax;
+                }
+                const int w = y - 1;
+                if (live && w >= ys && w < ye) {
+                    uint8_t* o = mf + (size_t)w * a.mstep + (size_t)x;
+                    if constexpr (RAG) {
+                        typedef uint32_t u2m __attribute__((ext_vector_type(2), aligned(1)));
+                        if (nvalid == 8) *(u2m*)o = u2m{mbits[0], mbits[1]};
+                        else
+                            for (int j = 0; j < nvalid; ++j) o[j] = (uint8_t)(mbits[j >> 2] >> (8 * (j & 3)));
+                    } else {
+                        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                        *(u2v*)o = u2v{mbits[0], mbits[1]};
+                    }
+                }
+            }
             // row y-AN (slot i) leaves, row y+RT+1 takes its slot
             accumulate(ring[i], true);
             ring[i] = ent;
@@ -185,8 +236,16 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 template <int B>
 void launch_resp(const HBArgs& a, dim3 grid, bool rag, hipStream_t st)
 {
-    if (rag) RCV_LAUNCH((k_harris_resp_rows<B, true>), grid, dim3(256), 0, st, a);
-    else RCV_LAUNCH((k_harris_resp_rows<B, false>), grid, dim3(256), 0, st, a);
+    const int mode = a.mask ? (a.resp ? 2 : 1) : 0;
+    if (rag) {
+        if (mode == 0) RCV_LAUNCH((k_harris_resp_rows<B, true, 0>), grid, dim3(256), 0, st, a);
+        else if (mode == 1) RCV_LAUNCH((k_harris_resp_rows<B, true, 1>), grid, dim3(256), 0, st, a);
+        else RCV_LAUNCH((k_harris_resp_rows<B, true, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        if (mode == 0) RCV_LAUNCH((k_harris_resp_rows<B, false, 0>), grid, dim3(256), 0, st, a);
+        else if (mode == 1) RCV_LAUNCH((k_harris_resp_rows<B, false, 1>), grid, dim3(256), 0, st, a);
+        else RCV_LAUNCH((k_harris_resp_rows<B, false, 2>), grid, dim3(256), 0, st, a);
+    }
 }
 
 } // namespace
@@ -195,42 +254,53 @@ void launch_resp(const HBArgs& a, dim3 grid, bool rag, hipStream_t st)
 size_t rcv_harris_plane_step(int cols) { return ((size_t)(cols + 24) * 2 + 15) & ~(size_t)15; }
 size_t rcv_harris_plane_margin() { return 16; }   // bytes in front of column 0
 
-// Does k_harris_resp_rows take this response image?  Any width >= 8, at least `block` rows, 4-byte aligned rows.
-bool rcv_harris_resp_rows_ok(const View& r, int block)
+// Does k_harris_resp_rows take an output image of this shape?  Any width >= 8, at least block + 2 rows (one reflection per row
+// index is enough then), 4-byte aligned response rows (f32); mask rows may have any alignment.
+bool rcv_harris_resp_rows_ok(const View& o, int block, bool is_resp)
 {
     if (block < 1 || block > 7) return false;
-    if (r.cols < 8 || r.rows < block || r.rows < 2) return false;
-    return !((uintptr_t)r.p % 4 || r.step % 4 || (r.n > 1 && r.fstride % 4));
+    if (o.cols < 8 || o.rows < block + 2) return false;
+    return !is_resp || !((uintptr_t)o.p % 4 || o.step % 4 || (o.n > 1 && o.fstride % 4));
 }
 
-// Response from the Sobel planes for any block 1..7.  ix / iy: views of column 0 of planes laid out as above (the margins are
-// filled here); RCV_ERR_UNSUPPORTED for shapes it does not take (per-sample kernels).
-int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k)
+// Response (r, may be null) and / or NMS mask (m, may be null; thr: its threshold) from the Sobel planes for any block 1..7.
+// ix / iy: views of column 0 of planes laid out as above (the margins are filled here); RCV_ERR_UNSUPPORTED for shapes it does
+// not take (per-sample kernels).
+int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View* r, const View* m, int block, float k, float thr)
 {
-    if (!rcv_harris_resp_rows_ok(r, block)) return RCV_ERR_UNSUPPORTED;
+    if (!r && !m) return RCV_ERR_ARG;
+    const View& o = r ? *r : *m;
+    if (r && !rcv_harris_resp_rows_ok(*r, block, true)) return RCV_ERR_UNSUPPORTED;
+    if (m && !rcv_harris_resp_rows_ok(*m, block, false)) return RCV_ERR_UNSUPPORTED;
+    if (r && m && (r->rows != m->rows || r->cols != m->cols || r->n != m->n)) return RCV_ERR_ARG;
     if (ix.step != iy.step || ix.fstride != iy.fstride || ix.step % 16 || (uintptr_t)ix.p % 16 || (uintptr_t)iy.p % 16 || (ix.n > 1 && ix.fstride % 16)) return RCV_ERR_UNSUPPORTED;
-    if (ix.step < rcv_harris_plane_step(r.cols) || (long long)r.rows * r.n > 0x7fffffff) return RCV_ERR_UNSUPPORTED;
+    if (ix.step < rcv_harris_plane_step(o.cols) || (long long)o.rows * o.n > 0x7fffffff) return RCV_ERR_UNSUPPORTED;
     {
-        const int total = r.rows * r.n;
-        RCV_LAUNCH(k_mirror_margins, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ix.p, iy.p, ix.step, ix.fstride, r.rows, r.cols, total);
+        const int total = o.rows * o.n;
+        RCV_LAUNCH(k_mirror_margins, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ix.p, iy.p, ix.step, ix.fstride, o.rows, o.cols, total);
     }
-    const bool rag = r.cols % 8 != 0 || (uintptr_t)r.p % 16 || r.step % 16 || (r.n > 1 && r.fstride % 16);
+    const bool rag = o.cols % 8 != 0 || (r && ((uintptr_t)r->p % 16 || r->step % 16 || (r->n > 1 && r->fstride % 16))) ||
+                     (m && ((uintptr_t)m->p % 8 || m->step % 8 || (m->n > 1 && m->fstride % 8)));
     HBArgs a;
     a.ix = ix.p;
     a.iy = iy.p;
-    a.resp = r.p;
+    a.resp = r ? r->p : nullptr;
+    a.mask = m ? m->p : nullptr;
     a.pstep = ix.step;
     a.pfs = ix.fstride;
-    a.rstep = r.step;
-    a.rfs = r.fstride;
-    a.rows = r.rows;
-    a.cols = r.cols;
-    a.nstrips = (r.cols + kStripPx - 1) / kStripPx;
-    int seg = r.rows;
-    while ((long long)a.nstrips * ((r.rows + seg - 1) / seg) * r.n < 8192 && seg > 48) seg = (seg + 1) / 2;
+    a.rstep = r ? r->step : 0;
+    a.rfs = r ? r->fstride : 0;
+    a.mstep = m ? m->step : 0;
+    a.mfs = m ? m->fstride : 0;
+    a.rows = o.rows;
+    a.cols = o.cols;
+    a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
+    a.nstrips = (o.cols + kStripPx - 1) / kStripPx;
+    int seg = o.rows;
+    while ((long long)a.nstrips * ((o.rows + seg - 1) / seg) * o.n < 8192 && seg > 48) seg = (seg + 1) / 2;
     a.seg_rows = seg;
-    a.nsegs = (r.rows + seg - 1) / seg;
-    const long long waves = (long long)a.nstrips * a.nsegs * r.n;
+    a.nsegs = (o.rows + seg - 1) / seg;
+    const long long waves = (long long)a.nstrips * a.nsegs * o.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const long long nblocks = (waves + 3) / 4;

@@ -16,8 +16,9 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& src, const View* mask, const View
 // cornerHarris response for any block 1..7 from i16 Sobel planes (rcv_harris_blocks.hip)
 size_t rcv_harris_plane_step(int cols);   // row step of the i16 planes the kernel reads (8 pixels of margin left, 16 right)
 size_t rcv_harris_plane_margin();         // bytes in front of column 0
-bool rcv_harris_resp_rows_ok(const View& r, int block);
-int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View& r, int block, float k);
+bool rcv_harris_resp_rows_ok(const View& out, int block, bool is_resp);
+// r: f32 response (may be null), m: u8 NMS mask with threshold thr (may be null)
+int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View* r, const View* m, int block, float k, float thr);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
 // integer filters on the streaming f32 kernel (exact): shapes the strip kernel does not take

@@ -1236,8 +1236,8 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
     """block sizes other than 2 on any width >= 8 (multiples of 8 and ragged ones, byte-aligned rows): streaming Sobel into i16
     planes with mirrored margins + the register-window response kernel (vertical running sums in a register ring, horizontal
     sliding sums with DPP halos, row segments) -- cornerHarris from gray and the pipeline from BGR (mask, mask + response;
-    streaming NMS) -- bit for bit against the oracle; batch of 3, padded steps.  Images with fewer rows than the block stay on
-    the per-sample kernels."""
+    the 3x3 NMS inside the same kernel) -- bit for bit against the oracle; batch of 3, padded steps.  Images with fewer than
+    block + 2 rows stay on the per-sample kernels."""
     n = 3
     r = np.random.default_rng(rows * 7919 + cols * 31 + block + _SOAK_SEED)
     gray = r.integers(0, 256, size=(n, rows, cols, 1), dtype=np.uint8)
@@ -1246,7 +1246,7 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
     src.upload(gray)
     resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=32 if cols % 8 == 0 else 4)
     launched = _kernels_launched(ctx, lambda: device.corner_harris(src, resp, block, 0.04))
-    streaming = rows >= block
+    streaming = rows >= block + 2
     assert ("k_harris_resp_rows" in launched) == streaming and ("k_sobel_rows" in launched) == streaming, launched
     got = resp.download()
     for i in range(n):
@@ -1262,7 +1262,7 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
         resp2 = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
         launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, resp2, block, 0.04, thr))
         assert ("k_harris_resp_rows" in launched) == streaming, launched
-        assert "k_nms3x3_rows" in launched, launched
+        assert ("k_nms3x3" in launched) == (not streaming), launched   # the NMS runs inside the response kernel
         gm = mask.download()
         for i in range(n):
             wm, wr = oracle.harris_pipeline(bgr[i], block, 0.04, thr, True)
@@ -1275,6 +1275,25 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
             resp2.free()
     for b in (src, resp, sb):
         b.free()
+
+
+@pytest.mark.parametrize("thr", [float("nan"), float("inf"), float("-inf"), 0.0, -1e-3, 3.0e-6])
+def test_harris_pipeline_block3_threshold_edge_values(ctx, oracle, thr):
+    """the NMS inside the general-block response kernel at threshold edge values (NaN keeps nothing, -inf keeps every local
+    maximum) against the oracle"""
+    rows, cols, n = 37, 72, 2
+    r = np.random.default_rng(77 + _SOAK_SEED)
+    bgr = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    bgr[:, 10:14, 20:26] = 255
+    sb, mask = device.DeviceBatch(ctx, n, rows, cols, 3), device.DeviceBatch(ctx, n, rows, cols, 1)
+    sb.upload(bgr)
+    launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, None, 3, 0.04, thr))
+    assert "k_harris_resp_rows" in launched and "k_nms3x3" not in launched, launched
+    gm = mask.download()
+    for i in range(n):
+        assert np.array_equal(gm[i], oracle.harris_pipeline(bgr[i], 3, 0.04, thr)), (thr, i)
+    sb.free()
+    mask.free()
 
 
 @pytest.mark.parametrize("rows,cols", [(4, 8), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (7, 12)])

@@ -211,8 +211,8 @@ def main():
            note="the fused kernel without its NMS stage")
     record("cornerHarris blockSize 3 (streaming Sobel + register-window response)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5,
            lambda: device.corner_harris(gq, rq, 3, 0.04), note="two launches; the i16 planes between them add 8 B/px of traffic (13 B/px moved)")
-    record("Harris pipeline blockSize 3 (BGR->mask, three launches)", "4K batch=64/GPU", s.n, 3840 * 2160, 4,
-           lambda: device.harris_pipeline(s, m, None, 3, 0.04, 1e-4), note="Sobel of BGR + response + NMS: 24 B/px moved")
+    record("Harris pipeline blockSize 3 (BGR->mask, two launches)", "4K batch=64/GPU", s.n, 3840 * 2160, 4,
+           lambda: device.harris_pipeline(s, m, None, 3, 0.04, 1e-4), note="Sobel of BGR into i16 planes + response and NMS in one kernel: 12 B/px moved")
     record("NMS 3x3 (f32 response -> mask)", "4K batch=64/GPU", rq.n, 3840 * 2160, 5, lambda: device.nms3x3(rq, m, 1e-4))
     gq.free(); rq.free()
     s.free(); d.free(); m.free()
