@@ -316,15 +316,21 @@ __global__ __launch_bounds__(kBlock) void k_bgr2gray(const uint8_t* __restrict__
     int y = blockIdx.y;
     const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
     uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * dstep;
-    int quads = vec ? cols / 4 : 0;
+    // vec = 0: rows of any alignment (an odd width of a packed image: step = cols * 3).  A row's misalignment is the same for all
+    // of its quads, so the 12 bytes of a quad are fetched as the ALIGNED dwords that contain them and shifted into place
+    // (unaligned per-lane loads would serialise in the address path); the four gray bytes go out as one unaligned dword store.
+    const int quads = cols / 4;
+    const unsigned mis = vec ? 0u : (unsigned)((uintptr_t)s & 3);
     for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
-        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12);
-        uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
+        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12 - mis);
+        const uint32_t e0 = sp[0], e1 = sp[1], e2 = sp[2], e3 = sp[mis ? 3 : 2];   // (an aligned quad needs no fourth dword: never read past it)
+        const uint32_t d0 = __builtin_amdgcn_alignbyte(e1, e0, mis), d1 = __builtin_amdgcn_alignbyte(e2, e1, mis), d2 = __builtin_amdgcn_alignbyte(e3, e2, mis);
         uint32_t g0 = gray1(d0 & 0xff, (d0 >> 8) & 0xff, (d0 >> 16) & 0xff);
         uint32_t g1 = gray1(d0 >> 24, d1 & 0xff, (d1 >> 8) & 0xff);
         uint32_t g2 = gray1((d1 >> 16) & 0xff, d1 >> 24, d2 & 0xff);
         uint32_t g3 = gray1((d2 >> 8) & 0xff, (d2 >> 16) & 0xff, d2 >> 24);
-        *(uint32_t*)(d + (size_t)q * 4) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        typedef uint32_t u1m __attribute__((aligned(1)));
+        *(u1m*)(d + (size_t)q * 4) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
     }
     for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock)
         d[x] = (uint8_t)gray1(s[3 * x], s[3 * x + 1], s[3 * x + 2]);
