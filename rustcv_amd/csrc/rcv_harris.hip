@@ -273,6 +273,10 @@ extern "C" int rcv_corner_harris_batch(rcv_ctx* ctx, const rcv_batch* gray, rcv_
         const int rc = rcv_harris_fused(ctx, g, nullptr, &r, block, k, 0.0f);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
+    {   // any other block size on aligned shapes: one launch (gray -> Sobel -> window sums -> response)
+        const int rc = rcv_harris_blocks_fused(ctx, g, &r, nullptr, block, k, 0.0f);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
     size_t plane = (size_t)g.n * g.rows * plane_step(g.cols);   // (>= the packed layout of the per-sample kernels)
     RCV_TRY(rcv_ws_reserve(ctx, 2 * (plane + 256)));
     uint8_t *wix, *wiy;
@@ -334,6 +338,10 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
         tb.frame_stride = tfs;
         RCV_TRY(rcv_cvt_color_batch(ctx, RCV_YUYV2BGR_STRIDED, bgr, &tb));
         return rcv_harris_pipeline_batch(ctx, &tb, mask, resp, block, k, thr);
+    }
+    {   // any other block size on aligned shapes: one launch (gray conversion, Sobel, window sums, response, NMS)
+        const int rc3 = rcv_harris_blocks_fused(ctx, s, resp ? &r : nullptr, &m, block, k, thr);
+        if (rc3 != RCV_ERR_UNSUPPORTED) return rc3;
     }
     // other shapes / block sizes: Ix, Iy (and the response when the caller does not want it, and the gray image for the
     // per-sample kernels) live in the workspace

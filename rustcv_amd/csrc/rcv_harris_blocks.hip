@@ -233,6 +233,271 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
     }
 }
 
+// ---- the same window, fed straight from the image: gray conversion and Sobel in front of it ---------------------------------
+// k_harris_blocks_fused: aligned shapes (width a multiple of 8, 8-byte aligned source rows) of a BGR or a gray source run ONE
+// launch for any block size: the front end of rcv_harris_fused.hip (8 pixels per lane, gray by two v_dot4 per pixel, Sobel in
+// packed i16 with the two previous rows' horizontal parts in registers, neighbours by DPP) produces the row of Ix, Iy that
+// enters the window, so the i16 planes (8 of the 13 / 12 bytes the two-launch path moves per pixel) never exist.  Rows outside
+// the image: the gray rows are fed by REFLECTED row index, which makes the Sobel of a virtual row u the mirror image of row -u
+// (Ix equal, Iy negated: negated back here), i.e. P(u) = P(-u) -- the box filter's reflection of the product image.  Columns:
+// the lane left of the image takes Ix, Iy of columns 1..3 from its right neighbour, the lane right of it those of
+// cols-2..cols-4 from its left neighbour (first / last strip only).
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t hpk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ uint32_t hpk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b)); }
+__device__ __forceinline__ uint32_t hpk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b)); }
+__device__ __forceinline__ uint32_t hpk_add2x(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2); }
+__device__ __forceinline__ uint32_t shr1u(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }   // from lane-1
+__device__ __forceinline__ uint32_t shl1u(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }   // from lane+1
+
+struct HFBArgs {
+    const uint8_t* src;
+    uint8_t *resp, *mask;
+    size_t sstep, sfs, rstep, rfs, mstep, mfs;
+    int rows, cols, nstrips, seg_rows, nsegs, total_waves, blocks_per_xcd;
+    float s2, k, thr_up;
+};
+
+// SRCK: 0 BGR, 2 gray.  MODE: 0 response only, 1 mask only, 2 both.
+template <int B, int SRCK, int MODE>
+__global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
+{
+    constexpr int AN = B / 2, RT = B - 1 - AN;
+    constexpr bool WANT_RESP = MODE != 1, WANT_MASK = MODE != 0, GRAY = SRCK == 2;
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+    if (wid >= a.total_waves) return;
+    const int strip = wid % a.nstrips;
+    wid /= a.nstrips;
+    const int seg = wid % a.nsegs;
+    const int frame = wid / a.nsegs;
+    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    const int x = strip * kStripPx + 8 * (lane - 1);
+    const int xc = min(max(x, 0), a.cols - 8);
+    const bool edgeL = x < 0, edgeR = x == a.cols;
+    const bool edge_wave = strip == 0 || strip == a.nstrips - 1;   // wave-uniform
+    const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    const uint8_t* const sf = a.src + (size_t)frame * a.sfs + (size_t)((GRAY ? 1 : 3) * xc);
+    uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
+    uint8_t* const mf = WANT_MASK ? a.mask + (size_t)frame * a.mfs : nullptr;
+    const float NEG_INF = -INFINITY;
+
+    struct Raw { uint32_t d[GRAY ? 2 : 6]; };
+    auto load_row = [&](int v) -> Raw {   // virtual gray row -> reflected source row (host: rows >= 8, one reflection is enough)
+        v = min(max(v, -6), a.rows + 5);
+        const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
+        const uint8_t* p = sf + (size_t)r * a.sstep;
+        Raw w;
+        const u2v q0 = *(const u2v*)p;
+        w.d[0] = q0.x; w.d[1] = q0.y;
+        if constexpr (!GRAY) {
+            const u2v q1 = *(const u2v*)(p + 8), q2 = *(const u2v*)(p + 16);
+            w.d[2] = q1.x; w.d[3] = q1.y; w.d[4] = q2.x; w.d[5] = q2.y;
+        }
+        return w;
+    };
+    struct RowPix { u4v x, y; };   // Ix and Iy of the lane's 8 pixels, packed i16 pairs
+    uint32_t h1a[4], h1b[4], h2a[4], h2b[4];   // Sobel horizontal parts of gray rows v-2, v-1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
+    // gray row v in, gradient row u = v-1 out (valid from the third row fed)
+    auto feed = [&](const Raw& q, int v) -> RowPix {
+        uint32_t lo, hi;
+        if constexpr (GRAY) {
+            lo = q.d[0];
+            hi = q.d[1];
+        } else {
+            auto gray_of = [](uint32_t px) -> uint32_t {   // (B,G,R,x) dword -> gray, bit-identical to RCV_BGR2GRAY
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);
+                return ((hi8 << 8) + lo8) >> 14;
+            };
+            uint32_t g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;
+                g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
+            }
+            lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+            hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+        }
+        if (edgeL) hi = hpk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
+        if (edgeR) lo = hpk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+        const uint32_t lf = shr1u(hi), rt = shl1u(lo);
+        uint32_t L[5], Cc[4];
+        L[0] = hpk(lf, lo, 0x0c000c07u);
+        L[1] = hpk(lo, lo, 0x0c020c01u);
+        L[2] = hpk(hi, lo, 0x0c040c03u);
+        L[3] = hpk(hi, hi, 0x0c020c01u);
+        L[4] = hpk(rt, hi, 0x0c040c03u);
+        Cc[0] = hpk(lo, lo, 0x0c010c00u);
+        Cc[1] = hpk(lo, lo, 0x0c030c02u);
+        Cc[2] = hpk(hi, hi, 0x0c010c00u);
+        Cc[3] = hpk(hi, hi, 0x0c030c02u);
+        const int u = v - 1;
+        const bool mirrored = u < 0 || u >= a.rows;   // scalar: the window of a virtual row is the mirror image of row -u: dy changes sign
+        uint32_t ox[4], oy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t h1 = hpk_sub(L[j + 1], L[j]);
+            const uint32_t h2 = hpk_add2x(hpk_add(L[j], L[j + 1]), Cc[j]);
+            ox[j] = hpk_add2x(hpk_add(h1a[j], h1), h1b[j]);
+            oy[j] = hpk_sub(h2, h2a[j]);
+            h1a[j] = h1b[j];
+            h1b[j] = h1;
+            h2a[j] = h2b[j];
+            h2b[j] = h2;
+        }
+        if (mirrored) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oy[j] = hpk_sub(0u, oy[j]);
+        }
+        if (edge_wave) {
+            // P(-j) = P(j), P(cols-1+j) = P(cols-1-j): the gradients of the mirrored columns from the neighbouring lane
+            const uint32_t tx0 = shl1u(ox[0]), tx1 = shl1u(ox[1]), ty0 = shl1u(oy[0]), ty1 = shl1u(oy[1]);   // lane+1: columns 0..3
+            const uint32_t sx2 = shr1u(ox[2]), sx3 = shr1u(ox[3]), sy2 = shr1u(oy[2]), sy3 = shr1u(oy[3]);   // lane-1: its columns 4..7
+            if (edgeL) {   // logical columns -3, -2, -1 (pixels 5, 6, 7 of this lane) := 3, 2, 1
+                ox[2] = tx1;
+                ox[3] = hpk(tx0, tx1, 0x07060100u);
+                oy[2] = ty1;
+                oy[3] = hpk(ty0, ty1, 0x07060100u);
+            }
+            if (edgeR) {   // logical columns cols, cols+1, cols+2 (pixels 0, 1, 2) := cols-2, cols-3, cols-4
+                ox[0] = hpk(sx2, sx3, 0x07060100u);
+                ox[1] = sx2;
+                oy[0] = hpk(sy2, sy3, 0x07060100u);
+                oy[1] = sy2;
+            }
+        }
+        return RowPix{u4v{ox[0], ox[1], ox[2], ox[3]}, u4v{oy[0], oy[1], oy[2], oy[3]}};
+    };
+
+    int vxx[8], vxy[8], vyy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vxx[j] = vxy[j] = vyy[j] = 0;
+    auto accumulate = [&](const RowPix& w, bool leave) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int gx0 = (int)(short)(w.x[d] & 0xffff), gx1 = (int)w.x[d] >> 16, gy0 = (int)(short)(w.y[d] & 0xffff), gy1 = (int)w.y[d] >> 16;
+            const int nx0 = leave ? -gx0 : gx0, nx1 = leave ? -gx1 : gx1, ny0 = leave ? -gy0 : gy0, ny1 = leave ? -gy1 : gy1;
+            vxx[2 * d] = mad24(nx0, gx0, vxx[2 * d]);
+            vxy[2 * d] = mad24(nx0, gy0, vxy[2 * d]);
+            vyy[2 * d] = mad24(ny0, gy0, vyy[2 * d]);
+            vxx[2 * d + 1] = mad24(nx1, gx1, vxx[2 * d + 1]);
+            vxy[2 * d + 1] = mad24(nx1, gy1, vxy[2 * d + 1]);
+            vyy[2 * d + 1] = mad24(ny1, gy1, vyy[2 * d + 1]);
+        }
+    };
+    auto hsum = [&](const int (&v)[8], int (&h)[8]) {
+        int e[8 + AN + RT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[AN + j] = v[j];
+#pragma unroll
+        for (int j = 1; j <= AN; ++j) e[AN - j] = shr1i(v[8 - j]);
+#pragma unroll
+        for (int j = 1; j <= RT; ++j) e[AN + 7 + j] = shl1i(v[j - 1]);
+        int s = e[0];
+#pragma unroll
+        for (int i = 1; i < B; ++i) s += e[i];
+        h[0] = s;
+#pragma unroll
+        for (int xx = 1; xx < 8; ++xx) {
+            s += e[xx + B - 1] - e[xx - 1];
+            h[xx] = s;
+        }
+    };
+    float m3a[8], m3b[8], rc[8], mlr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m3a[j] = m3b[j] = rc[j] = mlr[j] = NEG_INF;
+
+    const int yf = WANT_MASK ? ys - 1 : ys, yl = WANT_MASK ? ye : ye - 1;
+    // gradient rows come out of `advance` in order, starting two rows early (the Sobel state has to fill): the third one is row
+    // yf-AN, the first row of the window; two source rows are kept in flight
+    int vn = yf - AN - 1;
+    Raw r0 = load_row(vn), r1 = load_row(vn + 1);
+    auto advance = [&]() -> RowPix {
+        const Raw cur = r0;
+        r0 = r1;
+        r1 = load_row(vn + 2);
+        const RowPix g = feed(cur, vn);
+        ++vn;
+        return g;
+    };
+    (void)advance();
+    (void)advance();
+    RowPix ring[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+        ring[i] = advance();
+        accumulate(ring[i], false);
+    }
+    RowPix ent = advance();   // row yf+RT+1
+    for (int y0 = yf; y0 <= yl; y0 += B) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int y = y0 + i;
+            if (y > yl) break;
+            int hxx[8], hxy[8], hyy[8];
+            hsum(vxx, hxx);
+            hsum(vxy, hxy);
+            hsum(vyy, hyy);
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2 fa = f2{(float)hxx[j], (float)hxx[j + 4]} * a.s2, fb = f2{(float)hxy[j], (float)hxy[j + 4]} * a.s2, fc = f2{(float)hyy[j], (float)hyy[j + 4]} * a.s2;
+                const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
+                const f2 t4 = a.k * t3;
+                const f2 t5 = t4 * t3;
+                const f2 rr = (t1 - t2) - t5;
+                r[j] = rr.x;
+                r[j + 4] = rr.y;
+            }
+            if (WANT_RESP && live && y >= ys && y < ye) {
+                uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
+                __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
+                __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+            }
+            if constexpr (WANT_MASK) {
+                const bool rowout = y < 0 || y >= a.rows;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (rowout || x < 0 || x >= a.cols) ? NEG_INF : r[j];   // (cols % 8 == 0: whole lanes)
+                const float rl = shr1f(r[7]), rr = shl1f(r[0]);
+                uint32_t mbits[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float left = j ? r[j - 1] : rl, right = j < 7 ? r[j + 1] : rr;
+                    const float lrmax = fmaxf(fmaxf(left, right), a.thr_up);
+                    const float m3 = fmaxf(lrmax, r[j]);
+                    const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);
+                    const bool keep = rc[j] >= m8;
+                    mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                    m3a[j] = m3b[j];
+                    m3b[j] = m3;
+                    rc[j] = r[j];
+                    mlr[j] = lrmax;
+                }
+                const int w = y - 1;
+                if (live && w >= ys && w < ye) *(u2v*)(mf + (size_t)w * a.mstep + (size_t)x) = u2v{mbits[0], mbits[1]};
+            }
+            accumulate(ring[i], true);
+            ring[i] = ent;
+            accumulate(ring[i], false);
+            ent = advance();
+        }
+    }
+}
+
+template <int B, int SRCK>
+void launch_fused(const HFBArgs& a, dim3 grid, hipStream_t st)
+{
+    const int mode = a.mask ? (a.resp ? 2 : 1) : 0;
+    if (mode == 0) RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 0>), grid, dim3(256), 0, st, a);
+    else if (mode == 1) RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 1>), grid, dim3(256), 0, st, a);
+    else RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 2>), grid, dim3(256), 0, st, a);
+}
+
 template <int B>
 void launch_resp(const HBArgs& a, dim3 grid, bool rag, hipStream_t st)
 {
@@ -318,5 +583,59 @@ int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const Vie
     case 6: launch_resp<6>(a, grid, rag, ctx->stream); break;
     default: launch_resp<7>(a, grid, rag, ctx->stream); break;
     }
+    return rcv_launch_check(ctx);
+}
+
+// One launch for any block size on aligned shapes: BGR or gray source with 8-byte aligned rows, width a multiple of 8, >= 16
+// columns, at least max(block + 4, 8) rows; 16-byte aligned response rows, 8-byte aligned mask rows.  r and / or m (either may
+// be null).  RCV_ERR_UNSUPPORTED otherwise (the two-launch path through i16 planes takes ragged shapes).
+int rcv_harris_blocks_fused(rcv_ctx* ctx, const View& s, const View* r, const View* m, int block, float k, float thr)
+{
+    if (block < 1 || block > 7 || (!r && !m)) return RCV_ERR_UNSUPPORTED;
+    if (s.ch != 1 && s.ch != 3) return RCV_ERR_UNSUPPORTED;
+    if (s.cols % 8 != 0 || s.cols < 16 || s.rows < block + 4 || s.rows < 8) return RCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8)) return RCV_ERR_UNSUPPORTED;
+    if (r && ((uintptr_t)r->p % 16 || r->step % 16 || (r->n > 1 && r->fstride % 16))) return RCV_ERR_UNSUPPORTED;
+    if (m && ((uintptr_t)m->p % 8 || m->step % 8 || (m->n > 1 && m->fstride % 8))) return RCV_ERR_UNSUPPORTED;
+    HFBArgs a;
+    a.src = s.p;
+    a.resp = r ? r->p : nullptr;
+    a.mask = m ? m->p : nullptr;
+    a.sstep = s.step;
+    a.sfs = s.fstride;
+    a.rstep = r ? r->step : 0;
+    a.rfs = r ? r->fstride : 0;
+    a.mstep = m ? m->step : 0;
+    a.mfs = m ? m->fstride : 0;
+    a.rows = s.rows;
+    a.cols = s.cols;
+    a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
+    int seg = s.rows;
+    while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 8192 && seg > 96) seg = (seg + 1) / 2;
+    a.seg_rows = seg;
+    a.nsegs = (s.rows + seg - 1) / seg;
+    const long long waves = (long long)a.nstrips * a.nsegs * s.n;
+    if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
+    a.total_waves = (int)waves;
+    const long long nblocks = (waves + 3) / 4;
+    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
+    const double sc = 1.0 / (4.0 * (double)block * 255.0);
+    a.s2 = (float)(sc * sc);
+    a.k = k;
+    a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
+#define RCV_HB_CASE(BB)                                                         \
+    case BB:                                                                    \
+        if (s.ch == 1) launch_fused<BB, 2>(a, grid, ctx->stream);               \
+        else launch_fused<BB, 0>(a, grid, ctx->stream);                         \
+        break;
+    switch (block) {
+        RCV_HB_CASE(1) RCV_HB_CASE(2) RCV_HB_CASE(3) RCV_HB_CASE(4) RCV_HB_CASE(5) RCV_HB_CASE(6)
+    default:
+        if (s.ch == 1) launch_fused<7, 2>(a, grid, ctx->stream);
+        else launch_fused<7, 0>(a, grid, ctx->stream);
+        break;
+    }
+#undef RCV_HB_CASE
     return rcv_launch_check(ctx);
 }

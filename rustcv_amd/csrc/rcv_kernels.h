@@ -19,6 +19,8 @@ size_t rcv_harris_plane_margin();         // bytes in front of column 0
 bool rcv_harris_resp_rows_ok(const View& out, int block, bool is_resp);
 // r: f32 response (may be null), m: u8 NMS mask with threshold thr (may be null)
 int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const View* r, const View* m, int block, float k, float thr);
+// the same with gray conversion and Sobel in front of the window: one launch, aligned shapes, BGR or gray source
+int rcv_harris_blocks_fused(rcv_ctx* ctx, const View& s, const View* r, const View* m, int block, float k, float thr);
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta);
 int rcv_gauss_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize);
 // integer filters on the streaming f32 kernel (exact): shapes the strip kernel does not take

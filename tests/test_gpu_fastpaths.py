@@ -109,8 +109,9 @@ def test_fast_kernels_are_dispatched(ctx):
     ]
     # block sizes other than 2: streaming Sobel + the register-window response kernel + streaming NMS
     cases += [
-        ("cornerHarris blockSize 3 (gray)", lambda: device.corner_harris(gray, resp, 3, 0.04), "k_harris_resp_rows<"),
-        ("Harris pipeline blockSize 5 (BGR)", lambda: device.harris_pipeline(bgr, mask, None, 5, 0.04, 1e-4), "k_harris_resp_rows<"),
+        ("cornerHarris blockSize 3 (gray): one launch", lambda: device.corner_harris(gray, resp, 3, 0.04), "k_harris_blocks_fused<"),
+        ("Harris pipeline blockSize 5 (BGR): one launch", lambda: device.harris_pipeline(bgr, mask, None, 5, 0.04, 1e-4), "k_harris_blocks_fused<"),
+        ("Harris pipeline blockSize 3, packed 1919-wide BGR: Sobel planes + window kernel", lambda: device.harris_pipeline(ow, om, None, 3, 0.04, 1e-4), "k_harris_resp_rows<"),
     ]
     wrong = []
     for name, fn, want in cases:

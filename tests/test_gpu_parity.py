@@ -1233,8 +1233,9 @@ def test_corner_harris(ctx, oracle, rng, rows, cols, block):
 @pytest.mark.parametrize("rows,cols", [(7, 16), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (8, 24), (45, 497), (64, 1919), (23, 9), (31, 503)])
 @pytest.mark.parametrize("block", [1, 3, 4, 5, 6, 7])
 def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, block):
-    """block sizes other than 2 on any width >= 8 (multiples of 8 and ragged ones, byte-aligned rows): streaming Sobel into i16
-    planes with mirrored margins + the register-window response kernel (vertical running sums in a register ring, horizontal
+    """block sizes other than 2 on any width >= 8: aligned shapes run the one-launch kernel (gray conversion and Sobel in front of
+    the window, gradients of the mirrored columns from the neighbouring lanes), ragged ones (byte-aligned rows) streaming Sobel
+    into i16 planes with mirrored margins + the register-window response kernel (vertical running sums in a register ring, horizontal
     sliding sums with DPP halos, row segments) -- cornerHarris from gray and the pipeline from BGR (mask, mask + response;
     the 3x3 NMS inside the same kernel) -- bit for bit against the oracle; batch of 3, padded steps.  Images with fewer than
     block + 2 rows stay on the per-sample kernels."""
@@ -1246,7 +1247,10 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
     src.upload(gray)
     resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=32 if cols % 8 == 0 else 4)
     launched = _kernels_launched(ctx, lambda: device.corner_harris(src, resp, block, 0.04))
-    streaming = rows >= block + 2
+    # aligned shapes: ONE launch (gray -> Sobel -> window sums -> response [-> NMS]); ragged ones: Sobel into planes + the window kernel
+    fused = cols % 8 == 0 and cols >= 16 and rows >= max(block + 4, 8)
+    streaming = not fused and rows >= block + 2
+    assert ("k_harris_blocks_fused" in launched) == fused, launched
     assert ("k_harris_resp_rows" in launched) == streaming and ("k_sobel_rows" in launched) == streaming, launched
     got = resp.download()
     for i in range(n):
@@ -1261,8 +1265,8 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
         mask = _canary_batch(ctx, n, rows, cols, 1, pad=8)
         resp2 = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
         launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, resp2, block, 0.04, thr))
-        assert ("k_harris_resp_rows" in launched) == streaming, launched
-        assert ("k_nms3x3" in launched) == (not streaming), launched   # the NMS runs inside the response kernel
+        assert ("k_harris_blocks_fused" in launched) == fused and ("k_harris_resp_rows" in launched) == streaming, launched
+        assert ("k_nms3x3" in launched) == (not streaming and not fused), launched   # the NMS runs inside the window kernels
         gm = mask.download()
         for i in range(n):
             wm, wr = oracle.harris_pipeline(bgr[i], block, 0.04, thr, True)
@@ -1288,11 +1292,20 @@ def test_harris_pipeline_block3_threshold_edge_values(ctx, oracle, thr):
     sb, mask = device.DeviceBatch(ctx, n, rows, cols, 3), device.DeviceBatch(ctx, n, rows, cols, 1)
     sb.upload(bgr)
     launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, None, 3, 0.04, thr))
-    assert "k_harris_resp_rows" in launched and "k_nms3x3" not in launched, launched
+    assert "k_harris_blocks_fused" in launched and "k_nms3x3" not in launched, launched
     gm = mask.download()
     for i in range(n):
         assert np.array_equal(gm[i], oracle.harris_pipeline(bgr[i], 3, 0.04, thr)), (thr, i)
+    # the same through the two-launch path (a source whose rows are only byte-aligned)
+    sb2 = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 1)
+    sb2.upload(bgr)
+    launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb2, mask, None, 3, 0.04, thr))
+    assert "k_harris_resp_rows" in launched and "k_nms3x3" not in launched, launched
+    gm = mask.download()
+    for i in range(n):
+        assert np.array_equal(gm[i], oracle.harris_pipeline(bgr[i], 3, 0.04, thr)), (thr, "planes", i)
     sb.free()
+    sb2.free()
     mask.free()
 
 
@@ -1476,6 +1489,12 @@ def test_baseline_configs_at_full_size(ctx, oracle):
     wm, wr = oracle.harris_pipeline(frame, 2, 0.04, 1e-4, True)
     assert np.array_equal(r.download()[0].view(np.uint32), wr.view(np.uint32))
     assert np.array_equal(m.download()[0], wm) and wm.any()
+    # the same frame at blockSize 3 and 5 (the general-block one-launch kernel: all strips, segment seams, both image edges)
+    for block in (3, 5):
+        device.harris_pipeline(s, m, r, block, 0.04, 1e-4)
+        wm, wr = oracle.harris_pipeline(frame, block, 0.04, 1e-4, True)
+        assert np.array_equal(r.download()[0].view(np.uint32), wr.view(np.uint32)), block
+        assert np.array_equal(m.download()[0], wm) and wm.any(), block
     for x in (s, g, dx, dy, m, r):
         x.free()
 

@@ -209,10 +209,10 @@ def main():
     rq = B(64, 2160, 3840, 1, _ffi.RCV_32F)
     record("cornerHarris (gray -> f32 response)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5, lambda: device.corner_harris(gq, rq, 2, 0.04),
            note="the fused kernel without its NMS stage")
-    record("cornerHarris blockSize 3 (streaming Sobel + register-window response)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5,
-           lambda: device.corner_harris(gq, rq, 3, 0.04), note="two launches; the i16 planes between them add 8 B/px of traffic (13 B/px moved)")
-    record("Harris pipeline blockSize 3 (BGR->mask, two launches)", "4K batch=64/GPU", s.n, 3840 * 2160, 4,
-           lambda: device.harris_pipeline(s, m, None, 3, 0.04, 1e-4), note="Sobel of BGR into i16 planes + response and NMS in one kernel: 12 B/px moved")
+    record("cornerHarris blockSize 3 (one launch, general-block window kernel)", "4K batch=64/GPU", gq.n, 3840 * 2160, 5,
+           lambda: device.corner_harris(gq, rq, 3, 0.04))
+    record("Harris pipeline blockSize 3 (BGR->mask, one launch)", "4K batch=64/GPU", s.n, 3840 * 2160, 4,
+           lambda: device.harris_pipeline(s, m, None, 3, 0.04, 1e-4))
     record("NMS 3x3 (f32 response -> mask)", "4K batch=64/GPU", rq.n, 3840 * 2160, 5, lambda: device.nms3x3(rq, m, 1e-4))
     gq.free(); rq.free()
     s.free(); d.free(); m.free()
