@@ -191,13 +191,17 @@ __global__ __launch_bounds__(kBlock) void k_bgr2rgb_rows(const uint8_t* __restri
     const int y = blockIdx.y;
     const uint8_t* s = src + (size_t)blockIdx.z * sfs + (size_t)y * sstep;
     uint8_t* d = dst + (size_t)blockIdx.z * dfs + (size_t)y * cols * 3;
-    const int quads = vec ? cols / 4 : 0;
+    // vec = 0: rows of any alignment: the quad's 12 source bytes as the aligned dwords that contain them + v_alignbyte (the row's
+    // misalignment is the same for all its quads), the result as one unaligned 12-byte store
+    const int quads = cols / 4;
+    const unsigned mis = vec ? 0u : (unsigned)((uintptr_t)s & 3);
     for (int q = blockIdx.x * kBlock + threadIdx.x; q < quads; q += gridDim.x * kBlock) {
-        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12);
+        const uint32_t* sp = (const uint32_t*)(s + (size_t)q * 12 - mis);
+        const uint32_t e0 = sp[0], e1 = sp[1], e2 = sp[2], e3 = sp[mis ? 3 : 2];
         uint32_t w[3];
-        swap_rb4(sp[0], sp[1], sp[2], w);
-        struct U3 { uint32_t a, b, c; };
-        *(U3*)(d + (size_t)q * 12) = U3{w[0], w[1], w[2]};
+        swap_rb4(__builtin_amdgcn_alignbyte(e1, e0, mis), __builtin_amdgcn_alignbyte(e2, e1, mis), __builtin_amdgcn_alignbyte(e3, e2, mis), w);
+        typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+        *(u3m*)(d + (size_t)q * 12) = u3m{w[0], w[1], w[2]};
     }
     for (int x = quads * 4 + blockIdx.x * kBlock + threadIdx.x; x < cols; x += gridDim.x * kBlock) {
         d[3 * x] = s[3 * x + 2];
