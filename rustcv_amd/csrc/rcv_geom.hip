@@ -412,8 +412,10 @@ __device__ __forceinline__ void warp_bgr_wave(const View& s, const View& d, cons
                     asm("" : "+v"(o));
                     // 4 x {b g r 0} -> 12 bytes with three byte permutes
                     const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
-                    if (ragd) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
-                    else *(gU3*)(dfr + o) = val;
+                    typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+                    typedef __attribute__((address_space(1))) u3m gU3m;
+                    if (ragd && d.cols - xq < 4) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
+                    else *(gU3m*)(dfr + o) = val;
                 }
             };
             load_half(0, f0);
@@ -542,6 +544,9 @@ __device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint
     return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
 }
 
+// RAGS: source rows of any alignment (an odd width of a packed image): a chunk's 12 bytes are fetched as the 16 aligned bytes
+// that contain them and shifted into place with v_alignbyte when they are written to LDS.
+template <bool RAGS>
 __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
                                                                 int tiles_per_xcd)
 {
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     // every tap of the tile inside the source, one more row of slack below (the last 12-byte chunk of a patch row may read past
     // the row's end into the next row), 32-bit in-frame offsets, 4-byte aligned rows in every frame
     bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
-              ((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0 && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+              (RAGS || (((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0)) && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
               (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
     int ix0 = 0, iy0 = 0;
     if (ok) {
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq;
     // ---- staging plan: chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ... ----
     const int nchunks = prow * cpr;             // <= kWlMaxG * 256 (host)
-    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - 12u;
+    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - (RAGS ? 16u : 12u);
     unsigned goff[kWlMaxG], loff[kWlMaxG];
     bool gval[kWlMaxG];
 #pragma unroll
@@ -625,16 +630,26 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     typedef uint32_t u3v __attribute__((ext_vector_type(3)));
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) u3v gU3;
-    u3v G[kWlMaxG];
+    typedef __attribute__((address_space(1))) u4v gU4;
+    u4v G[kWlMaxG];          // (RAGS: 16 aligned bytes; else 12 bytes in .xyz)
+    unsigned gmis[kWlMaxG];  // RAGS: byte position of the chunk inside them
     auto gload = [&](int f) {
-        cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
+        const uint8_t* fb = s.p + (size_t)f * s.fstride;
+        const unsigned fmis = RAGS ? (unsigned)((uintptr_t)fb & 3) : 0u;   // the frame base, aligned down: offsets stay non-negative
+        cgp sf = (cgp)(fb - fmis);
         asm("" : "+s"(sf));
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (g < ng) {   // uniform
-                unsigned o = goff[g];
+                unsigned o = goff[g] + fmis;
                 asm("" : "+v"(o));
-                G[g] = *(const gU3*)(sf + o);
+                if constexpr (RAGS) {
+                    gmis[g] = o & 3u;
+                    G[g] = *(const gU4*)(sf + (o & ~3u));
+                } else {
+                    const u3v t = *(const gU3*)(sf + o);
+                    G[g] = u4v{t.x, t.y, t.z, 0u};
+                }
             }
     };
     const unsigned bufbytes = (unsigned)(pitch * prow);
@@ -643,8 +658,15 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
         uint8_t* buf = wl_lds + ((f - f0) & 1) * bufbytes;
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
-            if (gval[g])   // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
-                *(u4v*)(buf + loff[g]) = u4v{G[g].x, __builtin_amdgcn_alignbyte(G[g].y, G[g].x, 3), __builtin_amdgcn_alignbyte(G[g].z, G[g].y, 2), G[g].z >> 8};
+            if (gval[g]) {   // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
+                uint32_t c0 = G[g].x, c1 = G[g].y, c2 = G[g].z;
+                if constexpr (RAGS) {
+                    c0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]);
+                    c1 = __builtin_amdgcn_alignbyte(G[g].z, G[g].y, gmis[g]);
+                    c2 = __builtin_amdgcn_alignbyte(G[g].w, G[g].z, gmis[g]);
+                }
+                *(u4v*)(buf + loff[g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
+            }
         __syncthreads();
         if (f + 1 < f1) gload(f + 1);
         gp dfr = (gp)(d.p + (size_t)f * d.fstride);
@@ -667,8 +689,12 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
                 unsigned o = so[h];
                 asm("" : "+v"(o));
                 const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
-                if (ragd) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
-                else *(gU3*)(dfr + o) = val;
+                // (one store instruction for aligned and for byte-aligned rows -- the hardware takes either; only the row's last,
+                //  partial quad of a width that is not a multiple of 4 goes out byte by byte)
+                typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+                typedef __attribute__((address_space(1))) u3m gU3m;
+                if (ragd && d.cols - xq < 4) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
+                else *(gU3m*)(dfr + o) = val;
             }
         }
     }
@@ -1075,11 +1101,14 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
             const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
             const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;
+            const bool rags = (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4);   // byte-aligned source rows
             if (rcv_knobs().xcd_order != 0 && tiles < (1ull << 30)) {
                 const int tpx = (int)((tiles + 7) / 8);
-                RCV_LAUNCH(k_warp_affine_bgr_lds, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+                if (rags) RCV_LAUNCH(k_warp_affine_bgr_lds<true>, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+                else RCV_LAUNCH(k_warp_affine_bgr_lds<false>, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
             } else {
-                RCV_LAUNCH(k_warp_affine_bgr_lds, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
+                if (rags) RCV_LAUNCH(k_warp_affine_bgr_lds<true>, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
+                else RCV_LAUNCH(k_warp_affine_bgr_lds<false>, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
             }
             return rcv_launch_check(ctx);
         }
