@@ -782,33 +782,48 @@ __global__ __launch_bounds__(kBlock) void k_resize_bgr(View s, View d, float scx
     const int x0 = (int)x0f;
     const float fx = sx - x0f;
     struct U3 { uint32_t a, b, c; };
-    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-                       (unsigned long long)s.rows * s.step < (1ull << 32);
+    const bool small = s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    // Source rows of any alignment (an odd width of a packed image): the tap window is the 12 ALIGNED bytes that contain the 6 tap
+    // bytes; where they start depends on the row's own misalignment (a scalar per row) and the column's.  The frame base is
+    // aligned down so that offsets stay non-negative.
+    const unsigned fmis = (unsigned)((uintptr_t)sf & 3);
+    const uint8_t* sfa = sf - fmis;
     if (small && __all(x0 <= s.cols - 4)) {
         U3 ta[kRszRows], tb[kRszRows];
         float fy[kRszRows];
-        const unsigned xo = 3u * (unsigned)x0, sh = xo & 3u, xa = xo & ~3u;
+        unsigned sha[kRszRows], shb[kRszRows];
+        const unsigned xo = 3u * (unsigned)x0 + fmis;
 #pragma unroll
         for (int r = 0; r < kRszRows; ++r) {
             int y0, y1;
             resize_row(s, scy, min(ybase + r, d.rows - 1), y0, y1, fy[r]);
-            ta[r] = *(const U3*)(sf + (__umul24((unsigned)y0, (unsigned)s.step) + xa));
-            tb[r] = *(const U3*)(sf + (__umul24((unsigned)y1, (unsigned)s.step) + xa));
+            const unsigned oa = __umul24((unsigned)y0, (unsigned)s.step) + xo, ob = __umul24((unsigned)y1, (unsigned)s.step) + xo;
+            sha[r] = oa & 3u;
+            shb[r] = ob & 3u;
+            ta[r] = *(const U3*)(sfa + (oa & ~3u));
+            tb[r] = *(const U3*)(sfa + (ob & ~3u));
         }
         uint32_t px[kRszRows];
 #pragma unroll
         for (int r = 0; r < kRszRows; ++r) {
-            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sh);
-            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, sh);
+            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sha[r]), ahi = __builtin_amdgcn_alignbyte(ta[r].c, ta[r].b, sha[r]);
+            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, shb[r]), bhi = __builtin_amdgcn_alignbyte(tb[r].c, tb[r].b, shb[r]);
             px[r] = bilerp_bgr<true>(alo, ahi, blo, bhi, f2{fx, fy[r]});
         }
         // quad transpose: lane 4q+i stores pixels 4q..4q+3 of row ybase+i -- one full-wave store for the four rows
         static_assert(kRszRows == 4, "one quad transpose per thread");
         const int lane = threadIdx.x & 63, xs = x & ~3, yi = ybase + (lane & 3);
         quad_transpose4(px, lane);
-        if (xs < d.cols && yi < d.rows)
-            *(U3*)(dfr + (size_t)yi * d.step + (size_t)xs * 3) =
-                U3{__builtin_amdgcn_perm(px[1], px[0], 0x04020100u), __builtin_amdgcn_perm(px[2], px[1], 0x05040201u), __builtin_amdgcn_perm(px[3], px[2], 0x06050402u)};
+        if (xs < d.cols && yi < d.rows) {
+            // (one store instruction for aligned and byte-aligned destination rows; the row's last quad of a width that is not a
+            //  multiple of 4 goes out byte by byte)
+            typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+            const uint32_t va = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u), vb = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u),
+                           vc = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
+            uint8_t* q = dfr + (size_t)yi * d.step + (size_t)xs * 3;
+            if (d.cols - xs < 4) store_quad_ragged(q, va, vb, vc, d.cols - xs);
+            else *(u3m*)q = u3m{va, vb, vc};
+        }
         return;
     }
 #pragma unroll 1
@@ -1001,8 +1016,7 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
         }
     }
     float scx = (float)s.cols / (float)d.cols, scy = (float)s.rows / (float)d.rows;
-    if (s.ch == 3 && s.cols >= 4 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 &&
-        d.rows <= 65535 * kRszRows) {
+    if (s.ch == 3 && s.cols >= 4 && d.rows <= 65535 * kRszRows) {   // (any width / alignment of source and destination)
         RCV_LAUNCH(k_resize_bgr, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);

@@ -107,6 +107,13 @@ def test_fast_kernels_are_dispatched(ctx):
         ("Sobel, packed 1919-wide gray", lambda: device.sobel(og, odx, ody), "k_sobel_rows<0, false, true>"),
         ("Harris pipeline, packed 1919-wide BGR", lambda: device.harris_pipeline(ow, om, None, 2, 0.04, 1e-4), "k_harris_fused<false, 0, true, true>"),
     ]
+    oddsz = device.DeviceBatch(ctx, n, 1441, 2561, 3)
+    cases += [
+        ("resize BGR 4K -> 2561x1441 (odd destination width)", lambda: device.resize(bgr, oddsz), "k_resize_bgr"),
+        ("resize packed 1919-wide BGR -> 960x540", lambda: device.resize(ow, small), "k_resize_bgr"),
+        ("warpAffine between packed 1919-wide BGR images (byte-aligned rows)", lambda: device.warp_affine(ow, ow2, M), "k_warp_affine_bgr_lds<true>"),
+        ("cvtColor BGR2GRAY, packed 1919-wide", lambda: device.cvt_color(ow, og2, _ffi.RCV_BGR2GRAY), "k_bgr2gray"),
+    ]
     # block sizes other than 2: streaming Sobel + the register-window response kernel + streaming NMS
     cases += [
         ("cornerHarris blockSize 3 (gray): one launch", lambda: device.corner_harris(gray, resp, 3, 0.04), "k_harris_blocks_fused<"),
@@ -120,7 +127,7 @@ def test_fast_kernels_are_dispatched(ctx):
         print(f"{name:72s} {ms:7.3f} ms   {launched}")
         if want not in launched or "generic" in launched:
             wrong.append((name, want, launched))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om, pg, pg2):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om, pg, pg2, oddsz):
         b.free()
     assert not wrong, wrong
 
