@@ -853,24 +853,30 @@ __global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float sc
     const float x0f = floorf(sx);
     const int x0 = (int)x0f;
     const float fx = sx - x0f;
-    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-                       (unsigned long long)s.rows * s.step < (1ull << 32);
-    if (small && __all(x0 <= s.cols - 8)) {   // the aligned 8-byte window [x0 & ~3, +8) ends inside the row
+    const bool small = s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    // (source rows of any alignment: the tap window is the 8 ALIGNED bytes that contain the tap pair, as in k_resize_bgr)
+    const unsigned fmis = (unsigned)((uintptr_t)sf & 3);
+    const uint8_t* sfa = sf - fmis;
+    if (small && __all(x0 <= s.cols - 8)) {   // the aligned 8-byte window ends inside the row
         struct U2 { uint32_t a, b; };
         U2 ta[kRszRows], tb[kRszRows];
         float fy[kRszRows];
-        const unsigned sh = (unsigned)x0 & 3u, xa = (unsigned)x0 & ~3u;
+        unsigned sha[kRszRows], shb[kRszRows];
+        const unsigned xo = (unsigned)x0 + fmis;
 #pragma unroll
         for (int r = 0; r < kRszRows; ++r) {
             int y0, y1;
             resize_row(s, scy, min(ybase + r, d.rows - 1), y0, y1, fy[r]);
-            ta[r] = *(const U2*)(sf + (__umul24((unsigned)y0, (unsigned)s.step) + xa));
-            tb[r] = *(const U2*)(sf + (__umul24((unsigned)y1, (unsigned)s.step) + xa));
+            const unsigned oa = __umul24((unsigned)y0, (unsigned)s.step) + xo, ob = __umul24((unsigned)y1, (unsigned)s.step) + xo;
+            sha[r] = oa & 3u;
+            shb[r] = ob & 3u;
+            ta[r] = *(const U2*)(sfa + (oa & ~3u));
+            tb[r] = *(const U2*)(sfa + (ob & ~3u));
         }
         uint32_t px[kRszRows];
 #pragma unroll
         for (int r = 0; r < kRszRows; ++r) {
-            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh);
+            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sha[r]), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, shb[r]);
             const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
             const f2 tb2 = pk_fma_bc<0>(f2{fx, fy[r]}, p1 - p0, p0);          // {top, bottom}: fma(fx, p01 - p00, p00)
             px[r] = (uint32_t)(int)floorf(fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f);   // an integer in [0, 255]
@@ -878,7 +884,14 @@ __global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float sc
         static_assert(kRszRows == 4, "one quad transpose per thread");
         const int lane = threadIdx.x & 63, xs = x & ~3, yi = ybase + (lane & 3);
         quad_transpose4(px, lane);
-        if (xs < d.cols && yi < d.rows) *(uint32_t*)(dfr + (size_t)yi * d.step + xs) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        if (xs < d.cols && yi < d.rows) {   // any destination alignment; the row's last quad of a ragged width byte by byte
+            typedef uint32_t u1m __attribute__((aligned(1)));
+            uint8_t* q = dfr + (size_t)yi * d.step + xs;
+            const uint32_t v = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            if (d.cols - xs >= 4) *(u1m*)q = v;
+            else
+                for (int j = 0; j < d.cols - xs; ++j) q[j] = (uint8_t)(v >> (8 * j));
+        }
         return;
     }
 #pragma unroll 1
@@ -1021,7 +1034,7 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);
     }
-    if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0 && d.rows <= 65535 * kRszRows) {
+    if (s.ch == 1 && s.cols >= 8 && d.rows <= 65535 * kRszRows) {   // (any width / alignment of source and destination)
         RCV_LAUNCH(k_resize_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (unsigned)((d.rows + kRszRows - 1) / kRszRows), d.n),
                            dim3(kBlock), 0, ctx->stream, s, d, scx, scy);
         return rcv_launch_check(ctx);
