@@ -718,7 +718,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Aff
     const float ya = fmaf(A.m[3], fxx, fmaf(A.m[4], fy0, A.m[5])), yb = fmaf(A.m[3], fxx, fmaf(A.m[4], fy1, A.m[5]));
     // (sx, sy are monotonic in the row index for a fixed lane: the first and the last row bound all eight; NaN -> false)
     const bool inter = fminf(xa, xb) >= 0.0f && fmaxf(xa, xb) < (float)(s.cols - 7) && fminf(ya, yb) >= 0.0f && fmaxf(ya, yb) < (float)(s.rows - 1);
-    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    const bool small = s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    // (source rows of any alignment: tap windows are the 8 ALIGNED bytes that contain each tap pair; the frame base is aligned down)
+    const unsigned fmis = (unsigned)((uintptr_t)sf & 3);
+    const uint8_t* sfa = sf - fmis;
     const int xq = x & ~3, yi = ybase + (lane & 3);
     uint32_t px[kWarpRows];
     if (small && __all(inter)) {
@@ -726,20 +729,21 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Aff
         struct U2 { uint32_t a, b; };
         U2 ta[kWarpRows], tb[kWarpRows];
         f2 fxy[kWarpRows];
-        unsigned sh[kWarpRows];
+        unsigned sh[kWarpRows], shb[kWarpRows];
 #pragma unroll
         for (int r = 0; r < kWarpRows; ++r) {
             const float fyy = (float)min(ybase + r, d.rows - 1);
             const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
             fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
-            const unsigned off = __umul24((unsigned)(int)sxy.y, sstep) + (unsigned)(int)sxy.x;
+            const unsigned off = __umul24((unsigned)(int)sxy.y, sstep) + (unsigned)(int)sxy.x + fmis, offb = off + sstep;
             sh[r] = off & 3u;
-            ta[r] = *(const U2*)(sf + (off & ~3u));
-            tb[r] = *(const U2*)(sf + ((off & ~3u) + sstep));
+            shb[r] = offb & 3u;
+            ta[r] = *(const U2*)(sfa + (off & ~3u));
+            tb[r] = *(const U2*)(sfa + (offb & ~3u));
         }
 #pragma unroll
         for (int r = 0; r < kWarpRows; ++r) {
-            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, sh[r]);
+            const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sh[r]), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, shb[r]);
             // {top, bottom} as one packed pair: fma(fx, p01 - p00, p00), then v = fma(fy, bot - top, top), floor(v + 0.5)
             const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
             const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
@@ -757,7 +761,14 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Aff
     for (int h = 0; h < kWarpRows / 4; ++h) {
         uint32_t t[4] = {px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]};
         quad_transpose4(t, lane);
-        if (xq < d.cols && yi + 4 * h < d.rows) *(uint32_t*)(dfr + (size_t)(yi + 4 * h) * d.step + xq) = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+        if (xq < d.cols && yi + 4 * h < d.rows) {   // any destination alignment; the row's last quad of a ragged width byte by byte
+            typedef uint32_t u1m __attribute__((aligned(1)));
+            uint8_t* q = dfr + (size_t)(yi + 4 * h) * d.step + xq;
+            const uint32_t v = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+            if (d.cols - xq >= 4) *(u1m*)q = v;
+            else
+                for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(v >> (8 * j));
+        }
     }
 }
 
@@ -1142,7 +1153,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, gy, gz), dim3(kBlock), 0, ctx->stream, s, d, A, fpg);
         return rcv_launch_check(ctx);
     }
-    if (s.ch == 1 && s.cols >= 8 && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 && d.step % 4 == 0 && d.fstride % 4 == 0) {
+    if (s.ch == 1 && s.cols >= 8) {   // (any width / alignment of source and destination)
         RCV_LAUNCH(k_warp_affine_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0,
                            ctx->stream, s, d, A);
         return rcv_launch_check(ctx);
