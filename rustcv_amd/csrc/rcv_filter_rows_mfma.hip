@@ -108,6 +108,11 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 // kernel calls the three planes of a window are the same window in the three blocks, loaded as one dwordx4 each -- no
 // de-interleave at all.  The lane's four output pixels of the three blocks are three dwords 256 bytes apart: a 4 x 4 dword
 // transpose across the four 16-lane rows (2 v_permlane16_swap + 2 v_permlane32_swap) turns them into 16 consecutive bytes per lane.
+// SRC = 3: BGR with rows of ANY alignment and ANY width >= 16 (an odd width of a packed image: step = cols * 3).  A lane's 48
+// source bytes are fetched as the 13 ALIGNED dwords that contain them and shifted into place with v_alignbyte (the shift is the
+// row's own misalignment plus the chunk's: a per-lane value per row pair); the chunk that holds pixel `cols` is repaired at byte
+// granularity (its rv = 0..15 valid pixels moved to the front, three mirrored pixels behind them); stores are unaligned 12-byte
+// stores, the row's last 1-3 pixels byte by byte.
 template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
                                            uint8_t* dframe)
@@ -115,8 +120,10 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
     const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
-    constexpr bool GRAY = SRC == 2;
+    constexpr bool GRAY = SRC == 2, RAGB = SRC == 3;
     constexpr int SB = GRAY ? 1 : (SRC == 1 ? 2 : 3), CB = 16 * SB;   // source bytes per pixel / per 16-pixel chunk
+    const unsigned fmis = RAGB ? (unsigned)((uintptr_t)sframe & 3) : 0u;   // (RAGB) the frame base aligned down: offsets stay non-negative
+    const uint8_t* const sfa = sframe - fmis;
     const int rb = a.cols * (GRAY ? 1 : 3), rbs = a.cols * SB;        // destination / source row bytes
 
     v4i A[2][NP];
@@ -147,8 +154,10 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // The chunk that holds pixel `cols` (the first one past the row) has `rv` valid pixels in front of it: 4 when the width is a
     // multiple of 16; BGR also takes widths that are a multiple of 4 (a 1080-pixel portrait frame): rv = 0, 8, 12 then (the same in
     // every such lane of the launch: a scalar)
-    const int rv = (SRC == 0) ? ((a.cols & 15) + 4) & 15 : 4;
+    const int rv = (SRC == 0 || RAGB) ? ((a.cols & 15) + 4) & 15 : 4;   // (RAGB: any value 0..15)
     const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - rv * SB;
+    // (RAGB, rv = 14 / 15: the third / second and third mirrored pixel are the first pixels of the NEXT chunk)
+    const bool frn = EDGE && RAGB && rv >= 14 && cb == rbs - rv * SB + CB;
     unsigned cbo1 = 0, cbo2 = 0;
     bool fr1 = false, fr2 = false;
     if constexpr (GRAY) {
@@ -167,7 +176,9 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     asm volatile("" : "+v"(initv));
 
     v4i W[RP][3];   // raw source bytes until prepare() turns them into the B, G, R operands
-    auto request = [&](int pr, v4i(&dst)[3]) {
+    int Wx[RP], Wm[RP];   // RAGB: the 13th aligned dword of the lane's run and the byte shift of the run inside the 13
+    auto request = [&](int pr, int slot) {
+        v4i(&dst)[3] = W[slot];
         // rows 2*pr (lanes h = 0) and 2*pr + 1 (lanes h = 1) of the segment's window, mirrored at the image border (scalar math);
         // rows past the window re-read its last row (cache hits, never used)
         const int XR = (DBG & 128) ? 0 : RAD;   // (experiment: no halo rows)
@@ -203,11 +214,21 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             dst[2] = t0;
             return;
         }
+        if constexpr (RAGB) {
+            const unsigned offp = off + fmis, ao = offp & ~3u, mis = offp & 3u;
+            dst[0] = *(const v4i*)(sfa + ao);
+            dst[1] = *(const v4i*)(sfa + ao + 16);
+            dst[2] = *(const v4i*)(sfa + ao + 32);
+            Wx[slot] = *(const int*)(sfa + ao + (mis ? 48u : 44u));   // (an aligned run needs no 13th dword: never read past it)
+            Wm[slot] = (int)mis;
+            return;
+        }
         dst[0] = *(const v4i*)(sframe + off);
         dst[1] = *(const v4i*)(sframe + off + 16);
         if constexpr (SRC == 0) dst[2] = *(const v4i*)(sframe + off + 32);
     };
-    auto prepare = [&](v4i(&w)[3]) {
+    auto prepare = [&](int slot) {
+        v4i(&w)[3] = W[slot];
         uint32_t pb[4], pg[4], prr[4];
         if constexpr (GRAY) {
 #pragma unroll
@@ -236,8 +257,13 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                 prr[i] = rcv_ashr_sat_pk4(sr[0], sr[1], sr[2], sr[3], 8);
             }
         } else {
-            const uint32_t r[12] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
-                                    (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
+            uint32_t r[13] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
+                              (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3], 0u};
+            if constexpr (RAGB) {
+                r[12] = (uint32_t)Wx[slot];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], (uint32_t)Wm[slot]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
         }
@@ -253,6 +279,13 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                     pp[0] = __builtin_amdgcn_perm(pp[0], pp[0], 0x01020300u);   // [x, px3, px2, px1]
                 }
             }
+            if (frn) {   // the lane read pixels cols-16..cols-1 (clamped): pixel 0 (and 1) of its chunk := cols-4 (cols-3, cols-4)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
+                    pp[0] = rv == 14 ? pp[3] : __builtin_amdgcn_perm(pp[3], pp[3], 0x00000001u);
+                }
+            }
             // right border: the lane read pixels cols-16..cols-1 instead of cols-rv..cols-rv+15: its rv valid pixels move down to
             // the front, pixels cols..cols+2 mirror cols-2..cols-4
             if (GRAY ? (fr || fr1 || fr2) : fr) {
@@ -261,7 +294,27 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                     if (GRAY && !(pl == 0 ? fr : (pl == 1 ? fr1 : fr2))) continue;
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
                     const uint32_t mir = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);   // [cols-2, cols-3, cols-4, x]
-                    if (SRC != 0 || rv == 4) {
+                    if (RAGB && (rv & 3) != 0) {
+                        // rv is any value: the plane's 16 bytes move down by 16 - rv bytes (whole dwords + a byte shift), then the
+                        // three mirrored bytes go in at byte rv (all positions are the same in every lane: scalars)
+                        const int sh16 = 16 - rv, sft = sh16 >> 2, a4 = rv >> 2;
+                        const uint32_t bs = (uint32_t)(sh16 & 3), b8 = 8u * (uint32_t)(rv & 3);
+                        const uint32_t L0 = pp[0], L1 = pp[1], L2 = pp[2], L3 = pp[3];
+                        auto pick = [&](int j) -> uint32_t { return j == 0 ? L0 : (j == 1 ? L1 : (j == 2 ? L2 : (j == 3 ? L3 : 0u))); };
+                        uint32_t T[5];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) T[i] = __builtin_amdgcn_alignbyte(pick(i + sft + 1), pick(i + sft), bs);
+                        T[4] = 0u;
+                        const uint32_t m0 = 0x00ffffffu << b8, m1 = 0x00ffffffu >> (32u - b8);   // (rv & 3 != 0: b8 = 8, 16, 24)
+                        const uint32_t v0 = mir << b8, v1 = mir >> (32u - b8);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            uint32_t t = T[i];
+                            t = i == a4 ? ((t & ~m0) | (v0 & m0)) : t;
+                            t = i == a4 + 1 ? ((t & ~m1) | (v1 & m1)) : t;
+                            pp[i] = t;
+                        }
+                    } else if (SRC == 1 || GRAY || rv == 4) {
                         pp[0] = pp[3];
                         pp[1] = mir;
                     } else if (rv == 8) {
@@ -285,9 +338,9 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     };
 
 #pragma unroll
-    for (int i = 0; i < RP - 1; ++i) request(i, W[i]);
+    for (int i = 0; i < RP - 1; ++i) request(i, i);
 #pragma unroll
-    for (int i = 0; i < NP - 1; ++i) prepare(W[i]);
+    for (int i = 0; i < NP - 1; ++i) prepare(i);
 
     const int nrows = ye - ys;
     auto finish = [&](v4i(&acc)[3], const v4i(&acc2)[3], int y) {
@@ -328,6 +381,16 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         uint8_t* drow = dframe + (size_t)y * a.dstep;
         if (DBG & 1) {
             if (o.a == 0x12345678u && o.b == 0x9abcdef0u) *(U3w*)dumpp = o;
+        } else if (EDGE && RAGB) {
+            // any width: a lane's four pixels may end past the row (its last 1-3 pixels byte by byte) or lie past it altogether
+            typedef uint32_t v3u1 __attribute__((ext_vector_type(3), aligned(1)));
+            if (so + 12 <= rb) *(v3u1*)(drow + so) = v3u1{o.a, o.b, o.c};
+            else if (so < rb) {
+                const uint32_t ow[3] = {o.a, o.b, o.c};
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (so + i < rb) drow[so + i] = (uint8_t)(ow[i >> 2] >> (8 * (i & 3)));
+            }
         } else if (EDGE) {
             *(U3w*)(so < rb ? drow + so : dumpp) = o;   // windows past the row end (partial last strip) go to the dump line
         } else if (DBG & 8) {
@@ -344,8 +407,8 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         for (int s = 0; s < RP; ++s) {
             const int u = u0 + s;
             if (u >= nsteps) break;
-            request(u + RP - 1, W[(s + RP - 1) % RP]);
-            prepare(W[(s + NP - 1) % RP]);
+            request(u + RP - 1, (s + RP - 1) % RP);
+            prepare((s + NP - 1) % RP);
             v4i acc[2][3], acc2[2][3];
             const v4i zerov = v4i{0, 0, 0, 0};
 #pragma unroll
@@ -478,6 +541,12 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
         return;
     }
     constexpr int kAll = (1 << (2 * ((KS + 1) / 2))) - 1;
+    if (src_yuyv == 3) {   // BGR, any width / alignment
+        if (dmask == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 3>), grid, dim3(64), lds, st, a);
+        else if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll, 3>), grid, dim3(64), lds, st, a);
+        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll, 3>), grid, dim3(64), lds, st, a);
+        return;
+    }
     if (dmask != 0) {   // two weight tables
         if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>), grid, dim3(64), lds, st, a);
         else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll>), grid, dim3(64), lds, st, a);
@@ -507,11 +576,17 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     // widths: a multiple of 16 pixels; BGR -> BGR also any multiple of 4 (the right-border repair knows the four residues) with
     // rows that are only 4-byte aligned (a packed 1080-pixel-wide portrait frame: step = 3240): its loads and stores are dword-
     // aligned dwordx4 / dwordx3, which cost the same as 16-byte aligned ones
+    // BGR -> BGR on any other width / alignment (an odd width of a packed image: byte-aligned rows): the SRC = 3 instantiation
+    // (aligned dwords + v_alignbyte on the load side, byte-granular border repair, unaligned stores)
     const int wq = src_yuyv == 0 ? 4 : 16, al = src_yuyv == 0 ? 4 : 16;
-    if (s.cols % wq != 0 || s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
+    if (s.cols < 16 || s.rows < 4) return RCV_ERR_UNSUPPORTED;
+    const bool fits = s.cols % wq == 0 && !((uintptr_t)s.p % al || s.step % al || (s.n > 1 && s.fstride % al)) &&
+                      !((uintptr_t)d.p % al || d.step % al || (d.n > 1 && d.fstride % al));
+    if (!fits) {
+        if (src_yuyv != 0) return RCV_ERR_UNSUPPORTED;
+        src_yuyv = 3;
+    }
     const long long rb = (long long)s.cols * (gray ? 1 : 3);
-    if ((uintptr_t)s.p % al || s.step % al || (s.n > 1 && s.fstride % al)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)d.p % al || d.step % al || (d.n > 1 && d.fstride % al)) return RCV_ERR_UNSUPPORTED;
     // in-frame source offsets are 32-bit
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
@@ -532,7 +607,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
     if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
-    if (dual && src_yuyv) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR only)
+    if (dual && (src_yuyv == 1 || src_yuyv == 2)) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR only)
 
     if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
         int8_t m8[49], s8[49];

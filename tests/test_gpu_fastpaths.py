@@ -99,8 +99,9 @@ def test_fast_kernels_are_dispatched(ctx):
     device.synth(og, 1, 14, 0)
     kf5 = np.full((5, 5), 1 / 25, np.float32)
     cases += [
-        ("filter2D 7x7 i8, packed 1919-wide BGR (odd width)", lambda: device.filter2d(ow, ow2, k7, shift=6), "k_filter_f32_stream<"),
-        ("GaussianBlur 5x5 int, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 5, 0.0), "k_filter_f32_stream<"),
+        ("filter2D 7x7 i8, packed 1919-wide BGR (odd width: the MFMA kernel's any-width instantiation)", lambda: device.filter2d(ow, ow2, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 3>"),
+        ("GaussianBlur 5x5 int, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 5, 0.0), "k_filter_rows_mfma<KS, 3, 0, 0, 3>"),
+        ("GaussianBlur 7x7 int, packed 1919-wide BGR (two weight tables)", lambda: device.gaussian_blur(ow, ow2, 7, 0.0), "k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll, 3>"),
         ("GaussianBlur 7x7 sigma 1.5, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 7, 1.5), "k_filter_f32_stream<"),
         ("filter2D 5x5 f32, packed 1919-wide BGR", lambda: device.filter2d(ow, ow2, kf5), "k_filter_f32_stream<"),
         ("filter2D 7x7 i8, packed 1919-wide gray", lambda: device.filter2d(og, og2, k7, shift=6), "k_filter_f32_stream<"),

@@ -1058,19 +1058,26 @@ def test_warp_affine_bgr_kernel_degenerate_matrices(ctx, oracle, rng, M):
 
 
 @pytest.mark.parametrize("rows,cols", [(40, 20), (33, 36), (64, 1080), (50, 1084), (37, 1088), (29, 1092), (45, 252), (31, 260), (70, 264), (19, 268), (23, 772),
-                                       (41, 1548), (16, 16), (90, 28)])
-def test_row_streaming_kernel_on_widths_that_are_multiples_of_4(ctx, oracle, knob, rows, cols):
-    """the row-streaming MFMA kernel on BGR widths with every residue mod 16 (a packed 1080-pixel-wide frame: rows only 4-byte
-    aligned, the right-border chunk holds 0 / 4 / 8 / 12 valid pixels, partial last windows and strips): filter2D 3 / 5 / 7 and
-    the integer GaussianBlur (two weight tables at 7) against the oracle; frames 4-byte aligned only"""
+                                       (41, 1548), (16, 16), (90, 28),
+                                       (40, 17), (33, 37), (64, 1079), (50, 1081), (37, 1082), (29, 1083), (45, 253), (31, 254), (70, 255), (19, 257), (23, 258),
+                                       (41, 259), (90, 29), (12, 18), (25, 19), (30, 21), (30, 22), (30, 23), (44, 769), (44, 770), (44, 771), (27, 511), (27, 513),
+                                       (64, 1919), (20, 3839)])
+def test_row_streaming_kernel_on_any_width(ctx, oracle, knob, rows, cols):
+    """the row-streaming MFMA kernel on BGR widths with every residue mod 16: multiples of 4 on 4-byte aligned rows (a packed
+    1080-pixel-wide frame; the right-border chunk holds 0 / 4 / 8 / 12 valid pixels) and ANY other width on byte-aligned rows (the
+    SRC = 3 instantiation: aligned dwords + v_alignbyte on the load side, byte-granular border repair with 0..15 valid pixels --
+    for 14 and 15 the mirrored pixels spill into the next chunk --, unaligned stores, the row's last 1-3 pixels byte by byte);
+    partial last windows and strips; filter2D 3 / 5 / 7 and the integer GaussianBlur (two weight tables at 7) against the
+    oracle; frames start at any byte"""
     knob("RCV_F7_ROWS", 1)
     n = 3
+    fa = 4 if cols % 4 == 0 else 1   # frame alignment
     for ks in (3, 5, 7):
         rng = np.random.default_rng(1000 * rows + 7 * cols + ks + _SOAK_SEED)
         frames = rng.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
         k = rng.integers(-20, 21, size=(ks, ks)).astype(np.int8)
-        src = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + 4 * int(rng.integers(0, 3)))
-        dst = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + 4 * int(rng.integers(1, 3)))
+        src = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + fa * int(rng.integers(0, 3)))
+        dst = device.DeviceBatch(ctx, n, rows, cols, 3, frame_stride=rows * cols * 3 + fa * int(rng.integers(1, 3)))
         src.upload(frames)
         dst.memset(0xEE)
         launched = _kernels_launched(ctx, lambda: device.filter2d(src, dst, k, shift=6))
@@ -1091,10 +1098,11 @@ def test_row_streaming_kernel_on_widths_that_are_multiples_of_4(ctx, oracle, kno
 @pytest.mark.parametrize("rows,cols", [(37, 41), (64, 333), (129, 1919), (30, 1021), (200, 47)])
 @pytest.mark.parametrize("ch", [1, 3])
 def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
-    """odd widths of packed images (step = cols * channels: rows start at any byte, frames too): integer filter2D 3/5/7, integer
-    GaussianBlur, GaussianBlur sigma > 0 and f32 filter2D all run the streaming kernel's unaligned instantiation (window fetched
-    as aligned dwords + one v_alignbyte shift per row, unaligned dword stores, the row's last 1-3 bytes by the edge launch) --
-    bit for bit against the oracle, padding between frames untouched, and never the per-sample kernels"""
+    """odd widths of packed images (step = cols * channels: rows start at any byte, frames too): GaussianBlur sigma > 0, f32
+    filter2D and the one-channel integer filters run the streaming kernel's unaligned instantiation (window fetched as aligned
+    dwords + one v_alignbyte shift per row, unaligned dword stores, the row's last 1-3 bytes by the edge launch), the BGR integer
+    filters the row-streaming MFMA kernel's any-width instantiation -- bit for bit against the oracle, padding between frames
+    untouched, and never the per-sample kernels"""
     n = 3
     r = np.random.default_rng(rows * 4099 + cols * 7 + ch + _SOAK_SEED)
     frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
@@ -1103,11 +1111,13 @@ def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
     src.upload(frames)
     img = lambda i: frames[i] if ch == 3 else frames[i, :, :, 0]   # noqa: E731
 
-    def check(tag, fn, ref):
+    def check(tag, fn, ref, mfma=False):
         dst = device.DeviceBatch(ctx, n, rows, cols, ch, frame_stride=fs + 2)
         dst.memset(0xCD)
         launched = _kernels_launched(ctx, lambda: fn(dst))
-        assert "k_filter_f32_stream<" in launched and "generic" not in launched, (tag, launched)
+        # BGR integer filters: the row-streaming MFMA kernel's any-width instantiation; everything else: the streaming VALU kernel
+        want = "k_filter_rows_mfma<" if (mfma and ch == 3 and cols >= 16) else "k_filter_f32_stream<"
+        assert want in launched and "generic" not in launched, (tag, launched)
         raw = dst.download_bytes()[: n * dst.frame_stride].reshape(n, dst.frame_stride)
         for i in range(n):
             got = raw[i, : rows * cols * ch].reshape(rows, cols, ch)
@@ -1118,8 +1128,8 @@ def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
 
     for ks in (3, 5, 7):
         k = r.integers(-9, 10, size=(ks, ks)).astype(np.int8)
-        check(f"filter2D i8 {ks}", lambda d, k=k: device.filter2d(src, d, k, shift=5), lambda a, k=k: oracle.filter2d_i8(a, k, 5))
-        check(f"Gaussian int {ks}", lambda d, ks=ks: device.gaussian_blur(src, d, ks, 0.0), lambda a, ks=ks: oracle.gaussian_blur(a, ks, 0.0))
+        check(f"filter2D i8 {ks}", lambda d, k=k: device.filter2d(src, d, k, shift=5), lambda a, k=k: oracle.filter2d_i8(a, k, 5), mfma=True)
+        check(f"Gaussian int {ks}", lambda d, ks=ks: device.gaussian_blur(src, d, ks, 0.0), lambda a, ks=ks: oracle.gaussian_blur(a, ks, 0.0), mfma=True)
         check(f"Gaussian sigma {ks}", lambda d, ks=ks: device.gaussian_blur(src, d, ks, 1.3), lambda a, ks=ks: oracle.gaussian_blur(a, ks, 1.3))
         kf = (r.standard_normal((ks, ks)) / ks).astype(np.float32)
         check(f"filter2D f32 {ks}", lambda d, kf=kf: device.filter2d(src, d, kf, delta=1.5), lambda a, kf=kf: oracle.filter2d_f32(a, kf, 1.5))
