@@ -37,7 +37,10 @@ struct GrayW {
     int acc_init, shift;
 };
 
-template <int KS, bool DUAL, bool EDGE>
+// RAG: rows of any alignment and any width >= 12 (an odd width of a packed image: step = cols): the row's misalignment is the same
+// for every thread, so the 12-byte window is fetched as the four ALIGNED dwords that contain it and shifted into place with
+// v_alignbyte; unaligned dword stores; the row's last 1-3 pixels byte by byte (EDGE launch).
+template <int KS, bool DUAL, bool EDGE, bool RAG = false>
 __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, GrayW<KS> W, int seg_rows, int edge_nl, int edge_nr)
 {
     constexpr int RAD = KS / 2;
@@ -45,10 +48,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (EDGE) {
         if (t >= edge_nl + edge_nr) return;
-        if (t >= edge_nl) t = s.cols / 4 - edge_nr + (t - edge_nl);
+        if (t >= edge_nl) t = (s.cols + 3) / 4 - edge_nr + (t - edge_nl);
     }
     const int xb0 = 4 * t;
     if (xb0 >= s.cols) return;
+    if (RAG && !EDGE && xb0 + 4 > s.cols) return;   // the row's last, partial group belongs to the EDGE launch
     const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride + xb0;
@@ -70,6 +74,14 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
             for (int i = 0; i < 3; ++i)
                 w.d[i] = (uint32_t)row[goff[4 * i]] | ((uint32_t)row[goff[4 * i + 1]] << 8) | ((uint32_t)row[goff[4 * i + 2]] << 16) |
                          ((uint32_t)row[goff[4 * i + 3]] << 24);
+        } else if constexpr (RAG) {
+            const uint8_t* p = row + wstart;
+            const unsigned mis = (unsigned)((uintptr_t)p & 3);
+            const uint32_t* base = (const uint32_t*)(p - mis);
+            const uint32_t e0 = base[0], e1 = base[1], e2 = base[2], e3 = base[mis ? 3 : 2];   // (aligned window: no fourth dword)
+            w.d[0] = __builtin_amdgcn_alignbyte(e1, e0, mis);
+            w.d[1] = __builtin_amdgcn_alignbyte(e2, e1, mis);
+            w.d[2] = __builtin_amdgcn_alignbyte(e3, e2, mis);
         } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i) w.d[i] = *(const uint32_t*)(row + wstart + 4 * i);
@@ -122,7 +134,19 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
             if constexpr (DUAL) accq[done][j] = 0;
         }
         const uint32_t o = rcv_ashr_sat_pk4(v[0], v[1], v[2], v[3], W.shift);
-        if (y >= ys && y < ye) *(uint32_t*)(df + (size_t)y * d.step) = o;
+        if (y >= ys && y < ye) {
+            if constexpr (RAG) {
+                uint8_t* q = df + (size_t)y * d.step;
+                if (xb0 + 4 <= s.cols) {
+                    typedef uint32_t u1m __attribute__((aligned(1)));
+                    *(u1m*)q = o;
+                } else {
+                    for (int b = 0; b < s.cols - xb0; ++b) q[b] = (uint8_t)(o >> (8 * b));
+                }
+            } else {
+                *(uint32_t*)(df + (size_t)y * d.step) = o;
+            }
+        }
     };
 
     int r0 = ys - RAD;
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_gray_dot4(View s, View d, Gra
     }
 }
 
-template <int KS, bool DUAL>
+template <int KS, bool DUAL, bool RAG = false>
 int launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int shift)
 {
     constexpr int RAD = KS / 2;
@@ -156,16 +180,18 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int shi
     (void)RAD;
     W.shift = shift;
     W.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
-    const unsigned gx = (unsigned)((s.cols / 4 + kBlock - 1) / kBlock);
+    const int nthreads = (s.cols + 3) / 4;   // per row (RAG: the last one may own fewer than 4 pixels)
+    const unsigned gx = (unsigned)((nthreads + kBlock - 1) / kBlock);
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, false>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, false, RAG>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
     RCV_TRY(rcv_launch_check(ctx));
     // threads whose 12-byte window [xb0 - 4, xb0 + 8) leaves the row: the first one and the last one (xb0 = cols - 4)
-    const int nl = 1, nr = s.cols / 4 - 1 >= 1 ? 1 : 0;
+    // (a width that is not a multiple of 4: the last two threads, the partial one and the one before it)
+    const int nl = 1, nr = min(nthreads - 1, s.cols % 4 ? 2 : 1);
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
-    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, true>), dim3(1, (unsigned)((s.rows + eseg - 1) / eseg), s.n), dim3(64), 0, ctx->stream, s, d, W,
+    RCV_LAUNCH((k_filter_gray_dot4<KS, DUAL, true, RAG>), dim3(1, (unsigned)((s.rows + eseg - 1) / eseg), s.n), dim3(64), 0, ctx->stream, s, d, W,
                        eseg, nl, nr);
     return rcv_launch_check(ctx);
 }
@@ -176,16 +202,18 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int shi
 int rcv_filter_i16_gray(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift)
 {
     if (s.ch != 1 || d.ch != 1 || (ksize != 3 && ksize != 5 && ksize != 7)) return RCV_ERR_UNSUPPORTED;
-    if (s.cols % 4 != 0 || s.cols < 12 || s.rows > 65535 * 8) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4)) return RCV_ERR_UNSUPPORTED;
-    if ((uintptr_t)d.p % 4 || d.step % 4 || (d.n > 1 && d.fstride % 4)) return RCV_ERR_UNSUPPORTED;
+    if (s.cols < 12 || s.rows > 65535 * 8) return RCV_ERR_UNSUPPORTED;
+    const bool rag = s.cols % 4 != 0 || (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4) || (uintptr_t)d.p % 4 || d.step % 4 ||
+                     (d.n > 1 && d.fstride % 4);
     bool dual = false;
     for (int i = 0; i < ksize * ksize; ++i) {
         if (k[i] < -512 || k[i] > 511) return RCV_ERR_UNSUPPORTED;
         if (k[i] < -128 || k[i] > 127) dual = true;
     }
-#define RCV_CASE(KS)                                                              \
-    if (ksize == KS) return dual ? launch<KS, true>(ctx, s, d, k, shift) : launch<KS, false>(ctx, s, d, k, shift);
+#define RCV_CASE(KS)                                                                                                          \
+    if (ksize == KS)                                                                                                          \
+        return rag ? (dual ? launch<KS, true, true>(ctx, s, d, k, shift) : launch<KS, false, true>(ctx, s, d, k, shift))     \
+                   : (dual ? launch<KS, true>(ctx, s, d, k, shift) : launch<KS, false>(ctx, s, d, k, shift));
     RCV_CASE(3) RCV_CASE(5) RCV_CASE(7)
 #undef RCV_CASE
     return RCV_ERR_UNSUPPORTED;

@@ -104,7 +104,7 @@ def test_fast_kernels_are_dispatched(ctx):
         ("GaussianBlur 7x7 int, packed 1919-wide BGR (two weight tables)", lambda: device.gaussian_blur(ow, ow2, 7, 0.0), "k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll, 3>"),
         ("GaussianBlur 7x7 sigma 1.5, packed 1919-wide BGR", lambda: device.gaussian_blur(ow, ow2, 7, 1.5), "k_filter_f32_stream<"),
         ("filter2D 5x5 f32, packed 1919-wide BGR", lambda: device.filter2d(ow, ow2, kf5), "k_filter_f32_stream<"),
-        ("filter2D 7x7 i8, packed 1919-wide gray", lambda: device.filter2d(og, og2, k7, shift=6), "k_filter_f32_stream<"),
+        ("filter2D 7x7 i8, packed 1919-wide gray", lambda: device.filter2d(og, og2, k7, shift=6), "k_filter_gray_dot4<"),
         ("Sobel, packed 1919-wide gray", lambda: device.sobel(og, odx, ody), "k_sobel_rows<0, false, true>"),
         ("Harris pipeline, packed 1919-wide BGR", lambda: device.harris_pipeline(ow, om, None, 2, 0.04, 1e-4), "k_harris_fused<false, 0, true, true>"),
     ]

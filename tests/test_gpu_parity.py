@@ -1099,9 +1099,9 @@ def test_row_streaming_kernel_on_any_width(ctx, oracle, knob, rows, cols):
 @pytest.mark.parametrize("ch", [1, 3])
 def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
     """odd widths of packed images (step = cols * channels: rows start at any byte, frames too): GaussianBlur sigma > 0, f32
-    filter2D and the one-channel integer filters run the streaming kernel's unaligned instantiation (window fetched as aligned
-    dwords + one v_alignbyte shift per row, unaligned dword stores, the row's last 1-3 bytes by the edge launch), the BGR integer
-    filters the row-streaming MFMA kernel's any-width instantiation -- bit for bit against the oracle, padding between frames
+    filter2D run the streaming kernel's unaligned instantiation (window fetched as aligned dwords + one v_alignbyte shift per
+    row, unaligned dword stores, the row's last 1-3 bytes by the edge launch), the BGR integer filters the row-streaming MFMA
+    kernel's any-width instantiation, the one-channel integer filters the dot4 kernel's -- bit for bit against the oracle, padding between frames
     untouched, and never the per-sample kernels"""
     n = 3
     r = np.random.default_rng(rows * 4099 + cols * 7 + ch + _SOAK_SEED)
@@ -1116,7 +1116,7 @@ def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
         dst.memset(0xCD)
         launched = _kernels_launched(ctx, lambda: fn(dst))
         # BGR integer filters: the row-streaming MFMA kernel's any-width instantiation; everything else: the streaming VALU kernel
-        want = "k_filter_rows_mfma<" if (mfma and ch == 3 and cols >= 16) else "k_filter_f32_stream<"
+        want = ("k_filter_rows_mfma<" if ch == 3 and cols >= 16 else "k_filter_gray_dot4<" if ch == 1 and cols >= 12 else "k_filter_f32_stream<") if mfma else "k_filter_f32_stream<"
         assert want in launched and "generic" not in launched, (tag, launched)
         raw = dst.download_bytes()[: n * dst.frame_stride].reshape(n, dst.frame_stride)
         for i in range(n):
