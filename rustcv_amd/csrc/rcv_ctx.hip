@@ -36,6 +36,7 @@ static void load_knobs()
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
     g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
+    g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
     g_knobs_loaded = true;
 }
 const RcvKnobs& rcv_knobs()

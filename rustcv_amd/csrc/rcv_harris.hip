@@ -322,6 +322,10 @@ extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv
     }
     if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    if (rcv_knobs().harris_general > 0 && s.ch != 2) {   // (A/B and tests: the general-block kernel at blockSize 2 as well)
+        const int rcg = rcv_harris_blocks_fused(ctx, s, resp ? &r : nullptr, &m, block, k, thr);
+        if (rcg != RCV_ERR_UNSUPPORTED) return rcg;
+    }
     int rc = rcv_harris_fused(ctx, s, &m, resp ? &r : nullptr, block, k, thr);
     if (rc != RCV_ERR_UNSUPPORTED) return rc;
     if (s.ch == 2) {

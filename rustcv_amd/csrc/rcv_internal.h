@@ -74,6 +74,7 @@ struct RcvKnobs {
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)
     int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)
+    int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too (A/B against the dedicated one, tests)
     int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS
 };
 const RcvKnobs& rcv_knobs();

@@ -1291,6 +1291,27 @@ def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, bloc
         b.free()
 
 
+def test_harris_general_block_kernel_at_block2(ctx, oracle, knob):
+    """RCV_HARRIS_GENERAL=1 routes blockSize 2 through the general-block one-launch kernel as well: same mask and response as the
+    dedicated kernel and the oracle (the dedicated kernel stays the default: 0.56 against 0.71 ms on 64 4K frames)"""
+    rows, cols, n = 150, 1000, 2
+    r = np.random.default_rng(4321 + _SOAK_SEED)
+    bgr = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    bgr[:, 40:47, 300:309] = 255
+    sb = device.DeviceBatch(ctx, n, rows, cols, 3)
+    sb.upload(bgr)
+    mask, resp = device.DeviceBatch(ctx, n, rows, cols, 1), device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_32F)
+    knob("RCV_HARRIS_GENERAL", 1)
+    launched = _kernels_launched(ctx, lambda: device.harris_pipeline(sb, mask, resp, 2, 0.04, 1e-5))
+    assert "k_harris_blocks_fused" in launched, launched
+    gm, gr = mask.download(), resp.download()
+    for i in range(n):
+        wm, wr = oracle.harris_pipeline(bgr[i], 2, 0.04, 1e-5, True)
+        assert np.array_equal(gm[i], wm) and np.array_equal(gr[i].view(np.uint32), wr.view(np.uint32)), i
+    for b in (sb, mask, resp):
+        b.free()
+
+
 @pytest.mark.parametrize("thr", [float("nan"), float("inf"), float("-inf"), 0.0, -1e-3, 3.0e-6])
 def test_harris_pipeline_block3_threshold_edge_values(ctx, oracle, thr):
     """the NMS inside the general-block response kernel at threshold edge values (NaN keeps nothing, -inf keeps every local
