@@ -1240,6 +1240,39 @@ def test_corner_harris(ctx, oracle, rng, rows, cols, block):
     assert np.array_equal(dst.to_array().view(np.uint32), want.view(np.uint32))  # bit-exact f32
 
 
+@pytest.mark.parametrize("block", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("cols", [512, 509])
+def test_corner_harris_saturated_gradients(ctx, oracle, block, cols):
+    """Black/white images drive |Ix|, |Iy| to 1020 and the window sums to their maximum (block^2 * 1020^2): blocks <= 4 hold them
+    in f32 (< 2^24: exact), larger ones in i32.  Stripes of period 4 (|Ix| = 1020 on half the columns), the same transposed,
+    a checkerboard of 2x2 cells, random binary pixels -- response bit for bit against the oracle, aligned (one-launch kernel)
+    and ragged width (planes + window kernel)."""
+    rows = 64
+    r = np.random.default_rng(block * 131 + cols + _SOAK_SEED)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    imgs = [((xx // 2) % 2) * 255, ((yy // 2) % 2) * 255, (((xx // 2) + (yy // 2)) % 2) * 255, r.integers(0, 2, size=(rows, cols)) * 255,
+            ((xx // 3) % 2) * 255, np.where(xx < cols // 2, 0, 255)]
+    gray = np.stack(imgs).astype(np.uint8)[..., None]
+    n = gray.shape[0]
+    src = device.DeviceBatch(ctx, n, rows, cols, 1)
+    src.upload(gray)
+    resp = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F, pad=32 if cols % 8 == 0 else 4)
+    device.corner_harris(src, resp, block, 0.04)
+    got = resp.download()
+    for i in range(n):
+        assert np.array_equal(got[i].view(np.uint32), oracle.corner_harris(gray[i, :, :, 0], block, 0.04).view(np.uint32)), ("cornerHarris", i)
+    _assert_canaries(resp)
+    mask = _canary_batch(ctx, n, rows, cols, 1, pad=8)
+    device.harris_pipeline(src, mask, None, block, 0.04, 1e-3)
+    gm = mask.download()
+    for i in range(n):
+        wr = oracle.corner_harris(gray[i, :, :, 0], block, 0.04)
+        assert np.array_equal(gm[i].reshape(rows, cols), oracle.nms3x3(wr, 1e-3).reshape(rows, cols)), ("mask", i)
+    _assert_canaries(mask)
+    for b in (src, resp, mask):
+        b.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(7, 16), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (8, 24), (45, 497), (64, 1919), (23, 9), (31, 503)])
 @pytest.mark.parametrize("block", [1, 3, 4, 5, 6, 7])
 def test_corner_harris_any_block_streaming_kernels(ctx, oracle, rows, cols, block):
