@@ -330,7 +330,12 @@ typedef short s2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t hpk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ uint32_t hpk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b)); }
 __device__ __forceinline__ uint32_t hpk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b)); }
-__device__ __forceinline__ uint32_t hpk_add2x(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2); }
+__device__ __forceinline__ uint32_t hpk_add2x(uint32_t a, uint32_t b)   // a + 2 * b on both halves, one instruction (as rcv_harris_fused.hip)
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(b), "v"(a));
+    return d;
+}
 __device__ __forceinline__ uint32_t shr1u(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }   // from lane-1
 __device__ __forceinline__ uint32_t shl1u(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }   // from lane+1
 
@@ -388,38 +393,48 @@ __global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
     for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
     // gray row v in, gradient row u = v-1 out (valid from the third row fed)
     auto feed = [&](const Raw& q, int v) -> RowPix {
-        uint32_t lo, hi;
+        uint32_t L[5], Cc[4];   // zero-extended gray pairs (g[2j-1], g[2j]) and (g[2j], g[2j+1])
         if constexpr (GRAY) {
-            lo = q.d[0];
-            hi = q.d[1];
+            uint32_t lo = q.d[0], hi = q.d[1];
+            if (edgeL) hi = hpk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
+            if (edgeR) lo = hpk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+            const uint32_t lf = shr1u(hi), rt = shl1u(lo);
+            L[0] = hpk(lf, lo, 0x0c000c07u);
+            L[1] = hpk(lo, lo, 0x0c020c01u);
+            L[2] = hpk(hi, lo, 0x0c040c03u);
+            L[3] = hpk(hi, hi, 0x0c020c01u);
+            L[4] = hpk(rt, hi, 0x0c040c03u);
+            Cc[0] = hpk(lo, lo, 0x0c010c00u);
+            Cc[1] = hpk(lo, lo, 0x0c030c02u);
+            Cc[2] = hpk(hi, hi, 0x0c010c00u);
+            Cc[3] = hpk(hi, hi, 0x0c030c02u);
         } else {
-            auto gray_of = [](uint32_t px) -> uint32_t {   // (B,G,R,x) dword -> gray, bit-identical to RCV_BGR2GRAY
-                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);
-                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);
-                return ((hi8 << 8) + lo8) >> 14;
+            // gray with the weights times 4 (7472, 38468, 19596 = 256*{29,150,76} + {48,68,140}, rounding term 4*8192): the value
+            // lands in bits 16..23, a whole byte the pair permutes read in place -- no shift, the eight values are never packed
+            // (rcv_harris_fused.hip, same front end)
+            auto gray_at_byte2 = [](uint32_t px) -> uint32_t {   // (B,G,R,x) dword -> RCV_BGR2GRAY << 16 (+ low bits)
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x004c961du, 0u, false);
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x008c4430u, 32768u, false);
+                return (hi8 << 8) + lo8;
             };
             uint32_t g[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;
-                g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
+                g[j] = gray_at_byte2(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
             }
-            lo = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-            hi = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+            if (edgeL) g[7] = g[1];
+            if (edgeR) g[0] = g[6];
+            const uint32_t lf = shr1u(g[7]), rt = shl1u(g[0]);
+            constexpr uint32_t kPair = 0x0c060c02u;
+            L[0] = hpk(g[0], lf, kPair);
+            L[1] = hpk(g[2], g[1], kPair);
+            L[2] = hpk(g[4], g[3], kPair);
+            L[3] = hpk(g[6], g[5], kPair);
+            L[4] = hpk(rt, g[7], kPair);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cc[j] = hpk(g[2 * j + 1], g[2 * j], kPair);
         }
-        if (edgeL) hi = hpk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
-        if (edgeR) lo = hpk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
-        const uint32_t lf = shr1u(hi), rt = shl1u(lo);
-        uint32_t L[5], Cc[4];
-        L[0] = hpk(lf, lo, 0x0c000c07u);
-        L[1] = hpk(lo, lo, 0x0c020c01u);
-        L[2] = hpk(hi, lo, 0x0c040c03u);
-        L[3] = hpk(hi, hi, 0x0c020c01u);
-        L[4] = hpk(rt, hi, 0x0c040c03u);
-        Cc[0] = hpk(lo, lo, 0x0c010c00u);
-        Cc[1] = hpk(lo, lo, 0x0c030c02u);
-        Cc[2] = hpk(hi, hi, 0x0c010c00u);
-        Cc[3] = hpk(hi, hi, 0x0c030c02u);
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;   // scalar: the window of a virtual row is the mirror image of row -u: dy changes sign
         uint32_t ox[4], oy[4];

@@ -43,7 +43,13 @@ struct HArgs {
 __device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b)); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b)); }
-__device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b) * (short)2); }
+// a + 2 * b on both halves in ONE instruction (the compiler turns the C expression into a packed shift and a packed add)
+__device__ __forceinline__ uint32_t pk_add2x(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(b), "v"(a));
+    return d;
+}
 // bound_ctrl: a lane without a source lane (lane 0 / lane 63) reads 0 -- the same value `old = 0` would leave, without the
 // v_mov that initialises `old` before every DPP
 __device__ __forceinline__ uint32_t shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }  // from lane-1
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     uint8_t* const mf = a.mask + (size_t)frame * a.mfs;
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
     constexpr bool YUYV = SRCK == 1, GRAY = SRCK == 2;
+    constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
 
@@ -156,10 +163,19 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         // ---- gray (8 px) -----------------------------------------------------------------------------------------
         // weights 1868, 9617, 4899 = 256*{7,37,19} + {76,145,35}: two v_dot4_u32_u8 per pixel on the pixel's (B,G,R,x) dword
         uint32_t g[8];
+        // TQ (aligned BGR / YUYV sources): the weights times 4 -- 7472, 38468, 19596 = 256*{29,150,76} + {48,68,140}, rounding term
+        // 4*8192 -- put the gray value (sum >> 14) into bits 16..23, a whole byte that the Sobel's byte permutes read in place:
+        // no shift, and no packing of the eight values
         auto gray_of = [](uint32_t px) -> uint32_t {
-            const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);   // 7*B + 37*G + 19*R
-            const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);  // 76*B + 145*G + 35*R + 8192
-            return ((hi8 << 8) + lo8) >> 14;
+            if constexpr (TQ) {
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x004c961du, 0u, false);
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x008c4430u, 32768u, false);
+                return (hi8 << 8) + lo8;
+            } else {
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);   // 7*B + 37*G + 19*R
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x0023914cu, 8192u, false);  // 76*B + 145*G + 35*R + 8192
+                return ((hi8 << 8) + lo8) >> 14;
+            }
         };
         if constexpr (GRAY) {
             // (the 8 gray pixels are the two source dwords themselves)
@@ -180,27 +196,43 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
                 g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
             }
         }
-        uint32_t lo = GRAY ? q.d[0] : g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = GRAY ? q.d[1] : g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
-        if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
-        if (RAG) {
-            const uint32_t l2 = pk(hi, lo, sel_lo), h2 = pk(hi, lo, sel_hi);
-            lo = l2;
-            hi = h2;
-        } else if (edgeR) {
-            lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
-        }
-        const uint32_t lf = shr1(hi), rt = shl1(lo);
         // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
-        uint32_t L[5], Cc[4];
-        L[0] = pk(lf, lo, 0x0c000c07u);
-        L[1] = pk(lo, lo, 0x0c020c01u);
-        L[2] = pk(hi, lo, 0x0c040c03u);
-        L[3] = pk(hi, hi, 0x0c020c01u);
-        L[4] = pk(rt, hi, 0x0c040c03u);
-        Cc[0] = pk(lo, lo, 0x0c010c00u);
-        Cc[1] = pk(lo, lo, 0x0c030c02u);
-        Cc[2] = pk(hi, hi, 0x0c010c00u);
-        Cc[3] = pk(hi, hi, 0x0c030c02u);
+        uint32_t L[5], Cc[4];   // zero-extended gray pairs (g[2j-1], g[2j]) and (g[2j], g[2j+1])
+        if constexpr (TQ) {
+            // the gray values sit in byte 2 of their dwords: the pairs are picked straight from there, the eight bytes are
+            // never packed into two dwords
+            if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
+            if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
+            const uint32_t lf = shr1(g[7]), rt = shl1(g[0]);
+            constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
+            L[0] = pk(g[0], lf, kPair);
+            L[1] = pk(g[2], g[1], kPair);
+            L[2] = pk(g[4], g[3], kPair);
+            L[3] = pk(g[6], g[5], kPair);
+            L[4] = pk(rt, g[7], kPair);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cc[j] = pk(g[2 * j + 1], g[2 * j], kPair);
+        } else {
+            uint32_t lo = GRAY ? q.d[0] : g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = GRAY ? q.d[1] : g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+            if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
+            if (RAG) {
+                const uint32_t l2 = pk(hi, lo, sel_lo), h2 = pk(hi, lo, sel_hi);
+                lo = l2;
+                hi = h2;
+            } else if (edgeR) {
+                lo = pk(hi, lo, 0x03020106u);   // x = cols mirrors cols-2
+            }
+            const uint32_t lf = shr1(hi), rt = shl1(lo);
+            L[0] = pk(lf, lo, 0x0c000c07u);
+            L[1] = pk(lo, lo, 0x0c020c01u);
+            L[2] = pk(hi, lo, 0x0c040c03u);
+            L[3] = pk(hi, hi, 0x0c020c01u);
+            L[4] = pk(rt, hi, 0x0c040c03u);
+            Cc[0] = pk(lo, lo, 0x0c010c00u);
+            Cc[1] = pk(lo, lo, 0x0c030c02u);
+            Cc[2] = pk(hi, hi, 0x0c010c00u);
+            Cc[3] = pk(hi, hi, 0x0c030c02u);
+        }
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
         // f32 stages on PACKED pairs {pixel j, pixel j+4} (v_pk_mul/add_f32): with this pairing the horizontal neighbour

@@ -98,7 +98,7 @@ def main():
         return device.DeviceBatch(ctx, max(1, int(round(n * a.scale))), r, c, ch, depth)
 
     def record(name, cfg, n, out_px, bpp, fn, note="", cpu=None):
-        if a.only and a.only.replace("_", " ") not in name:
+        if a.only and a.only.replace("_", " ") not in name + " @ " + cfg:   # "--only Sobel_3x3_->_dx,dy_i16_@_4K": op and config
             return
         ms = timeit(ctx, fn, a.steps, a.warmup)
         mpix = n * out_px / 1e6 / (ms * 1e-3)

@@ -21,8 +21,8 @@ run_op() {  # tag, --only pattern, kernel substring, algorithmic bytes per launc
 }
 PX4K=$((64*2160*3840)); PX8K=$((32*4320*7680))
 run_op bgr2gray_4k "BGR2GRAY" "k_bgr2gray16" $((PX4K*4))
-run_op sobel_4k "Sobel_3x3" "k_sobel_rows<0, false>" $((PX4K*5))
-run_op harris_4k "Harris_pipeline_(BGR" "k_harris_fused<false, 0," $((PX4K*4))
+run_op sobel_4k "Sobel_3x3_->_dx,dy_i16_@_4K" "k_sobel_rows<0, false" $((PX4K*5))
+run_op harris_4k "Harris_pipeline_(BGR->mask)_@_4K" "k_harris_fused<false, 0," $((PX4K*4))
 run_op harris_b3_4k "Harris_pipeline_blockSize_3" "k_harris_blocks_fused" $((PX4K*4))
 run_op warp_8k "warpAffine_bilinear_(rot_7deg)" "k_warp_affine_bgr_lds" $((PX8K*6))
 PXO=$((32*1080*1920))
