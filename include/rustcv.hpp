@@ -180,6 +180,13 @@ inline void filter2D_yuyv(Mat& src_yuyv, Mat& dst_bgr, const int8_t* kernel, int
     check(rcv_filter2d_i8_yuyv(Backend::instance().ctx(), &s, &d, kernel, ksize, shift), "filter2D_yuyv");
 }
 
+// integer filter2D -> BGR2GRAY -> Sobel of a BGR Mat in one launch ("next" row f1): dx, dy are i16 one-channel Mats
+inline void filter2D_sobel(Mat& src_bgr, Mat& dx, Mat& dy, const int8_t* kernel, int ksize, int shift)
+{
+    rcv_mat s = src_bgr.view(), a = dx.view(), b = dy.view();
+    check(rcv_filter2d_i8_sobel(Backend::instance().ctx(), &s, &a, &b, kernel, ksize, shift), "filter2D_sobel");
+}
+
 }  // namespace imgproc
 
 // Pinned-host staging ring ("next" row f3): the streaming replacement of the read() loop (rustcv/src/videoio/mod.rs:83-112).

@@ -110,6 +110,8 @@ SIGNATURES = {
     "rcv_filter2d_i8_yuyv_batch": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i]),
     "rcv_filter2d_f32": (_i, [_ctx, _mat, _mat, _P(_f), _i, _f]),
     "rcv_filter2d_f32_batch": (_i, [_ctx, _bat, _bat, _P(_f), _i, _f]),
+    "rcv_filter2d_i8_sobel": (_i, [_ctx, _mat, _mat, _mat, _P(C.c_int8), _i, _i]),
+    "rcv_filter2d_i8_sobel_batch": (_i, [_ctx, _bat, _bat, _bat, _P(C.c_int8), _i, _i]),
     "rcv_sobel": (_i, [_ctx, _mat, _mat, _mat]),
     "rcv_sobel_batch": (_i, [_ctx, _bat, _bat, _bat]),
     "rcv_resize": (_i, [_ctx, _mat, _mat]),

@@ -66,7 +66,20 @@ struct FRArgs {
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
+    uint8_t *gdx, *gdy;          // SOB: the i16 gradient planes (one channel), row step / frame stride in bytes
+    size_t gstep, gfs;
 };
+
+// packed i16 arithmetic on two pixels (the Sobel stage of the SOB instantiation; same forms as rcv_harris_fused.hip)
+typedef short fr_s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fr_pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(fr_s2v, a) - __builtin_bit_cast(fr_s2v, b)); }
+__device__ __forceinline__ uint32_t fr_pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(fr_s2v, a) + __builtin_bit_cast(fr_s2v, b)); }
+__device__ __forceinline__ uint32_t fr_pk_add2x(uint32_t a, uint32_t b)   // a + 2 * b on both halves
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(b), "v"(a));
+    return d;
+}
 
 struct U3w { uint32_t a, b, c; };
 
@@ -113,9 +126,18 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 // row's own misalignment plus the chunk's: a per-lane value per row pair); the chunk that holds pixel `cols` is repaired at byte
 // granularity (its rv = 0..15 valid pixels moved to the front, three mirrored pixels behind them); stores are unaligned 12-byte
 // stores, the row's last 1-3 pixels byte by byte.
-template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0>
+// SOB = 1 (BGR source, SRC = 0): filter2D -> BGR2GRAY -> Sobel in ONE launch; the filtered image never exists.  The row that
+// `finish` would store goes through the gray formula (weights times 4: the value lands in byte 2 of its dword, as in
+// rcv_harris_fused.hip) and a Sobel stage in packed i16 that keeps the horizontal parts of the two previous filtered rows in
+// registers: filtered row y completes gradient row y - 1.  The horizontal neighbours of a lane's four pixels live in lanes
+// l -+ 16 (or l +- 47 across windows): two ds_bpermute per row.  A wave's 256-pixel tile has no neighbours outside itself, so
+// the strips are laid 240 pixels apart and a strip stores tile pixels 8 .. 247 (strip 0: 0 .. 247, pixel -1 := pixel 1) -- whole
+// lane pairs, see the stores; the lane whose last pixel is the row's last takes pixel cols := cols - 2 from itself.  A band of gradient rows [oys, oye) runs
+// the filter over rows oys - 1 .. oye (clamped to the image); at the image's top / bottom the missing row is the mirror image
+// (gradient row 0 is formed from rows 1, 0, 1; row rows - 1 after the loop from rows - 2, rows - 1, rows - 2).
+template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
-                                           uint8_t* dframe)
+                                           uint8_t* dframe, const int oys = 0, const int oye = 0, uint8_t* dxf = nullptr, uint8_t* dyf = nullptr)
 {
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
@@ -154,7 +176,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // The chunk that holds pixel `cols` (the first one past the row) has `rv` valid pixels in front of it: 4 when the width is a
     // multiple of 16; BGR also takes widths that are a multiple of 4 (a 1080-pixel portrait frame): rv = 0, 8, 12 then (the same in
     // every such lane of the launch: a scalar)
-    const int rv = (SRC == 0 || RAGB) ? ((a.cols & 15) + 4) & 15 : 4;   // (RAGB: any value 0..15)
+    const int rv = (SRC == 0 || RAGB) ? ((a.cols & 15) + 4) & 15 : 4;   // (RAGB: any value 0..15; every strip starts at a multiple of 16 pixels)
     const bool fl = EDGE && cb < 0, fr = EDGE && cb == rbs - rv * SB;
     // (RAGB, rv = 14 / 15: the third / second and third mirrored pixel are the first pixels of the NEXT chunk)
     const bool frn = EDGE && RAGB && rv >= 14 && cb == rbs - rv * SB + CB;
@@ -343,10 +365,71 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     for (int i = 0; i < NP - 1; ++i) prepare(i);
 
     const int nrows = ye - ys;
+    // SOB: Sobel state (horizontal parts of filtered rows y-2, y-1 as packed i16 pairs) and the lane's place in the tile
+    uint32_t sh1a[2] = {0u, 0u}, sh1b[2] = {0u, 0u}, sh2a[2] = {0u, 0u}, sh2b[2] = {0u, 0u};
+    const int tpx = 16 * n + 4 * q, gpx = X / 3 + tpx;                      // the lane's first output pixel: in the tile / in the row
+    const bool g_first = X == 0 && lane == 0, g_last = gpx + 4 == a.cols;   // the lane holds the row's first / last pixel
+    const int addrL = 4 * (q > 0 ? lane - 16 : (n > 0 ? lane + 47 : lane)), addrR = 4 * (q < 3 ? lane + 16 : (n < 15 ? lane - 47 : lane));
+    // stores: lanes (n, q) and (n, q + 1), q even, hold eight consecutive pixels; after one v_permlane16_swap per dword the even
+    // lane has both lanes' dx and the odd lane both lanes' dy: ONE 16-byte store per lane and row.  Pair-local validity: tile
+    // pixels 8 .. 247 (strip 0: from 0), inside the row; a width that is not a multiple of 8 ends on a half pair.
+    const int tp2 = 16 * n + 8 * (q >> 1), gp2 = X / 3 + tp2;
+    const bool pair_ok = SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248;
+    const bool g_full = pair_ok && gp2 + 8 <= a.cols, g_half = pair_ok && gp2 + 8 > a.cols && gp2 + 4 <= a.cols;
+    uint8_t* const gplane = (q & 1) ? dyf : dxf;
+    typedef uint32_t fr_u2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t fr_u4 __attribute__((ext_vector_type(4)));
+    // gradient row gy from the horizontal parts of rows gy-1 (p1, p2), gy (c1) and gy+1 (n1, n2)
+    auto emit = [&](const uint32_t(&p1)[2], const uint32_t(&c1)[2], const uint32_t(&n1)[2], const uint32_t(&p2)[2], const uint32_t(&n2)[2], int gy) {
+        uint32_t x0 = fr_pk_add2x(fr_pk_add(p1[0], n1[0]), c1[0]), x1 = fr_pk_add2x(fr_pk_add(p1[1], n1[1]), c1[1]);
+        uint32_t y0 = fr_pk_sub(n2[0], p2[0]), y1 = fr_pk_sub(n2[1], p2[1]);
+        sw16(x0, y0);   // even q: (x0, x1) own dx, (y0, y1) the dx of lane + 16; odd q: (x0, x1) the dy of lane - 16, (y0, y1) own dy
+        sw16(x1, y1);
+        uint8_t* const o = gplane + (size_t)gy * a.gstep + 2 * (size_t)gp2;
+        // plain stores: the 480-byte row pieces of neighbouring strips share lines, which the L2 merges (non-temporal: 1.05
+        // instead of 0.78 ms on 64 4K frames)
+        if (g_full) *(fr_u4*)o = fr_u4{x0, x1, y0, y1};
+        else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
+    };
     auto finish = [&](v4i(&acc)[3], const v4i(&acc2)[3], int y) {
         if constexpr (DMASK != 0) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
+        }
+        if constexpr (SOB != 0) {
+            // the lane's four filtered pixels as (B,G,R,x) dwords out of the 12 interleaved bytes, gray into byte 2
+            const uint32_t oa = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+            const uint32_t ob = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+            const uint32_t oc = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+            const uint32_t px[4] = {oa, __builtin_amdgcn_alignbyte(ob, oa, 3), __builtin_amdgcn_alignbyte(oc, ob, 2), oc >> 8};
+            uint32_t g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px[i], 0x004c961du, 0u, false);      // 4 * (1868, 9617, 4899) = 256 * {29,150,76} + {48,68,140}
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px[i], 0x008c4430u, 32768u, false);  // (+ 4 * 8192): gray = bits 16..23
+                g[i] = (hi8 << 8) + lo8;
+            }
+            uint32_t gl = (uint32_t)__builtin_amdgcn_ds_bpermute(addrL, (int)g[3]), gr = (uint32_t)__builtin_amdgcn_ds_bpermute(addrR, (int)g[0]);
+            if (g_first) gl = g[1];   // pixel -1 := pixel 1
+            if (g_last) gr = g[2];    // pixel cols := pixel cols - 2
+            constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
+            const uint32_t Pa = __builtin_amdgcn_perm(g[0], gl, kPair), Pb = __builtin_amdgcn_perm(g[2], g[1], kPair), Pc = __builtin_amdgcn_perm(gr, g[3], kPair);
+            const uint32_t C0 = __builtin_amdgcn_perm(g[1], g[0], kPair), C1 = __builtin_amdgcn_perm(g[3], g[2], kPair);
+            const uint32_t h1[2] = {fr_pk_sub(Pb, Pa), fr_pk_sub(Pc, Pb)};
+            const uint32_t h2[2] = {fr_pk_add2x(fr_pk_add(Pa, Pb), C0), fr_pk_add2x(fr_pk_add(Pb, Pc), C1)};
+            const int gy = y - 1;
+            if (gy >= oys && gy < oye) {   // (scalar conditions)
+                if (gy == 0) emit(h1, sh1b, h1, h2, h2, gy);   // row -1 := row 1
+                else emit(sh1a, sh1b, h1, sh2a, h2, gy);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sh1a[j] = sh1b[j];
+                sh1b[j] = h1[j];
+                sh2a[j] = sh2b[j];
+                sh2b[j] = h2[j];
+            }
+            return;
         }
         if constexpr (GRAY) {
             // lane (q, n): four consecutive pixels of window n in each of the three blocks -> transpose -> window n of block q
@@ -431,9 +514,12 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             if (2 * u + 1 < nrows) finish(acc[1], acc2[1], ys + 2 * u + 1);
         }
     }
+    if constexpr (SOB != 0) {
+        if (oye == a.rows) emit(sh1a, sh1b, sh1a, sh2a, sh2a, a.rows - 1);   // the image's last row: row `rows` := row rows - 2
+    }
 }
 
-template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0>
+template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
 __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
 {
     const int lane = threadIdx.x;
@@ -449,7 +535,7 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
     // at one time, the slower its memory path (translation reach per XCD is the likely cause).  RCV_FR_ORDER keeps it measurable.
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (band >= a.nbands) return;
-    const int X = strip * 768;   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset)
+    const int X = strip * (SOB ? 720 : 768);   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset; SOB: strips 240 pixels apart)
     // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
     const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
@@ -460,7 +546,14 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
         const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
         const uint8_t* sframe = a.src + (size_t)frame * a.sfs;
         uint8_t* dframe = a.dst + (size_t)frame * a.dfs;
-        if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
+        if constexpr (SOB != 0) {
+            // gradient rows ys .. ye-1 need filtered rows ys-1 .. ye
+            const int fys = max(ys - 1, 0), fye = min(ye + 1, a.rows);
+            uint8_t* dxf = a.gdx + (size_t)frame * a.gfs;
+            uint8_t* dyf = a.gdy + (size_t)frame * a.gfs;
+            if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
+            else fr_segment<KS, PP, false, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
+        } else if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
         else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
         g0 += ye - ys;
     }
@@ -532,6 +625,10 @@ template <int KS>
 void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st)
 {
     const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
+    if (a.gdx) {   // filter2D -> gray -> Sobel (BGR source, one weight table: the caller checked)
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64), lds, st, a);
+        return;
+    }
     if (src_yuyv == 1) {   // (one weight table only: the caller checked)
         RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 1>), grid, dim3(64), lds, st, a);
         return;
@@ -565,8 +662,13 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 // Does this launch belong on the row-streaming kernel?  |weights| <= 511; BGR: rows 4-byte aligned, width a multiple of 4 pixels;
 // YUYV / gray sources: rows 16-byte aligned, width a multiple of 16; knob RCV_F7_ROWS = 1 takes every eligible shape (tests), 0 none, unset those with enough strip-rows to fill the GPU --
 // small launches keep the strip kernel's latency variant.
-int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size)
+// gx, gy (both or neither): the i16 gradient planes of the fused filter2D -> BGR2GRAY -> Sobel launch; `d` is not written then
+// (BGR source with 4-byte aligned rows and a width that is a multiple of 4, |weights| <= 127, 8-byte aligned gradient rows).
+int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size,
+                        const View* gx, const View* gy)
 {
+    const bool sob = gx != nullptr;
+    if (sob != (gy != nullptr)) return RCV_ERR_ARG;
     const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
@@ -583,14 +685,22 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     const bool fits = s.cols % wq == 0 && !((uintptr_t)s.p % al || s.step % al || (s.n > 1 && s.fstride % al)) &&
                       !((uintptr_t)d.p % al || d.step % al || (d.n > 1 && d.fstride % al));
     if (!fits) {
-        if (src_yuyv != 0) return RCV_ERR_UNSUPPORTED;
+        if (src_yuyv != 0 || sob) return RCV_ERR_UNSUPPORTED;
         src_yuyv = 3;
+    }
+    if (sob) {
+        if (src_yuyv != 0) return RCV_ERR_UNSUPPORTED;
+        for (const View* g : {gx, gy})
+            if (g->ch != 1 || g->rows != s.rows || g->cols != s.cols || g->n != s.n || (uintptr_t)g->p % 8 || g->step % 8 || (g->n > 1 && g->fstride % 8))
+                return RCV_ERR_UNSUPPORTED;
+        if (gx->step != gy->step || gx->fstride != gy->fstride) return RCV_ERR_UNSUPPORTED;
     }
     const long long rb = (long long)s.cols * (gray ? 1 : 3);
     // in-frame source offsets are 32-bit
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
-    const int nstrips = (int)((rb + 767) / 768);
+    // (sob: strips 240 pixels apart, each storing 240 pixels -- strip 0: 248)
+    const int nstrips = sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768);
     const long long G = (long long)s.n * s.rows;
     // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
     //  streaming VALU kernel: 4-7x slower even on one frame)
@@ -607,7 +717,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ksum += k[i];
     }
     if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
-    if (dual && (src_yuyv == 1 || src_yuyv == 2)) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR only)
+    if (dual && (src_yuyv == 1 || src_yuyv == 2 || sob)) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR -> BGR only)
 
     if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
         int8_t m8[49], s8[49];
@@ -652,6 +762,10 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.nstrips = nstrips;
     a.nframes = s.n;
     a.dual_shift = split2 ? 1 : 2;
+    a.gdx = sob ? gx->p : nullptr;
+    a.gdy = sob ? gy->p : nullptr;
+    a.gstep = sob ? gx->step : 0;
+    a.gfs = sob ? gx->fstride : 0;
     // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
     // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob
     // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).

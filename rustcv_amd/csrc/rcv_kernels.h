@@ -6,7 +6,8 @@
 
 int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize);
 int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
-int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size = false);   // rcv_filter_rows_mfma.hip, |k| <= 511
+int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv = 0, bool any_size = false,
+                        const View* gx = nullptr, const View* gy = nullptr);   // rcv_filter_rows_mfma.hip, |k| <= 511
 int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv);  // |k| <= 511
 int rcv_filter_i8_yuyv_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
 int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy);

@@ -280,6 +280,40 @@ extern "C" int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx
     return rcv_launch_check(ctx);
 }
 
+// filter2D (i8 weights) -> BGR2GRAY -> Sobel.  One launch of the row-streaming MFMA kernel where the shape allows
+// (rcv_filter_rows_mfma.hip, SOB instantiation); otherwise the two ordinary calls with the filtered image in the side buffer.
+extern "C" int rcv_filter2d_i8_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy, const int8_t* k, int ksize, int shift)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dx || !dy) return RCV_ERR_ARG;
+    View s, vx, vy;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dx, RCV_16S, &vx));
+    RCV_TRY(rcv_view_batch(dy, RCV_16S, &vy));
+    if (s.ch != 3 || vx.ch != 1 || vy.ch != 1) return RCV_ERR_UNSUPPORTED;
+    if (s.rows != vx.rows || s.cols != vx.cols || s.n != vx.n || s.rows != vy.rows || s.cols != vy.cols || s.n != vy.n) return RCV_ERR_ARG;
+    if (!k || !(ksize & 1) || ksize < 1 || ksize > 15 || shift < 0 || shift > 24) return RCV_ERR_ARG;
+    if (s.rows > 65535 || s.n > 65535) return RCV_ERR_UNSUPPORTED;
+    if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
+    if (ksize == 3 || ksize == 5 || ksize == 7) {
+        int16_t k16[49];
+        for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+        const int rc = rcv_filter_i16_rows(ctx, s, s, k16, ksize, shift, 0, true, &vx, &vy);   // (`d` is not written: the source stands in)
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
+    const size_t tstep = ((size_t)s.cols * 3 + 15) & ~(size_t)15, tfs = tstep * s.rows;
+    uint8_t* tmp;
+    RCV_TRY(rcv_side_reserve(ctx, tfs * s.n, &tmp));
+    rcv_batch tb = *src;
+    tb.frame0.data = tmp;
+    tb.frame0.cap = tfs;
+    tb.frame0.step = tstep;
+    tb.frame0.device = 1;
+    tb.frame_stride = tfs;
+    RCV_TRY(rcv_filter2d_i8_batch(ctx, src, &tb, k, ksize, shift));
+    return rcv_sobel_batch(ctx, &tb, dx, dy);
+}
+
 int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta, int xb_lo, int xb_hi)
 {
     if (xb_hi <= xb_lo) return RCV_OK;
@@ -335,6 +369,20 @@ extern "C" int rcv_filter2d_i8_yuyv(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* d
 extern "C" int rcv_filter2d_f32(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* k, int ksize, float delta)
 {
     RCV_UNARY_WRAPPER(rcv_filter2d_f32_batch(ctx, &bs, &bd, k, ksize, delta))
+}
+
+extern "C" int rcv_filter2d_i8_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy, const int8_t* k, int ksize, int shift)
+{
+    if (!src || !dx || !dy) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *d1, *d2;
+    RCV_TRY(stage_in(&st, src, true, false, &ds));
+    RCV_TRY(stage_in(&st, dx, true, true, &d1));
+    RCV_TRY(stage_in(&st, dy, true, true, &d2));
+    rcv_batch bs = rcv_single(ds), b1 = rcv_single(d1), b2 = rcv_single(d2);
+    int rc = rcv_filter2d_i8_sobel_batch(ctx, &bs, &b1, &b2, k, ksize, shift);
+    return stage_finish(&st, rc);
 }
 
 extern "C" int rcv_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy)

@@ -180,6 +180,14 @@ def filter2d_yuyv(src_yuyv, dst_bgr, kernel, shift=0):
                                                      k.shape[0], shift), "rcv_filter2d_i8_yuyv_batch")
 
 
+def filter2d_sobel(src_bgr, dx, dy, kernel, shift=0):
+    """fused integer filter2D -> BGR2GRAY -> Sobel of a BGR batch: the i16 gradients of the filtered image in one launch"""
+    k = np.ascontiguousarray(kernel, dtype=np.int8)
+    a, b, c = src_bgr.as_rcv(), dx.as_rcv(), dy.as_rcv()
+    _ffi.check(_ffi.lib().rcv_filter2d_i8_sobel_batch(_h(src_bgr), C.byref(a), C.byref(b), C.byref(c), k.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                      k.shape[0], shift), "rcv_filter2d_i8_sobel_batch")
+
+
 def sobel(src, dx, dy):
     a, b, c = src.as_rcv(), dx.as_rcv(), dy.as_rcv()
     _ffi.check(_ffi.lib().rcv_sobel_batch(_h(src), C.byref(a), C.byref(b), C.byref(c)), "rcv_sobel_batch")

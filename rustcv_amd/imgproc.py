@@ -100,6 +100,14 @@ def filter2d_yuyv(src_yuyv: Mat, dst_bgr: Mat, kernel, shift: int = 0, ctx=None)
                "rcv_filter2d_i8_yuyv")
 
 
+def filter2d_sobel(src_bgr: Mat, dx: Mat, dy: Mat, kernel, shift: int = 0, ctx=None):
+    """fused integer filter2D -> BGR2GRAY -> Sobel (== filter2d then sobel on its output, in one launch)"""
+    k = np.ascontiguousarray(kernel, dtype=np.int8)
+    s, a, b = src_bgr._as_rcv(), dx._as_rcv(), dy._as_rcv()
+    _ffi.check(_ffi.lib().rcv_filter2d_i8_sobel(_ctx(ctx), C.byref(s), C.byref(a), C.byref(b), k.ctypes.data_as(C.POINTER(C.c_int8)), k.shape[0], shift),
+               "rcv_filter2d_i8_sobel")
+
+
 def sobel(src: Mat, dx: Mat, dy: Mat, ctx=None):
     s, a, b = src._as_rcv(), dx._as_rcv(), dy._as_rcv()
     _ffi.check(_ffi.lib().rcv_sobel(_ctx(ctx), C.byref(s), C.byref(a), C.byref(b)), "rcv_sobel")

@@ -905,6 +905,57 @@ def test_sobel_of_bgr_source(ctx, oracle, rng, rows, cols):
         b.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(4, 16), (9, 20), (33, 248), (40, 252), (31, 256), (37, 260), (21, 496), (18, 500), (26, 504), (70, 520),
+                                       (64, 748), (19, 1032), (130, 1920), (300, 64), (5, 1000), (7, 3), (12, 18), (3, 64)])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
+    """f1: filter2D -> BGR2GRAY -> Sobel in one launch == sobel(bgr2gray(filter2d_i8(.))) of the oracle, bit
+    for bit.  The SOB instantiation of the row-streaming MFMA kernel takes BGR images with a width that is a multiple of 4 (>= 16,
+    >= 4 rows) on 4-byte aligned rows -- strips 240 pixels apart, so widths around the multiples of 240 put the row's end into every
+    place of a tile; every other shape runs the two ordinary launches through the side buffer.  Batch of 3 (bands cross frames),
+    padded steps, canaries around the i16 outputs; black/white frames drive the gradients to +-1020."""
+    n = 3
+    r = np.random.default_rng(rows * 1009 + cols * 7 + ksize + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    frames[1] = (r.integers(0, 2, size=(rows, cols, 1)) * 255).astype(np.uint8)   # saturated edges
+    k = r.integers(-8, 9, size=(ksize, ksize)).astype(np.int8)
+    k[ksize // 2, ksize // 2] = 40
+    shift = 6
+    aligned = cols % 4 == 0
+    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + (12 if aligned else 0))
+    src.upload(frames)
+    dx = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+    dy = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
+    launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, shift))
+    fused = aligned and cols >= 16 and rows >= 4
+    assert ("k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>" in launched) == fused, launched
+    assert ("k_sobel_rows" in launched or "k_sobel" in launched) == (not fused), launched
+    gx, gy = dx.download(), dy.download()
+    for i in range(n):
+        wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, shift)))
+        assert np.array_equal(gx[i].reshape(rows, cols), wx.reshape(rows, cols)), ("dx", i, np.argwhere(gx[i].reshape(rows, cols) != wx.reshape(rows, cols))[:4])
+        assert np.array_equal(gy[i].reshape(rows, cols), wy.reshape(rows, cols)), ("dy", i, np.argwhere(gy[i].reshape(rows, cols) != wy.reshape(rows, cols))[:4])
+    _assert_canaries(dx)
+    _assert_canaries(dy)
+    for b in (src, dx, dy):
+        b.free()
+
+
+def test_filter2d_sobel_host_mat_and_arguments(ctx, oracle, rng):
+    img = rand_img(rng, 31, 48, 3)
+    k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int8)
+    dx, dy = Mat(31, 48, 1, _ffi.RCV_16S), Mat(31, 48, 1, _ffi.RCV_16S)
+    imgproc.filter2d_sobel(Mat.from_array(img), dx, dy, k, 4, ctx)
+    wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(img, k, 4)))
+    assert np.array_equal(dx.to_array().reshape(31, 48), wx.reshape(31, 48)) and np.array_equal(dy.to_array().reshape(31, 48), wy.reshape(31, 48))
+    with pytest.raises(Exception):   # one-channel source
+        imgproc.filter2d_sobel(Mat.from_array(rand_img(rng, 8, 16, 1)), Mat(8, 16, 1, _ffi.RCV_16S), Mat(8, 16, 1, _ffi.RCV_16S), k, 4, ctx)
+    with pytest.raises(Exception):   # shape mismatch
+        imgproc.filter2d_sobel(Mat.from_array(img), Mat(31, 40, 1, _ffi.RCV_16S), dy, k, 4, ctx)
+    with pytest.raises(Exception):   # even kernel size
+        imgproc.filter2d_sobel(Mat.from_array(img), dx, dy, np.ones((2, 2), np.int8), 0, ctx)
+
+
 def test_sobel_of_bgr_source_host_mat(ctx, oracle, rng):
     img = rand_img(rng, 31, 48, 3)
     dx, dy = Mat(31, 48, 1, _ffi.RCV_16S), Mat(31, 48, 1, _ffi.RCV_16S)
@@ -1579,17 +1630,22 @@ def test_baseline_batch_geometries(ctx, oracle):
     device.cvt_color(s, g, _ffi.RCV_BGR2GRAY)
     device.sobel(g, dx, dy)
     device.harris_pipeline(s, m, None, 2, 0.04, 1e-4)          # config 5
+    fx, fy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+    device.filter2d_sobel(s, fx, fy, k7, 6)                    # config 3 as one launch: filter2D -> gray -> Sobel
     for i in (0, n // 2 - 1, n - 1):
         frame = s.download_frame(i)
         assert np.array_equal(frame, oracle.synth_frame(rows, cols, 3, 1, 0x5EED0003, i))
-        assert np.array_equal(d.download_frame(i), oracle.filter2d_i8(frame, k7, 6)), ("filter2D", i)
+        filtered = oracle.filter2d_i8(frame, k7, 6)
+        assert np.array_equal(d.download_frame(i), filtered), ("filter2D", i)
+        wfx, wfy = oracle.sobel(oracle.bgr2gray(filtered))
+        assert np.array_equal(fx.download_frame(i), wfx) and np.array_equal(fy.download_frame(i), wfy), ("filter2D -> Sobel", i)
         gray = oracle.bgr2gray(frame)
         assert np.array_equal(g.download_frame(i), gray), ("gray", i)
         wx, wy = oracle.sobel(gray)
         assert np.array_equal(dx.download_frame(i), wx) and np.array_equal(dy.download_frame(i), wy), ("sobel", i)
         wm = oracle.harris_pipeline(frame, 2, 0.04, 1e-4)
         assert np.array_equal(m.download_frame(i), wm) and wm.any(), ("harris", i)
-    for x in (s, d, g, dx, dy, m):
+    for x in (s, d, g, dx, dy, m, fx, fy):
         x.free()
     # config 4: 32 x 8K BGR, warpAffine (rotate 7 degrees) and resize to 1080p, and the fused form
     n, rows, cols = 32, 4320, 7680

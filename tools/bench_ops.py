@@ -170,6 +170,9 @@ def main():
     device.synth(o2, 1, SEED + 3, 0)
     record("Sobel of a BGR source, fused gray (next row f1)", "4K", o2.n, 3840 * 2160, 7, lambda: device.sobel(o2, dx, dy),
            note="3 B read + 4 B written per px; the two-launch chain BGR2GRAY + Sobel moves 9")
+    record("filter2D 7x7 i8 -> gray -> Sobel FUSED (config 3 in one launch, next row f1)", "4K batch=64", o2.n, 3840 * 2160, 7,
+           lambda: device.filter2d_sobel(o2, dx, dy, k7c, shift=6),
+           note="3 B read + 4 B written per px; filter2D + Sobel-of-BGR as two launches moves 13")
     o2.free()
     dx.free(); dy.free(); g.free()
 
