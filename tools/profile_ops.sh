@@ -30,3 +30,4 @@ run_op warp_resize_fused "warpAffine_+_resize" "k_warp_resize_box" $((PXO*30))
 run_op resize_5k "resize_8K_->_5K" "k_resize_bgr" $((32*2880*5120*975/100))
 run_op filter7_gray_4k "filter2D_7x7_i8_on_a_GRAY" "k_filter_rows_mfma<7, 3, 0, 0, 2>" $((PX4K*2))
 run_op nms_4k "NMS_3x3" "k_nms3x3_rows" $((PX4K*5))
+run_op filter_sobel_4k "filter2D_7x7_i8_->_gray_->_Sobel" "k_filter_rows_mfma<7, 3, 0, 0, 0, 1>" $((PX4K*7))
