@@ -941,6 +941,28 @@ def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
         b.free()
 
 
+def test_filter2d_sobel_fused_unequal_plane_layouts(ctx, oracle):
+    """gradient planes with different row steps, or rows that are not 8-byte aligned, take the two-launch path: same bytes"""
+    n, rows, cols = 2, 40, 512
+    r = np.random.default_rng(77 + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    k = r.integers(-6, 7, size=(5, 5)).astype(np.int8)
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    src.upload(frames)
+    for stepx, stepy in ((cols * 2 + 16, cols * 2 + 32), (cols * 2 + 2, cols * 2 + 2)):
+        dx = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=stepx)
+        dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=stepy)
+        launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, 5))
+        assert "k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>" not in launched and "k_sobel" in launched, launched
+        gx, gy = dx.download(), dy.download()
+        for i in range(n):
+            wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, 5)))
+            assert np.array_equal(gx[i].reshape(rows, cols), wx.reshape(rows, cols)) and np.array_equal(gy[i].reshape(rows, cols), wy.reshape(rows, cols))
+        dx.free()
+        dy.free()
+    src.free()
+
+
 def test_filter2d_sobel_host_mat_and_arguments(ctx, oracle, rng):
     img = rand_img(rng, 31, 48, 3)
     k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int8)
