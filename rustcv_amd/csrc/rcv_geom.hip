@@ -299,7 +299,7 @@ __device__ __forceinline__ void store_quad_ragged(uint8_t* q, uint32_t a, uint32
     }
 }
 
-// One wave's share of k_warp_affine_bgr / of the tiles k_warp_affine_bgr_lds cannot stage: column x, rows ybase .. ybase + 7 of
+// One wave's share of k_warp_affine_bgr / of the tiles k_warp_affine_lds<3> cannot stage: column x, rows ybase .. ybase + 7 of
 // frames f0 .. f1 - 1.  The map is the same for every frame of a batch, so the source coordinates, tap offsets and lerp weights
 // of the thread's 8 pixels -- a quarter of the interior path's arithmetic -- are computed once and reused for every frame.
 // The tap loads are unconditional (clamped tap windows): a branch around them would make the compiler wait vmcnt(0) row by row.
@@ -546,10 +546,16 @@ __device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint
 
 // RAGS: source rows of any alignment (an odd width of a packed image): a chunk's 12 bytes are fetched as the 16 aligned bytes
 // that contain them and shifted into place with v_alignbyte when they are written to LDS.
-template <bool RAGS>
-__global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
-                                                                int tiles_per_xcd)
+// CH = 1 (one-channel images): the same tiles, patch geometry and LDS layout (one dword per patch pixel).  A chunk's 4 pixels are
+// fetched as the 8 aligned bytes that contain pixels x .. x+4 and written as the four dwords {g(x) g(x+1) . .}: ONE ds_read2_b32
+// returns the two tap pairs of a pixel.  The lerp is k_warp_affine_gray's (same f32 operations, same order).
+__device__ __forceinline__ void warp_gray_frame(const View& s, const View& d, const Affine& A, const int frame, const int x, const int ybase);
+
+template <int CH, bool RAGS>
+__global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
+                                                            int tiles_per_xcd)
 {
+    constexpr bool AL = RAGS || CH == 1;   // chunks are fetched as aligned dwords and shifted into place
     extern __shared__ __attribute__((aligned(16))) uint8_t wl_lds[];
     // Tile order: hardware places block b on XCD b % 8.  With tiles_per_xcd > 0 every XCD works through its own contiguous run
     // of the (frame group, tile row, tile column) list in raster order: the patches of neighbouring tiles overlap (the bounding
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     // every tap of the tile inside the source, one more row of slack below (the last 12-byte chunk of a patch row may read past
     // the row's end into the next row), 32-bit in-frame offsets, 4-byte aligned rows in every frame
     bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
-              (RAGS || (((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0)) && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+              (AL || (((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0)) && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
               (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
     int ix0 = 0, iy0 = 0;
     if (ok) {
@@ -588,7 +594,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
         ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
     }
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {   // (the same value in every lane of the workgroup)
-        warp_bgr_wave(s, d, A, f0, f1, x, ybase);
+        if constexpr (CH == 3) warp_bgr_wave(s, d, A, f0, f1, x, ybase);
+        else
+            for (int f = f0; f < f1; ++f) warp_gray_frame(s, d, A, f, x, ybase);
         return;
     }
     ix0 = __builtin_amdgcn_readfirstlane(ix0);
@@ -609,10 +617,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     const int xq = x & ~3, yi = ybase + (lane & 3);
     unsigned so[kWarpRows / 4];
 #pragma unroll
-    for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + 3u * (unsigned)xq;
+    for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + (unsigned)CH * (unsigned)xq;
     // ---- staging plan: chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ... ----
     const int nchunks = prow * cpr;             // <= kWlMaxG * 256 (host)
-    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - (RAGS ? 16u : 12u);
+    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - (CH == 1 ? 8u : (RAGS ? 16u : 12u));
     unsigned goff[kWlMaxG], loff[kWlMaxG];
     bool gval[kWlMaxG];
 #pragma unroll
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
         gval[g] = c < nchunks;
         const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
         // rows below the source and a chunk past the frame's end are read from a clamped position: no tap lies in them
-        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(3 * (ix0 + 4 * col)), frame_lim);
+        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(CH * (ix0 + 4 * col)), frame_lim);
         loff[g] = (unsigned)(row * pitch + 16 * col);
     }
     const int ng = (nchunks + kBlock - 1) / kBlock;
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
     unsigned gmis[kWlMaxG];  // RAGS: byte position of the chunk inside them
     auto gload = [&](int f) {
         const uint8_t* fb = s.p + (size_t)f * s.fstride;
-        const unsigned fmis = RAGS ? (unsigned)((uintptr_t)fb & 3) : 0u;   // the frame base, aligned down: offsets stay non-negative
+        const unsigned fmis = AL ? (unsigned)((uintptr_t)fb & 3) : 0u;   // the frame base, aligned down: offsets stay non-negative
         cgp sf = (cgp)(fb - fmis);
         asm("" : "+s"(sf));
 #pragma unroll
@@ -643,7 +651,13 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
             if (g < ng) {   // uniform
                 unsigned o = goff[g] + fmis;
                 asm("" : "+v"(o));
-                if constexpr (RAGS) {
+                if constexpr (CH == 1) {
+                    typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(1))) u2v_ gU2;
+                    gmis[g] = o & 3u;
+                    const u2v_ t = *(const gU2*)(sf + (o & ~3u));
+                    G[g] = u4v{t.x, t.y, 0u, 0u};
+                } else if constexpr (RAGS) {
                     gmis[g] = o & 3u;
                     G[g] = *(const gU4*)(sf + (o & ~3u));
                 } else {
@@ -658,7 +672,13 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
         uint8_t* buf = wl_lds + ((f - f0) & 1) * bufbytes;
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
-            if (gval[g]) {   // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
+            if (gval[g]) {
+                if constexpr (CH == 1) {   // pixels x .. x+4 -> four dwords {g(x+i) g(x+i+1) . .}
+                    const uint32_t e0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]), e1 = __builtin_amdgcn_alignbyte(0u, G[g].y, gmis[g]);
+                    *(u4v*)(buf + loff[g]) = u4v{e0, __builtin_amdgcn_alignbyte(e1, e0, 1), __builtin_amdgcn_alignbyte(e1, e0, 2), __builtin_amdgcn_alignbyte(e1, e0, 3)};
+                    continue;
+                }
+                // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
                 uint32_t c0 = G[g].x, c1 = G[g].y, c2 = G[g].z;
                 if constexpr (RAGS) {
                     c0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]);
@@ -679,12 +699,30 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
                 const int r = 4 * h + i;
                 const uint32_t* pa = (const uint32_t*)(buf + la[r]);
                 const uint32_t* pb = (const uint32_t*)(buf + la[r] + pitch);
-                t[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[r]);
+                if constexpr (CH == 1) {
+                    const uint32_t a = pa[0], b = pb[0];
+                    const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
+                    const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
+                    t[i] = (uint32_t)(int)floorf(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
+                } else {
+                    t[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[r]);
+                }
             }
             // quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
             // (the same transpose through LDS -- four dword writes and one ds_read_b128 per wave instead of 16 VALU
             //  instructions -- timed the same: 1.655 against 1.645 ms)
             quad_transpose4(t, lane);
+            if constexpr (CH == 1) {
+                if (xq < d.cols && yi + 4 * h < d.rows) {   // lane 4q+i: pixels 4q .. 4q+3 of row 4h+i as one dword
+                    typedef uint32_t u1m __attribute__((aligned(1)));
+                    uint8_t* q = d.p + (size_t)f * d.fstride + so[h];
+                    const uint32_t v = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+                    if (d.cols - xq >= 4) *(u1m*)q = v;
+                    else
+                        for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(v >> (8 * j));
+                }
+                continue;
+            }
             if (xq < d.cols && yi + 4 * h < d.rows) {
                 unsigned o = so[h];
                 asm("" : "+v"(o));
@@ -705,14 +743,12 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr_lds(View s, View d, 
 // per source row: 16 tap loads in flight per lane), shifts it into place with v_alignbyte, lerps top and bottom rows as one
 // packed-f32 pair, and after a quad transpose every lane stores the 4 pixels of one row as a dword.  Waves that touch the
 // border run warp_px<1> per pixel (same f32 operations, same order).
-__global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Affine A)
+__device__ __forceinline__ void warp_gray_frame(const View& s, const View& d, const Affine& A, const int frame, const int x, const int ybase)
 {
-    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
-    uint8_t* dfr = d.p + (size_t)blockIdx.z * d.fstride;
+    const uint8_t* sf = s.p + (size_t)frame * s.fstride;
+    uint8_t* dfr = d.p + (size_t)frame * d.fstride;
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * kBlock + threadIdx.x;   // d.cols % 4 == 0: quads never straddle the row end
     const float fxx = (float)min(x, d.cols - 1);
-    const int ybase = blockIdx.y * kWarpRows;
     const float fy0 = (float)min(ybase, d.rows - 1), fy1 = (float)min(ybase + kWarpRows - 1, d.rows - 1);
     const float xa = fmaf(A.m[0], fxx, fmaf(A.m[1], fy0, A.m[2])), xb = fmaf(A.m[0], fxx, fmaf(A.m[1], fy1, A.m[2]));
     const float ya = fmaf(A.m[3], fxx, fmaf(A.m[4], fy0, A.m[5])), yb = fmaf(A.m[3], fxx, fmaf(A.m[4], fy1, A.m[5]));
@@ -770,6 +806,11 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Aff
                 for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(v >> (8 * j));
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_warp_affine_gray(View s, View d, Affine A)
+{
+    warp_gray_frame(s, d, A, (int)blockIdx.z, (int)(blockIdx.x * kBlock + threadIdx.x), (int)blockIdx.y * kWarpRows);
 }
 
 // ---- bilinear resize, BGR, any scale: the register scheme of k_warp_affine_bgr ------------------------------------------
@@ -1056,7 +1097,7 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
     return rcv_launch_check(ctx);
 }
 
-// Patch geometry of k_warp_affine_bgr_lds for the map M: staged rows, 4-pixel chunks per row and the LDS row pitch.  Extents
+// Patch geometry of k_warp_affine_lds for the map M: staged rows, 4-pixel chunks per row and the LDS row pitch.  Extents
 // from the matrix with slack for the floor, the right / lower tap and the 4-pixel alignment of the patch's first column.  The
 // pitch is the one -- of the multiples of 16 bytes that keep both buffers within 64 KB -- for which the 32 lanes of a tap read
 // (ds_read_b32 groups, bank = dword index mod 32) collide least: the lanes of a wave walk along a source row and step to the
@@ -1119,7 +1160,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     Affine A;
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
-    if (s.ch == 3 && s.cols >= 3) {   // (any destination width / alignment: ragged destinations store their quads piecewise)
+    if ((s.ch == 3 && s.cols >= 3) || (s.ch == 1 && s.cols >= 8)) {   // (any destination width / alignment: ragged destinations store their quads piecewise)
         const unsigned gx = (unsigned)((d.cols + kWarpTW - 1) / kWarpTW), band = kWarpRows * (kBlock / kWarpTW);
         const unsigned gy = (unsigned)((d.rows + band - 1) / band);
         // frames per workgroup (the coordinate arithmetic is shared inside a group): as many of 8 / 4 / 2 as still leave >= 8192 workgroups
@@ -1140,18 +1181,18 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
             const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;
             const bool rags = (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4);   // byte-aligned source rows
-            if (rcv_knobs().xcd_order != 0 && tiles < (1ull << 30)) {
-                const int tpx = (int)((tiles + 7) / 8);
-                if (rags) RCV_LAUNCH(k_warp_affine_bgr_lds<true>, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
-                else RCV_LAUNCH(k_warp_affine_bgr_lds<false>, dim3((unsigned)tpx * 8), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
-            } else {
-                if (rags) RCV_LAUNCH(k_warp_affine_bgr_lds<true>, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
-                else RCV_LAUNCH(k_warp_affine_bgr_lds<false>, dim3(lgx, lgy, gz), dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, 0);
-            }
+            const bool xcd = rcv_knobs().xcd_order != 0 && tiles < (1ull << 30);
+            const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
+            const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
+            if (s.ch == 1) RCV_LAUNCH((k_warp_affine_lds<1, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+            else if (rags) RCV_LAUNCH((k_warp_affine_lds<3, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+            else RCV_LAUNCH((k_warp_affine_lds<3, false>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
             return rcv_launch_check(ctx);
         }
-        RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, gy, gz), dim3(kBlock), 0, ctx->stream, s, d, A, fpg);
-        return rcv_launch_check(ctx);
+        if (s.ch == 3) {
+            RCV_LAUNCH(k_warp_affine_bgr, dim3(gx, gy, gz), dim3(kBlock), 0, ctx->stream, s, d, A, fpg);
+            return rcv_launch_check(ctx);
+        }
     }
     if (s.ch == 1 && s.cols >= 8) {   // (any width / alignment of source and destination)
         RCV_LAUNCH(k_warp_affine_gray, dim3((unsigned)((d.cols + kBlock - 1) / kBlock), (d.rows + kWarpRows - 1) / kWarpRows, d.n), dim3(kBlock), 0,

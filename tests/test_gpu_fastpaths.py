@@ -71,8 +71,8 @@ def test_fast_kernels_are_dispatched(ctx):
         ("Harris pipeline gray", lambda: device.harris_pipeline(gray, mask, None, 2, 0.04, 1e-4), "k_harris_fused<false, 2>"),
         ("cornerHarris gray", lambda: device.corner_harris(gray, resp, 2, 0.04), "k_harris_fused<true, 2, false>"),
         ("NMS 3x3", lambda: device.nms3x3(resp, mask, 1e-4), "k_nms3x3_rows"),
-        ("warpAffine BGR", lambda: device.warp_affine(bgr, bgr2, M), "k_warp_affine_bgr"),
-        ("warpAffine gray", lambda: device.warp_affine(gray, gray2, M), "k_warp_affine_gray"),
+        ("warpAffine BGR", lambda: device.warp_affine(bgr, bgr2, M), "k_warp_affine_lds<3, false>"),
+        ("warpAffine gray", lambda: device.warp_affine(gray, gray2, M), "k_warp_affine_lds<1, true>"),
         ("resize BGR 4K -> 960x540 (box)", lambda: device.resize(bgr, small), "k_resize_box<4>"),
         ("fused warp -> 4x down-scale", lambda: device.warp_affine_resize(bgr, small, M, rows, cols), "k_warp_resize_box<4>"),
         ("cvtColor BGR2GRAY", lambda: device.cvt_color(bgr, gray2, _ffi.RCV_BGR2GRAY), "k_bgr2gray16"),
@@ -112,7 +112,7 @@ def test_fast_kernels_are_dispatched(ctx):
     cases += [
         ("resize BGR 4K -> 2561x1441 (odd destination width)", lambda: device.resize(bgr, oddsz), "k_resize_bgr"),
         ("resize packed 1919-wide BGR -> 960x540", lambda: device.resize(ow, small), "k_resize_bgr"),
-        ("warpAffine between packed 1919-wide BGR images (byte-aligned rows)", lambda: device.warp_affine(ow, ow2, M), "k_warp_affine_bgr_lds<true>"),
+        ("warpAffine between packed 1919-wide BGR images (byte-aligned rows)", lambda: device.warp_affine(ow, ow2, M), "k_warp_affine_lds<3, true>"),
         ("cvtColor BGR2GRAY, packed 1919-wide", lambda: device.cvt_color(ow, og2, _ffi.RCV_BGR2GRAY), "k_bgr2gray"),
     ]
     # block sizes other than 2: streaming Sobel + the register-window response kernel + streaming NMS

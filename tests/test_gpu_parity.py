@@ -1217,9 +1217,10 @@ def _kernels_launched(ctx, fn):
     return L.rcv__debug_kernels().decode()
 
 
+@pytest.mark.parametrize("ch", [3, 1])
 @pytest.mark.parametrize("case", range(14))
-def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case):
-    """the LDS-staged BGR warp (source patch of a 64 x 32 tile copied to LDS, taps from LDS) on maps whose patch fits --
+def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case, ch):
+    """the LDS-staged warp, BGR and one-channel (source patch of a 64 x 32 tile copied to LDS, taps from LDS) on maps whose patch fits --
     rotations of any angle, scales, shears, translations -- over images with interior tiles, border tiles and tiles wholly
     outside the source; batches split into frame groups of 1 / 2 / 3 / 8 frames (incomplete last group); same bytes as the
     oracle and as the gather kernel (RCV_WARP_LDS=0)"""
@@ -1244,26 +1245,27 @@ def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case):
     else:             # general affine near the identity
         M = (np.array([1, 0, 0, 0, 1, 0]) + rng.uniform(-0.25, 0.25, 6) * np.array([1, 1, 40, 1, 1, 40])).astype(np.float32)
     M = np.asarray(M, np.float32)
-    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
-    src, dst = device.DeviceBatch(ctx, n, sr, sc, 3), device.DeviceBatch(ctx, n, dr, dc, 3, step=dc * 3 + (4 if case % 2 == 0 else 1) * int(rng.integers(0, 3)))
+    frames = rng.integers(0, 256, size=(n, sr, sc, ch), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, sr, sc, ch, step=sc * ch + (int(rng.integers(0, 4)) if ch == 1 and case % 3 == 0 else 0))   # (one channel: rows of any alignment)
+    dst = device.DeviceBatch(ctx, n, dr, dc, ch, step=dc * ch + (4 if case % 2 == 0 else 1) * int(rng.integers(0, 3)))
     src.upload(frames)
-    want = [oracle.warp_affine(frames[i], M, dr, dc) for i in range(n)]
+    want = [oracle.warp_affine(frames[i] if ch == 3 else frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, ch) for i in range(n)]
     for fpg in (0, 1, 2, 3, 8):
         if fpg:
             knob("RCV_WARP_FPG", fpg)
         dst.memset(0xAB)
         launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
-        assert "k_warp_affine_bgr_lds" in launched, (launched, M)
+        assert ("k_warp_affine_lds<%d" % ch) in launched, (launched, M)
         got = dst.download()
         for i in range(n):
-            assert np.array_equal(got[i], want[i]), (case, fpg, i, M.tolist(), (sr, sc, dr, dc))
+            assert np.array_equal(got[i].reshape(dr, dc, ch), want[i]), (case, fpg, i, M.tolist(), (sr, sc, dr, dc))
     knob("RCV_WARP_LDS", 0)
     dst.memset(0xCD)
     launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
-    assert launched.split(";") == ["k_warp_affine_bgr"], launched
+    assert launched.split(";") == ["k_warp_affine_bgr" if ch == 3 else "k_warp_affine_gray"], launched
     got = dst.download()
     for i in range(n):
-        assert np.array_equal(got[i], want[i]), (case, "gather", i)
+        assert np.array_equal(got[i].reshape(dr, dc, ch), want[i]), (case, "gather", i)
     src.free()
     dst.free()
 

@@ -24,7 +24,7 @@ run_op bgr2gray_4k "BGR2GRAY" "k_bgr2gray16" $((PX4K*4))
 run_op sobel_4k "Sobel_3x3_->_dx,dy_i16_@_4K" "k_sobel_rows<0, false" $((PX4K*5))
 run_op harris_4k "Harris_pipeline_(BGR->mask)_@_4K" "k_harris_fused<false, 0," $((PX4K*4))
 run_op harris_b3_4k "Harris_pipeline_blockSize_3" "k_harris_blocks_fused" $((PX4K*4))
-run_op warp_8k "warpAffine_bilinear_(rot_7deg)" "k_warp_affine_bgr_lds" $((PX8K*6))
+run_op warp_8k "warpAffine_bilinear_(rot_7deg)" "k_warp_affine_lds<3" $((PX8K*6))
 PXO=$((32*1080*1920))
 run_op warp_resize_fused "warpAffine_+_resize" "k_warp_resize_box" $((PXO*30))
 run_op resize_5k "resize_8K_->_5K" "k_resize_bgr" $((32*2880*5120*975/100))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak_warp.py [N] -- N seeded random (shape, map, batch, frames-per-workgroup) cases of the BGR warpAffine against the oracle,
+"""tools/soak_warp.py [N] [CH] -- N seeded random (shape, map, batch, frames-per-workgroup) cases of the BGR (CH = 1: one-channel) warpAffine against the oracle,
 run from the repo root on a GPU box; prints how many launches took the LDS-staged kernel and the number of mismatches (round 2: 400 cases,
 676 launches on the LDS kernel, 0 mismatches)."""
 import os, sys
@@ -19,6 +19,7 @@ L = _ffi.lib()
 bad = 0
 nlds = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+CH = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 for case in range(N):
     rng = np.random.default_rng(0xABCD00 + case)
     sr, sc = int(rng.integers(40, 700)), int(rng.integers(40, 900))
@@ -36,9 +37,9 @@ for case in range(N):
     elif kind == 6: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, 0, 0) * np.float32(rng.uniform(0.5, 1.6))
     else: M = np.array([float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 800)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 600))], np.float32)
     M = np.asarray(M, np.float32)
-    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
-    src = device.DeviceBatch(ctx, n, sr, sc, 3)
-    dst = device.DeviceBatch(ctx, n, dr, dc, 3)
+    frames = rng.integers(0, 256, size=(n, sr, sc, CH), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, sr, sc, CH, step=sc * CH + (int(rng.integers(0, 4)) if CH == 1 and case % 2 else 0))
+    dst = device.DeviceBatch(ctx, n, dr, dc, CH)
     src.upload(frames)
     for fpg in (0, int(rng.integers(1, 9))):
         os.environ.pop("RCV_WARP_FPG", None)
@@ -52,10 +53,10 @@ for case in range(N):
         nlds += "lds" in k
         got = dst.download()
         for i in range(n):
-            want = oracle.warp_affine(frames[i], M, dr, dc)
-            if not np.array_equal(got[i], want):
+            want = oracle.warp_affine(frames[i] if CH == 3 else frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, CH)
+            if not np.array_equal(got[i].reshape(dr, dc, CH), want):
                 bad += 1
-                print("MISMATCH", case, fpg, i, k, M.tolist(), (sr, sc, dr, dc, n), int((got[i] != want).sum()), flush=True)
+                print("MISMATCH", case, fpg, i, k, M.tolist(), (sr, sc, dr, dc, n), int((got[i].reshape(dr, dc, CH) != want).sum()), flush=True)
                 break
     src.free(); dst.free()
 print(f"soak: {N} cases, {nlds} launches on the LDS kernel, {bad} mismatches")
