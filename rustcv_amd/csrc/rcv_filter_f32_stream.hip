@@ -207,15 +207,38 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     // outputs above the segment, which are never stored).
     int r0 = ys - RAD;
     r0 = r0 >= 0 ? r0 / KS * KS : -((-r0 + KS - 1) / KS) * KS;
-    uint32_t cur[NR], nxt[NR];
-    load_row(r0, cur);
+    // AH rows are in flight while one is consumed: two for the separable passes (the 7-tap Gaussian 1.05 -> 0.95 ms on 64 4K
+    // frames, 9 taps 1.33 -> 1.24, one-channel 7 taps 0.38 -> 0.33), one for the dense kernels (VALU-bound: a second row in
+    // flight costs registers and time, 7x7 1.88 -> 2.1 ms).  The AH + 1 row buffers take their roles by static index inside the
+    // unrolled block of KS rows, so rows are not copied from buffer to buffer; after the block the live ones move back to the
+    // canonical places (once per KS rows, and not at all when KS is a multiple of AH + 1).
+#ifndef RCV_FS_AHEAD
+#define RCV_FS_AHEAD (SEP ? 2 : 1)
+#endif
+    constexpr int AH = RCV_FS_AHEAD, NBUF = AH + 1;
+    uint32_t B[NBUF][NR];
+#pragma unroll
+    for (int i = 0; i < AH; ++i) load_row(r0 + i, B[i]);
     for (int rb = r0; rb <= ye - 1 + RAD; rb += KS) {
         static_for<0, KS>([&](auto I) __attribute__((always_inline)) {
-            load_row(rb + I + 1, nxt);   // next row in flight while this one is consumed
-            feed(cur, rb + I, I);
-#pragma unroll
-            for (int q = 0; q < NR; ++q) cur[q] = nxt[q];
+            constexpr int c = decltype(I)::value % NBUF, l = (decltype(I)::value + AH) % NBUF;
+            load_row(rb + I + AH, B[l]);
+            feed(B[c], rb + I, I);
         });
+        constexpr int sh = KS % NBUF;   // the live rows sit in B[(sh + j) % NBUF], j = 0 .. AH-1
+        if constexpr (sh != 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                if constexpr (NBUF == 2) B[0][q] = B[1][q];
+                else if constexpr (sh == 1) {
+                    B[0][q] = B[1][q];
+                    B[1][q] = B[2][q];
+                } else {
+                    B[1][q] = B[0][q];
+                    B[0][q] = B[2][q];
+                }
+            }
+        }
     }
 }
 
