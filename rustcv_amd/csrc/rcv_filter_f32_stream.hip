@@ -65,8 +65,21 @@ __device__ __forceinline__ f2 pk_fma_w(int half, f2 wp, f2 x, f2 acc)
 // ALIGNED dwords that contain it and shifted into place with v_alignbyte (unaligned per-lane loads would serialise in the
 // address path); results go out as unaligned dword stores, the row's last partial dword byte by byte (EDGE instantiation).
 template <int KS, int CH, bool SEP, bool EDGE, int BPT, bool RAG = false>
-__global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows, int edge_nl, int edge_nr)
+__global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FWeights<KS, SEP> W, int seg_rows, int edge_nl, int edge_nr, int gx, int gy,
+                                                              int nblocks, int blocks_per_xcd)
 {
+    // Block order (speed only): hardware places block b on XCD b % 8; with blocks_per_xcd > 0 (one-dimensional grid) every XCD works
+    // through its own contiguous eighth of the (frame, row segment, column block) list, so that what ONE XCD has in flight is a
+    // compact address range
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (blocks_per_xcd > 0) {
+        const int tb = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);
+        if (tb >= nblocks) return;
+        bz = tb / (gx * gy);
+        const int rem = tb - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
     constexpr int RAD = KS / 2;
     constexpr int LEAD = RAD * CH;                 // bytes of halo on each side of the 4 owned bytes
     constexpr int LEADW = (LEAD + 3) / 4 * 4;      // window starts LEADW bytes before the owned dword
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     constexpr int NP = BPT / 2;                      // packed sample pairs per thread
     constexpr int NR = EDGE ? NB : (RAG ? NW + 2 : NW);   // registers per staged row (RAG: NW + 1 aligned dwords and the byte shift)
     const int rowbytes = s.cols * CH;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = bx * (int)blockDim.x + (int)threadIdx.x;
     if (EDGE) {
         if (t >= edge_nl + edge_nr) return;
         if (t >= edge_nl) t = (rowbytes + BPT - 1) / BPT - edge_nr + (t - edge_nl);
@@ -84,9 +97,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     const int xb0 = BPT * t;
     if (xb0 >= rowbytes) return;
     if (RAG && !EDGE && xb0 + BPT > rowbytes) return;   // the row's last, partial dword belongs to the EDGE launch
-    const int ys = blockIdx.y * seg_rows, ye = min(s.rows, ys + seg_rows);
-    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
-    uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride + xb0;
+    const int ys = by * seg_rows, ye = min(s.rows, ys + seg_rows);
+    const uint8_t* sf = s.p + (size_t)bz * s.fstride;
+    uint8_t* df = d.p + (size_t)bz * d.fstride + xb0;
     // The window is clamped into the row, so the first/last few threads of a row compute garbage: the host
     // re-does exactly those byte columns with the generic kernel right after this launch (no divergent slow path here).
     const int wstart = EDGE ? 0 : min(max(xb0 - LEADW, 0), rowbytes - 4 * NW);
@@ -258,7 +271,13 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     int seg = s.rows;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < 4096 && seg > 8 * KS) seg = (seg + 1) / 2;
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
-    RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), dim3(gx, gy, s.n), dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0);
+    {
+        const long long nb = (long long)gx * gy * s.n;
+        const bool xcd = rcv_knobs().xcd_order != 0 && nb < (1LL << 30);
+        const int bpx = xcd ? (int)((nb + 7) / 8) : 0;
+        const dim3 grid = xcd ? dim3((unsigned)bpx * 8u) : dim3(gx, gy, s.n);
+        RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
+    }
     RCV_TRY(rcv_launch_check(ctx));
     // threads whose window [xb0 - LEADW, xb0 - LEADW + 4 NW) left the row computed garbage: the first nl and the last nr of a
     // row -- redone by the EDGE instantiation (one wave per row segment: rows are short work, so use many small segments)
@@ -267,7 +286,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     const int nl = min((LEADW + BPT - 1) / BPT, nthreads), nr = max(0, min(nthreads - hi_begin / BPT, nthreads - nl));
     const int eseg = 4 * KS < 32 ? 32 : 4 * KS;
     RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, true, BPT, RAG>), dim3((unsigned)((nl + nr + 63) / 64), (unsigned)((s.rows + eseg - 1) / eseg), s.n),
-                       dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr);
+                       dim3(64), 0, ctx->stream, s, d, W, eseg, nl, nr, 0, 0, 0, 0);
     return rcv_launch_check(ctx);
 }
 
