@@ -38,7 +38,7 @@ for (rows, cols) in ((2160, 3840), (2159, 3839), (2160, 3838), (2160, 3836)):
            ("gray filter 7x7", lambda: device.filter2d(gray, gray2, k7, shift=6)),
            ("BGRA -> BGR", lambda: device.cvt_color(bgra, bgr2, _ffi.RCV_BGRA2BGR)), ("BGR -> RGB", lambda: device.cvt_color(bgr, bgr2, _ffi.RCV_BGR2RGB)),
            ("BGR -> BGRX", lambda: device.cvt_color(bgr, bgra, _ffi.RCV_BGR2BGRX)),
-           ("Sobel of BGR", lambda: device.sobel(bgr, dx, dy)), ("fused warp + 2x down-scale", lambda: device.warp_affine_resize(bgr, half, M, 2 * (rows // 2), 2 * (cols // 2)))]
+           ("Sobel of BGR", lambda: device.sobel(bgr, dx, dy)), ("filter2D 7x7 -> gray -> Sobel", lambda: device.filter2d_sobel(bgr, dx, dy, k7, shift=6)), ("fused warp + 2x down-scale", lambda: device.warp_affine_resize(bgr, half, M, 2 * (rows // 2), 2 * (cols // 2)))]
     print(f"---- {cols} x {rows}, {n} frames")
     for name, fn in ops:
         print(f"{name:24s} {t(fn):8.3f} ms   {kern(fn)}", flush=True)
