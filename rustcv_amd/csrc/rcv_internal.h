@@ -161,3 +161,28 @@ static inline rcv_batch rcv_single(const rcv_mat* dev)
 }
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Row-segment height for SMALL launches of the VALU-bound register-window kernels (one wave per (strip, segment, frame)); returns
+// 0 when the launch is large (more than 4 waves per SIMD at 90-row segments: the caller's own plan for full GPUs applies).  When
+// all waves of a launch are resident at once, every SIMD issues for its waves in turn and the launch takes ceil(waves / SIMDs)
+// segment times -- not ceil(waves / resident slots); a SIMD with a single wave cannot hide its memory latency (x1.25), with two
+// barely (x1.06).  `overhead` = rows a segment streams beyond its own (halo + pipeline fill + set-up).  Measured with the Harris
+// pipeline on 1 / 4 / 8 / 16 4K frames: 0.046 -> 0.027, 0.070 -> 0.040, 0.098 -> 0.076, 0.158 -> 0.147 ms.
+static inline int rcv_plan_seg_rows(int rows, long long waves_per_seg, int cu_count, int overhead, int min_seg)
+{
+    const long long simds = 4LL * (cu_count > 0 ? cu_count : 256);
+    if (waves_per_seg * ((rows + 89) / 90) > 4 * simds) return 0;
+    int seg = rows;
+    double best = 1e300;
+    for (int ns = 1; ns <= rows; ++ns) {
+        const int sr = (rows + ns - 1) / ns;
+        if (ns > 1 && sr < min_seg) break;
+        const long long per_simd = (waves_per_seg * ((rows + sr - 1) / sr) + simds - 1) / simds;
+        const double cost = (double)per_simd * (sr + overhead) * (per_simd < 2 ? 1.25 : (per_simd < 3 ? 1.06 : 1.0));
+        if (cost < best) {
+            best = cost;
+            seg = sr;
+        }
+    }
+    return seg;
+}
