@@ -274,6 +274,10 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     // 0.326 ms at 4096 workgroups, 0.287 / 0.932 / 0.306 at 2048-3072; 3 taps the other way (0.758 -> 0.736 at 8192)
     constexpr int kMinBlocks = KS <= 3 ? 8192 : 2560;
     while ((long long)gx * ((s.rows + seg - 1) / seg) * s.n < kMinBlocks && seg > 8 * KS) seg = (seg + 1) / 2;
+    {   // small launches: every SIMD one wave, as short as the halo allows (rcv_plan_seg_rows; 2 * (KS - 1) halo / stream-start rows)
+        const int small = rcv_plan_seg_rows(s.rows, 4LL * gx * s.n, ctx->cu_count, 2 * (KS - 1) + 4, 2 * KS);
+        if (small > 0 && small < seg) seg = small;
+    }
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
     {
         const long long nb = (long long)gx * gy * s.n;

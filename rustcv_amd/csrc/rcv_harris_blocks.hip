@@ -739,7 +739,7 @@ int rcv_harris_blocks_fused(rcv_ctx* ctx, const View& s, const View* r, const Vi
     int seg = s.rows;
     while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 8192 && seg > 96) seg = (seg + 1) / 2;
     {   // small launches: rcv_plan_seg_rows (block + 3 rows of pipeline fill, + set-up)
-        const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, block + 10, 32);
+        const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, block + 10, 16);
         if (small > 0) seg = small;
     }
     a.seg_rows = seg;

@@ -454,7 +454,7 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
         }
     }
     {   // small launches: rcv_plan_seg_rows (a segment streams 5 rows of halo / pipeline fill, ~8 more in set-up time)
-        const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, 13, 32);
+        const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, 13, 16);
         if (small > 0) seg = small;
     }
     if (rcv_knobs().harris_seg_rows > 0) seg = rcv_knobs().harris_seg_rows;
