@@ -313,7 +313,9 @@ int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksi
     }
     // 8 bytes per thread where rows and row ends are 8-byte aligned (the halo conversions are shared by twice the samples)
     const bool wide = (s.cols * s.ch) % 8 == 0 && (uintptr_t)s.p % 8 == 0 && s.step % 8 == 0 && (s.n <= 1 || s.fstride % 8 == 0) &&
-                      (uintptr_t)d.p % 8 == 0 && d.step % 8 == 0 && (d.n <= 1 || d.fstride % 8 == 0);
+                      (uintptr_t)d.p % 8 == 0 && d.step % 8 == 0 && (d.n <= 1 || d.fstride % 8 == 0) &&
+                      // (small launches -- at most ~2 rows of 8-byte threads per SIMD lane -- are latency-bound: twice the threads, half the work per row)
+                      (long long)s.rows * s.n * ((s.cols * s.ch + 7) / 8) > 128LL * 64 * 4 * ctx->cu_count;   // (one or two 4K frames, four 1080p: -15 % with 4-byte threads)
 #define RCV_CASE(KS, CH)                                                                 \
     if (ksize == KS && s.ch == CH) {                                                     \
         if (wide) {                                                                      \
