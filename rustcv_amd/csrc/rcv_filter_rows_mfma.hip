@@ -794,6 +794,10 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
             const long long most = (G + 31) / 32;
             if (nb > most) nb = most;
             if (nb < 1) nb = 1;
+            // few frames: every SIMD one or two waves of equal length (rcv_plan_seg_rows; a band streams ksize - 1 halo rows and fills
+            // its pipeline with a few more)
+            const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 16);
+            if (small > 0) nb = (G + small - 1) / small;
         }
         a.nbands = (int)nb;
         a.bands_per_xcd = (int)((nb + 7) / 8);
