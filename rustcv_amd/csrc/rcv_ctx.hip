@@ -5,13 +5,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 
 extern "C" int rcv_abi_version(void) { return RCV_ABI_VERSION; }
 
 // ---- environment knobs, read once ----
 static RcvKnobs g_knobs;
-static bool g_knobs_loaded = false;
+static std::once_flag g_knobs_once;
 static int env_int(const char* name, int unset)
 {
     const char* e = getenv(name);
@@ -30,6 +31,7 @@ static void load_knobs()
     g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
     g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
+    g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
@@ -37,14 +39,18 @@ static void load_knobs()
     g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
     g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
-    g_knobs_loaded = true;
 }
 const RcvKnobs& rcv_knobs()
 {
-    if (!g_knobs_loaded) load_knobs();   // (first use races only write the same values)
+    std::call_once(g_knobs_once, load_knobs);   // DeviceGroup's per-GPU threads may all arrive here first
     return g_knobs;
 }
-extern "C" void rcv__debug_reload_knobs(void) { load_knobs(); }
+// tests and tuning tools only, after setenv: the caller must have no launch in flight on another thread
+extern "C" void rcv__debug_reload_knobs(void)
+{
+    std::call_once(g_knobs_once, [] {});
+    load_knobs();
+}
 
 // ---- per-thread log of launched kernels (tests: which kernel did this entry point dispatch?) ----
 static thread_local char t_kernels[1024];
@@ -115,7 +121,7 @@ extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->kconst, 65536);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->kconst, RCV_KC_BYTES);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         rcv_ctx_destroy(c);

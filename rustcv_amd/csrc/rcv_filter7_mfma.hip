@@ -652,18 +652,18 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
 
     // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered).  While a graph is
     // being recorded the table goes into a buffer the graph owns, so that replays never depend on this cache.
-    const uint8_t* wtab = ctx->kconst;
+    const uint8_t* wtab = ctx->kconst + RCV_KC_F7_TAB;
     if (ctx->capturing) {
         int8_t tab[2 * 4 * 64 * 16];
         build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
         if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
-        RCV_TRY(rcv_const_table(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0, &wtab));
+        RCV_TRY(rcv_const_table(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, RCV_KC_F7_TAB, &wtab));
     } else if (!ctx->f7_valid || ctx->f7_ksize != ksize || ctx->f7_mode != mode || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
         int8_t tab[2 * 4 * 64 * 16];
         build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
         if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
         ctx->f7_valid = false;
-        RCV_TRY(rcv_upload_const(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, 0));
+        RCV_TRY(rcv_upload_const(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, RCV_KC_F7_TAB));
         RCV_HIP(hipStreamSynchronize(ctx->stream)); // `tab` is on this stack frame
         memcpy(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t));
         ctx->f7_ksize = ksize;
@@ -675,7 +675,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.src = s.p;
     a.dst = d.p;
     a.wtab = (const uint4*)wtab;
-    a.dump = ctx->kconst + 16384;
+    a.dump = ctx->kconst + RCV_KC_F7_DUMP;
     a.sstep = s.step;
     a.dstep = d.step;
     a.sfs = s.fstride;

@@ -64,6 +64,7 @@ struct FRArgs {
     int nstrips, nframes;
     int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
+    int wpb;                     // waves per workgroup (1, 2, 4 or 8): independent waves, neighbouring strips of a band on one CU
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
     uint8_t *gdx, *gdy;          // SOB: the i16 gradient planes (one channel), row step / frame stride in bytes
@@ -491,6 +492,16 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             const int u = u0 + s;
             if (u >= nsteps) break;
             request(u + RP - 1, (s + RP - 1) % RP);
+            if constexpr ((DBG & 256) != 0) {
+                // the kernel's memory pattern alone: the loads of the real kernel, and its stores fed with loaded bytes (no
+                // de-interleave, no MFMA, no epilogue) -- the ceiling of THIS access pattern (bench.py: copy_ceiling)
+                const v4i& w0 = W[s % RP][0];
+                const v4i& w1 = W[s % RP][1];
+                const int y = ys + 2 * u;
+                __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(dframe + (size_t)y * a.dstep + so));
+                if (2 * u + 1 < nrows) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(dframe + (size_t)(y + 1) * a.dstep + so));
+                continue;
+            }
             prepare((s + NP - 1) % RP);
             v4i acc[2][3], acc2[2][3];
             const v4i zerov = v4i{0, 0, 0, 0};
@@ -520,19 +531,26 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 }
 
 template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
-__global__ __launch_bounds__(64, 2) void k_filter_rows_mfma(FRArgs a)
+__global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
 {
-    const int lane = threadIdx.x;
+    // A workgroup is `wpb` independent waves (nothing is shared, no barrier): wave w of workgroup b takes item slot
+    // (b >> 3) * wpb + w of XCD b & 7, so that the waves of one workgroup -- one CU -- are neighbouring strips of one band: their
+    // seam lines meet in that CU's L1 and the CU streams wpb * 768 contiguous bytes per row (RCV_FR_WPB).
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // XCD-aware order (speed only): hardware places block b on XCD b % 8; each XCD gets a contiguous run of bands, and the strips
     // of one band -- which share the 128-B lines at their seams -- are neighbours in dispatch order on one L2
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int strip = slot % a.nstrips;
-    const int bi = slot / a.nstrips;   // dispatch order of this band on its XCD
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * a.wpb + wave;
     // Band order: every XCD works through its own contiguous eighth of the bands, so that what ONE XCD has in flight is a
     // compact piece of the batch (~21 neighbouring bands = one frame).  Measured on 64 4K frames (same box, same run): this
     // order 0.551 ms; bands dealt round-robin to the XCDs (order 1: each XCD's waves spread over eight frames) 0.600 ms; one
     // XCD's concurrent bands spread over its whole eighth 0.639 against 0.579 ms -- the wider the address range an XCD touches
     // at one time, the slower its memory path (translation reach per XCD is the likely cause).  RCV_FR_ORDER keeps it measurable.
+    // (Round 3, DESIGN.md 4.1 "sweep orders": order 1 with bands down to 8 rows -- the whole GPU inside one moving window of a
+    // few MB -- and a plain raster over (band, strip) were measured too: never better than this order, short bands much worse.)
+    const int strip = slot % a.nstrips;
+    const int bi = slot / a.nstrips;   // dispatch order of this band on its XCD
+    if (bi >= a.bands_per_xcd) return;
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (band >= a.nbands) return;
     const int X = strip * (SOB ? 720 : 768);   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset; SOB: strips 240 pixels apart)
@@ -580,30 +598,43 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
 {
 #ifdef RCV_ABLATE
     switch (rcv_debug_flags & 255) {
-    case 32: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 32>), grid, dim3(64), lds, st, a); return;
-    case 96: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 96>), grid, dim3(64), lds, st, a); return;
-    case 128: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 128>), grid, dim3(64), lds, st, a); return;
-    case 224: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 224>), grid, dim3(64), lds, st, a); return;
-    case 36: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 36>), grid, dim3(64), lds, st, a); return;
-    case 100: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 100>), grid, dim3(64), lds, st, a); return;
-    case 132: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 132>), grid, dim3(64), lds, st, a); return;
-    case 228: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 228>), grid, dim3(64), lds, st, a); return;
-    case 37: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 37>), grid, dim3(64), lds, st, a); return;
-    case 101: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 101>), grid, dim3(64), lds, st, a); return;
-    case 229: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 229>), grid, dim3(64), lds, st, a); return;
-    case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 1>), grid, dim3(64), lds, st, a); return;
-    case 2: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 2>), grid, dim3(64), lds, st, a); return;
-    case 3: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 3>), grid, dim3(64), lds, st, a); return;
-    case 4: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 4>), grid, dim3(64), lds, st, a); return;
-    case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 5>), grid, dim3(64), lds, st, a); return;
-    case 6: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 6>), grid, dim3(64), lds, st, a); return;
-    case 8: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 8>), grid, dim3(64), lds, st, a); return;
-    case 16: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 16>), grid, dim3(64), lds, st, a); return;
-    case 18: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 18>), grid, dim3(64), lds, st, a); return;
+    case 32: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 32>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 96: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 96>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 128: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 128>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 224: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 224>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 36: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 36>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 100: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 100>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 132: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 132>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 228: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 228>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 37: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 37>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 101: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 101>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 229: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 229>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 2: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 2>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 3: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 3>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 5>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 6: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 6>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 8: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 8>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 16: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 16>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 18: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 18>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 68: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 4>), grid, dim3(64 * a.wpb), lds, st, a); return;   // (64 + 4: adds instead of MFMAs)
     default: break;
     }
 #endif
-    RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64), lds, st, a);
+    // the kernel's own memory-only variant (its loads and its stores, nothing in between): bench.py times it next to the plain
+    // copies as the ceiling of THIS access pattern (rcv__debug_set(4); the output is not a filtered image)
+#ifdef RCV_ABLATE
+    constexpr bool kMemOnly = KS == 7;
+#else
+    constexpr bool kMemOnly = KS == 7 && PP == 3;
+#endif
+    if constexpr (kMemOnly) {
+        if ((rcv_debug_flags & 255) == 4) {
+            RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 260>), grid, dim3(64 * a.wpb), lds, st, a);
+            return;
+        }
+    }
+    RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64 * a.wpb), lds, st, a);
 }
 
 // which row pairs of which parity carry kernel rows [lo, hi]: the DMASK of a second table confined to those rows
@@ -624,34 +655,37 @@ constexpr int kCentre7 = rows_dmask(7, 2, 4);   // second table in kernel rows 2
 template <int KS>
 void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st)
 {
-    const dim3 grid((unsigned)(a.bands_per_xcd * a.nstrips * 8));
+    const dim3 grid((unsigned)(((long long)a.bands_per_xcd * a.nstrips + a.wpb - 1) / a.wpb * 8));
     if (a.gdx) {   // filter2D -> gray -> Sobel (BGR source, one weight table: the caller checked)
-        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64), lds, st, a);
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (src_yuyv == 1) {   // (one weight table only: the caller checked)
-        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 1>), grid, dim3(64), lds, st, a);
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (src_yuyv == 2) {   // one-channel images
-        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 2>), grid, dim3(64), lds, st, a);
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 2>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     constexpr int kAll = (1 << (2 * ((KS + 1) / 2))) - 1;
     if (src_yuyv == 3) {   // BGR, any width / alignment
-        if (dmask == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 3>), grid, dim3(64), lds, st, a);
-        else if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll, 3>), grid, dim3(64), lds, st, a);
-        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll, 3>), grid, dim3(64), lds, st, a);
+        if (dmask == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 3>), grid, dim3(64 * a.wpb), lds, st, a);
+        else if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll, 3>), grid, dim3(64 * a.wpb), lds, st, a);
+        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll, 3>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (dmask != 0) {   // two weight tables
-        if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>), grid, dim3(64), lds, st, a);
-        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll>), grid, dim3(64), lds, st, a);
+        if (KS == 7 && (dmask & ~kCentre7) == 0) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>), grid, dim3(64 * a.wpb), lds, st, a);
+        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
 #ifdef RCV_ABLATE   // profiling builds: prefetch depth selectable at run time (RCV_FR_PP)
     if (KS == 7 && pp == 2) return launch_rows_dbg<7, 2>(a, grid, lds, st);
     if (KS == 7 && pp == 4) return launch_rows_dbg<7, 4>(a, grid, lds, st);
+    if (KS == 7 && pp == 5) return launch_rows_dbg<7, 5>(a, grid, lds, st);
+    if (KS == 7 && pp == 6) return launch_rows_dbg<7, 6>(a, grid, lds, st);
+    if (KS == 7 && pp == 8) return launch_rows_dbg<7, 8>(a, grid, lds, st);
 #endif
     (void)pp;
     launch_rows_dbg<KS, 3>(a, grid, lds, st);
@@ -738,7 +772,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
                     if (tab[(size_t)(2 * np + t) * 1024 + i]) { dmask |= 1 << t; break; }
         }
         ctx->fr_valid = false;
-        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)(dual ? 4 : 2) * np * 1024, 32768));
+        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)(dual ? 4 : 2) * np * 1024, RCV_KC_FR_TAB));
         RCV_HIP(hipStreamSynchronize(ctx->stream));   // `tab` is on this stack frame
         memcpy(ctx->fr_k, k, (size_t)nk * sizeof(int16_t));
         ctx->fr_ksize = ksize;
@@ -751,8 +785,8 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     FRArgs a;
     a.src = s.p;
     a.dst = d.p;
-    a.wtab = (const uint4*)(ctx->kconst + 32768);
-    a.dump = ctx->kconst + 61440;
+    a.wtab = (const uint4*)(ctx->kconst + RCV_KC_FR_TAB);
+    a.dump = ctx->kconst + RCV_KC_FR_DUMP;
     a.sstep = s.step;
     a.dstep = d.step;
     a.sfs = s.fstride;
@@ -784,8 +818,8 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
             // n % 8 == 0 every XCD works on whole frames.  Measured on 64 4K frames: 21 bands per frame (8 rounds) 0.569 ms, 13.1
             // (5 rounds) 0.646, 15.75 / 18.4 (6 / 7 rounds) 0.592
             long long bpf = (want + s.n / 2) / s.n;
-            const long long most = (s.rows + 31) / 32;       // at least 32 rows per band
-            if (kn.fr_bpf > 0) bpf = kn.fr_bpf;             // tuning knob
+            long long most = (s.rows + 31) / 32;             // at least 32 rows per band
+            if (kn.fr_bpf > 0) bpf = kn.fr_bpf, most = (s.rows + 3) / 4;   // tuning knob (sweep-order ablation: bands down to 4 rows)
             bpf = bpf < 1 ? 1 : (bpf > most ? most : bpf);
             nb = bpf * s.n;
         } else {
@@ -801,14 +835,16 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         }
         a.nbands = (int)nb;
         a.bands_per_xcd = (int)((nb + 7) / 8);
-        a.order = kn.fr_order < 0 ? 0 : kn.fr_order;
+        a.order = kn.fr_order == 1 ? 1 : 0;
     }
     a.shift = shift;
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
+    a.wpb = kn.fr_wpb == 2 || kn.fr_wpb == 4 || kn.fr_wpb == 8 ? kn.fr_wpb : 1;
+    const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)
     const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
-    if (ksize == 7) launch_rows<7>(a, pp, lds, dmask, src_yuyv, ctx->stream);
-    else if (ksize == 5) launch_rows<5>(a, pp, lds, dmask, src_yuyv, ctx->stream);
-    else launch_rows<3>(a, pp, lds, dmask, src_yuyv, ctx->stream);
+    if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
+    else if (ksize == 5) launch_rows<5>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
+    else launch_rows<3>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
     return rcv_launch_check(ctx);
 }

@@ -14,7 +14,8 @@ struct rcv_import {
     hipExternalMemory_t ext;
     void* dev;
     size_t bytes;
-    int fd;   // our duplicate (-1 once the runtime has taken it over)
+    int fd;   // OUR duplicate of the caller's descriptor: this object owns it from dup() until rcv_import_release closes it (the HIP
+              // runtime imports through it and does not take it over; the caller's own fd is never closed here)
 };
 
 extern "C" int rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, size_t bytes, rcv_import** out, void** dev_ptr)
@@ -23,6 +24,7 @@ extern "C" int rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, siz
     *out = nullptr;
     *dev_ptr = nullptr;
     if (dmabuf_fd < 0 || bytes == 0) return RCV_ERR_ARG;
+    if (offset + bytes < offset) return RCV_ERR_SIZE;   // offset + bytes wraps size_t
     RCV_TRY(rcv_bind(ctx));
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;
     rcv_import* im = new (std::nothrow) rcv_import();
@@ -42,8 +44,16 @@ extern "C" int rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, siz
     hd.handle.fd = im->fd;
     // the external-memory object is the WHOLE DMA-BUF (its size from lseek, as for any dma-buf fd); [offset, offset + bytes) of it
     // is mapped below (a capture plane's data_offset; an exporter that sub-allocates)
+    // A DMA-BUF that reports a size SMALLER than offset + bytes cannot hold the described mapping: refuse it (mapping `bytes`
+    // anyway would hand out a device pointer that runs past the real buffer).  The caller's size is only trusted when the
+    // descriptor cannot report one (lseek fails or returns 0: some exporters do not implement it).
     const off_t total = lseek(im->fd, 0, SEEK_END);
-    hd.size = total > 0 && (size_t)total >= offset + bytes ? (size_t)total : offset + bytes;
+    if (total > 0 && (size_t)total < offset + bytes) {
+        close(im->fd);
+        delete im;
+        return RCV_ERR_SIZE;
+    }
+    hd.size = total > 0 ? (size_t)total : offset + bytes;
     hipError_t e = hipImportExternalMemory(&im->ext, &hd);
     if (e == hipSuccess) {
         hipExternalMemoryBufferDesc bd;

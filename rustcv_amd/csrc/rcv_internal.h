@@ -7,6 +7,21 @@
 
 #define RCV_MAX_STAGE 6
 
+// Layout of rcv_ctx::kconst (one 64-KiB device allocation per context: weight tables and the dump lines masked-off lanes store
+// to).  Every user takes its offset from here; the asserts keep the regions apart.
+constexpr size_t RCV_KC_F7_TAB = 0, RCV_KC_F7_TAB_BYTES = 8192;          // strip kernel: 2 x 4 tables x 64 lanes x 16 B
+constexpr size_t RCV_KC_SOBEL_DUMP = 8192, RCV_KC_SOBEL_DUMP_BYTES = 4096;   // 256 lanes x 16 B
+constexpr size_t RCV_KC_F7_DUMP = 16384, RCV_KC_F7_DUMP_BYTES = 4096;    // strip kernel: 3 KiB
+constexpr size_t RCV_KC_FR_TAB = 32768, RCV_KC_FR_TAB_BYTES = 16384;     // row kernel: up to 2 x 2 x 4 tables x 1 KiB (two weight tables)
+constexpr size_t RCV_KC_BENCH = 49152, RCV_KC_BENCH_BYTES = 4096;        // rcv__membench read-only dump (256 threads x 16 B)
+constexpr size_t RCV_KC_PROBE = 57344, RCV_KC_PROBE_BYTES = 128;         // rcv__clock_probe: 8 x 2 counters
+constexpr size_t RCV_KC_FR_DUMP = 61440, RCV_KC_FR_DUMP_BYTES = 1024;    // row kernel: 64 lanes x 16 B
+constexpr size_t RCV_KC_BYTES = 65536;
+static_assert(RCV_KC_F7_TAB + RCV_KC_F7_TAB_BYTES <= RCV_KC_SOBEL_DUMP && RCV_KC_SOBEL_DUMP + RCV_KC_SOBEL_DUMP_BYTES <= RCV_KC_F7_DUMP &&
+              RCV_KC_F7_DUMP + RCV_KC_F7_DUMP_BYTES <= RCV_KC_FR_TAB && RCV_KC_FR_TAB + RCV_KC_FR_TAB_BYTES <= RCV_KC_BENCH &&
+              RCV_KC_BENCH + RCV_KC_BENCH_BYTES <= RCV_KC_PROBE && RCV_KC_PROBE + RCV_KC_PROBE_BYTES <= RCV_KC_FR_DUMP &&
+              RCV_KC_FR_DUMP + RCV_KC_FR_DUMP_BYTES <= RCV_KC_BYTES, "kconst regions overlap");
+
 struct rcv_ctx {
     int device;
     hipStream_t stream;
@@ -24,7 +39,7 @@ struct rcv_ctx {
     // small device scratch for per-call constants (filter taps, weight tables)
     uint8_t* kconst;     // 64 KiB
     int cu_count;
-    // cached banded-weight table of the MFMA filter (rcv_filter7_mfma.hip), lives in kconst[0..4096)
+    // cached banded-weight table of the MFMA filter (rcv_filter7_mfma.hip), lives at RCV_KC_F7_TAB
     bool f7_valid;
     int f7_ksize;
     int f7_mode;         // 0 one table, 1 K = 4Q + R, 2 K = K1 + 2*T2 (which tables the cache holds)
@@ -32,7 +47,7 @@ struct rcv_ctx {
     // cached launch plan of the strip kernel (segment height, latency variant) for the last geometry
     int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_knob, f7_plan_seg_rows;
     bool f7_plan_lat_ok, f7_plan_lat;
-    // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), kconst[32768..40960)
+    // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), at RCV_KC_FR_TAB
     bool fr_valid, fr_split2;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
     bool wl_valid = false, wl_ok = false;
@@ -68,6 +83,7 @@ struct RcvKnobs {
     int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
     int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
     int fr_bpf;           // RCV_FR_BPF        bands per frame (batches of >= 8 frames; 0 = from RCV_FR_ROUNDS)
+    int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)

@@ -42,6 +42,64 @@ __global__ __launch_bounds__(kT) void k_copy_sweep(const uint4* __restrict__ s, 
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += 4 * stride) cp4<NTL, NTS>(s, d, i, stride, n);
 }
 
+// the same sweep with U accesses in flight per thread (10 <= variant < 22: what the in-flight depth and the nt flags are worth)
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(kT) void k_copy_sweep_u(const u4v* __restrict__ s, u4v* __restrict__ d, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += U * stride) {
+        u4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < n) v[u] = NTL ? __builtin_nontemporal_load(s + j) : s[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < n) {
+                if (NTS) __builtin_nontemporal_store(v[u], d + j);
+                else d[j] = v[u];
+            }
+        }
+    }
+}
+
+// Phase experiments (round 3): does it matter WHEN the GPU's reads and writes reach the memory system?  MODE 0: the plain nt
+// sweep; 1: every wave de-synchronised by pseudo-random sleeps; 2: clock-gated -- loads are only issued while bit `hbit` of the
+// chip-wide 100 MHz counter is 0 and stores while it is 1, so the whole GPU alternates between read and write bursts.
+template <int U, int MODE>
+__global__ __launch_bounds__(kT) void k_copy_phase(const u4v* __restrict__ s, u4v* __restrict__ d, size_t n, unsigned half_ticks)
+{
+    const size_t stride = (size_t)gridDim.x * kT;
+    unsigned rng = (blockIdx.x * 2654435761u) ^ ((threadIdx.x >> 6) * 40503u);
+    auto gate = [&](unsigned want) {
+        if (MODE != 2) return;
+        while (((unsigned)(__builtin_amdgcn_s_memrealtime() / half_ticks) & 1u) != want) __builtin_amdgcn_s_sleep(1);
+    };
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += U * stride) {
+        u4v v[U];
+        if (MODE == 1) {
+            rng = rng * 1664525u + 1013904223u;
+            const unsigned k = __builtin_amdgcn_readfirstlane(rng >> 26);   // 0..63 x 64 clocks
+            for (unsigned t = 0; t < k; ++t) __builtin_amdgcn_s_sleep(1);
+        }
+        gate(0u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < n) v[u] = __builtin_nontemporal_load(s + j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gate(1u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < n) __builtin_nontemporal_store(v[u], d + j);
+        }
+    }
+}
+
 // block-contiguous: every workgroup owns one contiguous slice of the buffer
 template <bool NTL, bool NTS>
 __global__ __launch_bounds__(kT) void k_copy_block(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n)
@@ -81,7 +139,46 @@ __global__ __launch_bounds__(kT) void k_write_sweep(uint4* __restrict__ d, size_
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) d[i] = v;
 }
 
+// one wave per XCD-ish (8 workgroups): core-clock cycles (s_memtime) per tick of the constant 100 MHz counter (s_memrealtime)
+// over `ticks` ticks -- the shader clock while whatever else runs on the GPU keeps running
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, unsigned ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0, c1 = c0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+        c1 = __builtin_amdgcn_s_memtime();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 } // namespace
+
+// Shader clock in MHz, sampled for `us` microseconds on the context's SIDE stream -- i.e. concurrently with whatever the caller
+// has enqueued on the context's stream (bench.py: the filter launches).  Blocks until the probe has finished.
+extern "C" int rcv__clock_probe(rcv_ctx* ctx, int us, float* mhz)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!mhz || us < 1 || us > 1000000) return RCV_ERR_ARG;
+    unsigned long long* d = (unsigned long long*)(ctx->kconst + RCV_KC_PROBE);
+    hipLaunchKernelGGL(k_clock_probe, dim3(8), dim3(64), 0, ctx->side, d, (unsigned)us * 100u);
+    unsigned long long h[16];
+    RCV_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->side));
+    RCV_HIP(hipStreamSynchronize(ctx->side));
+    double best = 0.0;
+    for (int i = 0; i < 8; ++i)
+        if (h[2 * i + 1]) {
+            const double f = (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;
+            if (f > best) best = f;
+        }
+    *mhz = (float)best;
+    return RCV_OK;
+}
 
 // variant: 0 hipMemcpyAsync D2D | 1 sweep | 2 block-contiguous | 3 sweep, nt loads + nt stores | 4 sweep, nt stores |
 //          5 block-contiguous, nt loads + nt stores | 6 read only | 7 write only | 8 XCD-local sweep | 9 XCD-local sweep, nt / nt
@@ -101,7 +198,7 @@ extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t by
     case 3: hipLaunchKernelGGL((k_copy_sweep<true, true>), g, b, 0, ctx->stream, s, d, n); break;
     case 4: hipLaunchKernelGGL((k_copy_sweep<false, true>), g, b, 0, ctx->stream, s, d, n); break;
     case 5: hipLaunchKernelGGL((k_copy_block<true, true>), g, b, 0, ctx->stream, s, d, n); break;
-    case 6: hipLaunchKernelGGL(k_read_sweep, g, b, 0, ctx->stream, s, (uint4*)(ctx->kconst + 49152), n); break;
+    case 6: hipLaunchKernelGGL(k_read_sweep, g, b, 0, ctx->stream, s, (uint4*)(ctx->kconst + RCV_KC_BENCH), n); break;
     case 7: hipLaunchKernelGGL(k_write_sweep, g, b, 0, ctx->stream, d, n, 0x5EEDu); break;
     case 8:
         if (grid % 8) return RCV_ERR_ARG;
@@ -111,7 +208,33 @@ extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t by
         if (grid % 8) return RCV_ERR_ARG;
         hipLaunchKernelGGL((k_copy_xcd<true, true>), g, b, 0, ctx->stream, s, d, n);
         break;
-    default: return RCV_ERR_ARG;
+    default:
+        if (variant >= 100 && variant < 400) {
+            // 100 + 100 * mode + 10 * ui + 0: U = 2 / 4 / 8 / 16 (ui 0..3); the gate's half period comes in `grid` bits 16..31 (ticks of 10 ns)
+            const int mode = (variant - 100) / 100, ui = ((variant - 100) % 100) / 10;
+            const unsigned half = (unsigned)grid >> 16;
+            const dim3 gg((unsigned)grid & 0xffffu);
+            const u4v* sv = (const u4v*)src;
+            u4v* dv = (u4v*)dst;
+            if (mode == 2 && half == 0) return RCV_ERR_ARG;
+#define RCV_PH(UI, U, M) if (ui == UI && mode == M) { hipLaunchKernelGGL((k_copy_phase<U, M>), gg, b, 0, ctx->stream, sv, dv, n, half ? half : 1u); return rcv_launch_check(ctx); }
+            RCV_PH(0, 2, 0) RCV_PH(1, 4, 0) RCV_PH(2, 8, 0) RCV_PH(3, 16, 0)
+            RCV_PH(0, 2, 1) RCV_PH(1, 4, 1) RCV_PH(2, 8, 1) RCV_PH(3, 16, 1)
+            RCV_PH(0, 2, 2) RCV_PH(1, 4, 2) RCV_PH(2, 8, 2) RCV_PH(3, 16, 2)
+#undef RCV_PH
+            return RCV_ERR_ARG;
+        }
+        if (variant >= 10 && variant < 22) {
+            const int nt = (variant - 10) & 3, ui = (variant - 10) >> 2;   // nt bit 0: loads, bit 1: stores; ui 0 / 1 / 2: 4 / 8 / 2 accesses in flight
+            const u4v* sv = (const u4v*)src;
+            u4v* dv = (u4v*)dst;
+#define RCV_MB_CASE(U, N, NL, NS) if (ui == (U == 4 ? 0 : (U == 8 ? 1 : 2)) && nt == N) { hipLaunchKernelGGL((k_copy_sweep_u<U, NL, NS>), g, b, 0, ctx->stream, sv, dv, n); break; }
+            RCV_MB_CASE(4, 0, false, false) RCV_MB_CASE(4, 1, true, false) RCV_MB_CASE(4, 2, false, true) RCV_MB_CASE(4, 3, true, true)
+            RCV_MB_CASE(8, 0, false, false) RCV_MB_CASE(8, 1, true, false) RCV_MB_CASE(8, 2, false, true) RCV_MB_CASE(8, 3, true, true)
+            RCV_MB_CASE(2, 0, false, false) RCV_MB_CASE(2, 1, true, false) RCV_MB_CASE(2, 2, false, true) RCV_MB_CASE(2, 3, true, true)
+#undef RCV_MB_CASE
+        }
+        return RCV_ERR_ARG;
     }
     return rcv_launch_check(ctx);
 }

@@ -289,7 +289,7 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     a.src = s.p;
     a.dx = dx.p;
     a.dy = dy.p;
-    a.dump = ctx->kconst + 8192;
+    a.dump = ctx->kconst + RCV_KC_SOBEL_DUMP;
     a.sstep = s.step;
     a.xstep = dx.step;
     a.ystep = dy.step;

@@ -98,6 +98,7 @@ class ImportedBuffer:
         h, p = C.c_void_p(), C.c_void_p()
         _ffi.check(_ffi.lib().rcv_import_dmabuf(ctx.handle, int(fd), int(offset), self.nbytes, C.byref(h), C.byref(p)), "rcv_import_dmabuf")
         self._h, self.ptr = h, p
+        self._views = 0           # live DeviceBatch views of the mapping (as_batch)
 
     def as_batch(self, n, rows, cols, channels, depth=_ffi.RCV_8U, step=None, frame_stride=None):
         """view the imported bytes as n frames (no allocation: the view does not own the memory)"""
@@ -112,9 +113,20 @@ class ImportedBuffer:
             raise ValueError("view larger than the imported buffer")
         b.ptr = self.ptr
         b.free = lambda: None     # the import owns the mapping
+        b._owner = self           # ... and the view keeps the import alive: dropping `imp` must not unmap memory a view still points at
+        self._views += 1
+        import weakref
+        weakref.finalize(b, ImportedBuffer._view_gone, self)
         return b
 
+    @staticmethod
+    def _view_gone(imp):
+        imp._views -= 1
+
     def release(self):
+        """unmap; refuses while views made by as_batch are alive (they would be dangling device pointers)"""
+        if self._h is not None and getattr(self, "_views", 0) > 0:
+            raise RuntimeError(f"ImportedBuffer.release(): {self._views} view(s) of the mapping are still alive")
         if self._h is not None:
             _ffi.lib().rcv_import_release(self._h)
             self._h, self.ptr = None, None

@@ -42,6 +42,58 @@ def test_report_takes_the_slowest_gpu_and_flags_mismatches():
     assert out["verified_frames"] == [0, 31, 63, 64, 95, 127]
 
 
+def test_report_configs_4_and_5():
+    """--config 4 / 5: same line format, the config's own metric, per-GPU batch and algorithmic bytes"""
+    r4 = dict(_rank(0.0355, 0.71, 0.0, [0, 15, 31]))
+    r4.pop("copy_ceiling_gbs"), r4.pop("copy_ceiling_kernel")
+    a = argparse.Namespace(batch=32, steps=50, warmup=5, config=4, unfused=False)
+    out, bad = bench.report(a, 1, [r4])
+    assert not bad and out["metric"].startswith("Mpixels/sec on 8K warpAffine") and out["config"]["frames_per_gpu"] == 32
+    assert out["roofline"]["alg_bytes_per_launch"] == 32 * 1080 * 1920 * 30 and "frac_of_copy_ceiling" not in out["roofline"]
+    assert abs(out["value"] - 32 * 4320 * 7680 * 50 / 0.0355 / 1e6) < 1 and "fused" in out["config"]["path"]
+    assert abs(out["config"]["output_mpix_s"] - 32 * 1080 * 1920 * 50 / 0.0355 / 1e6) < 1
+    a.unfused = True
+    out, _ = bench.report(a, 1, [r4])
+    assert out["roofline"]["alg_bytes_per_launch"] == 32 * (4320 * 7680 * 6 + 1080 * 1920 * 15) and "two launches" in out["config"]["path"]
+    a = argparse.Namespace(batch=64, steps=50, warmup=5, config=5)
+    out, bad = bench.report(a, 8, [dict(r4, verified_frames=[64 * r, 64 * r + 31, 64 * r + 63]) for r in range(8)])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 512 and "cornerHarris" in out["metric"]
+    assert out["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 4 and len(out["roofline"]["launch_ms_per_gpu"]) == 8
+    assert bench.CONFIGS[3]["batch"] == 64 and bench.CONFIGS[4]["batch"] * 8 == 256 and bench.CONFIGS[5]["batch"] * 8 == 512
+
+
+def test_report_memory_only_and_clock():
+    a = argparse.Namespace(batch=64, steps=50, warmup=5)
+    r = dict(_rank(0.0275, 0.55, 6000.0, [0, 31, 63]), memory_only_gbs=5800.0, shader_mhz_under_load=2100.0)
+    out, _ = bench.report(a, 1, [r])
+    assert out["roofline"]["memory_only_gbs"] == 5800.0 and abs(out["roofline"]["frac_of_memory_only"] - out["roofline"]["achieved"] / 5800.0) < 1e-4
+    assert out["roofline"]["shader_mhz_under_load"] == 2100.0
+
+
+def test_warp_matrix_is_the_survey_matrix():
+    import numpy as np
+    M = bench.warp_matrix()
+    t = np.deg2rad(7.0)
+    assert M.dtype == np.float32 and abs(M[0] - np.cos(t)) < 1e-6 and abs(M[3] - np.sin(t)) < 1e-6
+    # the centre of the frame maps to the centre + the translation
+    cx, cy = 3840.0, 2160.0
+    assert abs(M[0] * cx + M[1] * cy + M[2] - (cx + 13.25)) < 1e-2 and abs(M[3] * cx + M[4] * cy + M[5] - (cy - 8.5)) < 1e-2
+
+
 def test_bench_kernel_matches_the_oracle_generator(oracle):
     import numpy as np
     assert np.array_equal(bench.bench_kernel7(), oracle.bench_kernel7())
+
+
+def test_dispatch_overhead_summary():
+    """tools/dispatch_overhead.py's report arithmetic: medians, ratio against G = 1, and it never claims more than one device"""
+    from tools import dispatch_overhead as do
+    raw = {1: {"wall_s": [0.12, 0.11, 0.13], "steps": 200, "enqueue_us": [6.0], "frames": 64},
+           8: {"wall_s": [0.1144, 0.1133, 0.1122], "steps": 200, "enqueue_us": [9.0] * 7 + [17.0], "frames": 8}}
+    out = do.summarize(raw)
+    assert out["n_devices"] == 1 and [r["contexts"] for r in out["rows"]] == [1, 8]
+    assert abs(out["rows"][0]["wall_ms_per_step"] - 0.6) < 1e-9 and out["rows"][0]["vs_G1"] == 1.0
+    assert abs(out["rows"][1]["vs_G1"] - 0.1133 / 0.12) < 1e-3 and out["rows"][1]["enqueue_us"] == 10.0 and out["rows"][1]["enqueue_us_max"] == 17.0
+    assert abs(out["loss_at_max_G"] - (0.1133 / 0.12 - 1.0)) < 1e-3
+    full = do.summarize({1: raw[1], 8: dict(raw[8], wall_s=[0.98, 0.97, 0.99], frames=64)}, full=True)   # 8 x the work on one GPU
+    assert abs(full["rows"][1]["vs_G1"] - (0.98 / 200) / (8 * 0.12 / 200)) < 1e-3 and full["n_devices"] == 1

@@ -36,6 +36,7 @@ def test_import_dmabuf_argument_checks(ctx):
     assert L.rcv_import_dmabuf(ctx.handle, -1, 0, 4096, C.byref(h), C.byref(p)) == _ffi.RCV_ERR_ARG
     assert L.rcv_import_dmabuf(ctx.handle, 0, 0, 0, C.byref(h), C.byref(p)) == _ffi.RCV_ERR_ARG
     assert L.rcv_import_dmabuf(ctx.handle, 0, 0, 4096, None, C.byref(p)) == _ffi.RCV_ERR_ARG
+    assert L.rcv_import_dmabuf(ctx.handle, 0, 2**64 - 1, 4096, C.byref(h), C.byref(p)) == _ffi.RCV_ERR_SIZE   # offset + bytes wraps
     r, w = os.pipe()                                # a descriptor that is no DMA-BUF: a clean error, nothing leaked
     rc = L.rcv_import_dmabuf(ctx.handle, r, 0, 4096, C.byref(h), C.byref(p))
     assert rc in (_ffi.RCV_ERR_DEVICE, _ffi.RCV_ERR_OOM) and not h.value and not p.value
@@ -67,11 +68,42 @@ def test_import_dmabuf_round_trip(ctx, oracle, rng):
     back = src.download()                                        # read through the ORIGINAL allocation
     for i in range(n):
         assert np.array_equal(back[i], oracle.filter2d_i8(oracle.filter2d_i8(frames[i], k, 5), k, 5))
+    with pytest.raises(RuntimeError):
+        imp.release()                                            # a live view would become a dangling device pointer
+    del view
     imp.release()
     os.fstat(fd)                                                 # the caller's fd was not closed by the import
     hsa.hsa_amd_portable_close_dmabuf(fd)
     for b in (src, gray, dst):
         b.free()
+
+
+def test_import_view_keeps_the_mapping_alive_and_size_is_checked(ctx, oracle, rng):
+    """round-2 advisor findings: (1) `ImportedBuffer(...).as_batch(...)` with the import itself dropped must stay valid -- the view
+    owns a reference; (2) a DMA-BUF smaller than offset + bytes is refused instead of mapped past its end"""
+    n, rows, cols = 1, 64, 256
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    frames = rng.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    src.upload(frames)
+    fd, off, hsa = _export_dmabuf(src.ptr, src.nbytes)
+    view = device.ImportedBuffer(ctx, fd, src.nbytes, off).as_batch(n, rows, cols, 3, frame_stride=src.frame_stride)   # the import is a temporary
+    import gc
+    gc.collect()
+    gray = device.DeviceBatch(ctx, n, rows, cols, 1)
+    device.cvt_color(view, gray, _ffi.RCV_BGR2GRAY)
+    assert np.array_equal(gray.download()[0], oracle.bgr2gray(frames[0]))
+    del view                                                     # ... and the mapping goes with its last view
+    gc.collect()
+    total = os.lseek(fd, 0, os.SEEK_END)
+    L = _ffi.lib()
+    h, p = C.c_void_p(), C.c_void_p()
+    if total > 0:                                                # the exporter reports its size: one byte too many is refused
+        assert L.rcv_import_dmabuf(ctx.handle, fd, 0, total + 1, C.byref(h), C.byref(p)) == _ffi.RCV_ERR_SIZE and not h.value and not p.value
+        assert L.rcv_import_dmabuf(ctx.handle, fd, total, 1, C.byref(h), C.byref(p)) == _ffi.RCV_ERR_SIZE
+    os.fstat(fd)
+    hsa.hsa_amd_portable_close_dmabuf(fd)
+    src.free()
+    gray.free()
 
 
 def test_import_keeps_its_context_alive():
