@@ -32,6 +32,10 @@ static void load_knobs()
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
     g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
     g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
+    g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);
+    g_knobs.gr_seg = env_int("RCV_GR_SEG", 0);
+    g_knobs.gr_plain = env_int("RCV_GR_PLAIN", 0);
+    g_knobs.fr_band_rows = env_int("RCV_FR_BAND_ROWS", 0);
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);

@@ -738,7 +738,9 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     const long long G = (long long)s.n * s.rows;
     // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
     //  streaming VALU kernel: 4-7x slower even on one frame)
-    if (kn.f7_rows < 0 && !any_size && G * nstrips < 64LL * 10 * ctx->cu_count) return RCV_ERR_UNSUPPORTED;   // < 64 rows per wave slot
+    // launches below ~16 000 strip-rows (two 1080p BGR frames) keep the strip kernel's latency variant; above, this kernel with its
+    // per-SIMD band plan is faster (round 3, tools/small_filter_latency.py: one 4K frame 7x7 11.4 against 16.4 us)
+    if (kn.f7_rows < 0 && !any_size && G * nstrips < 16000LL * ctx->cu_count / 256) return RCV_ERR_UNSUPPORTED;
 
     // weights beyond i8: K = M + 2 * S when every weight fits that split (|w| <= 381; the integer Gaussian), else K = 4Q + R
     const int nk = ksize * ksize, np = (ksize + 1) / 2;
@@ -813,7 +815,14 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         const int rounds = kn.fr_rounds > 0 ? kn.fr_rounds : 8;
         const long long want = rounds * slots / a.nstrips;   // bands for `rounds` fills of the wave slots
         long long nb;
-        if (s.n >= 8) {
+        // launches of a few rounds: every SIMD the same number of equally long waves (rcv_plan_seg_rows with this kernel's own
+        // figures: two waves per SIMD at most, a lone wave leaves its SIMD half idle; a band streams ksize - 1 halo rows and fills
+        // its pipeline with a few more).  Whole bands per frame.
+        const int small = kn.fr_bpf > 0 ? 0 : rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 6, 2.3, 1.17, 2, 2);
+        if (small > 0 || kn.fr_band_rows > 0) {
+            const int br = kn.fr_band_rows > 0 ? kn.fr_band_rows : small;   // (knob: latency sweeps)
+            nb = (long long)((s.rows + br - 1) / br) * s.n;
+        } else if (s.n >= 8) {
             // a whole number of bands per FRAME: no band straddles a frame (one segment, one pipeline fill per wave), and with
             // n % 8 == 0 every XCD works on whole frames.  Measured on 64 4K frames: 21 bands per frame (8 rounds) 0.569 ms, 13.1
             // (5 rounds) 0.646, 15.75 / 18.4 (6 / 7 rounds) 0.592
@@ -828,10 +837,6 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
             const long long most = (G + 31) / 32;
             if (nb > most) nb = most;
             if (nb < 1) nb = 1;
-            // few frames: every SIMD one or two waves of equal length (rcv_plan_seg_rows; a band streams ksize - 1 halo rows and fills
-            // its pipeline with a few more)
-            const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 16);
-            if (small > 0) nb = (G + small - 1) / small;
         }
         a.nbands = (int)nb;
         a.bands_per_xcd = (int)((nb + 7) / 8);

@@ -83,6 +83,10 @@ struct RcvKnobs {
     int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
     int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
     int fr_bpf;           // RCV_FR_BPF        bands per frame (batches of >= 8 frames; 0 = from RCV_FR_ROUNDS)
+    int fr_band_rows;     // RCV_FR_BAND_ROWS  rows per band of the row-streaming kernel on launches of fewer than 8 frames (0 = per-SIMD plan)
+    int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian (rcv_gauss_rows.hip): 1 every eligible shape, 0 never, -1 (unset) small launches
+    int gr_plain;         // RCV_GR_PLAIN      its stores plain instead of non-temporal (ablation)
+    int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan)
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
@@ -184,17 +188,25 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 // segment times -- not ceil(waves / resident slots); a SIMD with a single wave cannot hide its memory latency (x1.25), with two
 // barely (x1.06).  `overhead` = rows a segment streams beyond its own (halo + pipeline fill + set-up).  Measured with the Harris
 // pipeline on 1 / 4 / 8 / 16 4K frames: 0.046 -> 0.027, 0.070 -> 0.040, 0.098 -> 0.076, 0.158 -> 0.147 ms.
-static inline int rcv_plan_seg_rows(int rows, long long waves_per_seg, int cu_count, int overhead, int min_seg)
+static inline int rcv_plan_seg_rows(int rows, long long waves_per_seg, int cu_count, int overhead, int min_seg, double lone = 1.25, double two = 1.06,
+                                    int occ = 64, int max_per_simd = 4)
 {
+    // occ: waves of this kernel a SIMD holds at once (the row-streaming MFMA kernel: 2); more waves per SIMD run in rounds
+    // lone / two: what one / two waves on a SIMD lose against three or more (they cannot hide each other's latencies).  The VALU
+    // register-window kernels: 1.25 / 1.06; the row-streaming MFMA kernel, whose lone wave leaves the SIMD half idle between its
+    // dependent MFMA chains: 2.3 / 1.17 (round 3, tools/config2_latency.py: one 4K frame 15.4 us at 32-row bands = one wave per
+    // SIMD, 10.8 us at 16-row bands = two).
     const long long simds = 4LL * (cu_count > 0 ? cu_count : 256);
-    if (waves_per_seg * ((rows + 89) / 90) > 4 * simds) return 0;
+    if (waves_per_seg * ((rows + 89) / 90) > max_per_simd * simds) return 0;
     int seg = rows;
     double best = 1e300;
     for (int ns = 1; ns <= rows; ++ns) {
         const int sr = (rows + ns - 1) / ns;
         if (ns > 1 && sr < min_seg) break;
         const long long per_simd = (waves_per_seg * ((rows + sr - 1) / sr) + simds - 1) / simds;
-        const double cost = (double)per_simd * (sr + overhead) * (per_simd < 2 ? 1.25 : (per_simd < 3 ? 1.06 : 1.0));
+        const auto pen = [&](long long w) { return w < 2 ? lone : (w < 3 ? two : 1.0); };
+        const long long full = per_simd / occ, rest = per_simd % occ;   // rounds of `occ` resident waves + one partial round
+        const double cost = (double)(sr + overhead) * ((double)full * occ * pen(occ) + (double)rest * (rest ? pen(rest) : 0.0));
         if (cost < best) {
             best = cost;
             seg = sr;

@@ -4,6 +4,7 @@
 #pragma once
 #include "rcv_internal.h"
 
+int rcv_gauss_int_rows(rcv_ctx* ctx, const View& s, const View& d, int ksize);    // rcv_gauss_rows.hip: small launches, ksize 3 / 5
 int rcv_gauss_int_tiled(rcv_ctx* ctx, const View& s, const View& d, int ksize);
 int rcv_filter_i8_fast(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv = 0, bool any_size = false,

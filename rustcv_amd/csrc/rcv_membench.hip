@@ -139,6 +139,11 @@ __global__ __launch_bounds__(kT) void k_write_sweep(uint4* __restrict__ d, size_
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) d[i] = v;
 }
 
+__global__ __launch_bounds__(64) void k_nop(int* p)
+{
+    if (p && threadIdx.x == 1234567) *p = 0;   // (never)
+}
+
 // one wave per XCD-ish (8 workgroups): core-clock cycles (s_memtime) per tick of the constant 100 MHz counter (s_memrealtime)
 // over `ticks` ticks -- the shader clock while whatever else runs on the GPU keeps running
 __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, unsigned ticks)
@@ -200,6 +205,7 @@ extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t by
     case 5: hipLaunchKernelGGL((k_copy_block<true, true>), g, b, 0, ctx->stream, s, d, n); break;
     case 6: hipLaunchKernelGGL(k_read_sweep, g, b, 0, ctx->stream, s, (uint4*)(ctx->kconst + RCV_KC_BENCH), n); break;
     case 7: hipLaunchKernelGGL(k_write_sweep, g, b, 0, ctx->stream, d, n, 0x5EEDu); break;
+    case 30: hipLaunchKernelGGL(k_nop, g, dim3(64), 0, ctx->stream, (int*)nullptr); break;   // launch-to-launch floor: `grid` empty workgroups
     case 8:
         if (grid % 8) return RCV_ERR_ARG;
         hipLaunchKernelGGL((k_copy_xcd<false, false>), g, b, 0, ctx->stream, s, d, n);

@@ -156,7 +156,9 @@ extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_b
     }
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;
     if (sigma <= 0.0) {
-        int rc = rcv_gauss_int_tiled(ctx, s, d, ksize);
+        int rc = rcv_gauss_int_rows(ctx, s, d, ksize);   // small launches (one 1080p frame: a latency problem)
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+        rc = rcv_gauss_int_tiled(ctx, s, d, ksize);
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
         static const int t3[3] = {1, 2, 1}, t5[5] = {1, 4, 6, 4, 1}, t7[7] = {2, 7, 14, 18, 14, 7, 2};
         TapsI32 tp;

@@ -44,6 +44,8 @@ def test_fast_kernels_are_dispatched(ctx):
     device.synth(gray16, 1, 12, 0)
     one = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
     one2 = device.DeviceBatch(ctx, 1, 1080, 1920, 3)
+    gone, gone2 = device.DeviceBatch(ctx, 1, 1080, 1920, 1), device.DeviceBatch(ctx, 1, 1080, 1920, 1)
+    one4k, one4k2 = device.DeviceBatch(ctx, 1, 2160, 3840, 3), device.DeviceBatch(ctx, 1, 2160, 3840, 3)
     device.synth(bgr, 1, 7, 0)
     device.synth(gray, 1, 8, 0)
     device.synth(yuyv, 2, 9, 0)
@@ -57,7 +59,10 @@ def test_fast_kernels_are_dispatched(ctx):
         ("GaussianBlur 5x5 int BGR, 8 x 4K (row-streaming MFMA kernel)", lambda: device.gaussian_blur(bgr, bgr2, 5, 0.0), "k_filter_rows_mfma<"),
         ("filter2D 7x7 BGR, one 1080p frame (strip kernel, latency variant)", lambda: device.filter2d(one, one2, k7, shift=6), "k_filter7_mfma<0, 0, 0, true>"),
         ("filter2D 7x7 gray, 16 x 4K (row-streaming kernel, gray variant)", lambda: device.filter2d(gray16, gray16b, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 2>"),
-        ("filter2D 7x7 gray, 8 x 4K (fewer than 64 rows per wave slot: strip kernel, gray variant)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter7_mfma<0, 0, 2>"),
+        ("filter2D 7x7 gray, 8 x 4K (row-streaming kernel, gray variant, per-SIMD band plan)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 2>"),
+        ("filter2D 7x7 gray, one 1080p frame (strip kernel, gray variant, latency variant)", lambda: device.filter2d(gone, gone2, k7, shift=6), "k_filter7_mfma<0, 0, 2, true>"),
+        ("GaussianBlur 5x5 int BGR, one 1080p frame (BASELINE config 2: register-window kernel)", lambda: device.gaussian_blur(one, one2, 5, 0.0), "k_gauss_rows<5, 3>"),
+        ("GaussianBlur 5x5 int BGR, one 4K frame (row-streaming MFMA kernel, per-SIMD band plan)", lambda: device.gaussian_blur(one4k, one4k2, 5, 0.0), "k_filter_rows_mfma<"),
         ("GaussianBlur 7x7 int gray (strip kernel, gray variant, two tables)", lambda: device.gaussian_blur(gray, gray2, 7, 0.0), "k_filter7_mfma<0, 2, 2>"),
         ("GaussianBlur 7x7 int BGR, 8 x 4K (row-streaming kernel, two weight tables)", lambda: device.gaussian_blur(bgr, bgr2, 7, 0.0), "k_filter_rows_mfma<KS, 3, 0, KS == 7 ? kCentre7 : kAll>"),
         ("GaussianBlur 7x7 int BGR, one 1080p frame (two-table strip kernel)", lambda: device.gaussian_blur(one, one2, 7, 0.0), "k_filter7_mfma<0, 2>"),
@@ -128,7 +133,7 @@ def test_fast_kernels_are_dispatched(ctx):
         print(f"{name:72s} {ms:7.3f} ms   {launched}")
         if want not in launched or "generic" in launched:
             wrong.append((name, want, launched))
-    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om, pg, pg2, oddsz):
+    for b in (bgr, bgr2, gray, gray2, yuyv, dx, dy, resp, mask, small, pw, pw2, one, one2, gone, gone2, one4k, one4k2, gray16, gray16b, ow, ow2, og, og2, odx, ody, om, pg, pg2, oddsz):
         b.free()
     assert not wrong, wrong
 

@@ -400,12 +400,71 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, shift,
         assert (padbytes == 0xAB).all()
 
 
+GAUSS_ROWS_SHAPES = [(3, 16, 3), (5, 32, 3), (33, 240, 3), (40, 336, 3), (19, 496, 3), (70, 672, 3), (300, 1008, 3), (9, 2000, 3), (1080, 1920, 3),
+                     (3, 32, 1), (17, 992, 1), (40, 1008, 1), (64, 4000, 1), (7, 48, 1)]
+
+
+@pytest.mark.parametrize("rows,cols,ch", GAUSS_ROWS_SHAPES)
+@pytest.mark.parametrize("ksize", [3, 5])
+@pytest.mark.parametrize("seg", [0, 4, 5, 13])
+def test_gaussian_int_rows_kernel(ctx, oracle, rng, knob, rows, cols, ch, ksize, seg):
+    """round 3: the register-window integer Gaussian for small launches (rcv_gauss_rows.hip; BASELINE config 2).  Strips of 992
+    bytes: one strip, a second strip of ONE lane (336 px BGR / 1008 px gray), a strip that ends exactly at the row end (992 px gray);
+    segment seams at every height (RCV_GR_SEG), rows fewer than one segment; batch of 3 with padded steps and canaries; a
+    saturated region (sums reach 255 * D exactly); the full 1080p frame of config 2."""
+    knob("RCV_GAUSS_ROWS")
+    if seg:
+        knob("RCV_GR_SEG", seg)
+    n = 1 if rows >= 1000 else 3
+    img = rand_img(rng, rows, cols, ch).reshape(rows, cols, ch)
+    img[: rows // 3] = 255
+    img[:, :2] = 7
+    frames = np.stack([np.roll(img, 3 * i, axis=1) if i < 2 else img[::-1].copy() for i in range(n)])
+    src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + 32)
+    dst = _canary_batch(ctx, n, rows, cols, ch, pad=48)
+    src.upload(frames if ch == 3 else frames[..., 0])
+    _ffi.lib().rcv__debug_kernels_reset()
+    device.gaussian_blur(src, dst, ksize, 0.0)
+    assert "k_gauss_rows<" in _ffi.lib().rcv__debug_kernels().decode()
+    got = dst.download()
+    for i in range(n):
+        want = oracle.gaussian_blur(frames[i] if ch == 3 else frames[i][..., 0], ksize, 0.0)
+        assert np.array_equal(got[i], want), (i, np.argwhere(got[i] != want)[:5])
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
+def test_gaussian_int_rows_kernel_takes_config2_by_default(ctx, oracle):
+    """BASELINE config 2 (one 1080p BGR frame, 5x5, sigma 0) runs on the register-window kernel without any knob; launches that
+    fill the GPU several times over stay on the MFMA kernels; ksize 7 (sums beyond 16 bits) and unaligned rows never take it"""
+    L = _ffi.lib()
+    one, one2 = device.DeviceBatch(ctx, 1, 1080, 1920, 3), device.DeviceBatch(ctx, 1, 1080, 1920, 3)
+    device.synth(one, 0, 0x5EED0002, 0)
+
+    def kernel_of(fn):
+        L.rcv__debug_kernels_reset()
+        fn()
+        return L.rcv__debug_kernels().decode()
+    assert "k_gauss_rows<5, 3>" in kernel_of(lambda: device.gaussian_blur(one, one2, 5, 0.0))
+    assert np.array_equal(one2.download()[0], oracle.gaussian_blur(one.download()[0], 5, 0.0))
+    assert "k_gauss_rows<3, 3>" in kernel_of(lambda: device.gaussian_blur(one, one2, 3, 0.0))
+    assert "k_gauss_rows" not in kernel_of(lambda: device.gaussian_blur(one, one2, 7, 0.0))
+    big, big2 = device.DeviceBatch(ctx, 64, 1080, 1920, 3), device.DeviceBatch(ctx, 64, 1080, 1920, 3)
+    assert "k_gauss_rows" not in kernel_of(lambda: device.gaussian_blur(big, big2, 5, 0.0))
+    odd, odd2 = device.DeviceBatch(ctx, 1, 64, 1920, 3, step=1920 * 3 + 4), device.DeviceBatch(ctx, 1, 64, 1920, 3)
+    assert "k_gauss_rows" not in kernel_of(lambda: device.gaussian_blur(odd, odd2, 5, 0.0))
+    for b in (one, one2, big, big2, odd, odd2):
+        b.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(4, 16), (33, 240), (19, 496), (300, 272)])
 @pytest.mark.parametrize("ksize", [3, 5, 7])
 @pytest.mark.parametrize("full_tables", [False, True, "rows"])
 def test_gaussian_int_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, full_tables):
     """integer GaussianBlur on the MFMA strip kernel.  ksize 7 has weights up to 324: two weight tables, by default the
     centre split K = K1 + 2*T2 (second table in kernel rows 2..4 only), with RCV_F7_DUAL_FULL the general K = 4Q + R"""
+    knob("RCV_GAUSS_ROWS", 0)   # (these small shapes would otherwise take the register-window kernel of rcv_gauss_rows.hip)
     if full_tables == "rows":
         knob("RCV_F7_ROWS")   # (ksize 3 / 5: weights inside i8 -> the row-streaming kernel; 7 stays on the two-table strip kernel)
     elif full_tables:
