@@ -195,11 +195,13 @@ int rcv_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch
 int rcv_filter2d_i8_sobel(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dx, rcv_mat* dy, const int8_t* k, int ksize, int shift);
 int rcv_filter2d_i8_sobel_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy, const int8_t* k, int ksize, int shift);
 
-/* bilinear, output size = dst->rows x dst->cols */
+/* bilinear, output size = dst->rows x dst->cols.  u8 (1 / 3 / 4 channels; result rounded half up) or RCV_32F (1 / 3 / 4 channels:
+ * the unrounded interpolated value, same f32 operations in the same order -- SURVEY.md 8-A; src and dst of the same depth) */
 int rcv_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst);
 int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst);
 
-/* bilinear, M[6] row-major 2x3 maps dst->src, constant border 0 */
+/* bilinear, M[6] row-major 2x3 maps dst->src, constant border 0.  u8 or RCV_32F images as for rcv_resize (f32: e.g. the
+ * cornerHarris response map; bit-identical to the CPU oracle, inside north_star's 1-ULP allowance) */
 int rcv_warp_affine(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M);
 int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M);
 

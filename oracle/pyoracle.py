@@ -46,6 +46,8 @@ def lib():
         _lib.orc_sobel.argtypes = [_u8p, C.c_size_t, _i16p, C.c_size_t, _i16p, C.c_size_t, C.c_int, C.c_int]
         _lib.orc_resize.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         _lib.orc_warp_affine.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _f32p]
+        _lib.orc_resize_f32.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        _lib.orc_warp_affine_f32.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t, C.c_int, C.c_int, C.c_int, _f32p]
         _lib.orc_corner_harris.argtypes = [_u8p, C.c_size_t, _f32p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float]
         _lib.orc_nms3x3.argtypes = [_f32p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_float]
         _lib.orc_harris_pipeline.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _f32p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
@@ -229,6 +231,30 @@ def warp_affine(img, M, drows, dcols):
     m = np.ascontiguousarray(M, dtype=np.float32).reshape(6)
     out = _out_like(drows, dcols, ch)
     lib().orc_warp_affine(_p(a, _u8p), st, r, c, _p(out, _u8p), dcols * ch, drows, dcols, ch, _p(m, _f32p))
+    return out
+
+
+def _img_f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    r, c, ch = a.shape
+    return a, c * ch * 4, r, c, ch
+
+
+def resize_f32(img, drows, dcols):
+    """RCV_32F resize: the unrounded interpolated value (same f32 operations, same order as `resize`)"""
+    a, st, r, c, ch = _img_f32(img)
+    out = _out_like(drows, dcols, ch, np.float32)
+    lib().orc_resize_f32(_p(a, _f32p), st, r, c, _p(out, _f32p), dcols * ch * 4, drows, dcols, ch)
+    return out
+
+
+def warp_affine_f32(img, M, drows, dcols):
+    a, st, r, c, ch = _img_f32(img)
+    m = np.ascontiguousarray(M, dtype=np.float32).reshape(6)
+    out = _out_like(drows, dcols, ch, np.float32)
+    lib().orc_warp_affine_f32(_p(a, _f32p), st, r, c, _p(out, _f32p), dcols * ch * 4, drows, dcols, ch, _p(m, _f32p))
     return out
 
 

@@ -487,6 +487,75 @@ void orc_warp_affine(const uint8_t* src, size_t sstep, int srows, int scols,
         }
 }
 
+/* RCV_32F images ("warp_affine (u8/f32 ...)"; the Harris response map): the same sampling rules and the same
+ * f32 operations in the same order as the u8 functions above -- top = fmaf(fx, p01 - p00, p00), bot likewise, v = fmaf(fy, bot -
+ * top, top) -- with f32 taps and the UNROUNDED v as the result.  Steps in bytes.  north_star's 1-ULP clause applies to these. */
+void orc_resize_f32(const float* src, size_t sstep, int srows, int scols,
+                    float* dst, size_t dstep, int drows, int dcols, int ch)
+{
+    float scx = (float)scols / (float)dcols, scy = (float)srows / (float)drows;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y) {
+        float sy = ((float)y + 0.5f) * scy - 0.5f;
+        if (sy < 0.0f) sy = 0.0f;
+        if (sy > (float)(srows - 1)) sy = (float)(srows - 1);
+        int y0 = (int)floorf(sy);
+        float fy = sy - (float)y0;
+        int y1 = y0 + 1 < srows ? y0 + 1 : srows - 1;
+        const float* ra = (const float*)((const uint8_t*)src + (size_t)y0 * sstep);
+        const float* rb = (const float*)((const uint8_t*)src + (size_t)y1 * sstep);
+        float* out = (float*)((uint8_t*)dst + (size_t)y * dstep);
+        for (int x = 0; x < dcols; ++x) {
+            float sx = ((float)x + 0.5f) * scx - 0.5f;
+            if (sx < 0.0f) sx = 0.0f;
+            if (sx > (float)(scols - 1)) sx = (float)(scols - 1);
+            int x0 = (int)floorf(sx);
+            float fx = sx - (float)x0;
+            int x1 = x0 + 1 < scols ? x0 + 1 : scols - 1;
+            for (int c = 0; c < ch; ++c) {
+                float p00 = ra[(size_t)x0 * ch + c], p01 = ra[(size_t)x1 * ch + c];
+                float p10 = rb[(size_t)x0 * ch + c], p11 = rb[(size_t)x1 * ch + c];
+                float top = fmaf(fx, p01 - p00, p00);
+                float bot = fmaf(fx, p11 - p10, p10);
+                out[(size_t)x * ch + c] = fmaf(fy, bot - top, top);
+            }
+        }
+    }
+}
+
+void orc_warp_affine_f32(const float* src, size_t sstep, int srows, int scols,
+                         float* dst, size_t dstep, int drows, int dcols, int ch, const float* M)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            float fxx = (float)x, fyy = (float)y;
+            float sx = fmaf(M[0], fxx, fmaf(M[1], fyy, M[2]));
+            float sy = fmaf(M[3], fxx, fmaf(M[4], fyy, M[5]));
+            float* d = (float*)((uint8_t*)dst + (size_t)y * dstep) + (size_t)x * ch;
+            if (!(sx > -1.0f && sx < (float)scols && sy > -1.0f && sy < (float)srows)) {
+                for (int c = 0; c < ch; ++c) d[c] = 0.0f;
+                continue;
+            }
+            float x0f = floorf(sx), y0f = floorf(sy);
+            int x0 = (int)x0f, y0 = (int)y0f;
+            float fx = sx - x0f, fy = sy - y0f;
+            int x1 = x0 + 1, y1 = y0 + 1;
+            int vx0 = x0 >= 0, vx1 = x1 < scols, vy0 = y0 >= 0, vy1 = y1 < srows;
+            const float* ra = (const float*)((const uint8_t*)src + (size_t)(vy0 ? y0 : 0) * sstep);
+            const float* rb = (const float*)((const uint8_t*)src + (size_t)(vy1 ? y1 : 0) * sstep);
+            for (int c = 0; c < ch; ++c) {
+                float p00 = (vx0 && vy0) ? ra[(size_t)x0 * ch + c] : 0.0f;
+                float p01 = (vx1 && vy0) ? ra[(size_t)x1 * ch + c] : 0.0f;
+                float p10 = (vx0 && vy1) ? rb[(size_t)x0 * ch + c] : 0.0f;
+                float p11 = (vx1 && vy1) ? rb[(size_t)x1 * ch + c] : 0.0f;
+                float top = fmaf(fx, p01 - p00, p00);
+                float bot = fmaf(fx, p11 - p10, p10);
+                d[c] = fmaf(fy, bot - top, top);
+            }
+        }
+}
+
 /* Harris response from integer Sobel; box sums exact i32; six separate f32 ops */
 static void harris_from_sobel(const int16_t* ix, const int16_t* iy, float* resp, size_t rstep,
                               int rows, int cols, int block, float k)

@@ -90,6 +90,12 @@ void orc_resize(const uint8_t* src, size_t sstep, int srows, int scols,
 void orc_warp_affine(const uint8_t* src, size_t sstep, int srows, int scols,
                      uint8_t* dst, size_t dstep, int drows, int dcols, int ch, const float* M);
 
+/* RCV_32F images: the same rules and f32 operation order, f32 taps, the unrounded interpolated value as the result */
+void orc_resize_f32(const float* src, size_t sstep, int srows, int scols,
+                    float* dst, size_t dstep, int drows, int dcols, int ch);
+void orc_warp_affine_f32(const float* src, size_t sstep, int srows, int scols,
+                         float* dst, size_t dstep, int drows, int dcols, int ch, const float* M);
+
 int orc_corner_harris(const uint8_t* gray, size_t sstep, float* resp, size_t rstep,
                       int rows, int cols, int block, float k);
 void orc_nms3x3(const float* resp, size_t rstep, uint8_t* mask, size_t mstep,

@@ -1,4 +1,4 @@
-// rcv_geom.hip -- bilinear resize and warpAffine (u8, channels 1/3/4).  Not in the reference
+// rcv_geom.hip -- bilinear resize and warpAffine (u8 and f32, channels 1/3/4).  Not in the reference
 // (SURVEY.md F1); semantics SURVEY.md 8-A == oracle/rcv_oracle.c orc_resize / orc_warp_affine.
 // f32 evaluation order is fixed and spelled out op by op; built with -ffp-contract=off.
 #include "rcv_internal.h"
@@ -1044,6 +1044,88 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     }
 }
 
+// ---- RCV_32F images (SURVEY.md 8-A "warp_affine (u8/f32 ...)"; the cornerHarris response map) --------------------------------
+// The same sampling rules and the same f32 operations in the same order as the u8 kernels (top = fma(fx, p01 - p00, p00), bot
+// likewise, v = fma(fy, bot - top, top); oracle: orc_resize_f32 / orc_warp_affine_f32) with f32 taps and the unrounded v as the
+// result.  One thread per output pixel; HBM-bound at 4 B read + 4 B written per sample, nothing to fuse.
+template <int CH>
+__global__ __launch_bounds__(kBlock) void k_resize_f32(View s, View d, float scx, float scy)
+{
+    const int y = blockIdx.y;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    float* drow = (float*)(d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step);
+    int y0, y1;
+    float fy;
+    resize_row(s, scy, y, y0, y1, fy);
+    const float* ra = (const float*)(sf + (size_t)y0 * s.step);
+    const float* rb = (const float*)(sf + (size_t)y1 * s.step);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
+        float sx = ((float)x + 0.5f) * scx - 0.5f;
+        sx = sx < 0.0f ? 0.0f : sx;
+        sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
+        const int x0 = (int)floorf(sx);
+        const float fx = sx - (float)x0;
+        const int x1 = x0 + 1 < s.cols ? x0 + 1 : s.cols - 1;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const float p00 = ra[(size_t)x0 * CH + c], p01 = ra[(size_t)x1 * CH + c];
+            const float p10 = rb[(size_t)x0 * CH + c], p11 = rb[(size_t)x1 * CH + c];
+            const float top = fmaf(fx, p01 - p00, p00);
+            const float bot = fmaf(fx, p11 - p10, p10);
+            drow[(size_t)x * CH + c] = fmaf(fy, bot - top, top);
+        }
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(kBlock) void k_warp_affine_f32(View s, View d, Affine A)
+{
+    const int y = blockIdx.y;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    float* drow = (float*)(d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step);
+    const float fyy = (float)y;
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
+        const float fxx = (float)x;
+        const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        float* o = drow + (size_t)x * CH;
+        if (!(sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows)) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) o[c] = 0.0f;
+            continue;
+        }
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float fx = sx - x0f, fy = sy - y0f;
+        const bool vx0 = x0 >= 0, vx1 = x0 + 1 < s.cols, vy0 = y0 >= 0, vy1 = y0 + 1 < s.rows;
+        const float* ra = (const float*)(sf + (size_t)(vy0 ? y0 : 0) * s.step);
+        const float* rb = (const float*)(sf + (size_t)(vy1 ? y0 + 1 : 0) * s.step);
+        const size_t xa = (size_t)(vx0 ? x0 : 0) * CH, xb = (size_t)(vx1 ? x0 + 1 : 0) * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const float p00 = (vx0 && vy0) ? ra[xa + c] : 0.0f, p01 = (vx1 && vy0) ? ra[xb + c] : 0.0f;
+            const float p10 = (vx0 && vy1) ? rb[xa + c] : 0.0f, p11 = (vx1 && vy1) ? rb[xb + c] : 0.0f;
+            const float top = fmaf(fx, p01 - p00, p00);
+            const float bot = fmaf(fx, p11 - p10, p10);
+            o[c] = fmaf(fy, bot - top, top);
+        }
+    }
+}
+
+// views of an RCV_32F source / destination pair: 1, 3 or 4 channels, 4-byte aligned rows and frames
+int check_geom_f32(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    RCV_TRY(rcv_view_batch(src, RCV_32F, s));
+    RCV_TRY(rcv_view_batch(dst, RCV_32F, d));
+    if (s->ch != d->ch || s->n != d->n) return RCV_ERR_ARG;
+    if (s->ch != 1 && s->ch != 3 && s->ch != 4) return RCV_ERR_UNSUPPORTED;
+    if (d->rows > 65535 || d->n > 65535) return RCV_ERR_UNSUPPORTED;
+    for (const View* v : {s, d})
+        if ((uintptr_t)v->p % 4 || v->step % 4 || (v->n > 1 && v->fstride % 4)) return RCV_ERR_ARG;   // f32 samples are 4-byte aligned
+    return RCV_OK;
+}
+
 int check_geom(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
 {
     if (!src || !dst) return RCV_ERR_ARG;
@@ -1068,6 +1150,16 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
 {
     RCV_TRY(rcv_bind(ctx));
     View s, d;
+    if (src && dst && src->frame0.depth == RCV_32F) {   // f32 images: the unrounded interpolated value
+        RCV_TRY(check_geom_f32(src, dst, &s, &d));
+        if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
+        if (s.rows == 0 || s.cols == 0) return RCV_ERR_ARG;
+        const float fscx = (float)s.cols / (float)d.cols, fscy = (float)s.rows / (float)d.rows;
+        if (s.ch == 1) RCV_LAUNCH(k_resize_f32<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
+        else if (s.ch == 3) RCV_LAUNCH(k_resize_f32<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
+        else RCV_LAUNCH(k_resize_f32<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
+        return rcv_launch_check(ctx);
+    }
     RCV_TRY(check_geom(src, dst, &s, &d));
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     if (s.rows == 0 || s.cols == 0) return RCV_ERR_ARG;
@@ -1156,6 +1248,16 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     RCV_TRY(rcv_bind(ctx));
     if (!M) return RCV_ERR_ARG;
     View s, d;
+    if (src && dst && src->frame0.depth == RCV_32F) {   // f32 images: the unrounded interpolated value, constant border 0.0f
+        RCV_TRY(check_geom_f32(src, dst, &s, &d));
+        if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
+        Affine Af;
+        for (int i = 0; i < 6; ++i) Af.m[i] = M[i];
+        if (s.ch == 1) RCV_LAUNCH(k_warp_affine_f32<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);
+        else if (s.ch == 3) RCV_LAUNCH(k_warp_affine_f32<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);
+        else RCV_LAUNCH(k_warp_affine_f32<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);
+        return rcv_launch_check(ctx);
+    }
     RCV_TRY(check_geom(src, dst, &s, &d));
     if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
     Affine A;

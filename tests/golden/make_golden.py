@@ -37,7 +37,12 @@ KAT = {
 
 
 def main():
-    json.dump(KAT, open(os.path.join(HERE, "kat_reference.json"), "w"), indent=1)
+    # kat_reference.json also holds hand-derived vectors that were added to the file directly (the put_text blend KATs): keep
+    # every key this script does not own
+    kat_path = os.path.join(HERE, "kat_reference.json")
+    kat = json.load(open(kat_path)) if os.path.exists(kat_path) else {}
+    kat.update(KAT)
+    json.dump(kat, open(kat_path, "w"), indent=1)
     rng = np.random.default_rng(20260928)
     g = {}
     bgr = rng.integers(0, 256, size=(37, 48, 3), dtype=np.uint8)
@@ -74,6 +79,10 @@ def main():
     g["nms"] = orc.nms3x3(g["harris_b2"], 1e-4)
     g["synth_scene"] = orc.synth_frame(24, 40, 3, 1, 0x5EED0003, 2)
     g["synth_noise"] = orc.synth_frame(8, 8, 3, 0, 0x5EED0003, 0)
+    # RCV_32F geometry (round 3): the Harris response map through the f32 warp / resize (no further random draws above this line
+    # were added: the earlier arrays are unchanged)
+    g["warp_f32"] = orc.warp_affine_f32(g["harris_b2"], M, 29, 41)
+    g["resize_f32_17x23"] = orc.resize_f32(g["harris_b2"], 17, 23)
     np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **g)
     print("wrote", len(g), "arrays")
 

@@ -76,6 +76,14 @@ def test_golden_geometry(ctx, G):
     assert np.array_equal(_run(lambda s, d: imgproc.resize(s, d, ctx), bgr, 9, 12, 3), G["resize_9x12"])
     assert np.array_equal(_run(lambda s, d: imgproc.resize(s, d, ctx), bgr, 50, 70, 3), G["resize_50x70"])
     assert np.array_equal(_run(lambda s, d: imgproc.warp_affine(s, d, G["warp_M"], ctx), bgr, 37, 48, 3), G["warp"])
+    # RCV_32F (round 3): the stored Harris response map through the f32 warp / resize, against the STORED bits
+    resp = Mat.from_array(G["harris_b2"])
+    out = Mat(29, 41, 1, _ffi.RCV_32F)
+    imgproc.warp_affine(resp, out, G["warp_M"], ctx)
+    assert np.array_equal(out.to_array().view(np.uint32), G["warp_f32"].view(np.uint32))
+    out = Mat(17, 23, 1, _ffi.RCV_32F)
+    imgproc.resize(resp, out, ctx)
+    assert np.array_equal(out.to_array().view(np.uint32), G["resize_f32_17x23"].view(np.uint32))
 
 
 def test_golden_synthetic_frames(ctx, G):

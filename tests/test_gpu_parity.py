@@ -1969,6 +1969,99 @@ def _assert_canaries(b):
     assert (raw[:, b.rows * b.step:] == 0xCD).all(), "inter-frame gap overwritten"
 
 
+def _ulp_distance(a, b):
+    """distance in units in the last place between two f32 arrays (NaN == NaN; +0 == -0)"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)      # sign-magnitude -> a monotonic integer line
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    d = np.abs(ia - ib)
+    d[both_nan] = 0
+    d[np.isnan(a) ^ np.isnan(b)] = 2 ** 40
+    return d
+
+
+F32_GEOM = [(53, 71, 60, 80, 1), (37, 48, 37, 48, 1), (64, 96, 16, 24, 1), (16, 24, 61, 97, 3), (5, 7, 9, 3, 4), (1, 1, 4, 5, 1), (270, 480, 1080, 1920, 1)]
+
+
+@pytest.mark.parametrize("srows,scols,drows,dcols,ch", F32_GEOM)
+def test_resize_f32(ctx, oracle, rng, srows, scols, drows, dcols, ch):
+    """SURVEY.md 8-A / north_star: RCV_32F bilinear paths within 1 ULP of the CPU oracle.  The evaluation order is fixed on both
+    sides (explicit fmaf, no contraction), so the expectation is bit-exact; the test asserts the 1-ULP bar and reports which."""
+    n = 2
+    frames = (rng.standard_normal((n, srows, scols, ch)) * rng.choice([1e-3, 1.0, 3e4])).astype(np.float32)
+    src = device.DeviceBatch(ctx, n, srows, scols, ch, _ffi.RCV_32F, step=scols * ch * 4 + 16)
+    dst = _canary_batch(ctx, n, drows, dcols, ch, _ffi.RCV_32F, pad=32)
+    src.upload(frames)
+    device.resize(src, dst)
+    got = dst.download()
+    worst = 0
+    for i in range(n):
+        want = oracle.resize_f32(frames[i] if ch > 1 else frames[i][..., 0], drows, dcols)
+        worst = max(worst, int(_ulp_distance(got[i], want).max()))
+    print(f"resize f32 {srows}x{scols} -> {drows}x{dcols} ch={ch}: max ULP distance {worst} ({'bit-exact' if worst == 0 else 'within 1 ULP' if worst <= 1 else 'FAIL'})")
+    assert worst <= 1
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
+@pytest.mark.parametrize("srows,scols,drows,dcols,ch", F32_GEOM)
+@pytest.mark.parametrize("deg,scale", [(7.0, 1.0), (-31.0, 0.8), (90.0, 1.0), (0.0, 1.3)])
+def test_warp_affine_f32(ctx, oracle, rng, srows, scols, drows, dcols, ch, deg, scale):
+    n = 2
+    t = np.deg2rad(deg)
+    c, s_ = np.cos(t) / scale, np.sin(t) / scale
+    cx, cy = scols / 2, srows / 2
+    M = np.array([c, -s_, cx - c * (dcols / 2) + s_ * (drows / 2) + 0.37, s_, c, cy - s_ * (dcols / 2) - c * (drows / 2) - 0.61], np.float32)
+    frames = (rng.standard_normal((n, srows, scols, ch)) * 1e-3).astype(np.float32)   # the magnitude of a Harris response map
+    src = device.DeviceBatch(ctx, n, srows, scols, ch, _ffi.RCV_32F)
+    dst = _canary_batch(ctx, n, drows, dcols, ch, _ffi.RCV_32F, pad=16)
+    src.upload(frames)
+    device.warp_affine(src, dst, M)
+    got = dst.download()
+    worst = 0
+    for i in range(n):
+        want = oracle.warp_affine_f32(frames[i] if ch > 1 else frames[i][..., 0], M, drows, dcols)
+        worst = max(worst, int(_ulp_distance(got[i], want).max()))
+    print(f"warpAffine f32 rot {deg} scale {scale} {srows}x{scols} -> {drows}x{dcols} ch={ch}: max ULP distance {worst}")
+    assert worst <= 1
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
+def test_geom_f32_special_values_and_arguments(ctx, oracle, rng):
+    """inf / NaN / denormal / signed-zero taps go through the same arithmetic on both sides (NaN where the oracle has NaN); host
+    Mats work; mixed depths, misaligned rows and the fused warp -> resize entry point (u8 only) are refused"""
+    rows, cols = 40, 56
+    img = (rng.standard_normal((rows, cols)) * 1e-2).astype(np.float32)
+    img[3, 4], img[10, 20], img[11, 21], img[30, 5], img[31, 6] = np.inf, -np.inf, np.nan, np.float32(1e-42), -0.0
+    M = np.array([0.98, -0.17, 2.5, 0.17, 0.98, -3.25], np.float32)
+    src, dst = Mat.from_array(img), Mat(rows, cols, 1, _ffi.RCV_32F)
+    imgproc.warp_affine(src, dst, M, ctx)
+    assert int(_ulp_distance(dst.to_array(), oracle.warp_affine_f32(img, M, rows, cols)).max()) <= 1
+    dst2 = Mat(23, 31, 1, _ffi.RCV_32F)
+    imgproc.resize(src, dst2, ctx)
+    assert int(_ulp_distance(dst2.to_array(), oracle.resize_f32(img, 23, 31)).max()) <= 1
+    L = _ffi.lib()
+    f = device.DeviceBatch(ctx, 1, rows, cols, 1, _ffi.RCV_32F)
+    u = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    bf, bu = f.as_rcv(), u.as_rcv()
+    Mp = M.ctypes.data_as(C.POINTER(C.c_float))
+    assert L.rcv_resize_batch(ctx.handle, C.byref(bf), C.byref(bu)) == _ffi.RCV_ERR_UNSUPPORTED        # f32 -> u8
+    assert L.rcv_warp_affine_batch(ctx.handle, C.byref(bu), C.byref(bf), Mp) == _ffi.RCV_ERR_UNSUPPORTED
+    assert L.rcv_warp_affine_resize_batch(ctx.handle, C.byref(bf), C.byref(bf), Mp, rows, cols) == _ffi.RCV_ERR_UNSUPPORTED
+    mis = f.as_rcv()
+    mis.frame0.data = f.ptr.value + 2                                                                  # f32 samples must be 4-byte aligned
+    mis.frame0.cap -= 4
+    mis.frame0.rows -= 1
+    assert L.rcv_resize_batch(ctx.handle, C.byref(mis), C.byref(bf)) == _ffi.RCV_ERR_ARG
+    f.free()
+    u.free()
+
+
 def test_image_beyond_4gib(ctx, oracle):
     """one 50 000 x 30 000 BGR image (4.5 GB: in-frame byte offsets exceed 2^32, so the 24-bit / 32-bit offset fast paths must
     step aside): row slabs of filter2D, gray filter2D, warpAffine and the Harris pipeline against the oracle, including rows

@@ -247,6 +247,8 @@ def test_oracle_matches_golden(oracle, gold):
     assert np.array_equal(oracle.warp_affine(bgr, gold["warp_M"], 37, 48), gold["warp"])
     assert np.array_equal(oracle.corner_harris(gray, 2, 0.04).view(np.uint32), gold["harris_b2"].view(np.uint32))
     assert np.array_equal(oracle.nms3x3(gold["harris_b2"], 1e-4), gold["nms"])
+    assert np.array_equal(oracle.warp_affine_f32(gold["harris_b2"], gold["warp_M"], 29, 41).view(np.uint32), gold["warp_f32"].view(np.uint32))
+    assert np.array_equal(oracle.resize_f32(gold["harris_b2"], 17, 23).view(np.uint32), gold["resize_f32_17x23"].view(np.uint32))
     assert np.array_equal(oracle.synth_frame(24, 40, 3, 1, 0x5EED0003, 2), gold["synth_scene"])
     assert np.array_equal(oracle.synth_frame(8, 8, 3, 0, 0x5EED0003, 0), gold["synth_noise"])
 

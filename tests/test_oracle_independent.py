@@ -76,6 +76,32 @@ def test_warp_affine_under_rotation(oracle, big, deg, tx, ty, scale):
     _close_to_rounding(oracle.warp_affine(gray, M, hg, wg), npref.warp_affine_f64(gray, M, hg, wg)[:, :, 0], f"warp gray {deg}")
 
 
+@pytest.mark.parametrize("ch", [1, 3])
+def test_f32_geometry_against_float64(oracle, ch):
+    """RCV_32F resize / warpAffine (round 3): the f32 oracle against a float64 evaluation of the same sampling rule on a
+    203 x 301 field of Harris-response magnitude.  The specification fixes f32 COORDINATES (sx = fmaf(M0, x, fmaf(M1, y, M2)) in
+    f32), so the two differ by the coordinate rounding times the local slope plus a few value roundings: bounded well below 1e-4 of
+    the field's range -- a wrong tap, weight, clamp or border rule would be off by the order of the range itself."""
+    rng = np.random.default_rng(0xF32)
+    img = (rng.standard_normal((203, 301, ch)) * 1e-3).astype(np.float32)
+    img = img[..., 0] if ch == 1 else img
+    span = float(np.abs(img).max())
+    for drows, dcols in ((203, 301), (57, 80), (400, 450), (1, 1)):
+        got = oracle.resize_f32(img, drows, dcols).reshape(drows, dcols, ch)
+        assert np.abs(got - npref.resize_f64(img, drows, dcols)).max() <= 1e-4 * span
+    for deg, tx, ty, scale in ((7.0, 13.25, -8.5, 1.0), (-31.0, 40.0, 10.0, 0.8), (90.0, 0.0, 0.0, 1.0), (180.0, 0.3, 0.7, 1.3)):
+        t = np.deg2rad(deg)
+        c, s = np.cos(t) * scale, np.sin(t) * scale
+        cx, cy = 150.0, 101.0
+        M = np.array([c, -s, cx - c * cx + s * cy + tx, s, c, cy - s * cx - c * cy + ty], np.float32)
+        for drows, dcols in ((203, 301), (150, 400)):
+            got = oracle.warp_affine_f32(img, M, drows, dcols).reshape(drows, dcols, ch)
+            want = npref.warp_affine_f64(img, M, drows, dcols)
+            # at the source's border a coordinate within rounding of -1 / cols switches a whole tap on or off: compare away from it
+            bad = np.abs(got - want) > 1e-4 * span
+            assert bad.mean() < 1e-3, (deg, drows, dcols, bad.sum())
+
+
 def test_rectangle_transliteration_including_wraps(oracle):
     """drawing.rs:67-106 line by line in Python (u64 wrapping index arithmetic) against the C restatement: clipped rectangles,
     thickness larger than the rectangle (rows / columns run past the far edge and, through the wrapping index, onto other
