@@ -40,6 +40,9 @@ static void load_knobs()
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
+    g_knobs.nms_seg = env_int("RCV_NMS_SEG", 0);
+    g_knobs.sobel_seg = env_int("RCV_SOBEL_SEG", 0);
+    g_knobs.sobel_plain = env_int("RCV_SOBEL_PLAIN", 0);
     g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
     g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
     g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);

@@ -229,10 +229,13 @@ int nms_launch(rcv_ctx* ctx, const View& r, const View& m, float thr)
     if (r.cols >= 4 && (uintptr_t)r.p % 4 == 0 && r.step % 4 == 0 && (r.n <= 1 || r.fstride % 4 == 0)) {
         const bool aligned = r.cols % 4 == 0 && (uintptr_t)r.p % 16 == 0 && r.step % 16 == 0 && (r.n <= 1 || r.fstride % 16 == 0) &&
                              (uintptr_t)m.p % 4 == 0 && m.step % 4 == 0 && (m.n <= 1 || m.fstride % 4 == 0);
-        // 64-row segments; small launches (a few frames): shorter ones, so that every SIMD has a wave (rcv_plan_seg_rows)
+        // small launches (a few frames): segments sized so that every SIMD has a wave (rcv_plan_seg_rows)
         const int gx0 = ((r.cols + 3) / 4 + kBlock - 1) / kBlock;
         const int small = rcv_plan_seg_rows(r.rows, 4LL * gx0 * r.n, ctx->cu_count, 6, 8);
-        const int seg = small > 0 && small < 64 ? small : 64;
+        // (launches that fill the GPU: 16-row segments -- round 3, tools/ablate_segs.py on 64 4K frames: 16 rows 0.509 ms, 32 rows 0.538,
+        //  64 rows 0.554: with the XCD-contiguous block order short segments keep what one XCD reads at a time compact)
+        int seg = small > 0 && small < 64 ? small : 16;
+        if (rcv_knobs().nms_seg > 0) seg = rcv_knobs().nms_seg;   // (tuning knob)
         dim3 grid((unsigned)gx0, (unsigned)((r.rows + seg - 1) / seg), r.n);
         const int gx = (int)grid.x, gy = (int)grid.y;
         const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;

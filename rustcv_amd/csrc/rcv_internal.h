@@ -90,6 +90,9 @@ struct RcvKnobs {
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
+    int sobel_seg;        // RCV_SOBEL_SEG     rows per segment of the Sobel kernel (0 = plan)
+    int sobel_plain;      // RCV_SOBEL_PLAIN   1: plain instead of non-temporal stores (A/B)
+    int nms_seg;          // RCV_NMS_SEG       rows per segment of the NMS kernel (0 = plan)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)

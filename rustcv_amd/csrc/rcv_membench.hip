@@ -139,6 +139,39 @@ __global__ __launch_bounds__(kT) void k_write_sweep(uint4* __restrict__ d, size_
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) d[i] = v;
 }
 
+// Store-pattern study (round 3, the Sobel kernel's store rate): waves own strips of `chunks` x 1 KB of a row in each of `planes`
+// planes and walk down `seg_rows` rows, as the register-window kernels do; NT: non-temporal stores.  Block order as in those
+// kernels (each XCD a contiguous run of the wave list) when blocks_per_xcd > 0.
+struct StoreArgs {
+    uint8_t* p[2];
+    size_t step, fstride;
+    int rows, nstrips, nsegs, seg_rows, total_waves, chunks, planes, blocks_per_xcd, pair_rows;
+};
+template <bool NT>
+__global__ __launch_bounds__(256) void k_store_strips(StoreArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+    if (wid >= a.total_waves) return;
+    const int strip = wid % a.nstrips;
+    wid /= a.nstrips;
+    const int seg = wid % a.nsegs, frame = wid / a.nsegs;
+    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    const u4v v = {(unsigned)wid, (unsigned)lane, 0x5EEDu, (unsigned)strip};
+    // pair_rows = r > 1: r rows of plane 0, then the same r rows of plane 1 (longer runs per plane before switching streams)
+    const int pr = a.pair_rows > 1 ? a.pair_rows : 1;
+    for (int y0 = ys; y0 < ye; y0 += pr)
+        for (int pl = 0; pl < a.planes; ++pl)
+            for (int y = y0; y < min(y0 + pr, ye); ++y) {
+                uint8_t* row = a.p[pl] + (size_t)frame * a.fstride + (size_t)y * a.step + (size_t)strip * 1024 * a.chunks + 16 * lane;
+                for (int c = 0; c < a.chunks; ++c) {
+                    if (NT) __builtin_nontemporal_store(v, (u4v*)(row + 1024 * c));
+                    else *(u4v*)(row + 1024 * c) = v;
+                }
+            }
+}
+
 __global__ __launch_bounds__(64) void k_nop(int* p)
 {
     if (p && threadIdx.x == 1234567) *p = 0;   // (never)
@@ -183,6 +216,34 @@ extern "C" int rcv__clock_probe(rcv_ctx* ctx, int us, float* mhz)
         }
     *mhz = (float)best;
     return RCV_OK;
+}
+
+// rows x row_bytes per plane per frame, n frames (frame stride = rows * step), written by strip-walking waves; see k_store_strips
+extern "C" int rcv__storebench(rcv_ctx* ctx, void* p0, void* p1, int n, int rows, int row_bytes, size_t step, int chunks, int planes, int seg_rows, int nt,
+                               int xcd_order, int wgs_per_cu, int pair_rows)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!p0 || (planes == 2 && !p1) || chunks < 1 || chunks > 4 || row_bytes % (1024 * chunks) || planes < 1 || planes > 2 || seg_rows < 1) return RCV_ERR_ARG;
+    StoreArgs a;
+    a.p[0] = (uint8_t*)p0;
+    a.p[1] = (uint8_t*)p1;
+    a.step = step;
+    a.fstride = (size_t)rows * step;
+    a.rows = rows;
+    a.nstrips = row_bytes / (1024 * chunks);
+    a.seg_rows = seg_rows;
+    a.nsegs = (rows + seg_rows - 1) / seg_rows;
+    a.total_waves = a.nstrips * a.nsegs * n;
+    a.chunks = chunks;
+    a.planes = planes;
+    a.pair_rows = pair_rows;
+    const long long nblocks = ((long long)a.total_waves + 3) / 4;
+    a.blocks_per_xcd = xcd_order ? (int)((nblocks + 7) / 8) : 0;
+    const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
+    const unsigned lds = wgs_per_cu > 0 ? (unsigned)((163840 / wgs_per_cu) & ~511) : 0u;
+    if (nt) hipLaunchKernelGGL((k_store_strips<true>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k_store_strips<false>), grid, dim3(256), lds, ctx->stream, a);
+    return rcv_launch_check(ctx);
 }
 
 // variant: 0 hipMemcpyAsync D2D | 1 sweep | 2 block-contiguous | 3 sweep, nt loads + nt stores | 4 sweep, nt stores |

@@ -22,6 +22,7 @@
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
+#include <type_traits>
 
 extern int rcv_debug_flags;
 
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     wid /= a.nstrips;
     const int seg = wid % a.nsegs;
     const int frame = wid / a.nsegs;
-    const int ys = seg * a.seg_rows, ye = min(a.rows, ys + a.seg_rows);
+    // segments of equal height up to one row (no short last segment: the launch ends when its slowest wave does)
+    const int ys = (int)((long long)a.rows * seg / a.nsegs), ye = (int)((long long)a.rows * (seg + 1) / a.nsegs);
     const int x = strip * kStripPx + 8 * lane;                 // first pixel of this lane's run (may be >= cols in the last strip)
     const int xc = min(x, a.cols - 8);                         // clamped load position
     const bool edgeR = x == a.cols;                            // lane right of the image: supplies the mirrored column cols-2
@@ -183,7 +185,9 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
 
-    auto feed = [&](const Row& rw, int r) {  // r = index of the row just loaded; emits output row r-1 when r-1 >= ys
+    // r = index of the row just loaded; emits output row r-1.  STORE = false: the segment's first two rows (no output row is complete yet)
+    auto feed = [&](const Row& rw, int r, auto store_tag) {
+        constexpr bool STORE = decltype(store_tag)::value;
         U2 v = rw.v;
         // x = cols mirrors cols-2: the lane just right of the image holds cols-8..cols-1 after clamping -> its byte 0 := byte 6
         if (RAG) v = U2{pk(v.hi, v.lo, sel_lo), pk(v.hi, v.lo, sel_hi)};
@@ -208,15 +212,21 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
         for (int j = 0; j < 4; ++j) {
             h1[j] = pk_sub(L[j + 1], L[j]);
             h2[j] = pk_add2x(pk_add(L[j], L[j + 1]), Cc[j]);
-            ox[j] = pk_add2x(pk_add(h1a[j], h1[j]), h1b[j]);
-            oy[j] = pk_sub(h2[j], h2a[j]);
+            if constexpr (STORE) {
+                ox[j] = pk_add2x(pk_add(h1a[j], h1[j]), h1b[j]);
+                oy[j] = pk_sub(h2[j], h2a[j]);
+            }
             h1a[j] = h1b[j];
             h1b[j] = h1[j];
             h2a[j] = h2b[j];
             h2b[j] = h2[j];
         }
+        if constexpr (!STORE) return;
         const int y = r - 1;
-        const bool st = live && y >= ys && y < ye;
+        // (the caller only feeds rows whose output row lies in [ys, ye): no store of a whole wave ever goes to the dump line --
+        //  non-temporal stores of many waves to one shared line serialise, which used to cost the rows a segment's last prefetch
+        //  group held beyond its end: 64 x 4K 0.53 -> 0.45 ms with segments of 8k - 2 rows, round 3)
+        const bool st = live;
         if (DBG & 1) {
             if (ox[0] == 0x12345678u && oy[1] == 0x9abcdef0u) *(uint4*)dump = make_uint4(ox[0], ox[1], oy[2], oy[3]);
             return;
@@ -258,19 +268,41 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
         __builtin_nontemporal_store(v4u{oy[0], oy[1], oy[2], oy[3]}, (v4u*)(st ? dyp + (size_t)y * a.ystep : dump));
     };
 
-    // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kRowsAhead, next group in flight while this one computes
+    // rows ys-1 .. ye are consumed (ye - ys + 2 rows); groups of kAheadRows, the next group in flight while this one computes.  The
+    // first two rows complete no output row (static no-store variant); full groups run unconditionally (counted vmcnt waits);
+    // the last, partial group checks row by row -- nothing is in flight behind it that a conservative wait could hurt.
     const int nrows = ye - ys + 2;
     constexpr int kAheadRows = BGR ? 4 : kRowsAhead;   // (a BGR row is 8 registers per lane)
+    const std::true_type yes{};
+    const std::false_type no{};
     Raw cur[kAheadRows], nxt[kAheadRows];
 #pragma unroll
     for (int i = 0; i < kAheadRows; ++i) cur[i] = load_raw(ys - 1 + i);
-    for (int g = 0; g < nrows; g += kAheadRows) {
+    int g = 0;
+    if (nrows >= kAheadRows) {   // (a segment has at least kAheadRows - 2 rows: host plan; tiny images take the tail below)
 #pragma unroll
-        for (int i = 0; i < kAheadRows; ++i) nxt[i] = load_raw(ys - 1 + g + kAheadRows + i);
+        for (int i = 0; i < kAheadRows; ++i) nxt[i] = load_raw(ys - 1 + kAheadRows + i);
+        feed(to_row(cur[0]), ys - 1, no);
+        feed(to_row(cur[1]), ys, no);
 #pragma unroll
-        for (int i = 0; i < kAheadRows; ++i) feed(to_row(cur[i]), ys - 1 + g + i);
+        for (int i = 2; i < kAheadRows; ++i) feed(to_row(cur[i]), ys - 1 + i, yes);
 #pragma unroll
         for (int i = 0; i < kAheadRows; ++i) cur[i] = nxt[i];
+        for (g = kAheadRows; g + kAheadRows <= nrows; g += kAheadRows) {
+#pragma unroll
+            for (int i = 0; i < kAheadRows; ++i) nxt[i] = load_raw(ys - 1 + g + kAheadRows + i);
+#pragma unroll
+            for (int i = 0; i < kAheadRows; ++i) feed(to_row(cur[i]), ys - 1 + g + i, yes);
+#pragma unroll
+            for (int i = 0; i < kAheadRows; ++i) cur[i] = nxt[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kAheadRows; ++i) {
+        const int r = ys - 1 + g + i;
+        if (g + i >= nrows) break;
+        if (r - 1 >= ys) feed(to_row(cur[i]), r, yes);
+        else feed(to_row(cur[i]), r, no);
     }
 }
 
@@ -299,11 +331,13 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     a.rows = s.rows;
     a.cols = s.cols;
     a.nstrips = (s.cols + kStripPx - 1) / kStripPx;
-    // enough waves to fill 256 CUs x 32 wave slots a few times; segments of >= 32 rows
-    int seg = s.rows;
-    while ((long long)a.nstrips * ((s.rows + seg - 1) / seg) * s.n < 16384 && seg > 32) seg = (seg + 1) / 2;
+    // Segments of ~24 rows, equal up to one row (round 3, tools/ablate_sobel.py on 64 4K frames: 12 ... 40 rows 0.417-0.420 ms, 68
+    // rows 0.439, 90 rows 0.445 -- with the XCD-contiguous block order shorter segments keep what one XCD has in flight more
+    // compact; a BGR source likes them shorter still: 12-20 rows 0.614-0.617 against 0.648 at 68).
+    int seg = s.ch == 3 ? 16 : 24;
+    if (rcv_knobs().sobel_seg > 0) seg = rcv_knobs().sobel_seg;   // (tuning knob)
     a.seg_rows = seg;
-    a.nsegs = (s.rows + seg - 1) / seg;
+    a.nsegs = s.rows >= 2 * seg ? (s.rows + seg / 2) / seg : 1;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
@@ -332,7 +366,8 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     default: RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a); break;
     }
 #else
-    RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a);
+    if (rcv_knobs().sobel_plain) RCV_LAUNCH((k_sobel_rows<4, false>), grid, dim3(256), lds, ctx->stream, a);   // (plain instead of non-temporal stores: A/B knob)
+    else RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a);
 #endif
     return rcv_launch_check(ctx);
 }
