@@ -4,7 +4,8 @@
 //! `unsafe impl Send` on the owning wrapper, `Drop` calls the C `free`).
 //!
 //! SOURCE ONLY -- never compiled in the build image (no rustc).  `ffi.rs` is generated from the C header and checked against
-//! it by tests/test_abi.py; this file adds the owning handle and the shims.  See INTEGRATION.md.
+//! it by tests/test_abi.py; this file adds the owning handle and the shims with the reference's exact signatures, `imgproc.rs` the
+//! safe facade for everything else (tests/test_abi.py checks that the two files together wrap every entry point).  See INTEGRATION.md.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_void;
 
@@ -12,6 +13,10 @@ use std::os::raw::c_void;
 /// the C ABI, the way `rustcv-camera/src/backend/macos/mod.rs:52-79` declares the whole of `bridge.h`).
 pub mod ffi;
 pub use ffi::*;
+
+/// Safe facade for the image operations and the device-resident batch path: `Mat`-shaped borrows, `DeviceBatch`, `StagingRing`,
+/// `Graph` and one wrapper per compute entry point (the Rust twin of include/rustcv.hpp).
+pub mod imgproc;
 
 /// Owning handle: one GPU + one HIP stream.  Not `Sync`; one thread per context (bridge.h:4-7).
 pub struct HipContext {
