@@ -138,6 +138,7 @@ DEBUG_SIGNATURES = {
     "rcv__debug_occupancy": (_i, []),
     "rcv__membench": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz, _i, _i]),
     "rcv__storebench": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i, _i]),
+    "rcv__debug_trace_buffer": (None, [C.c_void_p]),
     "rcv__clock_probe": (_i, [_ctx, _i, C.POINTER(C.c_float)]),
 }
 

@@ -48,6 +48,8 @@
 #include <string.h>
 
 extern int rcv_debug_flags;
+void* rcv_debug_trace = nullptr;   // device buffer for the per-wave timeline of profiling builds (rcv__debug_trace_buffer)
+extern "C" void rcv__debug_trace_buffer(void* p) { rcv_debug_trace = p; }
 
 namespace {
 
@@ -68,6 +70,12 @@ struct FRArgs {
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
     uint8_t *gdx, *gdy;          // SOB: the i16 gradient planes (one channel), row step / frame stride in bytes
+    // tn > 0: tapered bands (order 0, n % 8 == 0).  Every XCD's eighth of the frame-rows is cut into tn runs of equal bands, the
+    // last runs into shorter ones, so that the waves of the launch's last round finish together (see the host code).  Rows relative
+    // to the XCD's first row.
+    int tn, tnb[4];
+    long long tstart[4], tlen[4];
+    unsigned long long* trace;   // (DBG & 1024, profiling builds) per-wave {start, end} of the 100 MHz counter
     size_t gstep, gfs;
 };
 
@@ -538,6 +546,8 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     // seam lines meet in that CU's L1 and the CU streams wpb * 768 contiguous bytes per row (RCV_FR_WPB).
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long t_start = 0;
+    if constexpr ((DBG & 1024) != 0) t_start = __builtin_amdgcn_s_memrealtime();
     // XCD-aware order (speed only): hardware places block b on XCD b % 8; each XCD gets a contiguous run of bands, and the strips
     // of one band -- which share the 128-B lines at their seams -- are neighbours in dispatch order on one L2
     const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * a.wpb + wave;
@@ -552,13 +562,20 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     const int bi = slot / a.nstrips;   // dispatch order of this band on its XCD
     if (bi >= a.bands_per_xcd) return;
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
-    if (band >= a.nbands) return;
+    if (a.tn == 0 && band >= a.nbands) return;
     const int X = strip * (SOB ? 720 : 768);   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset; SOB: strips 240 pixels apart)
     // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
     const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
     long long g0 = G * band / a.nbands;
-    const long long g1 = G * (band + 1) / a.nbands;
+    long long g1 = G * (band + 1) / a.nbands;
+    if (a.tn > 0) {   // tapered: run r of this XCD's list, band b of the run (scalar)
+        int b = bi, r = 0;
+        while (r < a.tn - 1 && b >= a.tnb[r]) b -= a.tnb[r++];
+        const long long x0 = G / 8 * xcd + a.tstart[r];
+        g0 = x0 + a.tlen[r] * b / a.tnb[r];
+        g1 = x0 + a.tlen[r] * (b + 1) / a.tnb[r];
+    }
     while (g0 < g1) {   // (a band that crosses a frame boundary is two segments)
         const int frame = (int)(g0 / a.rows), ys = (int)(g0 - (long long)frame * a.rows);
         const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
@@ -574,6 +591,14 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
         } else if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
         else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
         g0 += ye - ys;
+    }
+    if constexpr ((DBG & 1024) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's last stores have left
+        if (lane == 0 && a.trace) {
+            const size_t w = (size_t)blockIdx.x * a.wpb + wave;
+            a.trace[2 * w] = t_start;
+            a.trace[2 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 
@@ -617,6 +642,7 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     case 8: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 8>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 16: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 16>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 18: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 18>), grid, dim3(64 * a.wpb), lds, st, a); return;
+    case 24: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 1024>), grid, dim3(64 * a.wpb), lds, st, a); return;   // wave timeline (rcv__debug_trace_buffer)
     case 68: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 4>), grid, dim3(64 * a.wpb), lds, st, a); return;   // (64 + 4: adds instead of MFMAs)
     default: break;
     }
@@ -698,8 +724,39 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 // small launches keep the strip kernel's latency variant.
 // gx, gy (both or neither): the i16 gradient planes of the fused filter2D -> BGR2GRAY -> Sobel launch; `d` is not written then
 // (BGR source with 4-byte aligned rows and a width that is a multiple of 4, |weights| <= 127, 8-byte aligned gradient rows).
+static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size, const View* gx,
+                       const View* gy);
+
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size,
                         const View* gx, const View* gy)
+{
+    // RCV_FR_CHUNK = c: a batch of more than c frames runs as consecutive launches of c frames on the same stream (experiment,
+    // round 3: launches of ONE round of waves -- 8 4K frames -- cost less per frame than the multi-round launch of 64)
+    const int chunk = rcv_knobs().fr_chunk;
+    if (chunk > 0 && s.n > chunk) {
+        for (int f0 = 0; f0 < s.n; f0 += chunk) {
+            const int nf = s.n - f0 < chunk ? s.n - f0 : chunk;
+            View sv = s, dv = d, xv, yv;
+            sv.p = s.p + (size_t)f0 * s.fstride;
+            dv.p = d.p + (size_t)f0 * d.fstride;
+            sv.n = dv.n = nf;
+            if (gx) {
+                xv = *gx;
+                yv = *gy;
+                xv.p = gx->p + (size_t)f0 * gx->fstride;
+                yv.p = gy->p + (size_t)f0 * gy->fstride;
+                xv.n = yv.n = nf;
+            }
+            const int rc = rows_launch(ctx, sv, dv, k, ksize, shift, src_yuyv, true, gx ? &xv : nullptr, gx ? &yv : nullptr);
+            if (rc != RCV_OK) return f0 == 0 ? rc : RCV_ERR_DEVICE;   // (a later chunk cannot be refused for its shape: same shape)
+        }
+        return RCV_OK;
+    }
+    return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy);
+}
+
+static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size, const View* gx,
+                       const View* gy)
 {
     const bool sob = gx != nullptr;
     if (sob != (gy != nullptr)) return RCV_ERR_ARG;
@@ -802,6 +859,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.gdy = sob ? gy->p : nullptr;
     a.gstep = sob ? gx->step : 0;
     a.gfs = sob ? gx->fstride : 0;
+    a.trace = (unsigned long long*)rcv_debug_trace;
     // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
     // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob
     // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).
@@ -841,6 +899,30 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
         a.nbands = (int)nb;
         a.bands_per_xcd = (int)((nb + 7) / 8);
         a.order = kn.fr_order == 1 ? 1 : 0;
+        a.tn = 0;
+        // Tapered bands (round 3, tools/wave_timeline.py): with equal bands the launch's LAST round of waves starts spread over
+        // one wave duration (56 us at 103-row bands) and the slots then drain for as long -- occupancy below 90 % for the last 60 us
+        // of a 605-us launch.  So the tail of every XCD's list -- about one round of its wave slots -- is cut finer: the first half
+        // into half-height bands, the second half into quarter-height ones; the last waves to start are the shortest.
+        if (small == 0 && kn.fr_band_rows == 0 && a.order == 0 && s.n >= 8 && s.n % 8 == 0 && kn.fr_taper != 0 && nb >= 64) {
+            const long long Lx = G / 8;
+            const double H = (double)G / (double)nb;                              // rows per (big) band
+            const double cb = 8.0 * ctx->cu_count / 8.0 / a.nstrips;             // bands one XCD has in flight (8 waves per CU)
+            const int pct = kn.fr_taper > 1 ? kn.fr_taper : 100;                // (knob: the tapered part in % of one round)
+            long long T = (long long)(cb * H * pct / 100.0 + 0.5);
+            if (T > Lx / 2) T = Lx / 2;
+            if (T >= (long long)(4 * H)) {
+                const long long head = Lx - T, ta = T / 2, tb = T - ta;
+                a.tn = 3;
+                a.tstart[0] = 0;          a.tlen[0] = head; a.tnb[0] = (int)(head / H + 0.5);
+                a.tstart[1] = head;       a.tlen[1] = ta;   a.tnb[1] = (int)(ta / (H / 2) + 0.5);
+                a.tstart[2] = head + ta;  a.tlen[2] = tb;   a.tnb[2] = (int)(tb / (H / 4) + 0.5);
+                a.tstart[3] = 0;          a.tlen[3] = 0;    a.tnb[3] = 1;
+                for (int i = 0; i < 3; ++i) a.tnb[i] = a.tnb[i] < 1 ? 1 : a.tnb[i];
+                a.bands_per_xcd = a.tnb[0] + a.tnb[1] + a.tnb[2];
+                a.nbands = a.bands_per_xcd * 8;
+            }
+        }
     }
     a.shift = shift;
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));

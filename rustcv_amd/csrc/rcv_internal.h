@@ -87,6 +87,8 @@ struct RcvKnobs {
     int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian (rcv_gauss_rows.hip): 1 every eligible shape, 0 never, -1 (unset) small launches
     int gr_plain;         // RCV_GR_PLAIN      its stores plain instead of non-temporal (ablation)
     int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan)
+    int fr_chunk;         // RCV_FR_CHUNK      frames per launch of the row-streaming kernel (0 = the whole batch in one launch)
+    int fr_taper;         // RCV_FR_TAPER      0: equal bands; unset / 1: tapered tail of one round; n > 1: tail of n % of a round
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)

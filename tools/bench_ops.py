@@ -97,7 +97,18 @@ def main():
     def B(n, r, c, ch, depth=_ffi.RCV_8U):
         return device.DeviceBatch(ctx, max(1, int(round(n * a.scale))), r, c, ch, depth)
 
-    def record(name, cfg, n, out_px, bpp, fn, note="", cpu=None):
+    def clock_under(fn):
+        """shader clock (MHz) sampled by a one-wave probe on the side stream while ~40 launches of `fn` are queued"""
+        f = C.c_float()
+        for _ in range(40):
+            fn()
+        _ffi.lib().rcv__clock_probe(ctx.handle, 3000, C.byref(f))
+        ctx.sync()
+        return float(f.value)
+
+    def record(name, cfg, n, out_px, bpp, fn, note="", cpu=None, valu=None):
+        """valu = VALU instructions per output pixel the op's arithmetic needs at least (packed FMAs count as one): the row then
+        carries its VALU roofline -- n * px * valu / (1024 SIMDs x 16 lanes per cycle x measured clock) / measured time"""
         if a.only and a.only.replace("_", " ") not in name + " @ " + cfg:   # "--only Sobel_3x3_->_dx,dy_i16_@_4K": op and config
             return
         ms = timeit(ctx, fn, a.steps, a.warmup)
@@ -105,10 +116,15 @@ def main():
         gbs = n * out_px * bpp / (ms * 1e-3) / 1e9
         row = {"op": name, "config": cfg, "frames": n, "ms_per_launch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3),
                "mpix_s": round(mpix, 1), "alg_bytes_per_px": bpp, "alg_gb_s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM, 4), "note": note}
+        if valu is not None:
+            mhz = clock_under(fn)
+            t_valu = n * out_px * valu / (1024 * 16 * mhz * 1e6)
+            row.update({"valu_instr_per_px": valu, "shader_mhz": round(mhz, 1), "valu_bound_ms": round(t_valu * 1e3, 4), "frac_valu_bound": round(t_valu / (ms * 1e-3), 4)})
         if a.cpu and cpu is not None:
             row["cpu"] = cpu()
         rows.append(row)
-        print(f"{name:34s} {cfg:34s} n={n:3d} {ms:9.4f} ms  {mpix:11.1f} Mpix/s  {gbs:8.1f} GB/s  {gbs / HBM * 100:5.1f} %  {row.get('cpu', '')}", flush=True)
+        vb = f"  VALU bound {row['frac_valu_bound'] * 100:5.1f} % @ {row['shader_mhz']:.0f} MHz" if valu is not None else ""
+        print(f"{name:34s} {cfg:34s} n={n:3d} {ms:9.4f} ms  {mpix:11.1f} Mpix/s  {gbs:8.1f} GB/s  {gbs / HBM * 100:5.1f} %{vb}  {row.get('cpu', '')}", flush=True)
 
     def cpu_time(fn, px, budget=4.0):
         from oracle import pyoracle as orc
@@ -192,15 +208,16 @@ def main():
     record("filter2D 7x7 i8 (>>6)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.filter2d(s, d, k7, shift=6))
     kf = (k7.astype(np.float32) / 64.0)
     record("filter2D 7x7 f32", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.filter2d(s, d, kf, delta=0.0),
-           note="VALU-bound by construction (49 dependent fmaf per sample), reported for completeness")
+           note="VALU-bound by construction (49 dependent fmaf per sample), reported for completeness", valu=147 / 2)   # 3 x 49 FMA per px, two per v_pk_fma_f32
     record("GaussianBlur 7x7 (sigma=0)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.gaussian_blur(s, d, 7, 0.0))
     record("GaussianBlur 7x7 (sigma=1.5)", "4K batch=64", s.n, 3840 * 2160, 6, lambda: device.gaussian_blur(s, d, 7, 1.5),
-           note="f32 separable path, 14 fmaf per sample")
+           note="f32 separable path, 14 fmaf per sample", valu=42 / 2)
     # ---- config 5: Harris pipeline on 4K BGR, 64 frames per GPU ----------------------------------------------
     m = B(64, 2160, 3840, 1)
     device.synth(s, 1, SEED + 5, 0)
     record("Harris pipeline (BGR->mask)", "4K batch=64/GPU", s.n, 3840 * 2160, 4, lambda: device.harris_pipeline(s, m, None, 2, 0.04, 1e-4),
-           cpu=lambda: cpu_time(lambda orc: orc.harris_pipeline(np.zeros((2160, 3840, 3), np.uint8), 2, 0.04, 1e-4), 3840 * 2160))
+           cpu=lambda: cpu_time(lambda orc: orc.harris_pipeline(np.zeros((2160, 3840, 3), np.uint8), 2, 0.04, 1e-4), 3840 * 2160),
+           valu=32)   # VALU instructions per pixel of the kernel as built (rocprofv3 SQ_INSTS_VALU, profiles/r02_op_harris_4k.txt)
     yq = B(64, 2160, 3840, 2)
     device.synth(yq, 2, SEED + 5, 0)
     record("Harris pipeline from a YUYV source (config 5 [or YUYV])", "4K batch=64/GPU", yq.n, 3840 * 2160, 3,
@@ -238,7 +255,7 @@ def main():
     device.synth(s, 0, SEED + 4, 0)
     M = rot_matrix(7.0, 7680 / 2, 4320 / 2, 13.25, -8.5)
     frac = warp_touched_fraction(M.astype(np.float64), 4320, 7680, 4320, 7680) if not a.only or "warpAffine bil" in a.only.replace("_", " ") or "GRAY" in a.only else 1.0
-    record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 3 + 3 * frac, lambda: device.warp_affine(s, d, M),
+    record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 3 + 3 * frac, lambda: device.warp_affine(s, d, M), valu=41,
            note=f"3 B written per output px + 3 B per DISTINCT in-bounds source px touched ({frac:.4f} per output px, counted on the host; upper bound 6)",
            cpu=lambda: cpu_time(lambda orc: orc.warp_affine(np.zeros((4320, 7680, 3), np.uint8), M, 4320, 7680), 7680 * 4320, 6.0))
     d.free()
@@ -248,7 +265,7 @@ def main():
     sg.free(); dg.free()
     d = B(32, 1080, 1920, 3)
     record("warpAffine + resize 8K -> 1080p FUSED (next row f1)", "8K batch=32/GPU", s.n, 1920 * 1080, 30,
-           lambda: device.warp_affine_resize(s, d, M, 4320, 7680),
+           lambda: device.warp_affine_resize(s, d, M, 4320, 7680), valu=290,
            note="30 B per OUTPUT px: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written; "
                 "the unfused pair moves 6 B/px of 8K intermediate on top")
     d2 = B(32, 2880, 5120, 3)

@@ -23,15 +23,18 @@ def bound_of(r):
     return "HBM"
 
 
-out = ["| op | config | frames | ms / launch | Gpix/s | algorithmic TB/s | % of 8 TB/s | bound | CPU oracle Mpix/s (cores) |", "|---|---|---|---|---|---|---|---|---|"]
+out = ["| op | config | frames | ms / launch | Gpix/s | algorithmic TB/s | % of 8 TB/s | % of the VALU roofline (instr/px @ measured clock) | bound | CPU oracle Mpix/s (cores) |", "|---|---|---|---|---|---|---|---|---|---|"]
 for r in d["rows"]:
     cpu = r.get("cpu")
     cpu_s = f"{cpu['mpix_s']:.0f} ({cpu['cores']})" if cpu else ""
     hbm = f"{r['alg_gb_s'] / 1e3:.2f} | {r['frac_hbm_peak'] * 100:.1f}" if r["alg_bytes_per_px"] else "– | –"
-    out.append(f"| {r['op']} | {r['config']} | {r['frames']} | {r['ms_per_launch']:.4f} | {r['mpix_s'] / 1e3:.0f} | {hbm} | {bound_of(r)} | {cpu_s} |")
+    valu = f"{r['frac_valu_bound'] * 100:.0f} ({r['valu_instr_per_px']:g} @ {r['shader_mhz'] / 1e3:.2f} GHz)" if "frac_valu_bound" in r else ""
+    out.append(f"| {r['op']} | {r['config']} | {r['frames']} | {r['ms_per_launch']:.4f} | {r['mpix_s'] / 1e3:.0f} | {hbm} | {valu} | {bound_of(r)} | {cpu_s} |")
 text = "\n".join(out) + "\n"
 sys.stdout.write(text)
 if len(sys.argv) <= 1:
     with open(os.path.join(ROOT, "profiles", "ops_table.md"), "w") as f:
         f.write("One MI355X, device-resident batches, sustained clocks (`python tools/bench_ops.py --cpu`; raw data: `ops_bench.json`).\n"
-                "Algorithmic bytes per pixel as DESIGN.md section 4 states them; launch-bound rows carry no roofline figure.\n\n" + text)
+                "Algorithmic bytes per pixel as DESIGN.md section 4 states them; launch-bound rows carry no roofline figure.  VALU roofline: the\n"
+                "op's VALU instructions per pixel (packed FMAs count once) x pixels / (1024 SIMDs x 16 lanes per cycle x the shader clock\n"
+                "measured under that op) / measured time -- min(HBM, VALU) is the bound of a row.\n\n" + text)
