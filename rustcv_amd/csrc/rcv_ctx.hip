@@ -32,6 +32,7 @@ static void load_knobs()
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
     g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
     g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
+    g_knobs.fr_sob192 = env_int("RCV_FR_SOB192", 0);
     g_knobs.fr_taper = env_int("RCV_FR_TAPER", -1);
     g_knobs.fr_chunk = env_int("RCV_FR_CHUNK", 0);
     g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);

@@ -66,6 +66,7 @@ struct FRArgs {
     int nstrips, nframes;
     int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
+    int sob192;                  // SOB: 1 = line-aligned 192-pixel strips with non-temporal stores (SOB = 2 instantiation)
     int wpb;                     // waves per workgroup (1, 2, 4 or 8): independent waves, neighbouring strips of a band on one CU
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
@@ -383,7 +384,9 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // lane has both lanes' dx and the odd lane both lanes' dy: ONE 16-byte store per lane and row.  Pair-local validity: tile
     // pixels 8 .. 247 (strip 0: from 0), inside the row; a width that is not a multiple of 8 ends on a half pair.
     const int tp2 = 16 * n + 8 * (q >> 1), gp2 = X / 3 + tp2;
-    const bool pair_ok = SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248;
+    // SOB = 2: strips 192 pixels apart (384 bytes = three whole lines of an i16 plane per wave and row: non-temporal stores); the tile
+    // starts 16 pixels left of the strip (strip 0: at pixel 0) and stores tile pixels 16 .. 207 (strip 0: 0 .. 191)
+    const bool pair_ok = SOB == 2 ? (tp2 >= (X == 0 ? 0 : 16) && tp2 < (X == 0 ? 192 : 208)) : (SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248);
     const bool g_full = pair_ok && gp2 + 8 <= a.cols, g_half = pair_ok && gp2 + 8 > a.cols && gp2 + 4 <= a.cols;
     uint8_t* const gplane = (q & 1) ? dyf : dxf;
     typedef uint32_t fr_u2 __attribute__((ext_vector_type(2)));
@@ -397,6 +400,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         uint8_t* const o = gplane + (size_t)gy * a.gstep + 2 * (size_t)gp2;
         // plain stores: the 480-byte row pieces of neighbouring strips share lines, which the L2 merges (non-temporal: 1.05
         // instead of 0.78 ms on 64 4K frames)
+        if constexpr (SOB == 2) {   // (row pieces are whole lines: no other wave writes into them)
+            if (g_full) __builtin_nontemporal_store(fr_u4{x0, x1, y0, y1}, (fr_u4*)o);
+            else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
+            return;
+        }
         if (g_full) *(fr_u4*)o = fr_u4{x0, x1, y0, y1};
         else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
     };
@@ -563,7 +571,9 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     if (bi >= a.bands_per_xcd) return;
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (a.tn == 0 && band >= a.nbands) return;
-    const int X = strip * (SOB ? 720 : 768);   // byte offset of the strip in a DESTINATION row (gray: also the pixel offset; SOB: strips 240 pixels apart)
+    // byte offset of the strip's TILE in a destination row (gray: also the pixel offset; SOB = 1: tiles 240 pixels apart; SOB = 2: 192
+    // apart, starting 16 pixels left of the pixels they store)
+    const int X = SOB == 2 ? (strip == 0 ? 0 : strip * 576 - 48) : strip * (SOB ? 720 : 768);
     // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
     const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
@@ -683,7 +693,8 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 {
     const dim3 grid((unsigned)(((long long)a.bands_per_xcd * a.nstrips + a.wpb - 1) / a.wpb * 8));
     if (a.gdx) {   // filter2D -> gray -> Sobel (BGR source, one weight table: the caller checked)
-        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
+        if (a.sob192) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 2>), grid, dim3(64 * a.wpb), lds, st, a);
+        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (src_yuyv == 1) {   // (one weight table only: the caller checked)
@@ -791,7 +802,11 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
     if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
     // (sob: strips 240 pixels apart, each storing 240 pixels -- strip 0: 248)
-    const int nstrips = sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768);
+    // SOB: 240-pixel strips with plain stores, or (gradient rows that start on 128-byte lines, width > 192; knob RCV_FR_SOB192) 192-pixel
+    // strips whose row pieces are whole lines -> non-temporal stores, at 33 % instead of 7 % redundant matrix work
+    const bool sob192 = sob && kn.fr_sob192 != 0 && s.cols > 192 && (uintptr_t)gx->p % 128 == 0 && gx->step % 128 == 0 && (gx->n <= 1 || gx->fstride % 128 == 0) &&
+                        (uintptr_t)gy->p % 128 == 0;
+    const int nstrips = sob192 ? (s.cols + 191) / 192 : (sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768));
     const long long G = (long long)s.n * s.rows;
     // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
     //  streaming VALU kernel: 4-7x slower even on one frame)
@@ -859,6 +874,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.gdy = sob ? gy->p : nullptr;
     a.gstep = sob ? gx->step : 0;
     a.gfs = sob ? gx->fstride : 0;
+    a.sob192 = sob192 ? 1 : 0;
     a.trace = (unsigned long long*)rcv_debug_trace;
     // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
     // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob

@@ -89,6 +89,7 @@ struct RcvKnobs {
     int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan)
     int fr_chunk;         // RCV_FR_CHUNK      frames per launch of the row-streaming kernel (0 = the whole batch in one launch)
     int fr_taper;         // RCV_FR_TAPER      0: equal bands; unset / 1: tapered tail of one round; n > 1: tail of n % of a round
+    int fr_sob192;        // RCV_FR_SOB192     fused filter -> Sobel: 0 = 240-pixel strips with plain stores, 1 (default where the planes allow) = line-aligned 192-pixel strips, nt stores
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)

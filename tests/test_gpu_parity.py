@@ -1000,6 +1000,40 @@ def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
         b.free()
 
 
+@pytest.mark.parametrize("rows,cols", [(9, 196), (12, 208), (33, 380), (40, 384), (31, 388), (37, 400), (21, 572), (18, 576), (26, 580), (70, 768),
+                                       (19, 1000), (130, 1920), (5, 3840), (66, 192 * 7 + 4)])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_filter2d_sobel_fused_line_aligned_strips(ctx, oracle, knob, rows, cols, ksize):
+    """round 3: the SOB = 2 instantiation -- strips 192 pixels apart whose row pieces are whole 128-byte lines of the i16 planes
+    (non-temporal stores), tiles starting 16 pixels left of the pixels they store; taken when the planes' rows start on lines.
+    Widths around the multiples of 192 put the row's end into every place of a tile; batch of 3, canaries in the row padding."""
+    knob("RCV_FR_SOB192", 1)
+    n = 3
+    r = np.random.default_rng(rows * 2003 + cols * 11 + ksize + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    frames[1] = (r.integers(0, 2, size=(rows, cols, 1)) * 255).astype(np.uint8)
+    k = r.integers(-8, 9, size=(ksize, ksize)).astype(np.int8)
+    k[ksize // 2, ksize // 2] = 40
+    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 12)
+    src.upload(frames)
+    gstep = (cols * 2 + 127) // 128 * 128 + 128
+    dx = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=gstep, frame_stride=rows * gstep + 512)
+    dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=gstep, frame_stride=rows * gstep + 512)
+    dx.memset(0xCD)
+    dy.memset(0xCD)
+    launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, 6))
+    assert "k_filter_rows_mfma<KS, 3, 0, 0, 0, 2>" in launched, launched
+    gx, gy = dx.download(), dy.download()
+    for i in range(n):
+        wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, 6)))
+        assert np.array_equal(gx[i].reshape(rows, cols), wx.reshape(rows, cols)), ("dx", i, np.argwhere(gx[i].reshape(rows, cols) != wx.reshape(rows, cols))[:4])
+        assert np.array_equal(gy[i].reshape(rows, cols), wy.reshape(rows, cols)), ("dy", i, np.argwhere(gy[i].reshape(rows, cols) != wy.reshape(rows, cols))[:4])
+    _assert_canaries(dx)
+    _assert_canaries(dy)
+    for b in (src, dx, dy):
+        b.free()
+
+
 def test_filter2d_sobel_fused_unequal_plane_layouts(ctx, oracle):
     """gradient planes with different row steps, or rows that are not 8-byte aligned, take the two-launch path: same bytes"""
     n, rows, cols = 2, 40, 512
