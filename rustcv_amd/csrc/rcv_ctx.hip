@@ -174,6 +174,9 @@ static void ctx_finalize(rcv_ctx* c)
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
         if (c->stage_buf[i]) (void)hipFree(c->stage_buf[i]);
     if (c->kconst) (void)hipFree(c->kconst);
+    if (c->fr_tabs) (void)hipFree(c->fr_tabs);
+    for (int e = 0; e < 4; ++e)
+        if (c->fr_tab[e].uploaded) (void)hipEventDestroy(c->fr_tab[e].uploaded);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

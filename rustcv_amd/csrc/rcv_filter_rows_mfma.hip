@@ -827,7 +827,23 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
     if (dual && (src_yuyv == 1 || src_yuyv == 2 || sob)) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR -> BGR only)
 
-    if (!ctx->fr_valid || ctx->fr_ksize != ksize || ctx->fr_split2 != split2 || memcmp(ctx->fr_k, k, (size_t)nk * sizeof(int16_t)) != 0) {
+    // weight tables: a small cache keyed by the kernel (see rcv_ctx::fr_tab)
+    if (!ctx->fr_tabs) RCV_HIP(hipMalloc((void**)&ctx->fr_tabs, 4 * 16384));
+    int slot = -1;
+    for (int e = 0; e < 4; ++e) {
+        const rcv_ctx::FrTab& t = ctx->fr_tab[e];
+        if (t.valid && t.ksize == ksize && t.split2 == split2 && memcmp(t.k, k, (size_t)nk * sizeof(int16_t)) == 0) slot = e;
+    }
+    if (slot < 0) {
+        slot = 0;
+        for (int e = 0; e < 4; ++e) {   // an empty entry, else the least recently used
+            if (!ctx->fr_tab[e].valid) { slot = e; break; }
+            if (ctx->fr_tab[e].stamp < ctx->fr_tab[slot].stamp) slot = e;
+        }
+        rcv_ctx::FrTab& t = ctx->fr_tab[slot];
+        if (!t.uploaded) RCV_HIP(hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming));
+        else RCV_HIP(hipEventSynchronize(t.uploaded));   // (its previous upload has long passed: three other kernels were used since)
+        t.valid = false;
         int8_t m8[49], s8[49];
         int dmask = 0;
         for (int i = 0; i < nk; ++i) {
@@ -837,29 +853,30 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             m8[i] = (int8_t)(dual ? (split2 ? w - 2 * sv : w - 4 * sv) : w);
             s8[i] = (int8_t)sv;
         }
-        int8_t tab[2 * 2 * 4 * 64 * 16];
-        build_rows_wtab(m8, ksize, tab);
+        static_assert(sizeof(t.host) == 2 * 2 * 4 * 64 * 16, "two weight tables of four row pairs");
+        build_rows_wtab(m8, ksize, t.host);
         if (dual) {
-            build_rows_wtab(s8, ksize, tab + (size_t)2 * np * 1024);
-            for (int t = 0; t < 2 * np; ++t)
+            build_rows_wtab(s8, ksize, t.host + (size_t)2 * np * 1024);
+            for (int q = 0; q < 2 * np; ++q)
                 for (int i = 0; i < 1024; ++i)
-                    if (tab[(size_t)(2 * np + t) * 1024 + i]) { dmask |= 1 << t; break; }
+                    if (t.host[(size_t)(2 * np + q) * 1024 + i]) { dmask |= 1 << q; break; }
         }
-        ctx->fr_valid = false;
-        RCV_TRY(rcv_upload_const(ctx, tab, (size_t)(dual ? 4 : 2) * np * 1024, RCV_KC_FR_TAB));
-        RCV_HIP(hipStreamSynchronize(ctx->stream));   // `tab` is on this stack frame
-        memcpy(ctx->fr_k, k, (size_t)nk * sizeof(int16_t));
-        ctx->fr_ksize = ksize;
-        ctx->fr_split2 = split2;
-        ctx->fr_dmask = dmask;
-        ctx->fr_valid = true;
+        // stream-ordered behind every kernel that still reads this entry's old table; the host copy lives in the context
+        RCV_HIP(hipMemcpyAsync(ctx->fr_tabs + (size_t)slot * 16384, t.host, (size_t)(dual ? 4 : 2) * np * 1024, hipMemcpyHostToDevice, ctx->stream));
+        RCV_HIP(hipEventRecord(t.uploaded, ctx->stream));
+        memcpy(t.k, k, (size_t)nk * sizeof(int16_t));
+        t.ksize = ksize;
+        t.split2 = split2;
+        t.dmask = dmask;
+        t.valid = true;
     }
-    const int dmask = ctx->fr_dmask;
+    ctx->fr_tab[slot].stamp = ++ctx->fr_clock;
+    const int dmask = ctx->fr_tab[slot].dmask;
 
     FRArgs a;
     a.src = s.p;
     a.dst = d.p;
-    a.wtab = (const uint4*)(ctx->kconst + RCV_KC_FR_TAB);
+    a.wtab = (const uint4*)(ctx->fr_tabs + (size_t)slot * 16384);
     a.dump = ctx->kconst + RCV_KC_FR_DUMP;
     a.sstep = s.step;
     a.dstep = d.step;

@@ -620,7 +620,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + (unsigned)CH * (unsigned)xq;
     // ---- staging plan: chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ... ----
     const int nchunks = prow * cpr;             // <= kWlMaxG * 256 (host)
-    const unsigned frame_lim = (unsigned)s.rows * (unsigned)s.step - (CH == 1 ? 8u : (RAGS ? 16u : 12u));
+    // (a frame's last row ends at (rows - 1) * step + cols * CH: a padded LAST row need not be allocated -- rcv_view guarantees no more)
+    const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * CH) - (CH == 1 ? 8u : (RAGS ? 16u : 12u))) & (AL ? ~0u : ~3u);
     unsigned goff[kWlMaxG], loff[kWlMaxG];
     bool gval[kWlMaxG];
 #pragma unroll

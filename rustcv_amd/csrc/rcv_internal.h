@@ -47,14 +47,23 @@ struct rcv_ctx {
     // cached launch plan of the strip kernel (segment height, latency variant) for the last geometry
     int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_knob, f7_plan_seg_rows;
     bool f7_plan_lat_ok, f7_plan_lat;
-    // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip), at RCV_KC_FR_TAB
-    bool fr_valid, fr_split2;
+    // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip): four entries, least recently used
+    // replaced, each with its own 16-KiB device region (fr_tabs) and a persistent host copy, so that a caller alternating between
+    // a few kernels (GaussianBlur, then filter2D, ...) neither rebuilds a table nor synchronises the stream (round 3)
+    struct FrTab {
+        bool valid, split2;
+        int ksize, dmask;
+        int16_t k[49];
+        unsigned long long stamp;
+        hipEvent_t uploaded;      // recorded behind the entry's last upload: its host copy may be rewritten once this has passed
+        int8_t host[16384];
+    } fr_tab[4];
+    uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
+    unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
     bool wl_valid = false, wl_ok = false;
     float wl_M[6] = {0, 0, 0, 0, 0, 0};
     int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
-    int fr_ksize, fr_dmask;
-    int16_t fr_k[49];
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
     // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
     bool capturing;

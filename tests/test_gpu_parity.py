@@ -400,6 +400,37 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, shift,
         assert (padbytes == 0xAB).all()
 
 
+def test_row_kernel_weight_table_cache(ctx, oracle, knob):
+    """round 3: the row-streaming kernel caches the banded weight tables of FOUR kernels per context and uploads a
+    new one stream-ordered without synchronising; a caller cycling through six kernels (more than the cache holds: entries are
+    replaced while earlier launches that read them are still queued) gets every result right, with no sync between the calls"""
+    knob("RCV_F7_ROWS")
+    knob("RCV_GAUSS_ROWS", 0)
+    r = np.random.default_rng(4242 + _SOAK_SEED)
+    n, rows, cols = 2, 96, 272
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    src.upload(frames)
+    kernels = [(r.integers(-9, 10, size=(ks, ks)).astype(np.int8), ks, sh) for ks, sh in ((7, 6), (5, 4), (3, 2), (7, 5), (5, 0), (7, 7))]
+    outs = [device.DeviceBatch(ctx, n, rows, cols, 3) for _ in range(3 * len(kernels) + 3)]
+    calls = []
+    for rep in range(3):
+        for k, ks, sh in kernels:
+            device.filter2d(src, outs[len(calls)], k, shift=sh)            # no sync: the queue holds launches of all six kernels
+            calls.append(("f", k, sh))
+    for ks in (3, 5, 7):
+        device.gaussian_blur(src, outs[len(calls)], ks, 0.0)               # (7: two weight tables)
+        calls.append(("g", ks, 0))
+    ctx.sync()
+    for out, (kind, k, sh) in zip(outs, calls):
+        got = out.download()
+        for i in range(n):
+            want = oracle.filter2d_i8(frames[i], k, sh) if kind == "f" else oracle.gaussian_blur(frames[i], k, 0.0)
+            assert np.array_equal(got[i], want), (kind, sh)
+    for b in outs + [src]:
+        b.free()
+
+
 GAUSS_ROWS_SHAPES = [(3, 16, 3), (5, 32, 3), (33, 240, 3), (40, 336, 3), (19, 496, 3), (70, 672, 3), (300, 1008, 3), (9, 2000, 3), (1080, 1920, 3),
                      (3, 32, 1), (17, 992, 1), (40, 1008, 1), (64, 4000, 1), (7, 48, 1)]
 
@@ -2001,6 +2032,38 @@ def _assert_canaries(b):
     body = raw[:, : b.rows * b.step].reshape(b.n, b.rows, b.step)
     assert (body[:, :, rowb:] == 0xCD).all(), "row padding overwritten"
     assert (raw[:, b.rows * b.step:] == 0xCD).all(), "inter-frame gap overwritten"
+
+
+def test_warp_lds_kernel_tight_last_frame(ctx, oracle):
+    """round-2 advisor: a batch whose LAST frame is allocated only up to (rows - 1) * step + cols * 3 (padded rows, the padding of the last
+    row not allocated -- what rcv_view guarantees): the LDS-staged warp kernel clamps its staging loads inside that extent"""
+    L = _ffi.lib()
+    n, rows, cols = 2, 200, 320
+    step = cols * 3 + 64
+    fs = rows * step
+    nbytes = (n - 1) * fs + (rows - 1) * step + cols * 3
+    r = np.random.default_rng(606 + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    raw = np.zeros(nbytes, np.uint8)
+    for i in range(n):
+        for y in range(rows):
+            o = i * fs + y * step
+            raw[o: o + cols * 3] = frames[i, y].reshape(-1)
+    p = C.c_void_p()
+    _ffi.check(L.rcv_malloc(ctx.handle, nbytes, C.byref(p)), "rcv_malloc")
+    _ffi.check(L.rcv_upload(ctx.handle, p, raw.ctypes.data, nbytes), "rcv_upload")
+    dst = device.DeviceBatch(ctx, n, rows, cols, 3)
+    sb = dst.as_rcv()
+    sb.frame0.data, sb.frame0.cap, sb.frame0.step, sb.frame_stride = p, (rows - 1) * step + cols * 3, step, fs
+    bd = dst.as_rcv()
+    M = np.array([0.9925, -0.1219, 20.0, 0.1219, 0.9925, -12.0], np.float32)
+    launched = _kernels_launched(ctx, lambda: _ffi.check(L.rcv_warp_affine_batch(ctx.handle, C.byref(sb), C.byref(bd), M.ctypes.data_as(C.POINTER(C.c_float))), "warp"))
+    assert "k_warp_affine_lds<3" in launched, launched
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.warp_affine(frames[i], M, rows, cols))
+    L.rcv_free(ctx.handle, p)
+    dst.free()
 
 
 def _ulp_distance(a, b):
