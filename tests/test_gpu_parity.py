@@ -400,6 +400,60 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, shift,
         assert (padbytes == 0xAB).all()
 
 
+@pytest.mark.parametrize("variant", ["bgr", "gray", "yuyv", "sobel", "dual"])
+@pytest.mark.parametrize("taper", [None, 0, 200])
+def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, taper):
+    """round 3: launches that fill the GPU several times over cut the tail of every XCD's band list into half- and quarter-height
+    bands (tapered bands; RCV_FR_TAPER=0: equal bands, 200: a tapered part twice as long).  32 frames of 1080p -- the smallest
+    BASELINE-shaped batch that takes this path -- EVERY frame against the oracle, for each source flavour of the row kernel (BGR,
+    one-channel, packed YUYV, the fused filter -> gray -> Sobel launch, two weight tables); band seams fall on different rows in each
+    setting, frame boundaries inside XCD ranges included (n % 8 == 0: four frames per XCD)"""
+    if taper is not None:
+        knob("RCV_FR_TAPER", taper)
+    knob("RCV_GAUSS_ROWS", 0)
+    n, rows, cols = 32, 1080, 1920
+    r = np.random.default_rng(991 + _SOAK_SEED)
+    k = r.integers(-8, 9, size=(7, 7)).astype(np.int8)
+    k[3, 3] = 33
+    L = _ffi.lib()
+    L.rcv__debug_kernels_reset()
+    ch, fam = {"bgr": (3, 1), "dual": (3, 1), "sobel": (3, 1), "gray": (1, 1), "yuyv": (2, 2)}[variant]
+    src = device.DeviceBatch(ctx, n, rows, cols, ch)
+    device.synth(src, fam, 77, 0)
+    frames = src.download()     # (the oracle works on what the device holds)
+    if variant == "sobel":
+        dx, dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+        device.filter2d_sobel(src, dx, dy, k, 6)
+        gx, gy = dx.download(), dy.download()
+        for i in range(n):
+            wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, 6)))
+            assert np.array_equal(gx[i], wx.reshape(rows, cols)) and np.array_equal(gy[i], wy.reshape(rows, cols)), i
+        outs = [dx, dy]
+    else:
+        dst = device.DeviceBatch(ctx, n, rows, cols, 1 if variant == "gray" else 3)
+        if variant == "dual":
+            device.gaussian_blur(src, dst, 7, 0.0)
+        elif variant == "yuyv":
+            device.filter2d_yuyv(src, dst, k, shift=6)
+        else:
+            device.filter2d(src, dst, k, shift=6)
+        got = dst.download()
+        for i in range(n):
+            if variant == "dual":
+                want = oracle.gaussian_blur(frames[i], 7, 0.0)
+            elif variant == "yuyv":
+                bgr = np.zeros(rows * cols * 3, np.uint8)
+                oracle.yuyv_to_bgr(frames[i].reshape(-1), bgr, cols, rows)
+                want = oracle.filter2d_i8(bgr.reshape(rows, cols, 3), k, 6)
+            else:
+                want = oracle.filter2d_i8(frames[i], k, 6)
+            assert np.array_equal(got[i], want.reshape(got[i].shape)), (variant, i, np.argwhere(got[i] != want.reshape(got[i].shape))[:3])
+        outs = [dst]
+    assert "k_filter_rows_mfma<" in L.rcv__debug_kernels().decode()
+    for b in outs + [src]:
+        b.free()
+
+
 def test_row_kernel_weight_table_cache(ctx, oracle, knob):
     """round 3: the row-streaming kernel caches the banded weight tables of FOUR kernels per context and uploads a
     new one stream-ordered without synchronising; a caller cycling through six kernels (more than the cache holds: entries are
