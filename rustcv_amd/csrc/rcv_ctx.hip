@@ -34,7 +34,6 @@ static void load_knobs()
     g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
     g_knobs.fr_sob192 = env_int("RCV_FR_SOB192", 0);
     g_knobs.fr_taper = env_int("RCV_FR_TAPER", -1);
-    g_knobs.fr_chunk = env_int("RCV_FR_CHUNK", 0);
     g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);
     g_knobs.gr_seg = env_int("RCV_GR_SEG", 0);
     g_knobs.gr_plain = env_int("RCV_GR_PLAIN", 0);
@@ -42,6 +41,7 @@ static void load_knobs()
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
+    g_knobs.warp_resize_lds = env_int("RCV_WARP_RESIZE_LDS", -1);
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
     g_knobs.nms_seg = env_int("RCV_NMS_SEG", 0);
     g_knobs.sobel_seg = env_int("RCV_SOBEL_SEG", 0);

@@ -741,28 +741,9 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size,
                         const View* gx, const View* gy)
 {
-    // RCV_FR_CHUNK = c: a batch of more than c frames runs as consecutive launches of c frames on the same stream (experiment,
-    // round 3: launches of ONE round of waves -- 8 4K frames -- cost less per frame than the multi-round launch of 64)
-    const int chunk = rcv_knobs().fr_chunk;
-    if (chunk > 0 && s.n > chunk) {
-        for (int f0 = 0; f0 < s.n; f0 += chunk) {
-            const int nf = s.n - f0 < chunk ? s.n - f0 : chunk;
-            View sv = s, dv = d, xv, yv;
-            sv.p = s.p + (size_t)f0 * s.fstride;
-            dv.p = d.p + (size_t)f0 * d.fstride;
-            sv.n = dv.n = nf;
-            if (gx) {
-                xv = *gx;
-                yv = *gy;
-                xv.p = gx->p + (size_t)f0 * gx->fstride;
-                yv.p = gy->p + (size_t)f0 * gy->fstride;
-                xv.n = yv.n = nf;
-            }
-            const int rc = rows_launch(ctx, sv, dv, k, ksize, shift, src_yuyv, true, gx ? &xv : nullptr, gx ? &yv : nullptr);
-            if (rc != RCV_OK) return f0 == 0 ? rc : RCV_ERR_DEVICE;   // (a later chunk cannot be refused for its shape: same shape)
-        }
-        return RCV_OK;
-    }
+    // (Round 3 experiments, removed: the batch as consecutive launches of 2 ... 32 frames -- 0.59 ... 0.82 ms against 0.55 for the one
+    //  launch -- and its two halves as concurrent launches on two streams, forked and joined per call: 0.615 against 0.582 ms;
+    //  profiles/r03_ablate_chunked_launches.txt.)
     return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy);
 }
 

@@ -64,6 +64,10 @@ struct rcv_ctx {
     bool wl_valid = false, wl_ok = false;
     float wl_M[6] = {0, 0, 0, 0, 0, 0};
     int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
+    // ... and of the fused warp -> 4x down-scale kernel (k_warp_resize_lds)
+    bool wr_valid = false, wr_ok = false;
+    float wr_M[6] = {0, 0, 0, 0, 0, 0};
+    int wr_pitch = 0, wr_prow = 0, wr_cpr = 0;
     // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
     // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
     bool capturing;
@@ -96,7 +100,6 @@ struct RcvKnobs {
     int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian (rcv_gauss_rows.hip): 1 every eligible shape, 0 never, -1 (unset) small launches
     int gr_plain;         // RCV_GR_PLAIN      its stores plain instead of non-temporal (ablation)
     int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan)
-    int fr_chunk;         // RCV_FR_CHUNK      frames per launch of the row-streaming kernel (0 = the whole batch in one launch)
     int fr_taper;         // RCV_FR_TAPER      0: equal bands; unset / 1: tapered tail of one round; n > 1: tail of n % of a round
     int fr_sob192;        // RCV_FR_SOB192     fused filter -> Sobel: 0 = 240-pixel strips with plain stores, 1 (default where the planes allow) = line-aligned 192-pixel strips, nt stores
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
@@ -106,6 +109,7 @@ struct RcvKnobs {
     int sobel_plain;      // RCV_SOBEL_PLAIN   1: plain instead of non-temporal stores (A/B)
     int nms_seg;          // RCV_NMS_SEG       rows per segment of the NMS kernel (0 = plan)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
+    int warp_resize_lds;  // RCV_WARP_RESIZE_LDS 1: the fused warp -> 4x resize on the LDS-staged kernel (slower: experiment record)
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)
     int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)

@@ -1283,6 +1283,39 @@ def test_warp_affine_resize_fused(ctx, oracle, rng, scale, dshape, M):
     dst.free()
 
 
+@pytest.mark.parametrize("kernel,fpg", [("lds", 0), ("lds", 3), ("lds-raster", 2), ("box", 0)])
+@pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "ident", "flip", "grow", "big"])
+def test_warp_affine_resize_fused_lds_tiles(ctx, oracle, rng, knob, kernel, fpg, M):
+    """the LDS-staged fused warp -> 4x kernel (16 x 16 output tiles: staged interior tiles, gather tiles at the source border and
+    outside, ragged last tile row / column, groups of frames with a short last group, both tile orders) and the gather kernel
+    it replaces produce the oracle's resize(warp_affine(.)) bit for bit"""
+    if kernel != "box":
+        knob("RCV_WARP_RESIZE_LDS", 1)   # (off by default: the gather kernel is faster)
+    if kernel == "lds-raster":
+        knob("RCV_XCD_ORDER", 0)
+    if fpg:
+        knob("RCV_WARP_FPG", fpg)
+    dr, dc = 52, 100                  # 4 x 7 tiles, the last row / column of tiles ragged (dc % 4 == 0)
+    mr, mc = 4 * dr, 4 * dc
+    sr, sc = mr + 37, mc + 22
+    Ms = {"rot7": _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, mc / 2, mr / 2, 20.0, 30.0),
+          "shear": np.array([1, 0.25, 3.5, -0.125, 1, 60.25], np.float32), "ident": np.array([1, 0, 4, 0, 1, 2], np.float32),
+          "flip": np.array([-1, 0, mc + 5.5, 0, -1, mr + 3.25], np.float32), "grow": np.array([0.5, 0, 40.3, 0, 0.5, 20.7], np.float32),
+          "big": np.array([3, 0, 0, 0, 3, 0], np.float32)}[M]           # (patch of a tile too large to stage: gather tiles only)
+    n = 5
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + 1 + (-(sc * 3 + 1)) % 4)
+    dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    device.warp_affine_resize(src, dst, Ms, mr, mc)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (kernel, M, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("M", [[np.nan, 0, 0, 0, 1, 0], [1, 0, np.nan, 0, 1, 0], [np.inf, 0, 0, 0, 1, 0], [1, np.inf, 3, 0, 1, 0],
                                [1, 0, 0, -np.inf, 1, 0], [0, 0, 5.5, 0, 0, 7.25], [1e-30, 0, 1, 0, 1e-30, 2], [-1, 0, 63, 0, -1, 31],
                                [1, 0, -0.999, 0, 1, -0.999], [1, 0, 0.999, 0, 1, 0.999], [1.0000001, 0, -1, 0, 1, -1]])
