@@ -186,6 +186,7 @@ def run_rank(a, rank, world, device, ctx, fence, torch):
     from rustcv_amd import _ffi, device as dev, shard
 
     L = _ffi.lib()
+    BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
     n, cfg = a.batch, a.config
     total_frames = n * world
     f0, f1 = shard.frame_range(total_frames, rank, world)  # contiguous frame range of this rank
@@ -230,7 +231,7 @@ def run_rank(a, rank, world, device, ctx, fence, torch):
         for _ in range(launches):
             fn()
         if probe_us:                             # shader clock while the queued launches run (a one-wave kernel on the side stream)
-            L.rcv__clock_probe(ctx.handle, probe_us, C.byref(mhz))
+            BL.rcv__clock_probe(ctx.handle, probe_us, C.byref(mhz))
         L.rcv_timer_stop(ctx.handle, C.byref(ms))  # records + synchronises the ctx stream
         return (float(ms.value), float(mhz.value)) if probe_us else float(ms.value)
 
@@ -290,7 +291,7 @@ def run_rank(a, rank, world, device, ctx, fence, torch):
         best, best_name = 0.0, None
         for variant, grid, name in CEILING_COPIES:
             def cp():
-                rc = L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid)
+                rc = BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid)
                 if rc != 0:
                     raise SystemExit(f"rcv__membench failed: {rc}")
             runup(cp)

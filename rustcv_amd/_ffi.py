@@ -129,16 +129,22 @@ SIGNATURES = {
     "rcv_synth_batch": (_i, [_ctx, _bat, _i, _u64, _u64]),
 }
 
-# debug / calibration entry points (not part of include/rustcv_hip.h): used by tests, tools and bench.py's copy-ceiling leg
+# test hooks inside the product library (not part of include/rustcv_hip.h): knob reload, dispatch trace, profiling-build flags
 DEBUG_SIGNATURES = {
     "rcv__debug_set": (None, [_i]),
     "rcv__debug_reload_knobs": (None, []),
     "rcv__debug_kernels": (C.c_char_p, []),
     "rcv__debug_kernels_reset": (None, []),
     "rcv__debug_occupancy": (_i, []),
+    "rcv__debug_trace_buffer": (None, [C.c_void_p]),
+}
+
+# measurement kernels (plain copies / stores of every shape, launch floor, shader-clock probe): librustcv_hip_bench.so, a separate
+# library on top of the product one -- bench.py's copy-ceiling leg and tools/ use it, nothing in rustcv_amd does
+BENCH_LIB_PATH = os.path.join(_HERE, "librustcv_hip_bench.so")
+BENCH_SIGNATURES = {
     "rcv__membench": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz, _i, _i]),
     "rcv__storebench": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i, _i]),
-    "rcv__debug_trace_buffer": (None, [C.c_void_p]),
     "rcv__clock_probe": (_i, [_ctx, _i, C.POINTER(C.c_float)]),
 }
 
@@ -162,6 +168,25 @@ def lib():
             raise ImportError("librustcv_hip.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+_bench_lib = None
+
+
+def bench_lib():
+    """Load librustcv_hip_bench.so (once; after the product library, whose context and launch helpers it uses)."""
+    global _bench_lib
+    if _bench_lib is None:
+        lib()
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise ImportError(f"{BENCH_LIB_PATH} is missing: build it with `make -C rustcv_amd/csrc`")
+        l = C.CDLL(BENCH_LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in BENCH_SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bench_lib = l
+    return _bench_lib
 
 
 def strerror(code):

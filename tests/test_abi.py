@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol():
     assert L.rcv_abi_version() == 1
 
 
+def test_measurement_kernels_live_outside_the_product_library():
+    """plain copies / store patterns / clock probe (bench.py's copy ceiling, tools/) are librustcv_hip_bench.so; the product
+    library exports the header's entry points and the rcv__debug_* test hooks only"""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    extra = sorted(e for e in exported if e.startswith("rcv_") and e not in _ffi.SIGNATURES and e not in _ffi.DEBUG_SIGNATURES)
+    assert not extra, extra
+    assert not any(name in exported for name in _ffi.BENCH_SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.BENCH_LIB_PATH], text=True)
+    bench = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert set(_ffi.BENCH_SIGNATURES) <= bench
+    _ffi.bench_lib()
+
+
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rustcv_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'

@@ -2539,3 +2539,106 @@ def test_harris_ragged_and_unaligned_shapes(ctx, oracle):
                 _assert_canaries(b)
                 b.free()
         src.free()
+
+
+# ---- round 3: seeded random-shape soaks of the kernels added this round (RCV_SOAK scales the case counts) -------------------------
+
+def test_gaussian_int_rows_kernel_random_shapes(ctx, oracle, knob):
+    """4 x RCV_SOAK random cases for the register-window integer Gaussian: any height, widths with 16-byte rows (1 / 3 channels),
+    ksize 3 / 5, segment heights 0 (planned) .. 40, batch 1..4, padded steps, pixel fields with saturated and zero regions"""
+    knob("RCV_GAUSS_ROWS")
+    r = np.random.default_rng(0x6A55 + _SOAK_SEED)
+    L = _ffi.lib()
+    for case in range(4 * _SOAK):
+        ch = int(r.choice([1, 3]))
+        cols = 16 * int(r.integers(1, 90)) if ch == 3 else 16 * int(r.integers(2, 260))
+        rows = int(r.integers(3, 120))
+        ksize = int(r.choice([3, 5]))
+        n = int(r.integers(1, 5))
+        seg = int(r.choice([0, 0, 3, 4, 7, 16, 40]))
+        if seg:
+            knob("RCV_GR_SEG", seg)
+        else:
+            knob("RCV_GR_SEG", 0)
+        frames = r.integers(0, 256, size=(n, rows, cols, ch), dtype=np.uint8)
+        frames[:, : rows // 4] = 255
+        frames[:, -(rows // 5 + 1):, : cols // 2] = 0
+        src = device.DeviceBatch(ctx, n, rows, cols, ch, step=cols * ch + 16 * int(r.integers(0, 4)))
+        dst = _canary_batch(ctx, n, rows, cols, ch, pad=16 * int(r.integers(1, 4)))
+        src.upload(frames if ch == 3 else frames[..., 0])
+        L.rcv__debug_kernels_reset()
+        device.gaussian_blur(src, dst, ksize, 0.0)
+        assert "k_gauss_rows<" in L.rcv__debug_kernels().decode(), (case, rows, cols, ch)
+        got = dst.download()
+        for i in range(n):
+            want = oracle.gaussian_blur(frames[i] if ch == 3 else frames[i][..., 0], ksize, 0.0)
+            assert np.array_equal(got[i], want), (case, rows, cols, ch, ksize, n, seg, i)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+
+
+def test_geometry_f32_random_shapes(ctx, oracle):
+    """2 x RCV_SOAK random cases each for the RCV_32F resize and warpAffine: shapes 1..90 px, 1 / 3 / 4 channels, up- and
+    down-scales, random affine maps (part of the output outside the source), values of mixed magnitude, padded steps: within
+    1 ULP of the oracle (expected and printed: bit-exact)"""
+    r = np.random.default_rng(0xF32 + _SOAK_SEED)
+    worst = 0
+    for case in range(2 * _SOAK):
+        ch = int(r.choice([1, 3, 4]))
+        srows, scols, drows, dcols = (int(v) for v in r.integers(1, 90, size=4))
+        n = int(r.integers(1, 4))
+        frames = (r.standard_normal((n, srows, scols, ch)) * r.choice([1e-6, 1e-3, 1.0, 255.0, 3e7])).astype(np.float32)
+        src = device.DeviceBatch(ctx, n, srows, scols, ch, _ffi.RCV_32F, step=scols * ch * 4 + 4 * int(r.integers(0, 5)))
+        for op in ("resize", "warp"):
+            dst = _canary_batch(ctx, n, drows, dcols, ch, _ffi.RCV_32F, pad=4 * int(r.integers(1, 9)))
+            src.upload(frames)
+            if op == "resize":
+                device.resize(src, dst)
+            else:
+                t = r.uniform(-np.pi, np.pi)
+                sc = r.uniform(0.3, 2.5)
+                M = np.array([np.cos(t) * sc, -np.sin(t) * sc, r.uniform(-10, scols), np.sin(t) * sc, np.cos(t) * sc, r.uniform(-10, srows)], np.float32)
+                device.warp_affine(src, dst, M)
+            got = dst.download()
+            for i in range(n):
+                f = frames[i] if ch > 1 else frames[i][..., 0]
+                want = oracle.resize_f32(f, drows, dcols) if op == "resize" else oracle.warp_affine_f32(f, M, drows, dcols)
+                dist = int(_ulp_distance(got[i], want).max())
+                worst = max(worst, dist)
+                assert dist <= 1, (case, op, srows, scols, drows, dcols, ch, i, dist)
+            _assert_canaries(dst)
+            dst.free()
+        src.free()
+    print(f"f32 geometry, {2 * _SOAK} random cases: max ULP distance {worst}")
+
+
+def test_row_kernel_random_batches(ctx, oracle, knob):
+    """RCV_SOAK random launches of the row-streaming MFMA kernel in its LARGE-launch regime (tapered bands when the batch is a
+    multiple of 8, plain bands otherwise, 1 / 2 / 4 waves per workgroup): 8..24 frames of 16k-aligned widths, ksize 3 / 5 / 7,
+    random i8 weights and shifts; three frames of each launch against the oracle"""
+    r = np.random.default_rng(0x7A9E + _SOAK_SEED)
+    L = _ffi.lib()
+    for case in range(max(2, _SOAK // 2)):
+        knob("RCV_F7_ROWS")
+        knob("RCV_FR_WPB", int(r.choice([1, 2, 4])))
+        knob("RCV_FR_TAPER", int(r.choice([0, 1, 1])))
+        ksize = int(r.choice([3, 5, 7]))
+        n = int(r.choice([8, 9, 16, 17, 24]))
+        rows, cols = int(r.integers(300, 700)), 16 * int(r.integers(60, 130))
+        k = r.integers(-128, 128, size=(ksize, ksize)).astype(np.int8)
+        shift = int(r.integers(0, 13))
+        src = device.DeviceBatch(ctx, n, rows, cols, 3)
+        dst = _canary_batch(ctx, n, rows, cols, 3, pad=16)
+        device.synth(src, 1, 0x5EED0100 + case + _SOAK_SEED, 0)
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, dst, k, shift=shift)
+        assert "k_filter_rows_mfma" in L.rcv__debug_kernels().decode()
+        frames = src.download()
+        got = dst.download()
+        for i in sorted({0, n // 2, n - 1}):
+            assert np.array_equal(got[i], oracle.filter2d_i8(frames[i], k, shift)), (case, n, rows, cols, ksize, shift, i)
+        _assert_canaries(dst)
+        src.free()
+        dst.free()
+

@@ -16,6 +16,7 @@ from rustcv_amd import _ffi, device  # noqa: E402
 from tools.ablate_sweep import setenv, timeit  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 
 
 def main():
@@ -42,7 +43,7 @@ def main():
                 v = 10 + 4 * ui + nt
 
                 def cp(v=v, g=g):
-                    assert L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g) == 0
+                    assert BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g) == 0
                 variants.append((f"sweep U={U} {ntn[nt]:9s} g={g}", {}, 0, cp))
     res = {v[0]: [] for v in variants}
     for rep in range(3):

@@ -13,6 +13,7 @@ from rustcv_amd import _ffi, device  # noqa: E402
 from tools.ablate_sweep import setenv, timeit  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 
 
 def main():
@@ -34,7 +35,7 @@ def main():
             variants.append((f"filter      PP={pp} wpc={wpc}", env, 0, flt))
 
     def cp(v, g):
-        return lambda: L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g)
+        return lambda: BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g)
     variants.append(("copy sweep U=2 nt both g=512", {}, 0, cp(21, 512)))
     variants.append(("copy sweep U=8 nt both g=256", {}, 0, cp(17, 256)))
     variants.append(("copy sweep U=4 plain g=256", {}, 0, cp(10, 256)))

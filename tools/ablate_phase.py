@@ -13,6 +13,7 @@ from rustcv_amd import _ffi, device  # noqa: E402
 from tools.ablate_sweep import setenv, timeit  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 
 
 def main():
@@ -26,7 +27,7 @@ def main():
 
     def cp(v, g, half=0):
         def f():
-            rc = L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g | (half << 16))
+            rc = BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g | (half << 16))
             assert rc == 0, rc
         return f
     variants = []

@@ -22,6 +22,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP", "RCV_FR_ORDER", "RCV_FR_BPF")
 
 
@@ -92,7 +93,7 @@ def main():
                  8: "copy XCD-local sweep", 9: "copy XCD-local sweep nt"}
         for variant, grid in ((0, 1), (1, 1024), (1, 2048), (2, 1024), (3, 512), (3, 2048), (5, 512), (5, 2048), (8, 1024), (8, 2048), (8, 4096), (9, 1024), (9, 2048), (9, 4096), (6, 2048), (7, 32768)):
             def cp(variant=variant, grid=grid):
-                assert L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid) == 0
+                assert BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid) == 0
             variants.append((f"{names[variant]} g={grid}", {}, 0, cp))
     res = {v[0]: [] for v in variants}
     for rep in range(3):

@@ -16,6 +16,7 @@ from rustcv_amd import _ffi, device  # noqa: E402
 from tools.ablate_sweep import timeit  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 
 
 def main():
@@ -34,7 +35,7 @@ def main():
         res[tag] = v
         print(f"{tag:86s} {v[1]:.4f} ms   {b / v[1] / 1e6:7.1f} GB/s of stores", flush=True)
     run("Sobel kernel (1 B read + 4 B written per px)", lambda: device.sobel(gray, dx, dy))
-    run("write-only sweep (membench 7, g=32768) of the same 2.12 GB", lambda: L.rcv__membench(ctx.handle, dx.ptr, dx.ptr, nbytes // 2, 7, 32768), nbytes // 2 * 1)
+    run("write-only sweep (membench 7, g=32768) of the same 2.12 GB", lambda: BL.rcv__membench(ctx.handle, dx.ptr, dx.ptr, nbytes // 2, 7, 32768), nbytes // 2 * 1)
     for nt in (1, 0):
         for chunks in (1, 2):   # 7680 = 7.5 KB: use 7168-byte rows (7 strips of 1 KB) / 6144 (3 strips of 2 KB) -- whole strips only
             rbw = (rb // (1024 * chunks)) * 1024 * chunks
@@ -49,7 +50,7 @@ def main():
                             b = n * rows * rbw * planes      # (one plane: half the bytes -- compare the RATES)
                             run(f"store strips {'nt   ' if nt else 'plain'} {chunks} KB per wave-row, {planes} plane(s), {seg:3d} rows per segment, {wgs or 'max'} WG/CU, runs of {pair}",
                                 lambda chunks=chunks, planes=planes, seg=seg, wgs=wgs, pair=pair, nt=nt, rbw=rbw:
-                                L.rcv__storebench(ctx.handle, dx.ptr, dy.ptr, n, rows, rbw, rb, chunks, planes, seg, nt, 1, wgs, pair), b)
+                                BL.rcv__storebench(ctx.handle, dx.ptr, dy.ptr, n, rows, rbw, rb, chunks, planes, seg, nt, 1, wgs, pair), b)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ablate_stores.json"), "w"), indent=1)
     for b in (gray, dx, dy):
         b.free()

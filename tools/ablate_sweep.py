@@ -27,6 +27,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 KNOBS = ("RCV_F7_ROWS", "RCV_FR_WPC", "RCV_FR_ROUNDS", "RCV_FR_PP", "RCV_FR_ORDER", "RCV_FR_BPF", "RCV_FR_PERSIST", "RCV_FR_WPB", "RCV_FR_GATE")
 
 
@@ -77,7 +78,7 @@ def main():
     names = {1: "copy sweep", 3: "copy sweep nt", 5: "copy block nt", 9: "copy XCD-local sweep nt"}
     for variant, grid in ((3, 512), (3, 1024), (3, 2048), (1, 1024), (5, 2048), (9, 2048)):
         def cp(variant=variant, grid=grid):
-            assert L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid) == 0
+            assert BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid) == 0
         variants.append((f"{names[variant]} g={grid}", {}, 0, cp))
     res = {v[0]: [] for v in variants}
     for rep in range(3):

@@ -102,7 +102,7 @@ def main():
         f = C.c_float()
         for _ in range(40):
             fn()
-        _ffi.lib().rcv__clock_probe(ctx.handle, 3000, C.byref(f))
+        _ffi.bench_lib().rcv__clock_probe(ctx.handle, 3000, C.byref(f))
         ctx.sync()
         return float(f.value)
 

@@ -16,11 +16,12 @@ from rustcv_amd import _ffi, device  # noqa: E402
 from tools.ablate_sweep import setenv  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 
 
 def clock(ctx, us=3000):
     f = C.c_float()
-    assert L.rcv__clock_probe(ctx.handle, us, C.byref(f)) == 0
+    assert BL.rcv__clock_probe(ctx.handle, us, C.byref(f)) == 0
     return round(float(f.value), 1)
 
 
@@ -52,7 +53,7 @@ def main():
     flt = lambda: device.filter2d(src, dst, k, shift=6)   # noqa: E731
 
     def cp(v, g):
-        return lambda: L.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g)
+        return lambda: BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, v, g)
     out = {"idle_mhz": clock(ctx)}
     variants = [("filter", {}, 0, flt), ("memory-only", {}, 4, flt), ("filter wpb=4", {"RCV_FR_WPB": 4}, 0, flt),
                 ("memory-only wpb=4", {"RCV_FR_WPB": 4}, 4, flt), ("strip kernel (round 1)", {"RCV_F7_ROWS": 0}, 0, flt),

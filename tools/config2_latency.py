@@ -12,6 +12,7 @@ import rustcv_amd as rcv  # noqa: E402
 from rustcv_amd import _ffi, device  # noqa: E402
 
 L = _ffi.lib()
+BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
 KNOBS = ("RCV_F7_ROWS", "RCV_FR_BAND_ROWS", "RCV_F7_NO_LAT", "RCV_GAUSS_ROWS", "RCV_GR_SEG", "RCV_FR_WPB", "RCV_GR_PLAIN")
 
 
@@ -30,7 +31,7 @@ def main():
     scratch = device.DeviceBatch(ctx, 1, 16, 16, 1)
     for g in (1, 256, 1024, 2048):
         def nop(g=g):
-            L.rcv__membench(ctx.handle, scratch.ptr, scratch.ptr, 16, 30, g)
+            BL.rcv__membench(ctx.handle, scratch.ptr, scratch.ptr, 16, 30, g)
         for _ in range(300):
             nop()
         ctx.sync()
@@ -46,7 +47,7 @@ def main():
     for v, g, nm in ((21, 256, "sweep U=2 nt g=256"), (21, 512, "sweep U=2 nt g=512"), (18, 512, "sweep U=2 plain g=512"), (10, 256, "sweep U=4 plain g=256"), (18, 1024, "sweep U=2 plain g=1024"),
                      (18, 2048, "sweep U=2 plain g=2048"), (0, 1, "hipMemcpyAsync D2D")):
         def cp(v=v, g=g):
-            L.rcv__membench(ctx.handle, fb.ptr, fa.ptr, nb, v, g)
+            BL.rcv__membench(ctx.handle, fb.ptr, fa.ptr, nb, v, g)
         for _ in range(300):
             cp()
         ctx.sync()
