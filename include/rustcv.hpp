@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "rustcv_hip.h"
 
@@ -84,6 +85,35 @@ inline int check(int rc, const char* what)
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + rcv_strerror(rc));
     return rc;
 }
+
+// One context per GPU of the node and the frame partition rule: batch entry points only enqueue work, so one host
+// thread drives every device -- for (rank) { op(group.ctx(rank), frames group.frames(n, rank)); } group.sync();  no collective.
+class DeviceGroup {
+public:
+    explicit DeviceGroup(int n_devices) { check(rcv_group_create(nullptr, n_devices, &g_), "rcv_group_create"); }
+    explicit DeviceGroup(const std::vector<int>& devices) { check(rcv_group_create(devices.data(), (int)devices.size(), &g_), "rcv_group_create"); }
+    ~DeviceGroup() { rcv_group_destroy(g_); }
+    DeviceGroup(const DeviceGroup&) = delete;
+    DeviceGroup& operator=(const DeviceGroup&) = delete;
+    int size() const { return rcv_group_size(g_); }
+    rcv_ctx* ctx(int rank) const
+    {
+        rcv_ctx* c = rcv_group_ctx(g_, rank);
+        if (!c) throw std::out_of_range("DeviceGroup::ctx: rank");
+        return c;
+    }
+    // frames [first, last) of a batch of n that belong to `rank`
+    std::pair<int64_t, int64_t> frames(int64_t n, int rank) const
+    {
+        int64_t a = 0, b = 0;
+        check(rcv_shard_range(n, rank, size(), &a, &b), "rcv_shard_range");
+        return {a, b};
+    }
+    void sync() { check(rcv_group_sync(g_), "rcv_group_sync"); }
+
+private:
+    rcv_group* g_ = nullptr;
+};
 
 namespace imgproc {
 

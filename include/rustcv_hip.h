@@ -108,6 +108,20 @@ int         rcv_sync(rcv_ctx* ctx);                       /* block until the ctx
 int         rcv_ctx_device(const rcv_ctx* ctx);
 void*       rcv_ctx_stream(const rcv_ctx* ctx);           /* the hipStream_t, for event timing by the harness */
 
+/* ---- device group: one context per GPU of the node, frame-sharded batches ------
+ * SURVEY.md 8(e) / north_star "independent per-GPU HIP streams, no RCCL collective": nothing in the reference to
+ * replace (one process, one device: rustcv/src/internal/runtime.rs:13).  Batch entry points only enqueue work, so one
+ * host thread can drive every device: op on rcv_group_ctx(g, i) over frames rcv_shard_range(n, i, G), then one
+ * rcv_group_sync.  devices == NULL: GPUs 0 .. n_devices-1 (RCV_ERR_DEVICE if the node has fewer).                  */
+typedef struct rcv_group rcv_group;
+int         rcv_group_create(const int* devices, int n_devices, rcv_group** out);
+void        rcv_group_destroy(rcv_group* g);
+int         rcv_group_size(const rcv_group* g);
+rcv_ctx*    rcv_group_ctx(rcv_group* g, int rank);       /* owned by the group; NULL if rank is out of range */
+int         rcv_group_sync(rcv_group* g);                /* every context's stream idle; the first error */
+/* frames [floor(rank*n/world), floor((rank+1)*n/world)) -- pure host arithmetic, no device needed */
+int         rcv_shard_range(int64_t n_frames, int rank, int world, int64_t* first, int64_t* last);
+
 /* ---- device memory for resident batches ------------------------------------- */
 int rcv_malloc(rcv_ctx* ctx, size_t bytes, void** out);
 int rcv_free(rcv_ctx* ctx, void* p);

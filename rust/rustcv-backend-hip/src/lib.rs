@@ -45,8 +45,55 @@ fn flat_view(src: &[u8]) -> rcv_mat {
 
 /// Contiguous frame range of GPU `rank` of `world` for a batch of `n_frames`: one `HipContext` and one host
 /// thread per GPU, no collective; `HipContext` is `Send`, so `std::thread::scope` over the contexts is the whole dispatcher.
+/// (The library's own `rcv_shard_range`: one rule for every host language.)
 pub fn frame_range(n_frames: usize, rank: usize, world: usize) -> (usize, usize) {
-    (rank * n_frames / world, (rank + 1) * n_frames / world)
+    let (mut first, mut last) = (0i64, 0i64);
+    let rc = unsafe { rcv_shard_range(n_frames as i64, rank as i32, world as i32, &mut first, &mut last) };
+    assert_eq!(rc, RCV_OK, "frame_range({n_frames}, {rank}, {world})");
+    (first as usize, last as usize)
+}
+
+/// One context per GPU of the node, owned together (north_star: "independent per-GPU HIP streams, no RCCL
+/// collective").  Batch entry points only enqueue work on their context's stream, so ONE host thread can drive every device:
+/// `for rank in 0..g.len() { op(g.ctx(rank), frames g.frames(n, rank)) }` and one `g.sync()`.  `ctx(rank)` borrows from the group.
+pub struct DeviceGroup {
+    raw: *mut rcv_group,
+    ctxs: Vec<std::mem::ManuallyDrop<HipContext>>,   // views of the group's contexts: destroyed by rcv_group_destroy, not by Drop
+}
+unsafe impl Send for DeviceGroup {}
+
+impl DeviceGroup {
+    /// GPUs `0..n_devices`; `Err(RCV_ERR_DEVICE)` when the node has fewer.
+    pub fn new(n_devices: usize) -> Result<Self, i32> {
+        Self::create(std::ptr::null(), n_devices)
+    }
+    /// An explicit list of device ordinals (an ordinal may repeat: two streams on one GPU).
+    pub fn with_devices(devices: &[i32]) -> Result<Self, i32> {
+        Self::create(devices.as_ptr(), devices.len())
+    }
+    fn create(devices: *const i32, n: usize) -> Result<Self, i32> {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { rcv_group_create(devices, n as i32, &mut raw) };
+        if rc != RCV_OK {
+            return Err(rc);
+        }
+        let len = unsafe { rcv_group_size(raw) }.max(0) as usize;
+        let ctxs = (0..len).map(|r| std::mem::ManuallyDrop::new(HipContext { raw: unsafe { rcv_group_ctx(raw, r as i32) } })).collect();
+        Ok(Self { raw, ctxs })
+    }
+    pub fn len(&self) -> usize { self.ctxs.len() }
+    pub fn is_empty(&self) -> bool { self.ctxs.is_empty() }
+    pub fn ctx(&self, rank: usize) -> &HipContext { &self.ctxs[rank] }
+    /// The half-open frame range `first..last` of a batch of `n_frames` that belongs to `rank`.
+    pub fn frames(&self, n_frames: usize, rank: usize) -> (usize, usize) { frame_range(n_frames, rank, self.len()) }
+    /// Every context's stream idle; the first error.
+    pub fn sync(&self) -> Result<(), i32> {
+        let rc = unsafe { rcv_group_sync(self.raw) };
+        if rc != RCV_OK { Err(rc) } else { Ok(()) }
+    }
+}
+impl Drop for DeviceGroup {
+    fn drop(&mut self) { unsafe { rcv_group_destroy(self.raw) } }
 }
 
 /// A capture buffer that lives in a DMA-BUF, mapped on the GPU without a copy: the consuming side of

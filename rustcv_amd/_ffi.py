@@ -86,6 +86,12 @@ SIGNATURES = {
     "rcv_ctx_destroy": (None, [_ctx]),
     "rcv_sync": (_i, [_ctx]),
     "rcv_ctx_device": (_i, [_ctx]),
+    "rcv_group_create": (_i, [_P(C.c_int), _i, _P(C.c_void_p)]),
+    "rcv_group_destroy": (None, [C.c_void_p]),
+    "rcv_group_size": (_i, [C.c_void_p]),
+    "rcv_group_ctx": (_ctx, [C.c_void_p, _i]),
+    "rcv_group_sync": (_i, [C.c_void_p]),
+    "rcv_shard_range": (_i, [C.c_int64, _i, _i, _P(C.c_int64), _P(C.c_int64)]),
     "rcv_ctx_stream": (C.c_void_p, [_ctx]),
     "rcv_malloc": (_i, [_ctx, _sz, _P(C.c_void_p)]),
     "rcv_free": (_i, [_ctx, C.c_void_p]),

@@ -77,3 +77,67 @@ class DeviceGroup:
 
     def __exit__(self, *a):
         self.close()
+
+
+class _GroupContext(Context):
+    """a context owned by an rcv_group: same interface, but closing it is the group's business"""
+
+    def __init__(self, handle, device):   # (no rcv_ctx_create)
+        self._h, self.device = handle, int(device)
+
+    def close(self):
+        self._h = None
+
+
+class NativeGroup:
+    """The library's own device group (`rcv_group_*`, include/rustcv_hip.h): one context per device, created and destroyed
+    together, driven from ONE host thread -- batch entry points only enqueue work on their context's stream, so
+
+        with NativeGroup(8) as g:
+            for rank in range(g.world):
+                op(g.ctxs[rank], *g.frames(n, rank))      # returns as soon as the launch is queued
+            g.sync()
+
+    keeps every GPU busy without a thread per device (the dispatcher a Rust / C++ host would write; `DeviceGroup` above is the
+    thread-per-device form)."""
+
+    def __init__(self, devices):
+        import ctypes as C
+        from . import _ffi
+        L = _ffi.lib()
+        devs = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+        arr = (C.c_int * len(devs))(*devs)
+        h = C.c_void_p()
+        _ffi.check(L.rcv_group_create(arr, len(devs), C.byref(h)), f"rcv_group_create({devs})")
+        self._h, self.devices = h, devs
+        self.ctxs = [_GroupContext(C.c_void_p(L.rcv_group_ctx(h, r)), devs[r]) for r in range(L.rcv_group_size(h))]
+
+    @property
+    def world(self):
+        return len(self.ctxs)
+
+    def frames(self, n_frames, rank):
+        import ctypes as C
+        from . import _ffi
+        a, b = C.c_int64(), C.c_int64()
+        _ffi.check(_ffi.lib().rcv_shard_range(int(n_frames), int(rank), self.world, C.byref(a), C.byref(b)), "rcv_shard_range")
+        return a.value, b.value
+
+    def sync(self):
+        from . import _ffi
+        _ffi.check(_ffi.lib().rcv_group_sync(self._h), "rcv_group_sync")
+
+    def close(self):
+        from . import _ffi
+        if self._h is not None:
+            for c in self.ctxs:
+                c.close()
+            _ffi.lib().rcv_group_destroy(self._h)
+            self._h, self.ctxs = None, []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+

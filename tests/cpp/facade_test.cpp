@@ -136,8 +136,50 @@ static void staging_ring_streams_frames_in_order()
     ASSERT(!ring.retire(out));
 }
 
+static void device_group_shards_a_batch_from_one_thread()
+{
+    // three contexts (= three streams) on GPU 0, 7 frames dealt 2 / 2 / 3; every rank's launches are queued before the one sync
+    DeviceGroup g(std::vector<int>{0, 0, 0});
+    ASSERT(g.size() == 3);
+    int64_t covered = 0;
+    const int n = 7, rows = 8, cols = 16;
+    std::vector<uint8_t> host((size_t)n * rows * cols * 4), out((size_t)n * rows * cols * 3, 0);
+    for (size_t i = 0; i < host.size(); ++i) host[i] = (uint8_t)(i * 7 + 3);
+    std::vector<void*> din(3, nullptr), dout(3, nullptr);
+    for (int r = 0; r < 3; ++r) {
+        auto fr = g.frames(n, r);
+        ASSERT(fr.first == covered && fr.second >= fr.first);
+        covered = fr.second;
+        const size_t nf = (size_t)(fr.second - fr.first), fin = (size_t)rows * cols * 4, fout = (size_t)rows * cols * 3;
+        check(rcv_malloc(g.ctx(r), nf * fin, &din[r]), "rcv_malloc");
+        check(rcv_malloc(g.ctx(r), nf * fout, &dout[r]), "rcv_malloc");
+        check(rcv_upload(g.ctx(r), din[r], host.data() + (size_t)fr.first * fin, nf * fin), "rcv_upload");
+        rcv_batch bi{}, bo{};
+        bi.frame0.data = din[r]; bi.frame0.cap = fin; bi.frame0.step = (size_t)cols * 4; bi.frame0.rows = rows; bi.frame0.cols = cols;
+        bi.frame0.channels = 4; bi.frame0.depth = RCV_8U; bi.frame0.device = RCV_DEVICE; bi.frame_stride = fin; bi.n = (int32_t)nf;
+        bo = bi;
+        bo.frame0.data = dout[r]; bo.frame0.cap = fout; bo.frame0.step = (size_t)cols * 3; bo.frame0.channels = 3; bo.frame_stride = fout;
+        check(rcv_cvt_color_batch(g.ctx(r), RCV_BGRA2BGR_STRIDED, &bi, &bo), "rcv_cvt_color_batch");   // queued, not waited for
+    }
+    ASSERT(covered == n);
+    g.sync();
+    for (int r = 0; r < 3; ++r) {
+        auto fr = g.frames(n, r);
+        const size_t nf = (size_t)(fr.second - fr.first), fout = (size_t)rows * cols * 3;
+        check(rcv_download(g.ctx(r), out.data() + (size_t)fr.first * fout, dout[r], nf * fout), "rcv_download");
+        check(rcv_free(g.ctx(r), din[r]), "rcv_free");
+        check(rcv_free(g.ctx(r), dout[r]), "rcv_free");
+    }
+    for (size_t px = 0; px < (size_t)n * rows * cols; ++px)
+        for (int c = 0; c < 3; ++c) ASSERT(out[3 * px + c] == host[4 * px + c]);
+    bool threw = false;
+    try { g.ctx(3); } catch (const std::out_of_range&) { threw = true; }
+    ASSERT(threw);
+}
+
 int main()
 {
+    device_group_shards_a_batch_from_one_thread();
     sobel_of_a_ramp();
     fused_warp_resize_identity_is_a_box_average();
     staging_ring_streams_frames_in_order();

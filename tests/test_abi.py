@@ -49,6 +49,33 @@ def test_measurement_kernels_live_outside_the_product_library():
     _ffi.bench_lib()
 
 
+def test_shard_range_is_the_partition_rule_of_the_harness():
+    """rcv_shard_range (pure host arithmetic, no device) == rustcv_amd.shard.frame_range for every (n, world, rank) tried: contiguous,
+    complete, sizes differ by at most one; bad arguments are refused"""
+    import ctypes as C
+    from rustcv_amd import shard
+    L = _ffi.lib()
+    a, b = C.c_int64(), C.c_int64()
+    for n in list(range(0, 40)) + [64, 255, 256, 512, 1000003, 2 ** 40 + 7]:
+        for world in (1, 2, 3, 4, 7, 8, 64):
+            end = 0
+            sizes = []
+            for r in range(world):
+                assert L.rcv_shard_range(n, r, world, C.byref(a), C.byref(b)) == 0
+                assert (a.value, b.value) == shard.frame_range(n, r, world)
+                assert a.value == end
+                end = b.value
+                sizes.append(b.value - a.value)
+            assert end == n and max(sizes) - min(sizes) <= 1
+    for bad in ((5, -1, 2), (5, 2, 2), (5, 0, 0), (-1, 0, 1)):
+        assert L.rcv_shard_range(*bad, C.byref(a), C.byref(b)) == _ffi.RCV_ERR_ARG
+    assert L.rcv_shard_range(5, 0, 1, None, C.byref(b)) == _ffi.RCV_ERR_ARG
+    assert L.rcv_group_size(None) == _ffi.RCV_ERR_ARG and not L.rcv_group_ctx(None, 0)
+    L.rcv_group_destroy(None)
+    h = C.c_void_p()
+    assert L.rcv_group_create(None, 0, C.byref(h)) == _ffi.RCV_ERR_ARG and not h
+
+
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rustcv_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
@@ -127,7 +154,7 @@ def _c_kind(ctype):
     const = t.startswith("const ")
     t = t[6:] if const else t
     base = t.replace("*", "").strip()
-    base = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int8_t": "i8", "size_t": "usize",
+    base = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "int8_t": "i8", "size_t": "usize",
             "float": "f32", "double": "f64", "char": "c_char", "void": "void"}.get(base, base)
     return (t.count("*"), const and t.count("*") > 0, base)
 
@@ -190,7 +217,7 @@ def test_rust_ffi_declares_the_whole_header():
     for name in hf:
         assert rf[name] == hf[name], (name, rf[name], hf[name])
     opaque = {k for k, v in rs.items() if not v}             # zero-sized handles (only a private field)
-    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph", "rcv_import"}
+    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph", "rcv_import", "rcv_group"}
     for name, fields in hs.items():
         assert rs[name] == fields, (name, rs[name], fields)
     assert rc == hc and len(hc) >= 29
@@ -253,12 +280,14 @@ def test_rust_facade_wraps_every_entry_point():
     for item in ("pub struct MatRef<", "pub struct MatMut<", "pub struct DeviceBatch<", "pub struct StagingRing<", "pub struct Graph<", "pub enum HipError",
                  "pub fn rgb_to_bgr(", "pub fn harris_pipeline_batch(", "pub fn filter2d_i8_batch(", "pub fn warp_affine_resize_batch("):
         assert item in img_rs, item
+    assert "pub struct DeviceGroup" in lib_rs and "impl Drop for DeviceGroup" in lib_rs and "pub fn frame_range(" in lib_rs
     for handle in ("DeviceBatch", "StagingRing", "Graph"):
         assert re.search(r"impl<'c> Drop for %s<'c>" % handle, img_rs), handle
     # every safe wrapper of a compute entry point exists under the C name minus its prefix
     for name in hf:
-        if name.startswith(("rcv_ring_", "rcv_graph_", "rcv_import_", "rcv_ctx_", "rcv_timer_")) or name in (
-                "rcv_malloc", "rcv_free", "rcv_upload", "rcv_download", "rcv_memset", "rcv_sync", "rcv_strerror", "rcv_synth_batch"):
+        if name.startswith(("rcv_ring_", "rcv_graph_", "rcv_import_", "rcv_ctx_", "rcv_timer_", "rcv_group_")) or name in (
+                "rcv_malloc", "rcv_free", "rcv_upload", "rcv_download", "rcv_memset", "rcv_sync", "rcv_strerror", "rcv_synth_batch", "rcv_shard_range"):
             continue
         assert re.search(r"pub fn %s\(" % name[4:], lib_rs + img_rs), name
     assert img_rs.count("{") == img_rs.count("}") and img_rs.count("(") == img_rs.count(")")   # (no compiler here: at least balanced)
+    assert lib_rs.count("{") == lib_rs.count("}") and lib_rs.count("(") == lib_rs.count(")")

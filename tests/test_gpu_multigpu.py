@@ -83,3 +83,40 @@ def test_two_contexts_on_one_device_in_two_threads(ctx):
         c.close()
     assert not errs, errs
     assert np.array_equal(np.concatenate(outs, axis=0), want)
+
+
+def test_native_group_one_thread_drives_every_context(oracle):
+    """rcv_group_* (include/rustcv_hip.h): three contexts -- three streams -- of GPU 0 as one group; a batch of 7 frames is dealt
+    2 / 2 / 3 by rcv_shard_range, ONE host thread queues the filter on every context and waits once; each shard equals the oracle.
+    (The N-device form of the same loop is what a one-GPU box cannot run; the group code does not depend on the ordinals.)"""
+    import numpy as np
+    from rustcv_amd import device
+    from rustcv_amd.multigpu import NativeGroup
+    n, rows, cols = 7, 96, 256
+    k = np.arange(-24, 25, dtype=np.int8).reshape(7, 7)
+    with NativeGroup([0, 0, 0]) as g:
+        assert g.world == 3 and [c.device for c in g.ctxs] == [0, 0, 0]
+        srcs, dsts, covered = [], [], 0
+        for r in range(g.world):
+            f0, f1 = g.frames(n, r)
+            assert f0 == covered
+            covered = f1
+            s = device.DeviceBatch(g.ctxs[r], f1 - f0, rows, cols, 3)
+            device.synth(s, 1, 0x5EED0E00, f0)
+            srcs.append(s)
+            dsts.append(device.DeviceBatch(g.ctxs[r], f1 - f0, rows, cols, 3))
+        assert covered == n
+        for r in range(g.world):
+            device.filter2d(srcs[r], dsts[r], k, shift=5)       # queued on context r's stream
+        g.sync()
+        for r in range(g.world):
+            frames, got = srcs[r].download(), dsts[r].download()
+            for i in range(len(frames)):
+                assert np.array_equal(got[i], oracle.filter2d_i8(frames[i], k, 5)), (r, i)
+            srcs[r].free()
+            dsts[r].free()
+    import pytest as _pt
+    from rustcv_amd import RcvError
+    with _pt.raises(RcvError):
+        NativeGroup([0, 4096])       # an ordinal the node does not have: RCV_ERR_DEVICE, nothing left behind
+
