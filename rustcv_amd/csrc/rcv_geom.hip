@@ -242,6 +242,27 @@ __device__ __forceinline__ f2 pk_fma_bc(f2 wp, f2 a, f2 b)
     return d;
 }
 
+// {floor(b), floor(g), floor(r), 0} of three values in [0, 256): v_cvt_u32_f32 truncates (= floor for these non-negative values)
+// and its SDWA form writes the low byte of the result straight into byte 0 / 1 / 2 of the destination, the other bytes kept --
+// three instructions for what v_floor_f32 + v_cvt_pk_u8_f32 need six (the interpolated value + 0.5 lies in [0.5, 255.5]: every
+// lerp result is between its two end points, so neither the saturation nor the rounding of v_cvt_pk_u8_f32 is ever used)
+__device__ __forceinline__ uint32_t pack_floor3(float b, float g, float r)
+{
+    uint32_t d;
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(b));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(g));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r));
+    return d;
+}
+
+// floor of a value in [0, 256) as an integer: one v_cvt_u32_f32 (truncation) instead of v_floor_f32 + v_cvt_i32_f32
+__device__ __forceinline__ uint32_t trunc_u32(float v)
+{
+    uint32_t d;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
 template <bool PIN>
 __device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, f2 fxy)
 {
@@ -261,9 +282,7 @@ __device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint3
     const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
     const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
     const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
-    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
-    px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
-    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+    return pack_floor3(v01.x, v01.y, v2);
 }   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
 // 4 x 4 transpose of dwords inside every quad of lanes: on return lane 4q+i holds in a[j] what lane 4q+j held in a[i].
@@ -539,9 +558,7 @@ __device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint
     const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
     const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
     const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
-    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.x), 0, 0u);
-    px = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v01.y), 1, px);
-    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v2), 2, px);
+    return pack_floor3(v01.x, v01.y, v2);
 }
 
 // RAGS: source rows of any alignment (an odd width of a packed image): a chunk's 12 bytes are fetched as the 16 aligned bytes
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
                     const uint32_t a = pa[0], b = pb[0];
                     const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
                     const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
-                    t[i] = (uint32_t)(int)floorf(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
+                    t[i] = trunc_u32(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
                 } else {
                     t[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[r]);
                 }
@@ -784,7 +801,7 @@ __device__ __forceinline__ void warp_gray_frame(const View& s, const View& d, co
             // {top, bottom} as one packed pair: fma(fx, p01 - p00, p00), then v = fma(fy, bot - top, top), floor(v + 0.5)
             const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
             const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
-            px[r] = (uint32_t)(int)floorf(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // interior: an integer in [0, 255]
+            px[r] = trunc_u32(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // interior: an integer in [0, 255]
         }
     } else {
 #pragma unroll 1
@@ -932,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float sc
             const uint32_t a = __builtin_amdgcn_alignbyte(ta[r].b, ta[r].a, sha[r]), b = __builtin_amdgcn_alignbyte(tb[r].b, tb[r].a, shb[r]);
             const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
             const f2 tb2 = pk_fma_bc<0>(f2{fx, fy[r]}, p1 - p0, p0);          // {top, bottom}: fma(fx, p01 - p00, p00)
-            px[r] = (uint32_t)(int)floorf(fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f);   // an integer in [0, 255]
+            px[r] = trunc_u32(fmaf(fy[r], tb2.y - tb2.x, tb2.x) + 0.5f);   // an integer in [0, 255]
         }
         static_assert(kRszRows == 4, "one quad transpose per thread");
         const int lane = threadIdx.x & 63, xs = x & ~3, yi = ybase + (lane & 3);
