@@ -41,6 +41,7 @@ static void load_knobs()
     g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
+    g_knobs.warp_gray4 = env_int("RCV_WARP_GRAY4", -1);
     g_knobs.warp_resize_lds = env_int("RCV_WARP_RESIZE_LDS", -1);
     g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
     g_knobs.nms_seg = env_int("RCV_NMS_SEG", 0);

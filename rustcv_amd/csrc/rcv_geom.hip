@@ -756,6 +756,165 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     }
 }
 
+// ---- one-channel warpAffine, FOUR FRAMES per LDS pass (round 3) ---------------------------------------------------------------
+// k_warp_affine_lds<1> stages one frame at a time: per frame and thread 3.5 chunk loads, 3.5 ds_write_b128, 16 ds_read_b32 and a
+// barrier for 8 cheap pixels (10 VALU each) -- the LDS pipe and the barrier, not the arithmetic, set its pace (1.06 ms for 32 8K
+// frames, 24 % of the HBM roofline).  A one-channel patch pixel fills one byte of its LDS dword; this kernel fills all four with
+// the SAME pixel of four consecutive frames {f0 f1 f2 f3}: a chunk's four dwords (one per frame, 4 pixels each) go through a
+// 4 x 4 byte transpose (8 v_perm) into one ds_write_b128, one ds_read_b64 returns a tap pair of all four frames, the coordinates /
+// weights are shared anyway, the lerps of two frames ride in one packed-f32 operation, the results of four frames go through ONE
+// quad transpose (as dwords {f0 f1 f2 f3}) and a byte transpose back.  A quarter of the LDS instructions and barriers per frame,
+// the same f32 operations per pixel in the same order.  Aligned sources only (base, step, frame stride multiples of 4: a chunk is
+// one aligned dword); everything else stays on k_warp_affine_lds<1>.
+__device__ __forceinline__ void bytes4x4_transpose(uint32_t (&v)[4])
+{
+    const uint32_t a = __builtin_amdgcn_perm(v[1], v[0], 0x05010400u), b = __builtin_amdgcn_perm(v[1], v[0], 0x07030602u);   // {v0.0 v1.0 v0.1 v1.1}, {v0.2 v1.2 v0.3 v1.3}
+    const uint32_t c = __builtin_amdgcn_perm(v[3], v[2], 0x05010400u), e = __builtin_amdgcn_perm(v[3], v[2], 0x07030602u);
+    v[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);   // {v0.0 v1.0 v2.0 v3.0}
+    v[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    v[2] = __builtin_amdgcn_perm(e, b, 0x05040100u);
+    v[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+}
+
+// NG: chunk slots per thread (prow * cpr <= 256 NG): 4 covers rotations up to ~10 degrees and keeps 8 registers of prefetch state free
+template <int NG>
+__global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
+                                                           int tiles_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_per_xcd > 0) {   // XCD-contiguous raster order (see k_warp_affine_lds)
+        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
+        if (t >= ntiles) return;
+        bz = t / (gx * gy);
+        const int rem = t - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
+    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
+    const float cx0 = (float)min(bx * kWlTW, d.cols - 1), cx1 = (float)min(bx * kWlTW + kWlTW - 1, d.cols - 1);
+    const float cy0 = (float)min(by * kWlTH, d.rows - 1), cy1 = (float)min(by * kWlTH + kWlTH - 1, d.rows - 1);
+    const float t0 = fmaf(A.m[1], cy0, A.m[2]), t1 = fmaf(A.m[1], cy1, A.m[2]), u0 = fmaf(A.m[4], cy0, A.m[5]), u1 = fmaf(A.m[4], cy1, A.m[5]);
+    const float xa = fmaf(A.m[0], cx0, t0), xb = fmaf(A.m[0], cx1, t0), xc = fmaf(A.m[0], cx0, t1), xd = fmaf(A.m[0], cx1, t1);
+    const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
+    const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+    const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
+              s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) &&
+              d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
+    int ix0 = 0, iy0 = 0;
+    if (ok) {
+        ix0 = (int)xmin & ~3;
+        iy0 = (int)ymin;
+        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) {
+        for (int f = f0; f < f1; ++f) warp_gray_frame(s, d, A, f, x, ybase);
+        return;
+    }
+    ix0 = __builtin_amdgcn_readfirstlane(ix0);
+    iy0 = __builtin_amdgcn_readfirstlane(iy0);
+    const float fxx = (float)min(x, d.cols - 1);
+    f2 fxy[kWarpRows];
+    unsigned la[kWarpRows];
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        const float fyy = (float)min(ybase + r, d.rows - 1);
+        const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
+        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};
+        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+    }
+    const int xq = x & ~3, yi = ybase + (lane & 3);
+    unsigned so[kWarpRows / 4];
+#pragma unroll
+    for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + (unsigned)xq;
+    // ---- staging plan: chunk c = 4 pixels = one aligned source dword per frame -> 16 LDS bytes {4 pixels x 4 frames} ----
+    const int nchunks = prow * cpr;
+    const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)s.cols - 4u) & ~3u;
+    unsigned goff[NG], loff[NG];
+    bool gval[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = (int)threadIdx.x + kBlock * g;
+        gval[g] = c < nchunks;
+        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;
+        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(ix0 + 4 * col), frame_lim);
+        loff[g] = (unsigned)(row * pitch + 16 * col);
+    }
+    const int ng = (nchunks + kBlock - 1) / kBlock;
+    typedef const __attribute__((address_space(1))) uint8_t* cgp;
+    typedef __attribute__((address_space(1))) uint32_t gU1;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    uint32_t G[NG][4];
+    auto gload = [&](int fb) {   // frames fb .. fb + 3 (past the group's last frame: that frame again, never stored)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cgp sf = (cgp)(s.p + (size_t)min(fb + k, f1 - 1) * s.fstride);
+            asm("" : "+s"(sf));
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if (g < ng) {   // uniform
+                    unsigned o = goff[g];
+                    asm("" : "+v"(o));
+                    G[g][k] = *(const gU1*)(sf + o);
+                }
+        }
+    };
+    const unsigned bufbytes = (unsigned)(pitch * prow);
+    const bool ragd = (d.cols & 3) != 0;
+    gload(f0);
+    int pass = 0;
+    for (int fb = f0; fb < f1; fb += 4, ++pass) {
+        uint8_t* buf = wg_lds + (pass & 1) * bufbytes;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (gval[g]) {
+                uint32_t v[4] = {G[g][0], G[g][1], G[g][2], G[g][3]};   // frame k: pixels x .. x+3
+                bytes4x4_transpose(v);                                  // pixel j: frames 0 .. 3
+                *(u4v*)(buf + loff[g]) = u4v{v[0], v[1], v[2], v[3]};
+            }
+        __syncthreads();
+        if (fb + 4 < f1) gload(fb + 4);
+#pragma unroll
+        for (int h = 0; h < kWarpRows / 4; ++h) {
+            uint32_t w[4];   // row 4h + i, this lane's pixel: {frame 0, 1, 2, 3}
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * h + i;
+                const uint32_t* pa = (const uint32_t*)(buf + la[r]);
+                const uint32_t* pb = (const uint32_t*)(buf + la[r] + pitch);
+                const uint32_t a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+                const f2 half2 = {0.5f, 0.5f};
+                // frames 0 and 1, frames 2 and 3: per frame top = fma(fx, p01 - p00, p00), bot = fma(fx, p11 - p10, p10),
+                // v = fma(fy, bot - top, top) + 0.5 -- k_warp_affine_gray's operations, two frames per packed instruction
+                const f2 p00 = {ub<0>(a0), ub<1>(a0)}, p01 = {ub<0>(a1), ub<1>(a1)}, p10 = {ub<0>(b0), ub<1>(b0)}, p11 = {ub<0>(b1), ub<1>(b1)};
+                const f2 q00 = {ub<2>(a0), ub<3>(a0)}, q01 = {ub<2>(a1), ub<3>(a1)}, q10 = {ub<2>(b0), ub<3>(b0)}, q11 = {ub<2>(b1), ub<3>(b1)};
+                const f2 top = pk_fma_bc<0>(fxy[r], p01 - p00, p00), bot = pk_fma_bc<0>(fxy[r], p11 - p10, p10);
+                const f2 tpq = pk_fma_bc<0>(fxy[r], q01 - q00, q00), btq = pk_fma_bc<0>(fxy[r], q11 - q10, q10);
+                const f2 v01 = pk_fma_bc<1>(fxy[r], bot - top, top) + half2, v23 = pk_fma_bc<1>(fxy[r], btq - tpq, tpq) + half2;
+                uint32_t px = pack_floor3(v01.x, v01.y, v23.x);
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(v23.y));
+                w[i] = px;
+            }
+            quad_transpose4(w, lane);   // lane 4q + i: row 4h + i, pixels 4q .. 4q+3, each {frame 0 .. 3}
+            bytes4x4_transpose(w);      // w[k]: frame k, pixels 4q .. 4q+3
+            if (xq < d.cols && yi + 4 * h < d.rows) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (fb + k < f1) {   // uniform
+                        typedef uint32_t u1m __attribute__((aligned(1)));
+                        uint8_t* q = d.p + (size_t)(fb + k) * d.fstride + so[h];
+                        if (!ragd || d.cols - xq >= 4) *(u1m*)q = w[k];
+                        else
+                            for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(w[k] >> (8 * j));
+                    }
+            }
+        }
+    }
+}
+
 // One-channel images: the scheme of k_warp_affine_bgr with 2-byte tap pairs.  One thread per output column and kWarpRows
 // rows; a wave whose taps all lie inside the source fetches each tap pair as the ALIGNED 8 bytes that contain it (one dwordx2
 // per source row: 16 tap loads in flight per lane), shifts it into place with v_alignbyte, lerps top and bottom rows as one
@@ -1446,6 +1605,22 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const bool xcd = rcv_knobs().xcd_order != 0 && tiles < (1ull << 30);
             const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
+            if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
+                // four frames per LDS pass: groups of 8 frames (two passes) while that leaves >= 4096 workgroups, else 4
+                // (32 x 8K: 4 / 8 / 16 / 32 frames per group 0.905 / 0.888 / 0.968 / 1.125 ms)
+                const unsigned long long t1 = (unsigned long long)lgx * lgy;
+                int fq = t1 * ((d.n + 7) / 8) >= 4096 ? 8 : 4;
+                if (rcv_knobs().warp_fpg > 0) fq = max(4, min(rcv_knobs().warp_fpg, d.n) & ~3);
+                const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
+                const unsigned long long tq = t1 * gzq;
+                // (plain raster order unless RCV_XCD_ORDER=1 asks for the XCD-contiguous one: measured 0.849 against 0.888 ms on 32 x 8K)
+                const bool xq = rcv_knobs().xcd_order > 0 && tq < (1ull << 30);
+                const int tpq = xq ? (int)((tq + 7) / 8) : 0;
+                const dim3 gridq = xq ? dim3((unsigned)tpq * 8) : dim3(lgx, lgy, gzq);
+                if (prow * cpr <= 4 * kBlock) RCV_LAUNCH(k_warp_gray_lds4<4>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
+                else RCV_LAUNCH(k_warp_gray_lds4<kWlMaxG>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
+                return rcv_launch_check(ctx);
+            }
             if (s.ch == 1) RCV_LAUNCH((k_warp_affine_lds<1, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
             else if (rags) RCV_LAUNCH((k_warp_affine_lds<3, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
             else RCV_LAUNCH((k_warp_affine_lds<3, false>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);

@@ -110,6 +110,7 @@ struct RcvKnobs {
     int nms_seg;          // RCV_NMS_SEG       rows per segment of the NMS kernel (0 = plan)
     int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
     int warp_resize_lds;  // RCV_WARP_RESIZE_LDS 1: the fused warp -> 4x resize on the LDS-staged kernel (slower: experiment record)
+    int warp_gray4;       // RCV_WARP_GRAY4    0: one-channel warpAffine never on the four-frames-per-pass kernel (k_warp_gray_lds4)
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)
     int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)

@@ -1283,6 +1283,41 @@ def test_warp_affine_resize_fused(ctx, oracle, rng, scale, dshape, M):
     dst.free()
 
 
+@pytest.mark.parametrize("n,fpg,kernel", [(4, 0, "quad"), (5, 0, "quad"), (9, 4, "quad"), (9, 8, "quad-xcd"), (17, 0, "quad"), (19, 16, "quad-xcd"), (6, 0, "single")])
+@pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "shift", "flip", "big"])
+@pytest.mark.parametrize("dshape", [(70, 200), (33, 131)])
+def test_warp_affine_gray_four_frames_per_pass(ctx, oracle, rng, knob, n, fpg, kernel, M, dshape):
+    """round 3: one-channel warpAffine with the SAME pixel of four consecutive frames in one LDS dword (k_warp_gray_lds4): frame
+    counts that are not a multiple of 4, groups with a short last pass, ragged destination widths (131), tiles at the source border
+    and outside (gather path), both tile orders, against the one-frame kernel's results (RCV_WARP_GRAY4=0) and the oracle"""
+    if kernel == "single":
+        knob("RCV_WARP_GRAY4", 0)
+    if kernel == "quad-xcd":
+        knob("RCV_XCD_ORDER", 1)
+    if fpg:
+        knob("RCV_WARP_FPG", fpg)
+    dr, dc = dshape
+    sr, sc = dr + 21, dc + 40
+    Ms = {"rot7": _rot(7.0, dc / 2, dr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, dc / 2, dr / 2, 20.0, 12.0),
+          "shear": np.array([1, 0.25, 3.5, -0.125, 1, 18.25], np.float32), "shift": np.array([1, 0, 7.5, 0, 1, 3.25], np.float32),
+          "flip": np.array([-1, 0, dc + 5.5, 0, -1, dr + 3.25], np.float32), "big": np.array([3, 0, 0, 0, 3, 0], np.float32)}[M]
+    src = device.DeviceBatch(ctx, n, sr, sc, 1, step=(sc + 3) // 4 * 4 + 4)
+    dst = _canary_batch(ctx, n, dr, dc, 1, pad=9)
+    frames = rng.integers(0, 256, size=(n, sr, sc), dtype=np.uint8)
+    src.upload(frames)
+    L = _ffi.lib()
+    L.rcv__debug_kernels_reset()
+    device.warp_affine(src, dst, Ms)
+    names = L.rcv__debug_kernels().decode()
+    assert ("k_warp_gray_lds4" in names) == (kernel != "single" and M != "big"), names   # ("big": the patch of a tile does not fit -> no LDS plan)
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.warp_affine(frames[i], Ms, dr, dc)), (kernel, M, n, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("kernel,fpg", [("lds", 0), ("lds", 3), ("lds-raster", 2), ("box", 0)])
 @pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "ident", "flip", "grow", "big"])
 def test_warp_affine_resize_fused_lds_tiles(ctx, oracle, rng, knob, kernel, fpg, M):
@@ -1466,7 +1501,8 @@ def test_warp_affine_bgr_lds_staged_kernel(ctx, oracle, knob, case, ch):
             knob("RCV_WARP_FPG", fpg)
         dst.memset(0xAB)
         launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
-        assert ("k_warp_affine_lds<%d" % ch) in launched, (launched, M)
+        # (one channel, >= 4 frames, 4-byte aligned source rows: the four-frames-per-pass kernel)
+        assert ("k_warp_affine_lds<%d" % ch) in launched or (ch == 1 and n >= 4 and "k_warp_gray_lds4" in launched), (launched, M)
         got = dst.download()
         for i in range(n):
             assert np.array_equal(got[i].reshape(dr, dc, ch), want[i]), (case, fpg, i, M.tolist(), (sr, sc, dr, dc))
