@@ -65,6 +65,30 @@ __global__ __launch_bounds__(kT) void k_copy_sweep_u(const u4v* __restrict__ s, 
     }
 }
 
+// Stream-count experiment (round 3): the nt sweep with U = 2 accesses in flight, but the buffer cut into `nstreams` equal contiguous
+// regions, each swept by its own share of the workgroups (region r: workgroups r, r + nstreams, ...) -- what a band-streaming stencil
+// does to the memory system (its resident waves walk ~136 separate row streams) without anything else of the stencil.  nstreams = 1
+// is the plain sweep.  XCDL: a region's workgroups are consecutive in the list of ONE XCD (block b runs on XCD b % 8) instead of
+// being dealt over all eight.
+template <bool XCDL>
+__global__ __launch_bounds__(kT) void k_copy_streams(const u4v* __restrict__ s, u4v* __restrict__ d, size_t n, int nstreams)
+{
+    int b = blockIdx.x;
+    const int G = gridDim.x;
+    if (XCDL) b = (b & 7) * (G / 8) + (b >> 3);   // position in the XCD-major list
+    const int per = G / nstreams;                  // workgroups per region (host: G % nstreams == 0)
+    const int r = XCDL ? b / per : b % nstreams, w = XCDL ? b % per : b / nstreams;
+    const size_t len = n / nstreams, base = (size_t)r * len;
+    const size_t stride = (size_t)per * kT;
+    for (size_t i = (size_t)w * kT + threadIdx.x; i < len; i += 2 * stride) {
+        u4v v0 = __builtin_nontemporal_load(s + base + i), v1 = v0;
+        const size_t j = i + stride;
+        if (j < len) v1 = __builtin_nontemporal_load(s + base + j);
+        __builtin_nontemporal_store(v0, d + base + i);
+        if (j < len) __builtin_nontemporal_store(v1, d + base + j);
+    }
+}
+
 // Phase experiments (round 3): does it matter WHEN the GPU's reads and writes reach the memory system?  MODE 0: the plain nt
 // sweep; 1: every wave de-synchronised by pseudo-random sleeps; 2: clock-gated -- loads are only issued while bit `hbit` of the
 // chip-wide 100 MHz counter is 0 and stores while it is 1, so the whole GPU alternates between read and write bursts.
@@ -275,6 +299,14 @@ extern "C" int rcv__membench(rcv_ctx* ctx, void* dst, const void* src, size_t by
         if (grid % 8) return RCV_ERR_ARG;
         hipLaunchKernelGGL((k_copy_xcd<true, true>), g, b, 0, ctx->stream, s, d, n);
         break;
+    case 40: case 41: {   // N-stream sweep: `grid` bits 0..15 workgroups, bits 16..31 streams (41: a stream's workgroups on one XCD)
+        const unsigned wgs = (unsigned)grid & 0xffffu, ns = (unsigned)grid >> 16;
+        if (ns < 1 || wgs % ns || (variant == 41 && (wgs % 8 || (wgs / 8) % (wgs / ns)))) return RCV_ERR_ARG;
+        if (n % ns) return RCV_ERR_ARG;
+        if (variant == 40) hipLaunchKernelGGL((k_copy_streams<false>), dim3(wgs), b, 0, ctx->stream, (const u4v*)src, (u4v*)dst, n, (int)ns);
+        else hipLaunchKernelGGL((k_copy_streams<true>), dim3(wgs), b, 0, ctx->stream, (const u4v*)src, (u4v*)dst, n, (int)ns);
+        break;
+    }
     default:
         if (variant >= 100 && variant < 400) {
             // 100 + 100 * mode + 10 * ui + 0: U = 2 / 4 / 8 / 16 (ui 0..3); the gate's half period comes in `grid` bits 16..31 (ticks of 10 ns)
