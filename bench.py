@@ -177,7 +177,9 @@ class Fence:
 # flight per thread in ONE global sweep are the best on every box, so those are in the list.
 CEILING_COPIES = ((0, 1, "hipMemcpyAsync D2D"), (1, 1024, "sweep g=1024"), (3, 512, "sweep U=4 nt g=512"), (5, 2048, "block nt g=2048"),
                   (9, 2048, "XCD-local sweep nt g=2048"), (21, 512, "sweep U=2 nt g=512"), (20, 768, "sweep U=2 nt stores g=768"),
-                  (10, 256, "sweep U=4 plain g=256"), (17, 256, "sweep U=8 nt g=256"), (21, 384, "sweep U=2 nt g=384"))
+                  (10, 256, "sweep U=4 plain g=256"), (17, 256, "sweep U=8 nt g=256"), (21, 384, "sweep U=2 nt g=384"),
+                  # (the sweep cut into 2 / 8 regions: the best copies of tools/ablate_streams.py)
+                  (40, 512 | (2 << 16), "2-region sweep U=2 nt g=512"), (40, 512 | (8 << 16), "8-region sweep U=2 nt g=512"))
 
 
 def run_rank(a, rank, world, device, ctx, fence, torch):
