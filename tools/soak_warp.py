@@ -18,13 +18,14 @@ ctx = rcv.Context(0)
 L = _ffi.lib()
 bad = 0
 nlds = 0
+nquad = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 CH = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 for case in range(N):
     rng = np.random.default_rng(0xABCD00 + case)
     sr, sc = int(rng.integers(40, 700)), int(rng.integers(40, 900))
     dr, dc = int(rng.integers(8, 600)), (4 * int(rng.integers(2, 220)) if case % 3 else int(rng.integers(5, 880)))   # every third case: any width
-    n = int(rng.integers(1, 10))
+    n = int(rng.integers(1, 10)) if case % 4 else int(rng.integers(4, 22))
     kind = case % 8
     if kind == 0: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)))
     elif kind == 1: M = rot(float(rng.choice([7.0, 45.0, 90.0, -90.0, 180.0, 0.1, 0.0])), sc / 2, sr / 2, 13.25, -8.5)
@@ -51,6 +52,7 @@ for case in range(N):
         ctx.sync()
         k = L.rcv__debug_kernels().decode()
         nlds += "lds" in k
+        nquad += "k_warp_gray_lds4" in k
         got = dst.download()
         for i in range(n):
             want = oracle.warp_affine(frames[i] if CH == 3 else frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, CH)
@@ -59,4 +61,4 @@ for case in range(N):
                 print("MISMATCH", case, fpg, i, k, M.tolist(), (sr, sc, dr, dc, n), int((got[i].reshape(dr, dc, CH) != want).sum()), flush=True)
                 break
     src.free(); dst.free()
-print(f"soak: {N} cases, {nlds} launches on the LDS kernel, {bad} mismatches")
+print(f"soak: {N} cases, {nlds} launches on the LDS kernels ({nquad} on the four-frames-per-pass one), {bad} mismatches")
