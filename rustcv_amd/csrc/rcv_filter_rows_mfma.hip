@@ -68,6 +68,7 @@ struct FRArgs {
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
     int sob192;                  // SOB: 1 = line-aligned 192-pixel strips with non-temporal stores (SOB = 2 instantiation)
     int wpb;                     // waves per workgroup (1, 2, 4 or 8): independent waves, neighbouring strips of a band on one CU
+    int phi;                     // (DBG & 512 experiment) this wave's parity of output row pairs
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
     uint8_t *gdx, *gdy;          // SOB: the i16 gradient planes (one channel), row step / frame stride in bytes
@@ -514,6 +515,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                 const v4i& w0 = W[s % RP][0];
                 const v4i& w1 = W[s % RP][1];
                 const int y = ys + 2 * u;
+                if ((DBG & 512) != 0 && (u & 1) != a.phi) continue;
                 __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(dframe + (size_t)y * a.dstep + so));
                 if (2 * u + 1 < nrows) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(dframe + (size_t)(y + 1) * a.dstep + so));
                 continue;
@@ -558,7 +560,13 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     if constexpr ((DBG & 1024) != 0) t_start = __builtin_amdgcn_s_memrealtime();
     // XCD-aware order (speed only): hardware places block b on XCD b % 8; each XCD gets a contiguous run of bands, and the strips
     // of one band -- which share the 128-B lines at their seams -- are neighbours in dispatch order on one L2
-    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * a.wpb + wave;
+    const int xcd = blockIdx.x & 7;
+    int slot = (int)(blockIdx.x >> 3) * a.wpb + wave;
+    // (DBG & 512, with 256: the memory pattern of TWO waves per (band, strip) that take alternate output row pairs -- both read every
+    //  input row, wave phi stores the row pairs u with (u & 1) == phi: half as many bands in flight at the same occupancy)
+    const int phi = (DBG & 512) ? (slot & 1) : 0;
+    if constexpr ((DBG & 512) != 0) slot >>= 1;
+    a.phi = phi;
     // Band order: every XCD works through its own contiguous eighth of the bands, so that what ONE XCD has in flight is a
     // compact piece of the batch (~21 neighbouring bands = one frame).  Measured on 64 4K frames (same box, same run): this
     // order 0.551 ms; bands dealt round-robin to the XCDs (order 1: each XCD's waves spread over eight frames) 0.600 ms; one
@@ -663,6 +671,14 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     constexpr bool kMemOnly = KS == 7;
 #else
     constexpr bool kMemOnly = KS == 7 && PP == 3;
+#endif
+#ifdef RCV_ABLATE
+    if constexpr (KS == 7) {
+        if ((rcv_debug_flags & 255) == 7) {   // memory-only, two waves per (band, strip): twice the workgroups for the same band plan
+            RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 772>), dim3(grid.x * 2), dim3(64 * a.wpb), lds, st, a);
+            return;
+        }
+    }
 #endif
     if constexpr (kMemOnly) {
         if ((rcv_debug_flags & 255) == 4) {
@@ -942,6 +958,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     a.wpb = kn.fr_wpb == 2 || kn.fr_wpb == 4 || kn.fr_wpb == 8 ? kn.fr_wpb : 1;
+    a.phi = 0;
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)
     const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
     if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
