@@ -68,7 +68,6 @@ struct FRArgs {
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
     int sob192;                  // SOB: 1 = line-aligned 192-pixel strips with non-temporal stores (SOB = 2 instantiation)
     int wpb;                     // waves per workgroup (1, 2, 4 or 8): independent waves, neighbouring strips of a band on one CU
-    int phi;                     // (DBG & 512 experiment) this wave's parity of output row pairs
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
     uint8_t *gdx, *gdy;          // SOB: the i16 gradient planes (one channel), row step / frame stride in bytes
@@ -515,7 +514,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                 const v4i& w0 = W[s % RP][0];
                 const v4i& w1 = W[s % RP][1];
                 const int y = ys + 2 * u;
-                if ((DBG & 512) != 0 && (u & 1) != a.phi) continue;
+                if ((DBG & 512) != 0 && (u & 1) != oys) continue;   // (this experiment passes the wave's parity in `oys`, unused without SOB)
                 __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(dframe + (size_t)y * a.dstep + so));
                 if (2 * u + 1 < nrows) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(dframe + (size_t)(y + 1) * a.dstep + so));
                 continue;
@@ -566,7 +565,6 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     //  input row, wave phi stores the row pairs u with (u & 1) == phi: half as many bands in flight at the same occupancy)
     const int phi = (DBG & 512) ? (slot & 1) : 0;
     if constexpr ((DBG & 512) != 0) slot >>= 1;
-    a.phi = phi;
     // Band order: every XCD works through its own contiguous eighth of the bands, so that what ONE XCD has in flight is a
     // compact piece of the batch (~21 neighbouring bands = one frame).  Measured on 64 4K frames (same box, same run): this
     // order 0.551 ms; bands dealt round-robin to the XCDs (order 1: each XCD's waves spread over eight frames) 0.600 ms; one
@@ -606,8 +604,8 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
             uint8_t* dyf = a.gdy + (size_t)frame * a.gfs;
             if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
             else fr_segment<KS, PP, false, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
-        } else if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
-        else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe);
+        } else if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe, phi);
+        else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe, phi);
         g0 += ye - ys;
     }
     if constexpr ((DBG & 1024) != 0) {
@@ -958,7 +956,6 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     a.wpb = kn.fr_wpb == 2 || kn.fr_wpb == 4 || kn.fr_wpb == 8 ? kn.fr_wpb : 1;
-    a.phi = 0;
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)
     const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
     if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
