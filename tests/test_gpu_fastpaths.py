@@ -77,7 +77,7 @@ def test_fast_kernels_are_dispatched(ctx):
         ("cornerHarris gray", lambda: device.corner_harris(gray, resp, 2, 0.04), "k_harris_fused<true, 2, false>"),
         ("NMS 3x3", lambda: device.nms3x3(resp, mask, 1e-4), "k_nms3x3_rows"),
         ("warpAffine BGR", lambda: device.warp_affine(bgr, bgr2, M), "k_warp_affine_lds<3, false>"),
-        ("warpAffine gray", lambda: device.warp_affine(gray, gray2, M), "k_warp_affine_lds<1, true>"),
+        ("warpAffine gray", lambda: device.warp_affine(gray, gray2, M), "k_warp_gray_lds4<4>"),
         ("resize BGR 4K -> 960x540 (box)", lambda: device.resize(bgr, small), "k_resize_box<4>"),
         ("fused warp -> 4x down-scale", lambda: device.warp_affine_resize(bgr, small, M, rows, cols), "k_warp_resize_box<4>"),
         ("cvtColor BGR2GRAY", lambda: device.cvt_color(bgr, gray2, _ffi.RCV_BGR2GRAY), "k_bgr2gray16"),
