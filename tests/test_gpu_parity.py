@@ -2678,3 +2678,24 @@ def test_row_kernel_random_batches(ctx, oracle, knob):
         src.free()
         dst.free()
 
+
+def test_geometry_f32_at_8k(ctx, oracle):
+    """north_star's 1-ULP clause at BASELINE configs[3] size: one 4320 x 7680 RCV_32F frame (one channel: a response map) through the
+    7-degree warp and the 4x down-scale to 1080p, every pixel against the oracle (expected and printed: 0 ULP)"""
+    rows, cols = 4320, 7680
+    r = np.random.default_rng(0x8F32)
+    frame = (r.standard_normal((rows, cols)) * 1e-3).astype(np.float32)
+    src = device.DeviceBatch(ctx, 1, rows, cols, 1, _ffi.RCV_32F)
+    src.upload(frame[None, :, :, None])
+    M = _rot(7.0, cols / 2, rows / 2, 13.25, -8.5)
+    dst = device.DeviceBatch(ctx, 1, rows, cols, 1, _ffi.RCV_32F)
+    device.warp_affine(src, dst, M)
+    d_warp = int(_ulp_distance(dst.download()[0], oracle.warp_affine_f32(frame, M, rows, cols)).max())
+    small = device.DeviceBatch(ctx, 1, 1080, 1920, 1, _ffi.RCV_32F)
+    device.resize(src, small)
+    d_resize = int(_ulp_distance(small.download()[0], oracle.resize_f32(frame, 1080, 1920)).max())
+    print(f"f32 geometry at 8K: warp max ULP distance {d_warp}, resize -> 1080p {d_resize}")
+    assert d_warp <= 1 and d_resize <= 1
+    for b in (src, dst, small):
+        b.free()
+
