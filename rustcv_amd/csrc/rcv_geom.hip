@@ -1427,6 +1427,137 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_f32(View s, View d, Affi
     }
 }
 
+// One-channel RCV_32F warpAffine through an LDS-staged source patch (round 3): k_warp_affine_lds's tiles, patch geometry, pitch planner
+// and double buffer with the patch held as the f32 samples themselves -- a chunk is 16 source bytes = one ds_write_b128, a tap
+// pair one ds_read2_b32, no conversion anywhere; a thread owns one column of 8 rows, so a wave's stores are whole 256-byte row
+// pieces.  Interior tiles only (every tap inside the source): border tiles and tiles outside run the per-pixel code of
+// k_warp_affine_f32 -- the same three fmaf per sample in the same order either way.
+__device__ __forceinline__ float warp_px_f32_1(const uint8_t* sf, const View& s, const Affine& A, float fxx, float fyy)
+{
+    const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+    const float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+    if (!(sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows)) return 0.0f;
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float fx = sx - x0f, fy = sy - y0f;
+    const bool vx0 = x0 >= 0, vx1 = x0 + 1 < s.cols, vy0 = y0 >= 0, vy1 = y0 + 1 < s.rows;
+    const float* ra = (const float*)(sf + (size_t)(vy0 ? y0 : 0) * s.step);
+    const float* rb = (const float*)(sf + (size_t)(vy1 ? y0 + 1 : 0) * s.step);
+    const size_t xa = (size_t)(vx0 ? x0 : 0), xb = (size_t)(vx1 ? x0 + 1 : 0);
+    const float p00 = (vx0 && vy0) ? ra[xa] : 0.0f, p01 = (vx1 && vy0) ? ra[xb] : 0.0f;
+    const float p10 = (vx0 && vy1) ? rb[xa] : 0.0f, p11 = (vx1 && vy1) ? rb[xb] : 0.0f;
+    const float top = fmaf(fx, p01 - p00, p00);
+    const float bot = fmaf(fx, p11 - p10, p10);
+    return fmaf(fy, bot - top, top);
+}
+
+__global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
+                                                         int tiles_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wf_lds[];
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (tiles_per_xcd > 0) {
+        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
+        if (t >= ntiles) return;
+        bz = t / (gx * gy);
+        const int rem = t - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
+    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
+    const float cx0 = (float)min(bx * kWlTW, d.cols - 1), cx1 = (float)min(bx * kWlTW + kWlTW - 1, d.cols - 1);
+    const float cy0 = (float)min(by * kWlTH, d.rows - 1), cy1 = (float)min(by * kWlTH + kWlTH - 1, d.rows - 1);
+    const float t0 = fmaf(A.m[1], cy0, A.m[2]), t1 = fmaf(A.m[1], cy1, A.m[2]), u0 = fmaf(A.m[4], cy0, A.m[5]), u1 = fmaf(A.m[4], cy1, A.m[5]);
+    const float xa = fmaf(A.m[0], cx0, t0), xb = fmaf(A.m[0], cx1, t0), xc = fmaf(A.m[0], cx0, t1), xd = fmaf(A.m[0], cx1, t1);
+    const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
+    const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+    const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
+              s.step >= 64 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    int ix0 = 0, iy0 = 0;
+    if (ok) {
+        ix0 = (int)xmin & ~3;
+        iy0 = (int)ymin;
+        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) {
+        if (x < d.cols)
+            for (int f = f0; f < f1; ++f) {
+                const uint8_t* sf = s.p + (size_t)f * s.fstride;
+#pragma unroll 1
+                for (int r = 0; r < kWarpRows; ++r)
+                    if (ybase + r < d.rows) *(float*)(d.p + (size_t)f * d.fstride + (size_t)(ybase + r) * d.step + 4 * (size_t)x) = warp_px_f32_1(sf, s, A, (float)x, (float)(ybase + r));
+            }
+        return;
+    }
+    ix0 = __builtin_amdgcn_readfirstlane(ix0);
+    iy0 = __builtin_amdgcn_readfirstlane(iy0);
+    const float fxx = (float)min(x, d.cols - 1);
+    f2 fxy[kWarpRows];
+    unsigned la[kWarpRows];
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) {
+        const float fyy = (float)min(ybase + r, d.rows - 1);
+        const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
+        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
+        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+    }
+    // ---- staging plan: chunk c = 4 samples = 16 source bytes (rows are 4-byte aligned) -> 16 LDS bytes ----
+    const int nchunks = prow * cpr;
+    const unsigned frame_lim = (unsigned)(s.rows - 1) * (unsigned)s.step + 4u * (unsigned)s.cols - 16u;
+    unsigned goff[kWlMaxG], loff[kWlMaxG];
+    bool gval[kWlMaxG];
+#pragma unroll
+    for (int g = 0; g < kWlMaxG; ++g) {
+        const int c = (int)threadIdx.x + kBlock * g;
+        gval[g] = c < nchunks;
+        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;
+        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + 4u * (unsigned)(ix0 + 4 * col), frame_lim);
+        loff[g] = (unsigned)(row * pitch + 16 * col);
+    }
+    const int ng = (nchunks + kBlock - 1) / kBlock;
+    typedef const __attribute__((address_space(1))) uint8_t* cgp;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+    typedef __attribute__((address_space(1))) u4a gU4a;
+    u4v G[kWlMaxG];
+    auto gload = [&](int f) {
+        cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
+        asm("" : "+s"(sf));
+#pragma unroll
+        for (int g = 0; g < kWlMaxG; ++g)
+            if (g < ng) {   // uniform
+                unsigned o = goff[g];
+                asm("" : "+v"(o));
+                const u4a t = *(const gU4a*)(sf + o);
+                G[g] = u4v{t.x, t.y, t.z, t.w};
+            }
+    };
+    const unsigned bufbytes = (unsigned)(pitch * prow);
+    const bool inx = x < d.cols;
+    gload(f0);
+    for (int f = f0; f < f1; ++f) {
+        uint8_t* buf = wf_lds + ((f - f0) & 1) * bufbytes;
+#pragma unroll
+        for (int g = 0; g < kWlMaxG; ++g)
+            if (gval[g]) *(u4v*)(buf + loff[g]) = G[g];
+        __syncthreads();
+        if (f + 1 < f1) gload(f + 1);
+        uint8_t* dcol = d.p + (size_t)f * d.fstride + 4 * (size_t)x;
+#pragma unroll
+        for (int r = 0; r < kWarpRows; ++r) {
+            const float* pa = (const float*)(buf + la[r]);
+            const float* pb = (const float*)(buf + la[r] + pitch);
+            const f2 p0 = {pa[0], pb[0]}, p1 = {pa[1], pb[1]};
+            const f2 tb = pk_fma_bc<0>(fxy[r], p1 - p0, p0);                     // {top, bottom}: fma(fx, p01 - p00, p00), fma(fx, p11 - p10, p10)
+            const float v = fmaf(fxy[r].y, tb.y - tb.x, tb.x);
+            if (inx && ybase + r < d.rows) *(float*)(dcol + (size_t)(ybase + r) * d.step) = v;
+        }
+    }
+}
+
 // views of an RCV_32F source / destination pair: 1, 3 or 4 channels, 4-byte aligned rows and frames
 int check_geom_f32(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
 {
@@ -1572,6 +1703,27 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
         Affine Af;
         for (int i = 0; i < 6; ++i) Af.m[i] = M[i];
+        if (s.ch == 1 && rcv_knobs().warp_lds != 0 && s.cols >= 16 && s.rows >= 4) {   // one channel: the LDS-staged kernel when the patch of a tile fits
+            if (!ctx->wl_valid || memcmp(ctx->wl_M, M, sizeof(ctx->wl_M)) != 0) {
+                ctx->wl_ok = warp_lds_plan(M, &ctx->wl_pitch, &ctx->wl_prow, &ctx->wl_cpr);
+                memcpy(ctx->wl_M, M, sizeof(ctx->wl_M));
+                ctx->wl_valid = true;
+            }
+            if (ctx->wl_ok) {
+                const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
+                const unsigned long long t1 = (unsigned long long)lgx * lgy;
+                int fpg = t1 * ((d.n + 7) / 8) >= 4096 ? 8 : (t1 * ((d.n + 3) / 4) >= 4096 ? 4 : (t1 * ((d.n + 1) / 2) >= 4096 ? 2 : 1));
+                if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
+                const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
+                const unsigned long long tiles = t1 * gz;
+                const bool xcd = rcv_knobs().xcd_order > 0 && tiles < (1ull << 30);
+                const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
+                const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
+                RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
+                           ctx->wl_prow, ctx->wl_cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+                return rcv_launch_check(ctx);
+            }
+        }
         if (s.ch == 1) RCV_LAUNCH(k_warp_affine_f32<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);
         else if (s.ch == 3) RCV_LAUNCH(k_warp_affine_f32<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);
         else RCV_LAUNCH(k_warp_affine_f32<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, Af);

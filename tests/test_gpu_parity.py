@@ -2699,3 +2699,42 @@ def test_geometry_f32_at_8k(ctx, oracle):
     for b in (src, dst, small):
         b.free()
 
+
+@pytest.mark.parametrize("fpg,xcd", [(0, 0), (2, 1), (8, 0), (3, 1)])
+@pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "shift", "flip", "big"])
+def test_warp_affine_f32_lds_kernel(ctx, oracle, rng, knob, fpg, xcd, M):
+    """one-channel RCV_32F warpAffine on the LDS-staged kernel (k_warp_f32_lds): interior tiles from LDS, border / outside tiles through
+    the per-pixel code, frame groups with a short last group, both tile orders, ragged widths, padded steps -- within 1 ULP of the oracle
+    (expected: bit-exact) and identical to the per-pixel kernel (RCV_WARP_LDS=0)"""
+    if fpg:
+        knob("RCV_WARP_FPG", fpg)
+    if xcd:
+        knob("RCV_XCD_ORDER", 1)
+    n, sr, sc, dr, dc = 5, 150, 300, 131, 259
+    Ms = {"rot7": _rot(7.0, dc / 2, dr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, dc / 2, dr / 2, 20.0, 12.0),
+          "shear": np.array([1, 0.25, 3.5, -0.125, 1, 18.25], np.float32), "shift": np.array([1, 0, 7.5, 0, 1, 3.25], np.float32),
+          "flip": np.array([-1, 0, dc + 5.5, 0, -1, dr + 3.25], np.float32), "big": np.array([3, 0, 0, 0, 3, 0], np.float32)}[M]
+    frames = (rng.standard_normal((n, sr, sc)) * rng.choice([1e-3, 1.0, 3e4])).astype(np.float32)
+    frames[:, 10:20, 30:60] = np.float32(1e-41)          # subnormals come through unchanged
+    src = device.DeviceBatch(ctx, n, sr, sc, 1, _ffi.RCV_32F, step=sc * 4 + 12)
+    dst = _canary_batch(ctx, n, dr, dc, 1, _ffi.RCV_32F, pad=20)
+    src.upload(frames[..., None])
+    L = _ffi.lib()
+    L.rcv__debug_kernels_reset()
+    device.warp_affine(src, dst, Ms)
+    assert ("k_warp_f32_lds" in L.rcv__debug_kernels().decode()) == (M != "big")
+    got = dst.download().copy()
+    worst = 0
+    for i in range(n):
+        worst = max(worst, int(_ulp_distance(got[i], oracle.warp_affine_f32(frames[i], Ms, dr, dc)).max()))
+    assert worst <= 1, worst
+    _assert_canaries(dst)
+    knob("RCV_WARP_LDS", 0)
+    dst.memset(0xCD)
+    L.rcv__debug_kernels_reset()
+    device.warp_affine(src, dst, Ms)
+    assert "k_warp_f32_lds" not in L.rcv__debug_kernels().decode()
+    assert np.array_equal(dst.download().view(np.uint32), got.view(np.uint32))
+    src.free()
+    dst.free()
+

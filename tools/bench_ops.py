@@ -254,7 +254,7 @@ def main():
     s, d = B(32, 4320, 7680, 3), B(32, 4320, 7680, 3)
     device.synth(s, 0, SEED + 4, 0)
     M = rot_matrix(7.0, 7680 / 2, 4320 / 2, 13.25, -8.5)
-    frac = warp_touched_fraction(M.astype(np.float64), 4320, 7680, 4320, 7680) if not a.only or "warpAffine bil" in a.only.replace("_", " ") or "GRAY" in a.only else 1.0
+    frac = warp_touched_fraction(M.astype(np.float64), 4320, 7680, 4320, 7680) if not a.only or "warpAffine bil" in a.only.replace("_", " ") or "GRAY" in a.only or "f32" in a.only else 1.0
     record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 3 + 3 * frac, lambda: device.warp_affine(s, d, M), valu=38,
            note=f"3 B written per output px + 3 B per DISTINCT in-bounds source px touched ({frac:.4f} per output px, counted on the host; upper bound 6)",
            cpu=lambda: cpu_time(lambda orc: orc.warp_affine(np.zeros((4320, 7680, 3), np.uint8), M, 4320, 7680), 7680 * 4320, 6.0))
@@ -276,6 +276,20 @@ def main():
            note="15 B per OUTPUT px: exact 4x touches the centre 2x2 of each 4x4 block",
            cpu=lambda: cpu_time(lambda orc: orc.resize(np.zeros((4320, 7680, 3), np.uint8), 1080, 1920), 1920 * 1080))
     s.free(); d.free()
+
+    # ---- RCV_32F geometry (the 1-ULP rows): a one-channel response map, 8 x 8K ----
+    sf, df = B(8, 4320, 7680, 1, _ffi.RCV_32F), B(8, 4320, 7680, 1, _ffi.RCV_32F)
+    sf.memset(0x3C)   # (every float 0.0115: timing only)
+    record("warpAffine bilinear f32 (rot 7deg)", "8K f32 1ch batch=8", sf.n, 7680 * 4320, 4 + 4 * frac, lambda: device.warp_affine(sf, df, M),
+           note="4 B written + 4 B per distinct source sample touched")
+    df.free()
+    df = B(8, 1080, 1920, 1, _ffi.RCV_32F)
+    record("resize f32 8K -> 1080p bilinear", "8K f32 1ch batch=8", sf.n, 1920 * 1080, 20, lambda: device.resize(sf, df),
+           note="4 source samples (16 B) read + 4 B written per output px")
+    df.free()
+    df = B(8, 2880, 5120, 1, _ffi.RCV_32F)
+    record("resize f32 8K -> 5K bilinear (general 1.5x)", "8K f32 1ch batch=8", sf.n, 5120 * 2880, 4 + 4 * 2.25, lambda: device.resize(sf, df))
+    sf.free(); df.free()
 
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump({"device": "MI355X (gfx950)", "steps": a.steps, "hbm_peak_gb_s": HBM, "rows": rows}, open(a.out, "w"), indent=1)
