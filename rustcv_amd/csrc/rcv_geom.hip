@@ -636,7 +636,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
 #pragma unroll
     for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + (unsigned)CH * (unsigned)xq;
     // ---- staging plan: chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ... ----
-    const int nchunks = prow * cpr;             // <= kWlMaxG * 256 (host)
+    const int nchunks = prow * cpr;
+    const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot             // <= kWlMaxG * 256 (host)
     // (a frame's last row ends at (rows - 1) * step + cols * CH: a padded LAST row need not be allocated -- rcv_view guarantees no more)
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * CH) - (CH == 1 ? 8u : (RAGS ? 16u : 12u))) & (AL ? ~0u : ~3u);
     unsigned goff[kWlMaxG], loff[kWlMaxG];
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     for (int g = 0; g < kWlMaxG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
-        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
+        const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
         // rows below the source and a chunk past the frame's end are read from a clamped position: no tap lies in them
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(CH * (ix0 + 4 * col)), frame_lim);
         loff[g] = (unsigned)(row * pitch + 16 * col);
@@ -832,6 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     for (int h = 0; h < kWarpRows / 4; ++h) so[h] = __umul24((unsigned)(yi + 4 * h), (unsigned)d.step) + (unsigned)xq;
     // ---- staging plan: chunk c = 4 pixels = one aligned source dword per frame -> 16 LDS bytes {4 pixels x 4 frames} ----
     const int nchunks = prow * cpr;
+    const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)s.cols - 4u) & ~3u;
     unsigned goff[NG], loff[NG];
     bool gval[NG];
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     for (int g = 0; g < NG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
-        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;
+        const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(ix0 + 4 * col), frame_lim);
         loff[g] = (unsigned)(row * pitch + 16 * col);
     }
@@ -1297,6 +1299,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_lds(View s, View d, Affi
     }
     // ---- staging plan (as k_warp_affine_lds): chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ...
     const int nchunks = prow * cpr;
+    const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * 3) - 12u) & ~3u;
     unsigned goff[kWlMaxG], loff[kWlMaxG];
     bool gval[kWlMaxG];
@@ -1304,7 +1307,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_lds(View s, View d, Affi
     for (int g = 0; g < kWlMaxG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
-        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;
+        const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(3 * (ix0 + 4 * col)), frame_lim);
         loff[g] = (unsigned)(row * pitch + 16 * col);
     }
@@ -1506,6 +1509,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     }
     // ---- staging plan: chunk c = 4 samples = 16 source bytes (rows are 4-byte aligned) -> 16 LDS bytes ----
     const int nchunks = prow * cpr;
+    const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = (unsigned)(s.rows - 1) * (unsigned)s.step + 4u * (unsigned)s.cols - 16u;
     unsigned goff[kWlMaxG], loff[kWlMaxG];
     bool gval[kWlMaxG];
@@ -1513,7 +1517,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     for (int g = 0; g < kWlMaxG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
-        const int row = gval[g] ? c / cpr : 0, col = gval[g] ? c - row * cpr : 0;
+        const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + 4u * (unsigned)(ix0 + 4 * col), frame_lim);
         loff[g] = (unsigned)(row * pitch + 16 * col);
     }
