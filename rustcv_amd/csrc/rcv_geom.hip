@@ -1395,6 +1395,43 @@ __global__ __launch_bounds__(kBlock) void k_resize_f32(View s, View d, float scx
     }
 }
 
+// One-channel RCV_32F resize, four output rows per thread: the column arithmetic once, the eight tap PAIRS {p(x0), p(x0 + 1)} of the four
+// rows as eight 8-byte loads issued before the first lerp (k_resize_f32<1> issues 4 scalar loads for one pixel).  The last column's
+// pair {p(cols-1), p(cols-1)} is read as the pair one column to the left and its upper half used twice.  Same three fmaf per sample.
+constexpr int kRszF32Rows = 4;
+__global__ __launch_bounds__(kBlock) void k_resize_f32_rows(View s, View d, float scx, float scy)
+{
+    const int ybase = blockIdx.y * kRszF32Rows;
+    const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
+    uint8_t* df = d.p + (size_t)blockIdx.z * d.fstride;
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
+        float sx = ((float)x + 0.5f) * scx - 0.5f;
+        sx = sx < 0.0f ? 0.0f : sx;
+        sx = sx > (float)(s.cols - 1) ? (float)(s.cols - 1) : sx;
+        const int x0 = (int)floorf(sx);
+        const float fx = sx - (float)x0;
+        const int xp = min(x0, s.cols - 2);   // (host: s.cols >= 2)
+        const bool last = x0 > xp;
+        f2u ta[kRszF32Rows], tb[kRszF32Rows];
+        float fy[kRszF32Rows];
+#pragma unroll
+        for (int r = 0; r < kRszF32Rows; ++r) {
+            int y0, y1;
+            resize_row(s, scy, min(ybase + r, d.rows - 1), y0, y1, fy[r]);
+            ta[r] = *(const f2u*)(sf + (size_t)y0 * s.step + 4 * (size_t)xp);
+            tb[r] = *(const f2u*)(sf + (size_t)y1 * s.step + 4 * (size_t)xp);
+        }
+#pragma unroll
+        for (int r = 0; r < kRszF32Rows; ++r) {
+            const float p00 = last ? ta[r].y : ta[r].x, p01 = ta[r].y, p10 = last ? tb[r].y : tb[r].x, p11 = tb[r].y;
+            const float top = fmaf(fx, p01 - p00, p00);
+            const float bot = fmaf(fx, p11 - p10, p10);
+            if (ybase + r < d.rows) *(float*)(df + (size_t)(ybase + r) * d.step + 4 * (size_t)x) = fmaf(fy[r], bot - top, top);
+        }
+    }
+}
+
 template <int CH>
 __global__ __launch_bounds__(kBlock) void k_warp_affine_f32(View s, View d, Affine A)
 {
@@ -1605,7 +1642,11 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
         if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
         if (s.rows == 0 || s.cols == 0) return RCV_ERR_ARG;
         const float fscx = (float)s.cols / (float)d.cols, fscy = (float)s.rows / (float)d.rows;
-        if (s.ch == 1) RCV_LAUNCH(k_resize_f32<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
+        if (s.ch == 1 && s.cols >= 2 && fscy < 2.5f) {   // (8 x 8K -> 5K: 0.41 -> 0.26 ms; a 4x down-scale reads rows 4 apart: 0.108 -> 0.115, stays on the one-row kernel)
+            dim3 g = px_grid(d);
+            g.y = (unsigned)((d.rows + kRszF32Rows - 1) / kRszF32Rows);
+            RCV_LAUNCH(k_resize_f32_rows, g, dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
+        } else if (s.ch == 1) RCV_LAUNCH(k_resize_f32<1>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
         else if (s.ch == 3) RCV_LAUNCH(k_resize_f32<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
         else RCV_LAUNCH(k_resize_f32<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, fscx, fscy);
         return rcv_launch_check(ctx);
