@@ -93,10 +93,20 @@ __device__ __forceinline__ void resize_px(const uint8_t* ra, const uint8_t* rb, 
             tb = (tb & 0xffffffull) | ((tb & 0xffffffull) << 24);
         }
     }
+    // four channels on 4-byte aligned rows: a tap is one dword (16 byte loads -> 4 dword loads per pixel)
+    const bool quad = CH == 4 && ((((uintptr_t)ra | (uintptr_t)rb) & 3) == 0);
+    uint32_t q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+    if (quad) {
+        q00 = ((const uint32_t*)ra)[x0]; q01 = ((const uint32_t*)ra)[x1];
+        q10 = ((const uint32_t*)rb)[x0]; q11 = ((const uint32_t*)rb)[x1];
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         float p00, p01, p10, p11;
-        if (wide) {
+        if (quad) {
+            p00 = (float)((q00 >> (8 * c)) & 0xff); p01 = (float)((q01 >> (8 * c)) & 0xff);
+            p10 = (float)((q10 >> (8 * c)) & 0xff); p11 = (float)((q11 >> (8 * c)) & 0xff);
+        } else if (wide) {
             p00 = (float)(uint32_t)((ta >> (8 * c)) & 0xff);
             p01 = (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff);
             p10 = (float)(uint32_t)((tb >> (8 * c)) & 0xff);
@@ -134,8 +144,13 @@ __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, fl
     resize_row(s, scy, y, y0, y1, fy);
     const uint8_t* ra = sf + (size_t)y0 * s.step;
     const uint8_t* rb = sf + (size_t)y1 * s.step;
-    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock)
-        resize_px<CH>(ra, rb, s, scx, fy, x, drow + (size_t)x * CH);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
+        if (CH == 4 && ((uintptr_t)drow & 3) == 0) {   // the pixel as one dword store
+            uint8_t o[4];
+            resize_px<CH>(ra, rb, s, scx, fy, x, o);
+            ((uint32_t*)drow)[x] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3 % CH] << 24);
+        } else resize_px<CH>(ra, rb, s, scx, fy, x, drow + (size_t)x * CH);
+    }
 }
 
 struct Affine { float m[6]; };
@@ -165,10 +180,20 @@ __device__ __forceinline__ void warp_px(const uint8_t* sf, const View& s, const 
         ta = load_taps6(ra, x0, s.cols * 3);
         tb = load_taps6(rb, x0, s.cols * 3);
     }
+    // four channels on 4-byte aligned rows: a tap is one dword (taps outside the source read a clamped position and count as 0)
+    const bool quad = CH == 4 && ((((uintptr_t)ra | (uintptr_t)rb) & 3) == 0);
+    uint32_t q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+    if (quad) {
+        q00 = (vx0 && vy0) ? *(const uint32_t*)(ra + xa) : 0u; q01 = (vx1 && vy0) ? *(const uint32_t*)(ra + xb) : 0u;
+        q10 = (vx0 && vy1) ? *(const uint32_t*)(rb + xa) : 0u; q11 = (vx1 && vy1) ? *(const uint32_t*)(rb + xb) : 0u;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         float p00, p01, p10, p11;
-        if (wide) {
+        if (quad) {
+            p00 = (float)((q00 >> (8 * c)) & 0xff); p01 = (float)((q01 >> (8 * c)) & 0xff);
+            p10 = (float)((q10 >> (8 * c)) & 0xff); p11 = (float)((q11 >> (8 * c)) & 0xff);
+        } else if (wide) {
             p00 = (vx0 && vy0) ? (float)(uint32_t)((ta >> (8 * c)) & 0xff) : 0.0f;
             p01 = (vx1 && vy0) ? (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff) : 0.0f;
             p10 = (vx0 && vy1) ? (float)(uint32_t)((tb >> (8 * c)) & 0xff) : 0.0f;
@@ -193,8 +218,13 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
     const uint8_t* sf = s.p + (size_t)blockIdx.z * s.fstride;
     uint8_t* drow = d.p + (size_t)blockIdx.z * d.fstride + (size_t)y * d.step;
     float fyy = (float)y;
-    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock)
-        warp_px<CH>(sf, s, A, (float)x, fyy, drow + (size_t)x * CH);
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < d.cols; x += gridDim.x * kBlock) {
+        if (CH == 4 && ((uintptr_t)drow & 3) == 0) {   // the pixel as one dword store
+            uint8_t o[4];
+            warp_px<CH>(sf, s, A, (float)x, fyy, o);
+            ((uint32_t*)drow)[x] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3 % CH] << 24);
+        } else warp_px<CH>(sf, s, A, (float)x, fyy, drow + (size_t)x * CH);
+    }
 }
 
 // BGR fast path: one thread per output pixel (adjacent lanes -> adjacent source taps -> L1-friendly), byte -> float by

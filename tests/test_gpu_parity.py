@@ -1246,7 +1246,7 @@ def _rot(deg, cx, cy, tx, ty):
 
 
 @pytest.mark.parametrize("shape", [(48, 64), (61, 127), (1, 1), (5, 3)])
-@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("ch", [1, 3, 4])
 @pytest.mark.parametrize("M", [np.array([1, 0, 0, 0, 1, 0], np.float32), np.array([1, 0, 0.5, 0, 1, 0.25], np.float32),
                                np.array([1, 0, -30.75, 0, 1, 1000], np.float32), np.array([0.5, 0.1, 3, -0.2, 1.7, -4], np.float32),
                                "rot7", np.array([1e9, 0, 0, 0, 1e-9, 0], np.float32)])
@@ -2737,4 +2737,28 @@ def test_warp_affine_f32_lds_kernel(ctx, oracle, rng, knob, fpg, xcd, M):
     assert np.array_equal(dst.download().view(np.uint32), got.view(np.uint32))
     src.free()
     dst.free()
+
+
+@pytest.mark.parametrize("pad_src,pad_dst", [(0, 0), (4, 8), (1, 0), (0, 3), (2, 2)])
+def test_four_channel_geometry_dword_and_byte_taps(ctx, oracle, rng, pad_src, pad_dst):
+    """4-channel u8 images through the generic resize / warpAffine kernels: taps as dwords and the pixel as one dword store on 4-byte
+    aligned rows, byte by byte on any other step -- batches of 3, padded steps, against the oracle"""
+    n, sr, sc, dr, dc = 3, 57, 83, 41, 122
+    frames = rng.integers(0, 256, size=(n, sr, sc, 4), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, sr, sc, 4, step=sc * 4 + pad_src)
+    src.upload(frames)
+    M = _rot(7.0, sc / 2, sr / 2, 3.25, -1.5)
+    for op in ("resize", "warp"):
+        dst = device.DeviceBatch(ctx, n, dr, dc, 4, step=dc * 4 + pad_dst)
+        dst.memset(0xEE)
+        if op == "resize":
+            device.resize(src, dst)
+        else:
+            device.warp_affine(src, dst, M)
+        got = dst.download()
+        for i in range(n):
+            want = oracle.resize(frames[i], dr, dc) if op == "resize" else oracle.warp_affine(frames[i], M, dr, dc)
+            assert np.array_equal(got[i], want), (op, i)
+        dst.free()
+    src.free()
 
