@@ -1833,10 +1833,10 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
-                // four frames per LDS pass: groups of 8 frames (two passes) while that leaves >= 4096 workgroups, else 4
-                // (32 x 8K: 4 / 8 / 16 / 32 frames per group 0.905 / 0.888 / 0.968 / 1.125 ms)
+                // four frames per LDS pass: one pass per workgroup, two for the largest launches (tools/ablate_gray4.py: 16 x 4K 0.125 ms
+                // with groups of 4 against 0.142 with 8, 64 x 1080p 0.139 / 0.151, 8 x 8K 0.233 / 0.246; 32 x 8K 0.861 / 0.850)
                 const unsigned long long t1 = (unsigned long long)lgx * lgy;
-                int fq = t1 * ((d.n + 7) / 8) >= 4096 ? 8 : 4;
+                int fq = t1 * ((d.n + 7) / 8) >= 32768 ? 8 : 4;
                 if (rcv_knobs().warp_fpg > 0) fq = max(4, min(rcv_knobs().warp_fpg, d.n) & ~3);
                 const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
                 const unsigned long long tq = t1 * gzq;
