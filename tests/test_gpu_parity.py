@@ -2762,3 +2762,44 @@ def test_four_channel_geometry_dword_and_byte_taps(ctx, oracle, rng, pad_src, pa
         dst.free()
     src.free()
 
+
+def test_batches_larger_than_the_whole_baseline_job(ctx, oracle):
+    """maximum sizes: 520 4K frames in ONE batch (12.9 GB in, more than config 5's whole 8-GPU job) through the filter, the Harris pipeline
+    and the Sobel of a BGR source, 130 8K frames (12.9 GB) through the fused warp + down-scale and the warp: first / middle / last frame
+    against the oracle -- frame offsets beyond 4 GB, band and tile counts beyond the BASELINE launches"""
+    from bench import bench_kernel7, warp_matrix
+    n, rows, cols = 520, 2160, 3840
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    device.synth(src, 1, 0x5EED0003, 0)
+    dst = device.DeviceBatch(ctx, n, rows, cols, 3)
+    k = bench_kernel7()
+    device.filter2d(src, dst, k, shift=6)
+    for i in (0, 259, 519):
+        assert np.array_equal(dst.download_frame(i), oracle.filter2d_i8(src.download_frame(i), k, 6)), i
+    dst.free()
+    mask = device.DeviceBatch(ctx, n, rows, cols, 1)
+    device.harris_pipeline(src, mask, None, 2, 0.04, 1e-4)
+    for i in (0, 300, 519):
+        assert np.array_equal(mask.download_frame(i), oracle.harris_pipeline(src.download_frame(i), 2, 0.04, 1e-4)), i
+    dx, dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S), device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S)
+    device.sobel(src, dx, dy)
+    for i in (0, 519):
+        gx, gy = oracle.sobel(oracle.bgr2gray(src.download_frame(i)))
+        assert np.array_equal(dx.download_frame(i), gx) and np.array_equal(dy.download_frame(i), gy), i
+    for b in (src, mask, dx, dy):
+        b.free()
+    n8 = 130
+    s8 = device.DeviceBatch(ctx, n8, 4320, 7680, 3)
+    device.synth(s8, 0, 0x5EED0004, 0)
+    d8 = device.DeviceBatch(ctx, n8, 1080, 1920, 3)
+    M = warp_matrix()
+    device.warp_affine_resize(s8, d8, M, 4320, 7680)
+    w8 = device.DeviceBatch(ctx, n8, 4320, 7680, 3)
+    device.warp_affine(s8, w8, M)
+    for i in (0, 129):
+        warped = oracle.warp_affine(s8.download_frame(i), M, 4320, 7680)
+        assert np.array_equal(w8.download_frame(i), warped), i
+        assert np.array_equal(d8.download_frame(i), oracle.resize(warped, 1080, 1920)), i
+    for b in (s8, d8, w8):
+        b.free()
+
