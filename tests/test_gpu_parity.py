@@ -2803,3 +2803,15 @@ def test_batches_larger_than_the_whole_baseline_job(ctx, oracle):
     for b in (s8, d8, w8):
         b.free()
 
+
+def test_frame_larger_than_4_gib():
+    """maximum sizes: ONE 36 000 x 40 000 BGR frame (4.32 GB: rows * step > 2^32) through filter2D, both Gaussians, BGR2GRAY, Sobel, the Harris
+    pipeline, warpAffine and resize -- the kernels that keep 32-bit in-frame offsets must hand it over; top and bottom 96 rows of every
+    result (the bottom ones lie beyond the 4-GiB offset) against the oracle on the matching source slices (tools/huge_frame.py)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "huge_frame.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "mismatches: 0" in r.stdout
+
