@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rustcv_amd as rcv
 from rustcv_amd import _ffi, device
