@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- the north-star measurement (BASELINE.json): 4K u8 BGR 7x7 filter2D, batch 64 per GPU.
+"""bench.py -- the north-star measurement (BASELINE.json): 4K u8 BGR 7x7 filter2D, batches of 64 frames per launch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          one process; N > 1: one host thread + one context per GPU
+    python bench.py [--gpus N] [--steps K] [--warmup W]          one process; N > 1: one host thread per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     one process per GPU (RCCL)
-    python bench.py --config 4|5 ...     the two configs BASELINE.json names as 8-GPU, same line format, per-GPU batch fixed:
-        4: 8K BGR warpAffine (rotation 7 deg) + resize -> 1080p, 32 frames per GPU (the fused launch rcv_warp_affine_resize_batch;
-           --unfused: the two launches through an 8K intermediate)
-        5: 4K cornerHarris pipeline (BGR -> gray -> Sobel -> response -> 3x3 NMS -> mask), 64 frames per GPU
+    python bench.py --config 4|5 ...     the two configs BASELINE.json names as 8-GPU as the headline, same line format:
+        4: 8K BGR warpAffine (rotation 7 deg) + resize -> 1080p, 32 frames per launch (the fused launch
+           rcv_warp_affine_resize_batch; --unfused: the two launches through an 8K intermediate)
+        5: 4K cornerHarris pipeline (BGR -> gray -> Sobel -> response -> 3x3 NMS -> mask), 64 frames per launch
 
-A "step" is one pass of the hot path over one batch: (config 3, the default) rcv_filter2d_i8_batch on 64 device-resident
-3840x2160 BGR frames (integer 7x7 kernel of SURVEY.md 8(d), >>6, saturate).  Frames are generated ON DEVICE before the timed region (no PCIe in
-`value`).  Per-GPU work is fixed (weak scaling): rank r owns frames [64r, 64r+64) (rustcv_amd.shard.frame_range); frames are
-independent, so there is no data-path collective -- only a barrier and the max over ranks of the elapsed time (RCCL under
-torch.distributed.run, a thread barrier in the one-process form).  `--gpus N` on a node with fewer GPUs fails.
+What runs (config 3, the default).  The reference's caller is a frame STREAM (rustcv/src/videoio/mod.rs:168-265 feeding
+examples/camera_demo.rs:50-76), so consecutive batches are independent.  Every GPU keeps `--in-flight` F = 2 batches in flight: F
+contexts (= HIP streams) on the one device (rcv_group_create with a repeated ordinal), each with its OWN 64-frame source and
+destination.  A "step" is one rcv_filter2d_i8_batch of 64 device-resident 3840x2160 BGR frames on EVERY context (integer 7x7
+kernel of SURVEY.md 8(d), >>6, saturate): F launches per GPU and step, enqueued by one host thread; the launches of the F
+streams overlap on the GPU and fill each other's ramp-up and tail.  `value` = all pixels of all launches / wall-clock.  Frames are
+generated ON DEVICE before the timed region (no PCIe in `value`).  Per-GPU work is fixed (weak scaling): rank r owns frames
+[128 r, 128 r + 128), its context j the 64 from 128 r + 64 j; frames are independent, so there is no data-path collective -- only a
+barrier and the max over ranks of the elapsed time (RCCL under torch.distributed.run, a thread barrier in the one-process form).
+`--gpus N` on a node with fewer GPUs fails.  `--in-flight 1` is the round-1..3 measurement (one stream).
 
 Prints ONE JSON line on rank 0 with the contract keys plus
-  "roofline":     the dominant kernel's algorithmic HBM bytes / its SUSTAINED launch time -- HIP events on the kernel's own
-                  stream around >= 400 back-to-back launches (launch_ms); the same after an idle gap over 20 launches
-                  (launch_ms_first20: boost clocks) for comparison -- against the 8 TB/s HBM3E peak; copy_ceiling_gbs = the best
-                  plain device copy of the same 2 x 1.59 GB measured in this run (the rate the memory system of THIS box gives);
-                  memory_only_gbs = the kernel's own loads and stores with nothing in between (the ceiling of ITS access
-                  pattern); shader_mhz_under_load = the shader clock sampled while the sustained launches run
-  "verified_frames": frames of the LAST timed launch's output compared bit for bit with the CPU oracle (mismatch: exit 1)
+  "roofline":     the dominant kernel's algorithmic HBM bytes per launch / launch_ms, against the 8 TB/s HBM3E peak.
+                  launch_ms = HIP events on the kernels' own streams around >= 400 back-to-back steps, divided by the number of
+                  LAUNCHES in the window (F per step): the SUSTAINED time per 64-frame launch with F in flight.  With F > 1 the
+                  kernels overlap, so ONE kernel's own duration (what rocprofv3 reports) is about F x launch_ms; the figure is
+                  bytes moved / wall time (profiles/r04_inflight_kernel_trace.txt shows the overlap).  single_stream = the same
+                  launch alone on one stream (the round-1..3 figure).  copy_ceiling_gbs = the best plain device copy of the
+                  same 2 x 1.59 GB measured in this run; memory_only_gbs = the kernel's own loads and stores with nothing in
+                  between; shader_mhz_under_load = the shader clock sampled while launches run (a separate window)
+  "verified_frames": frames of the LAST timed launches' outputs (every context) compared bit for bit with the CPU oracle
+                  (mismatch: exit 1)
+  "other_configs": (default run at N = 1 only) compact records of BASELINE configs 4 and 5 measured in the same process:
+                  {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic}, verified}
   "cpu_baseline": the C oracle (a port: C restatement, the Rust reference cannot be built here) timed on this box's host
                   cores on a bounded sample of the same workload.
 """
@@ -30,7 +40,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -46,18 +55,21 @@ SEED = 0x5EED0003
 # bytes per frame of the dominant kernel.
 CONFIGS = {
     3: {"metric": "Mpixels/sec on 4K 7x7 filter2D", "batch": 64, "px": ROWS * COLS, "alg_bytes": ROWS * COLS * 6, "dtype": "u8", "bound": "hbm",
-        "workload": "4K (3840x2160) u8 BGR 7x7 filter2D, integer weights >>6, batch=64 frames per GPU (BASELINE configs[2])"},
+        "workload": "4K (3840x2160) u8 BGR 7x7 filter2D, integer weights >>6, batches of 64 frames (BASELINE configs[2])"},
     # fused warp -> exact 4x down-scale: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written
-    # per OUTPUT pixel; `value` counts the 8K pixels of the warped image the launch stands for
-    4: {"metric": "Mpixels/sec on 8K warpAffine + resize->1080p", "batch": 32, "px": 4320 * 7680, "alg_bytes": 1080 * 1920 * 30, "dtype": "f32 bilinear on u8", "bound": "hbm",
-        "workload": "8K (7680x4320) u8 BGR warpAffine (bilinear, rotation 7 deg + translation, constant border) + resize -> 1080p, batch=32 frames per GPU "
+    # per OUTPUT pixel.  `value` counts the 1080p OUTPUT pixels the launch produces ("quote Mpix/s on
+    # output pixels and, separately, input pixels"); config.input_mpix_s is the 8K source-pixel rate
+    4: {"metric": "Mpixels/sec (1080p output pixels) on 8K warpAffine + resize->1080p", "batch": 32, "px": 1080 * 1920, "alg_bytes": 1080 * 1920 * 30,
+        "dtype": "f32 bilinear on u8", "bound": "hbm",
+        "workload": "8K (7680x4320) u8 BGR warpAffine (bilinear, rotation 7 deg + translation, constant border) + resize -> 1080p, batches of 32 frames "
                     "(BASELINE configs[3]: 256 frames over 8 GPUs)"},
     5: {"metric": "Mpixels/sec on 4K cornerHarris pipeline", "batch": 64, "px": ROWS * COLS, "alg_bytes": ROWS * COLS * 4, "dtype": "i16 / i32 / f32 on u8", "bound": "hbm",
-        "workload": "4K (3840x2160) u8 BGR cornerHarris pipeline (cvtColor -> Sobel -> response, blockSize 2, k 0.04 -> 3x3 NMS -> u8 mask), batch=64 frames per GPU "
+        "workload": "4K (3840x2160) u8 BGR cornerHarris pipeline (cvtColor -> Sobel -> response, blockSize 2, k 0.04 -> 3x3 NMS -> u8 mask), batches of 64 frames "
                     "(BASELINE configs[4]: 512 frames over 8 GPUs)"},
 }
 SEEDS = {3: 0x5EED0003, 4: 0x5EED0004, 5: 0x5EED0005}
 HARRIS_THR = 1e-4
+TRAFFIC_KEYS = {3: "filter2d_i8_7x7_hbm_bytes_per_launch", 4: "warp_resize_fused_hbm_bytes_per_launch", 5: "harris_pipeline_hbm_bytes_per_launch"}
 
 
 def warp_matrix():
@@ -68,26 +80,38 @@ def warp_matrix():
     return np.array([c, -s_, cx - c * cx + s_ * cy + 13.25, s_, c, cy - s_ * cx - c * cy - 8.5], np.float32)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json config (default 3: the north star)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight per GPU = contexts (streams) per GPU, each with its own buffers (default: 2 for config 3, else 1)")
     ap.add_argument("--unfused", action="store_true", help="config 4: warpAffine and resize as two launches through an 8K intermediate")
-    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's per-GPU batch, 64 / 32 / 64)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default: the config's per-GPU batch, 64 / 32 / 64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the timed launch's output")
-    ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run copy ceiling")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run copy ceiling and the memory-only variant")
+    ap.add_argument("--no-probe", action="store_true", help="skip the shader-clock probe")
+    ap.add_argument("--no-others", action="store_true", help="skip the compact config-4 / config-5 records of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-time budget of the cpu_baseline sample")
     ap.add_argument("--family", type=int, default=0, help="synthetic family: 0 noise (default), 1 scene")
-    ap.add_argument("--sustained", type=int, default=400, help="launches of the sustained roofline window (at least --steps)")
+    ap.add_argument("--sustained", type=int, default=400, help="steps of the sustained roofline window (at least --steps)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed run-up of the same step before the W warmup steps: the GPU needs tens of ms of load to reach its "
                          "sustained clocks")
-    a = ap.parse_args()
+    ap.add_argument("--devices", default="",
+                    help="TEST ONLY: explicit device ordinal per rank, e.g. 0,0 = two ranks time-sharing GPU 0 (exercises the N > 1 code on a "
+                         "one-GPU box; the line then says n_gpus = the number of DISTINCT devices and contexts = the ranks)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="TEST ONLY: this rank raises after the warmup (a failing rank must end the job non-zero, not hang it)")
+    ap.add_argument("--dist-backend", default="nccl", help="TEST ONLY: torch.distributed backend of the one-process-per-GPU form (nccl = RCCL)")
+    a = ap.parse_args(argv)
     if a.batch <= 0:
         a.batch = CONFIGS[a.config]["batch"]
+    if a.in_flight <= 0:
+        a.in_flight = 2 if a.config == 3 else 1
+    a.device_list = [int(d) for d in a.devices.split(",")] if a.devices else None
     return a
 
 
@@ -162,8 +186,8 @@ class Fence:
     def __init__(self, dist=None, tbarrier=None):
         self.dist, self.tb = dist, tbarrier
 
-    def __call__(self, ctx, torch, device):
-        ctx.sync()
+    def __call__(self, lanes, torch, device):
+        lanes.sync()                      # every context of this rank idle
         torch.cuda.synchronize(device)
         if self.dist is not None:
             self.dist.barrier()
@@ -182,165 +206,277 @@ CEILING_COPIES = ((0, 1, "hipMemcpyAsync D2D"), (1, 1024, "sweep g=1024"), (3, 5
                   (40, 512 | (2 << 16), "2-region sweep U=2 nt g=512"), (40, 512 | (8 << 16), "8-region sweep U=2 nt g=512"))
 
 
-def run_rank(a, rank, world, device, ctx, fence, torch):
-    """everything one GPU does; returns its measurements"""
-    import numpy as np
-    from rustcv_amd import _ffi, device as dev, shard
+class Lane:
+    """one context (= one HIP stream) of a GPU with its own source / destination batch of config `cfg`; step() enqueues one launch"""
 
-    L = _ffi.lib()
-    BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
-    n, cfg = a.batch, a.config
-    total_frames = n * world
-    f0, f1 = shard.frame_range(total_frames, rank, world)  # contiguous frame range of this rank
-    assert f1 - f0 == n
-    rows, cols, fam, seed = synth_args(cfg, a.family)
-    src = dev.DeviceBatch(ctx, n, rows, cols, CH)
-    dev.synth(src, fam, seed, f0)
-    mid = None
-    if cfg == 3:
-        dst = dev.DeviceBatch(ctx, n, ROWS, COLS, CH)
-        k = bench_kernel7()
-        kp = k.ctypes.data_as(C.POINTER(C.c_int8))
-        bs, bd = src.as_rcv(), dst.as_rcv()
-
-        def step():
-            rc = L.rcv_filter2d_i8_batch(ctx.handle, C.byref(bs), C.byref(bd), kp, 7, 6)
-            if rc != 0:
-                raise SystemExit(f"rcv_filter2d_i8_batch failed: {rc} {_ffi.strerror(rc)}")
-    elif cfg == 4:
-        dst = dev.DeviceBatch(ctx, n, 1080, 1920, CH)
-        M = warp_matrix()
-        if a.unfused:
-            mid = dev.DeviceBatch(ctx, n, 4320, 7680, CH)
+    def __init__(self, a, cfg, ctx, frame_base, n=None, unfused=False):
+        from rustcv_amd import _ffi, device as dev
+        self.cfg, self.ctx, self.base = cfg, ctx, frame_base
+        self.n = n = n or a.batch
+        rows, cols, fam, seed = synth_args(cfg, a.family)
+        self.synth = (rows, cols, fam, seed)
+        self.src = dev.DeviceBatch(ctx, n, rows, cols, CH)
+        dev.synth(self.src, fam, seed, frame_base)
+        self.mid = None
+        L = _ffi.lib()
+        if cfg == 3:
+            self.dst = dst = dev.DeviceBatch(ctx, n, ROWS, COLS, CH)
+            self.k = k = bench_kernel7()
+            kp = k.ctypes.data_as(C.POINTER(C.c_int8))
+            self.bs, self.bd = bs, bd = self.src.as_rcv(), dst.as_rcv()
+            h = ctx.handle
 
             def step():
-                dev.warp_affine(src, mid, M)
-                dev.resize(mid, dst)
+                rc = L.rcv_filter2d_i8_batch(h, C.byref(bs), C.byref(bd), kp, 7, 6)
+                if rc != 0:
+                    raise SystemExit(f"rcv_filter2d_i8_batch failed: {rc} {_ffi.strerror(rc)}")
+        elif cfg == 4:
+            self.dst = dst = dev.DeviceBatch(ctx, n, 1080, 1920, CH)
+            M = warp_matrix()
+            src = self.src
+            if unfused:
+                self.mid = mid = dev.DeviceBatch(ctx, n, 4320, 7680, CH)
+
+                def step():
+                    dev.warp_affine(src, mid, M)
+                    dev.resize(mid, dst)
+            else:
+                def step():
+                    dev.warp_affine_resize(src, dst, M, 4320, 7680)
         else:
+            self.dst = dst = dev.DeviceBatch(ctx, n, ROWS, COLS, 1)
+            src = self.src
+
             def step():
-                dev.warp_affine_resize(src, dst, M, 4320, 7680)
-    else:
-        dst = dev.DeviceBatch(ctx, n, ROWS, COLS, 1)
+                dev.harris_pipeline(src, dst, None, 2, 0.04, HARRIS_THR)
+        self.step = step
+        self.dst.memset(0)
+        ctx.sync()
 
-        def step():
-            dev.harris_pipeline(src, dst, None, 2, 0.04, HARRIS_THR)
-    dst.memset(0)
-    ctx.sync()
+    def verify(self, orc):
+        """frames first / middle / last of this lane's LAST launch against the oracle: (checked frame numbers, mismatching ones)"""
+        import numpy as np
+        rows, cols, fam, seed = self.synth
+        n = self.n
+        frames = sorted({0, n // 2 - 1 if n > 1 else 0, n - 1})
+        bad = []
+        for i in frames:
+            got = self.dst.download_frame(i)
+            want = oracle_step(orc, self.cfg, orc.synth_frame(rows, cols, CH, fam, seed, self.base + i))
+            if not np.array_equal(got, want):
+                bad.append(self.base + i)
+        return [self.base + i for i in frames], bad
 
-    def timed(launches, fn=step, probe_us=0):
-        ms, mhz = C.c_float(0.0), C.c_float(0.0)
-        L.rcv_timer_start(ctx.handle)            # hipEvent on the stream the kernel is launched on
-        for _ in range(launches):
-            fn()
-        if probe_us:                             # shader clock while the queued launches run (a one-wave kernel on the side stream)
-            BL.rcv__clock_probe(ctx.handle, probe_us, C.byref(mhz))
-        L.rcv_timer_stop(ctx.handle, C.byref(ms))  # records + synchronises the ctx stream
-        return (float(ms.value), float(mhz.value)) if probe_us else float(ms.value)
+    def free(self):
+        for b in (self.src, self.dst, self.mid):
+            if b is not None:
+                b.free()
 
-    L.rcv__debug_kernels_reset()
-    step()
-    ctx.sync()
-    kernel_name = L.rcv__debug_kernels().decode()
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:   # untimed: clocks settle under the real load
+
+def settle(ms, step, sync):
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e3 < ms:   # untimed: clocks settle under the real load
         for _ in range(8):
             step()
-        ctx.sync()
+        sync()
+
+
+def run_rank(a, rank, world, device, fence, torch):
+    """everything one GPU does; returns its measurements"""
+    from rustcv_amd import _ffi, multigpu
+
+    L = _ffi.lib()
+    n, cfg, F = a.batch, a.config, a.in_flight
+    lanes = multigpu.NativeGroup.in_flight(device, F)     # F contexts = F streams on this GPU (rcv_group_create, repeated ordinal)
+    f0 = rank * F * n                                      # this rank's contiguous frame range [f0, f0 + F n): shard.frame_range(world F n, rank, world)
+    lane = [Lane(a, cfg, lanes.ctxs[j], f0 + j * n, unfused=a.unfused) for j in range(F)]
+    ctx0 = lanes.ctxs[0]
+
+    def step():                    # one launch on every context, enqueued by this one host thread
+        for ln in lane:
+            ln.step()
+
+    def timed_group(steps):        # events on every context's stream: ms from the first start to the latest stop
+        lanes.timer_start()
+        for _ in range(steps):
+            step()
+        return lanes.timer_stop()
+
+    def timed0(launches, fn=None):   # one stream alone: hipEvents on context 0's stream
+        fn = fn or lane[0].step
+        ms = C.c_float(0.0)
+        L.rcv_timer_start(ctx0.handle)
+        for _ in range(launches):
+            fn()
+        L.rcv_timer_stop(ctx0.handle, C.byref(ms))   # records + synchronises the ctx stream
+        return float(ms.value)
+
+    L.rcv__debug_kernels_reset()
+    lane[0].step()
+    lanes.sync()
+    kernel_name = L.rcv__debug_kernels().decode()
+    settle(a.settle_ms, step, lanes.sync)
     for _ in range(a.warmup):
         step()
-    fence(ctx, torch, device)
+    if rank == a.fail_rank:
+        raise RuntimeError(f"--fail-rank {rank}: injected failure")
+    fence(lanes, torch, device)
     t0 = time.perf_counter()
-    ev_ms = timed(a.steps)
-    fence(ctx, torch, device)
+    ev_ms = timed_group(a.steps)
+    fence(lanes, torch, device)
     elapsed = time.perf_counter() - t0
-    res = {"elapsed": elapsed, "ev_ms_steps": ev_ms / a.steps, "kernel": kernel_name}
+    res = {"elapsed": elapsed, "ev_ms_steps": ev_ms / a.steps, "kernel": kernel_name, "in_flight": F, "device": int(device)}
 
-    # ---- roofline window: sustained clocks.  No idle gap before it (the timed steps just ran), >= 400 launches back to back ----
+    # ---- roofline window: sustained clocks.  No idle gap before it (the timed steps just ran), >= 400 steps back to back ----
     ns = max(a.sustained, a.steps)
-    ms, mhz = timed(ns, probe_us=20000)
-    res["launch_ms"] = ms / ns
-    res["launches_sustained"] = ns
-    res["shader_mhz_under_load"] = round(mhz, 1)
-    # the same launch after an idle gap, over 20 launches: what a short window sees (boost clocks) -- for comparison only
-    ctx.sync()
+    res["launch_ms"] = timed_group(ns) / (ns * F)        # per 64-frame launch with F in flight (bytes moved / wall time)
+    res["launches_sustained"] = ns * F
+    if F > 1:                                            # the same launch alone on one stream (the round-1..3 figure)
+        settle(30.0, lane[0].step, lanes.sync)
+        res["single_launch_ms"] = timed0(ns) / ns
+    # the same step after an idle gap, over 20 steps: what a short window sees (clocks coming back up) -- for comparison only
+    lanes.sync()
     time.sleep(0.25)
-    res["launch_ms_first20"] = timed(20) / 20
+    res["launch_ms_first20"] = timed_group(20) / (20 * F)
+    if not a.no_probe:
+        # shader clock while launches run: a one-wave kernel on the side stream, in its OWN window (the probe blocks the host for 20 ms)
+        BL = _ffi.bench_lib()
+        settle(30.0, step, lanes.sync)
+        mhz = C.c_float(0.0)
+        for _ in range(60):
+            step()
+        BL.rcv__clock_probe(ctx0.handle, 20000, C.byref(mhz))
+        lanes.sync()
+        res["shader_mhz_under_load"] = round(float(mhz.value), 1)
 
-    # ---- the benchmarked launch's bytes against the oracle (outside every timed region) ----
+    # ---- the benchmarked launches' bytes against the oracle (outside every timed region) ----
     if not a.no_verify:
         from oracle import pyoracle as orc   # the checker, never the thing measured
-        bad = []
-        frames = sorted({0, n // 2 - 1 if n > 1 else 0, n - 1})
-        for i in frames:
-            got = dst.download_frame(i)
-            want = oracle_step(orc, cfg, orc.synth_frame(rows, cols, CH, fam, seed, f0 + i))
-            if not np.array_equal(got, want):
-                bad.append(f0 + i)
-        res["verified_frames"] = [f0 + i for i in frames]
-        res["mismatched_frames"] = bad
+        res["verified_frames"], res["mismatched_frames"] = [], []
+        for ln in lane:
+            ok, bad = ln.verify(orc)
+            res["verified_frames"] += ok
+            res["mismatched_frames"] += bad
 
-    # ---- ceiling of this box in this run (config 3): plain device copies of the same buffers and the kernel's own memory-only
-    # ---- variant (its loads and its stores with nothing in between); dst is scratch from here on ----
+    # ---- ceiling of this box in this run (config 3): plain device copies of one lane's buffers and the kernel's own memory-only
+    # ---- variant (its loads and its stores with nothing in between), one stream; dst is scratch from here on ----
     if not a.no_ceiling and cfg == 3:
+        BL = _ffi.bench_lib()   # copy / store / clock probes: librustcv_hip_bench.so, not part of the product library
         nbytes = n * ROWS * COLS * CH
-
-        def runup(fn):
-            t_run = time.perf_counter()
-            while (time.perf_counter() - t_run) * 1e3 < 60.0:   # run-up: the copies get the same warm clocks as the filter
-                for _ in range(8):
-                    fn()
-                ctx.sync()
+        src, dst = lane[0].src, lane[0].dst
         best, best_name = 0.0, None
         for variant, grid, name in CEILING_COPIES:
             def cp():
-                rc = BL.rcv__membench(ctx.handle, dst.ptr, src.ptr, nbytes, variant, grid)
+                rc = BL.rcv__membench(ctx0.handle, dst.ptr, src.ptr, nbytes, variant, grid)
                 if rc != 0:
                     raise SystemExit(f"rcv__membench failed: {rc}")
-            runup(cp)
-            gbs = 2 * nbytes / (timed(100, cp) / 100) / 1e6
+            settle(60.0, cp, lanes.sync)      # run-up: the copies get the same warm clocks as the filter
+            gbs = 2 * nbytes / (timed0(100, cp) / 100) / 1e6
             if gbs > best:
                 best, best_name = gbs, name
         res["copy_ceiling_gbs"] = best
         res["copy_ceiling_kernel"] = best_name
-        L.rcv__debug_set(4)          # k_filter_rows_mfma<.., 260>: the launch's own loads and stores, no arithmetic
-        runup(step)
-        res["memory_only_gbs"] = 2 * nbytes / (timed(100) / 100) / 1e6
-        L.rcv__debug_set(0)
-    src.free()
-    dst.free()
-    if mid is not None:
-        mid.free()
+        # the memory-only variant is selected by a PROCESS-WIDE flag: in the one-process form no rank may flip it while another one
+        # is still timing real launches -- everybody arrives, rank 0 sets it, everybody measures, everybody arrives, rank 0 clears it
+        fence(lanes, torch, device)
+        if rank == 0 or fence.tb is None:
+            L.rcv__debug_set(4)          # k_filter_rows_mfma<.., 260>: the launch's own loads and stores, no arithmetic
+        fence(lanes, torch, device)
+        settle(60.0, lane[0].step, lanes.sync)
+        res["memory_only_gbs"] = 2 * nbytes / (timed0(100) / 100) / 1e6
+        fence(lanes, torch, device)
+        if rank == 0 or fence.tb is None:
+            L.rcv__debug_set(0)
+        fence(lanes, torch, device)
+    for ln in lane:
+        ln.free()
+
+    # ---- compact records of the other two BASELINE configs (default run, one GPU): same process, one stream each ----
+    if cfg == 3 and world == 1 and not a.no_others:
+        res["other_configs"] = {str(c): other_config(a, c, ctx0, lanes) for c in (4, 5)}
+    lanes.close()
     return res
+
+
+def load_traffic(cfg):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), or None"""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tpath)).get(TRAFFIC_KEYS[cfg])
+    except Exception:
+        return None
+
+
+def other_config(a, cfg, ctx, lanes, launches=100):
+    """BASELINE config 4 or 5 at its per-GPU batch on one stream: settle, `launches` sustained launches between HIP events, first /
+    middle / last frame against the oracle.  A compact record in the format of the headline's roofline."""
+    from rustcv_amd import _ffi
+    L = _ffi.lib()
+    c = CONFIGS[cfg]
+    ln = Lane(a, cfg, ctx, 0, n=c["batch"])
+    L.rcv__debug_kernels_reset()
+    ln.step()
+    ctx.sync()
+    kernel = L.rcv__debug_kernels().decode()
+    settle(100.0, ln.step, ctx.sync)
+    ms = C.c_float(0.0)
+    t0 = time.perf_counter()
+    L.rcv_timer_start(ctx.handle)
+    for _ in range(launches):
+        ln.step()
+    L.rcv_timer_stop(ctx.handle, C.byref(ms))
+    wall = time.perf_counter() - t0
+    launch_ms = float(ms.value) / launches
+    alg = c["batch"] * c["alg_bytes"]
+    ach = alg / (launch_ms * 1e-3) / 1e9
+    rec = {"metric": c["metric"], "value": round(c["batch"] * c["px"] * launches / wall / 1e6, 1), "unit": "Mpix/s", "steps": launches,
+           "ms_per_step": round(wall / launches * 1e3, 4), "frames_per_launch": c["batch"], "dtype": c["dtype"], "workload": c["workload"],
+           "roofline": {"bound": c["bound"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": load_traffic(cfg), "kernel": kernel, "launch_ms": round(launch_ms, 4), "launches": launches, "alg_bytes_per_launch": alg}}
+    if cfg == 4:
+        rec["input_mpix_s"] = round(c["batch"] * 4320 * 7680 * launches / wall / 1e6, 1)
+        rec["path"] = "one fused launch (rcv_warp_affine_resize_batch)"
+    if not a.no_verify:
+        from oracle import pyoracle as orc
+        ok, bad = ln.verify(orc)
+        rec["verified_frames"] = ok
+        rec["verified"] = "bit-exact vs the CPU oracle" if not bad else f"MISMATCH in frames {bad}"
+        rec["mismatched_frames"] = bad
+    ln.free()
+    return rec
 
 
 def report(a, world, results):
     n = a.batch
     cfg = getattr(a, "config", 3)
     c = CONFIGS[cfg]
-    total_frames = n * world
+    F = results[0].get("in_flight", 1)
+    total_frames = n * F * world
     elapsed = max(r["elapsed"] for r in results)
     launch_ms = max(r["launch_ms"] for r in results)
     px_per_step = total_frames * c["px"]
     value = px_per_step * a.steps / elapsed / 1e6
-    alg_bytes = n * c["alg_bytes"]   # per launch, per GPU
+    alg_bytes = n * c["alg_bytes"]   # per launch
     unfused = cfg == 4 and getattr(a, "unfused", False)
     if unfused:
         alg_bytes = n * (4320 * 7680 * 6 + 1080 * 1920 * 15)   # upper bound of the warp (6 B per 8K px) + the exact-4x resize (15 B per output px)
     ach = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get({3: "filter2d_i8_7x7_hbm_bytes_per_launch", 4: "warp_resize_fused_hbm_bytes_per_launch",
-                                                  5: "harris_pipeline_hbm_bytes_per_launch"}[cfg] if not unfused else "-")
-        except Exception:
-            traffic = None
+    traffic = None if unfused else load_traffic(cfg)
     roof = {"bound": c["bound"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE of this kernel, collected in a separate profiled run (not measured here)",
-            "kernel": results[0]["kernel"], "launch_ms": round(launch_ms, 4), "launches": results[0]["launches_sustained"],
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE of this kernel per launch, collected in a separate profiled run (not measured here)"
+                               if traffic is not None else "no PMC pass recorded for this launch"),
+            "kernel": results[0]["kernel"], "launch_ms": round(launch_ms, 4), "launches": results[0]["launches_sustained"], "in_flight": F,
             "launch_ms_first20": round(max(r["launch_ms_first20"] for r in results), 4),
-            "launch_ms_timed_steps": round(max(r["ev_ms_steps"] for r in results), 4),
+            "launch_ms_timed_steps": round(max(r["ev_ms_steps"] for r in results) / F, 4),
             "alg_bytes_per_launch": alg_bytes}
+    if F > 1:
+        roof["launch_ms_note"] = (f"{F} launches in flight on {F} streams: launch_ms = sustained window / launches in it (bytes moved / wall time); one kernel's own "
+                                  f"duration under rocprofv3 is about {F} x that because the kernels overlap")
+    if "single_launch_ms" in results[0]:
+        s_ms = max(r["single_launch_ms"] for r in results)
+        s_ach = alg_bytes / (s_ms * 1e-3) / 1e9
+        roof["single_stream"] = {"launch_ms": round(s_ms, 4), "achieved": round(s_ach, 1), "frac": round(s_ach / HBM_PEAK_GBS, 4)}
     if "shader_mhz_under_load" in results[0]:
         roof["shader_mhz_under_load"] = min(r["shader_mhz_under_load"] for r in results)
     if "copy_ceiling_gbs" in results[0]:
@@ -350,17 +486,25 @@ def report(a, world, results):
         roof["frac_of_copy_ceiling"] = round(ach / ceil, 4)
     if "memory_only_gbs" in results[0]:
         mo = min(r["memory_only_gbs"] for r in results)
-        roof["memory_only_gbs"] = round(mo, 1)          # the kernel's own loads + stores, nothing in between
+        roof["memory_only_gbs"] = round(mo, 1)          # the kernel's own loads + stores, nothing in between, one stream
         roof["frac_of_memory_only"] = round(ach / mo, 4)
     if world > 1:
         roof["launch_ms_per_gpu"] = [round(r["launch_ms"], 4) for r in results]
-    config = {"workload": c["workload"], "frames_per_gpu": n, "global_batch": total_frames, "parallelism": f"frame-sharded x{world}, no collective"}
+    n_devices = len({r.get("device", i) for i, r in enumerate(results)})
+    par = f"frame-sharded x{n_devices}, no collective"
+    if F > 1:
+        par += f"; {F} batches in flight per GPU ({F} contexts = HIP streams per device, own buffers each)"
+    config = {"workload": c["workload"], "frames_per_launch": n, "launches_per_step_per_gpu": F, "frames_per_gpu": n * F, "global_batch": total_frames,
+              "parallelism": par}
+    if n_devices != world:   # (--devices 0,0: ranks time-sharing a device -- a test of the N > 1 code, not a scaling number)
+        config["contexts"] = world
+        config["note"] = f"{world} ranks on {n_devices} device(s): TEST of the multi-rank path, not a scaling measurement"
     if cfg == 4:
         config["path"] = "two launches (warpAffine, resize) through an 8K intermediate" if unfused else "one fused launch (rcv_warp_affine_resize_batch)"
-        config["output_mpix_s"] = round(total_frames * 1080 * 1920 * a.steps / elapsed / 1e6, 1)
+        config["input_mpix_s"] = round(total_frames * 4320 * 7680 * a.steps / elapsed / 1e6, 1)
     out = {
         "metric": c["metric"], "value": round(value, 1), "unit": "Mpix/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+        "n_gpus": n_devices, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": c["dtype"],
         "data": "synthetic (splitmix64 counter noise, generated on device)" if cfg != 5 else "synthetic (splitmix64 scene family: ramp + checkerboard + moving square, generated on device)",
         "config": config,
@@ -371,6 +515,10 @@ def report(a, world, results):
         out["verified_frames"] = sorted(f for r in results for f in r["verified_frames"])
         bad = sorted(f for r in results for f in r["mismatched_frames"])
         out["verified"] = "bit-exact vs the CPU oracle" if not bad else f"MISMATCH in frames {bad}"
+    if "other_configs" in results[0]:
+        out["other_configs"] = results[0]["other_configs"]
+        for rec in out["other_configs"].values():
+            bad += rec.pop("mismatched_frames", [])
     return out, bad
 
 
@@ -380,6 +528,8 @@ def main():
     under_launcher = "RANK" in os.environ
     if under_launcher and env_world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={env_world}")
+    if a.device_list is not None and len(a.device_list) != a.gpus:
+        raise SystemExit(f"--devices names {len(a.device_list)} ranks but --gpus is {a.gpus}")
 
     import torch  # first: librustcv_hip.so then binds to the HIP runtime torch already loaded
     if not torch.cuda.is_available():
@@ -390,14 +540,18 @@ def main():
         # ---- one process per GPU (torch.distributed.run): RCCL carries the barrier and the max over ranks ----
         import torch.distributed as dist
         rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), env_world
+        if a.device_list is not None:
+            local = a.device_list[rank]
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
         dist.barrier()   # the first collective builds the RCCL communicator (hundreds of ms): keep that out of the run-up
         torch.cuda.synchronize()
-        ctx = rcv.Context(local)
-        res = run_rank(a, rank, world, local, ctx, Fence(dist=dist), torch)
+        res = run_rank(a, rank, world, local, Fence(dist=dist), torch)
         gathered = [None] * world
         dist.all_gather_object(gathered, res)
         bad = []
@@ -408,18 +562,18 @@ def main():
             print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
-        ctx.close()
         sys.exit(1 if bad else 0)
 
-    # ---- one process: one context + one host thread per GPU (rustcv_amd.multigpu.DeviceGroup) ----
+    # ---- one process: one host thread per GPU (rustcv_amd.multigpu.DeviceGroup supplies threads + barrier) ----
     have = rcv.device_count()
-    if a.gpus < 1 or a.gpus > have:
+    devices = a.device_list if a.device_list is not None else list(range(a.gpus))
+    if a.gpus < 1 or max(devices) >= have:
         raise SystemExit(f"--gpus {a.gpus}: this node exposes {have} GPU(s) to this process")
     world = a.gpus
-    group = rcv.DeviceGroup(world)
+    group = rcv.DeviceGroup(devices)
     # the group's OWN barrier: DeviceGroup.run aborts it when a rank raises, so the other ranks leave the fence instead of hanging
     fence = Fence(tbarrier=group.barrier if world > 1 else None)
-    results = group.run(lambda r, ctx: run_rank(a, r, world, group.devices[r], ctx, fence, torch))
+    results = group.run(lambda r, ctx: run_rank(a, r, world, group.devices[r], fence, torch))
     out, bad = report(a, world, results)
     if not a.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.config, a.family)

@@ -110,6 +110,17 @@ public:
         return {a, b};
     }
     void sync() { check(rcv_group_sync(g_), "rcv_group_sync"); }
+    // `depth` contexts (= HIP streams) on ONE GPU: a frame stream keeps `depth` batches in flight, batch k on ctx(k % depth),
+    // each context with its own buffers (rustcv_hip.h, "An ordinal may repeat"; 64 x 4K filter2D: -10 % per batch at depth 2)
+    static std::vector<int> in_flight(int device, int depth) { return std::vector<int>((size_t)(depth < 1 ? 1 : depth), device); }
+    // events on every context's stream: elapsed ms from the first start to the latest stop
+    void timer_start() { check(rcv_group_timer_start(g_), "rcv_group_timer_start"); }
+    float timer_stop()
+    {
+        float ms = 0.0f;
+        check(rcv_group_timer_stop(g_, &ms), "rcv_group_timer_stop");
+        return ms;
+    }
 
 private:
     rcv_group* g_ = nullptr;

@@ -71,6 +71,13 @@ impl DeviceGroup {
     pub fn with_devices(devices: &[i32]) -> Result<Self, i32> {
         Self::create(devices.as_ptr(), devices.len())
     }
+    /// `depth` contexts (= HIP streams) on ONE GPU.  A frame stream -- the reference's caller, `VideoCapture::read` in a loop
+    /// (rustcv/src/videoio/mod.rs:168-265) -- keeps `depth` batches in flight: batch k on `ctx(k % depth)`, every context with
+    /// its own source / destination buffers.  Consecutive launches then overlap (64 x 4K 7x7 filter2D at depth 2: one batch per
+    /// 0.55 ms instead of 0.61 ms).  Ordering holds per context only.
+    pub fn in_flight(device: i32, depth: usize) -> Result<Self, i32> {
+        Self::with_devices(&vec![device; depth.max(1)])
+    }
     fn create(devices: *const i32, n: usize) -> Result<Self, i32> {
         let mut raw = std::ptr::null_mut();
         let rc = unsafe { rcv_group_create(devices, n as i32, &mut raw) };
@@ -90,6 +97,19 @@ impl DeviceGroup {
     pub fn sync(&self) -> Result<(), i32> {
         let rc = unsafe { rcv_group_sync(self.raw) };
         if rc != RCV_OK { Err(rc) } else { Ok(()) }
+    }
+}
+impl DeviceGroup {
+    /// Records an event on every context's stream (rank order).
+    pub fn timer_start(&self) -> Result<(), i32> {
+        let rc = unsafe { rcv_group_timer_start(self.raw) };
+        if rc != RCV_OK { Err(rc) } else { Ok(()) }
+    }
+    /// Records a second event on every stream, waits for all of them; milliseconds from the first start to the latest stop.
+    pub fn timer_stop(&self) -> Result<f32, i32> {
+        let mut ms = 0f32;
+        let rc = unsafe { rcv_group_timer_stop(self.raw, &mut ms) };
+        if rc != RCV_OK { Err(rc) } else { Ok(ms) }
     }
 }
 impl Drop for DeviceGroup {

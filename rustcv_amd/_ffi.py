@@ -91,6 +91,8 @@ SIGNATURES = {
     "rcv_group_size": (_i, [C.c_void_p]),
     "rcv_group_ctx": (_ctx, [C.c_void_p, _i]),
     "rcv_group_sync": (_i, [C.c_void_p]),
+    "rcv_group_timer_start": (_i, [C.c_void_p]),
+    "rcv_group_timer_stop": (_i, [C.c_void_p, _P(_f)]),
     "rcv_shard_range": (_i, [C.c_int64, _i, _i, _P(C.c_int64), _P(C.c_int64)]),
     "rcv_ctx_stream": (C.c_void_p, [_ctx]),
     "rcv_malloc": (_i, [_ctx, _sz, _P(C.c_void_p)]),
@@ -152,6 +154,7 @@ BENCH_SIGNATURES = {
     "rcv__membench": (_i, [_ctx, C.c_void_p, C.c_void_p, _sz, _i, _i]),
     "rcv__storebench": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i, _i]),
     "rcv__clock_probe": (_i, [_ctx, _i, C.POINTER(C.c_float)]),
+    "rcv__stripwalk": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i]),
 }
 
 _lib = None

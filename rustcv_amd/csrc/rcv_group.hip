@@ -68,3 +68,38 @@ extern "C" int rcv_group_sync(rcv_group* g)
     }
     return first;
 }
+
+// Stream timing across the group (bench.py: two batches in flight on two contexts of ONE device overlap, so no single stream's
+// events bracket the work).  start: one event on every context's stream, in rank order; stop: one event on every stream, then
+// wait for all of them.  Elapsed = the latest stop against the EARLIEST-recorded start of its device (rank order: the first
+// context of that device) -- events of one device share a clock, events of different devices do not, so a multi-device group
+// reports the maximum over its devices of each device's own span.
+extern "C" int rcv_group_timer_start(rcv_group* g)
+{
+    if (!g) return RCV_ERR_ARG;
+    for (rcv_ctx* c : g->ctxs) RCV_TRY(rcv_timer_start(c));
+    return RCV_OK;
+}
+
+extern "C" int rcv_group_timer_stop(rcv_group* g, float* elapsed_ms)
+{
+    if (!g || !elapsed_ms) return RCV_ERR_ARG;
+    for (rcv_ctx* c : g->ctxs) {
+        if (c->capturing) return RCV_ERR_UNSUPPORTED;
+        RCV_TRY(rcv_bind(c));
+        RCV_HIP(hipEventRecord(c->ev1, c->stream));
+    }
+    float best = 0.0f;
+    for (rcv_ctx* c : g->ctxs) {
+        RCV_TRY(rcv_bind(c));
+        RCV_HIP(hipEventSynchronize(c->ev1));
+        rcv_ctx* first = c;
+        for (rcv_ctx* o : g->ctxs)
+            if (o->device == c->device) { first = o; break; }
+        float ms = 0.0f;
+        RCV_HIP(hipEventElapsedTime(&ms, first->ev0, c->ev1));
+        if (ms > best) best = ms;
+    }
+    *elapsed_ms = best;
+    return RCV_OK;
+}

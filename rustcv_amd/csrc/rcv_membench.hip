@@ -196,6 +196,78 @@ __global__ __launch_bounds__(256) void k_store_strips(StoreArgs a)
             }
 }
 
+// Strip-walker copy (round 4): the access pattern of a row-streaming stencil without the stencil -- which STRIP WIDTH / rows per
+// request / depth does this memory system like, at a fixed number of resident waves?  A wave (= a 64-thread workgroup) owns a
+// strip of W bytes of every row of a band and walks down it; one request = three 16-byte accesses per lane = 3072 bytes = R = 3072 / W
+// whole strip-rows; DEPTH requests are in flight; every loaded byte is stored (non-temporal) to the same place in dst.  Bands,
+// band order (each XCD a contiguous run of bands, the strips of a band neighbours) and occupancy (wpc waves per CU through an
+// untouched dynamic-LDS request) as in k_filter_rows_mfma, whose plain instantiation is W = 768, R = 2, four requests in flight.
+// halo > 0: a band also reads (never stores) `halo` rows above itself, like a 7-row stencil's band.
+struct WalkArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    size_t step, fstride;
+    int rows, nframes, nstrips, W, R, nbands, bands_per_xcd, halo, ntl;
+};
+template <int DEPTH>
+__global__ __launch_bounds__(64) void k_strip_walk(WalkArgs a)
+{
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3);
+    const int strip = slot % a.nstrips, bi = slot / a.nstrips;
+    if (bi >= a.bands_per_xcd) return;
+    const int band = xcd * a.bands_per_xcd + bi;
+    if (band >= a.nbands) return;
+    const long long G = (long long)a.nframes * a.rows;
+    long long g0 = G * band / a.nbands;
+    const long long g1 = G * (band + 1) / a.nbands;
+    const int spr = a.W >> 4;   // 16-byte slots per strip-row
+    // the lane's three slots of a request: row and byte offset inside the R x W block
+    size_t off[3];
+    int rowj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int sidx = lane + 64 * j;
+        rowj[j] = sidx / spr;
+        off[j] = (size_t)rowj[j] * a.step + (size_t)(sidx % spr) * 16 + (size_t)strip * a.W;
+    }
+    while (g0 < g1) {
+        const int frame = (int)(g0 / a.rows), ys = (int)(g0 - (long long)frame * a.rows);
+        const int ye = (int)min((long long)a.rows, ys + (g1 - g0));
+        const uint8_t* sf = a.src + (size_t)frame * a.fstride;
+        uint8_t* df = a.dst + (size_t)frame * a.fstride;
+        const int y0 = max(ys - a.halo, 0);
+        const int nreq = (ye - y0 + a.R - 1) / a.R;
+        u4v v[DEPTH][3];
+        auto request = [&](int r, u4v(&d)[3]) {
+            const int yb = y0 + r * a.R;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int y = min(yb + rowj[j], ye - 1) - (yb + rowj[j]);   // rows past the band re-read its last row
+                const u4v* p = (const u4v*)(sf + (size_t)yb * a.step + off[j] + (long long)y * (long long)a.step);
+                d[j] = a.ntl ? __builtin_nontemporal_load(p) : *p;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i) request(i < nreq ? i : nreq - 1, v[i]);
+        for (int r0 = 0; r0 < nreq; r0 += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const int r = r0 + s;
+                if (r >= nreq) break;
+                request(min(r + DEPTH - 1, nreq - 1), v[(s + DEPTH - 1) % DEPTH]);
+                const int yb = y0 + r * a.R;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int y = yb + rowj[j];
+                    if (y >= ys && y < ye) __builtin_nontemporal_store(v[s][j], (u4v*)(df + (size_t)yb * a.step + off[j]));
+                }
+            }
+        }
+        g0 += ye - ys;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_nop(int* p)
 {
     if (p && threadIdx.x == 1234567) *p = 0;   // (never)
@@ -267,6 +339,54 @@ extern "C" int rcv__storebench(rcv_ctx* ctx, void* p0, void* p1, int n, int rows
     const unsigned lds = wgs_per_cu > 0 ? (unsigned)((163840 / wgs_per_cu) & ~511) : 0u;
     if (nt) hipLaunchKernelGGL((k_store_strips<true>), grid, dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL((k_store_strips<false>), grid, dim3(256), lds, ctx->stream, a);
+    return rcv_launch_check(ctx);
+}
+
+// strip-walker copy of n frames of rows x row_bytes (frame stride = rows * step): strip width W (3072 % W == 0, row_bytes % W == 0,
+// W % 16 == 0), `depth` requests of 3072 bytes in flight per wave (1, 2, 4), `rounds` bands per wave slot, wpc waves per CU (<= 8 ... 32),
+// halo rows re-read per band, nt loads or plain.  Asynchronous on the context's stream.
+extern "C" int rcv__stripwalk(rcv_ctx* ctx, void* dst, const void* src, int n, int rows, int row_bytes, size_t step, int W, int depth, int rounds, int wpc,
+                              int halo, int nt_loads)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!dst || !src || n < 1 || rows < 1 || W < 16 || W % 16 || 3072 % W || row_bytes % W || step % 16 || rounds < 1 || wpc < 1 || wpc > 32) return RCV_ERR_ARG;
+    WalkArgs a;
+    a.src = (const uint8_t*)src;
+    a.dst = (uint8_t*)dst;
+    a.step = step;
+    a.fstride = (size_t)rows * step;
+    a.rows = rows;
+    a.nframes = n;
+    a.W = W;
+    a.R = 3072 / W;
+    a.nstrips = row_bytes / W;
+    a.halo = halo;
+    a.ntl = nt_loads;
+    const long long slots = (long long)wpc * ctx->cu_count;
+    long long nb = (long long)rounds * slots / a.nstrips;
+    if (n >= 8) {   // whole bands per frame, as the filter plans them
+        long long bpf = (nb + n / 2) / n;
+        bpf = bpf < 1 ? 1 : bpf;
+        nb = bpf * n;
+    }
+    nb = nb < 8 ? 8 : nb;
+    a.nbands = (int)nb;
+    a.bands_per_xcd = (int)((nb + 7) / 8);
+    const dim3 grid((unsigned)((long long)a.bands_per_xcd * a.nstrips * 8));
+    const unsigned lds = wpc < 32 ? (unsigned)((163840 / wpc) & ~511) : 0u;
+    if (lds > 65536u) {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            (void)hipFuncSetAttribute((const void*)k_strip_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            (void)hipFuncSetAttribute((const void*)k_strip_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            (void)hipFuncSetAttribute((const void*)k_strip_walk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        }
+    }
+    if (depth == 1) hipLaunchKernelGGL((k_strip_walk<1>), grid, dim3(64), lds, ctx->stream, a);
+    else if (depth == 2) hipLaunchKernelGGL((k_strip_walk<2>), grid, dim3(64), lds, ctx->stream, a);
+    else if (depth == 4) hipLaunchKernelGGL((k_strip_walk<4>), grid, dim3(64), lds, ctx->stream, a);
+    else return RCV_ERR_ARG;
     return rcv_launch_check(ctx);
 }
 

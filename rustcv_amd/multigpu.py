@@ -112,6 +112,25 @@ class NativeGroup:
         self._h, self.devices = h, devs
         self.ctxs = [_GroupContext(C.c_void_p(L.rcv_group_ctx(h, r)), devs[r]) for r in range(L.rcv_group_size(h))]
 
+    @classmethod
+    def in_flight(cls, device, depth=2):
+        """`depth` contexts (= HIP streams) on ONE GPU: a frame stream keeps `depth` batches in flight, batch k on
+        ctxs[k % depth], every context with its own src / dst buffers, so that consecutive launches overlap (64 x 4K 7x7
+        filter2D at depth 2: one batch per 0.55 ms instead of 0.61 ms -- DESIGN.md 4.1 round 4).  Ordering holds per context."""
+        return cls([int(device)] * max(1, int(depth)))
+
+    def timer_start(self):
+        from . import _ffi
+        _ffi.check(_ffi.lib().rcv_group_timer_start(self._h), "rcv_group_timer_start")
+
+    def timer_stop(self):
+        """ms from the first context's start event to the latest stop event (waits for every stream)"""
+        import ctypes as C
+        from . import _ffi
+        ms = C.c_float(0.0)
+        _ffi.check(_ffi.lib().rcv_group_timer_stop(self._h, C.byref(ms)), "rcv_group_timer_stop")
+        return float(ms.value)
+
     @property
     def world(self):
         return len(self.ctxs)

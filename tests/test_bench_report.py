@@ -22,12 +22,59 @@ def test_report_single_gpu():
     px = 64 * 2160 * 3840
     assert not bad and out["n_gpus"] == 1 and out["unit"] == "Mpix/s" and out["higher_is_better"] and out["vs_baseline"] is None
     assert abs(out["value"] - px * 50 / 0.0275 / 1e6) < 1 and abs(out["ms_per_step"] - 0.55) < 1e-9
+    assert out["roofline"]["in_flight"] == 1 and "single_stream" not in out["roofline"] and out["config"]["frames_per_gpu"] == 64
     r = out["roofline"]
     assert r["alg_bytes_per_launch"] == px * 6 == 3185049600 and r["peak"] == 8000.0 and r["bound"] == "hbm"
     assert abs(r["achieved"] - 3185049600 / 0.55e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
     assert abs(r["frac_of_copy_ceiling"] - r["achieved"] / 6000.0) < 1e-4
     assert out["verified_frames"] == [0, 31, 63] and out["verified"].startswith("bit-exact")
     assert out["dtype"] == "u8" and out["scaling"] == "weak" and "workload" in out["config"] and "model" not in out["config"]
+
+
+def test_report_two_batches_in_flight():
+    """round 4: F = 2 contexts per GPU, one 64-frame launch each per step.  value counts the pixels of BOTH launches over the wall
+    time; roofline.launch_ms is the sustained window divided by the LAUNCHES in it (bytes moved / wall time), the one-stream figure
+    sits beside it, and every context's frames are in verified_frames"""
+    a = argparse.Namespace(batch=64, steps=20, warmup=5)
+    r = dict(_rank(0.0220, 0.548, 6000.0, [0, 31, 63, 64, 95, 127]), in_flight=2, single_launch_ms=0.610, launches_sustained=800, ev_ms_steps=1.10, device=0)
+    out, bad = bench.report(a, 1, [r])
+    px = 64 * 2160 * 3840
+    assert not bad and out["n_gpus"] == 1 and out["config"]["global_batch"] == 128 and out["config"]["frames_per_launch"] == 64
+    assert out["config"]["launches_per_step_per_gpu"] == 2 and "2 batches in flight" in out["config"]["parallelism"]
+    assert abs(out["value"] - 2 * px * 20 / 0.0220 / 1e6) < 1 and abs(out["ms_per_step"] - 1.1) < 1e-9
+    assert abs(out["value"] - 128 * 2160 * 3840 / out["ms_per_step"] / 1e3) < 1          # value == global_batch pixels / ms_per_step
+    rf = out["roofline"]
+    assert rf["in_flight"] == 2 and rf["alg_bytes_per_launch"] == 3185049600 and rf["launches"] == 800
+    assert abs(rf["achieved"] - 3185049600 / 0.548e-3 / 1e9) < 0.1 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-4
+    assert rf["single_stream"]["launch_ms"] == 0.61 and abs(rf["single_stream"]["frac"] - 3185049600 / 0.61e-3 / 1e9 / 8000.0) < 1e-4
+    assert abs(rf["launch_ms_timed_steps"] - 0.55) < 1e-9 and "overlap" in rf["launch_ms_note"]
+    assert out["verified_frames"] == [0, 31, 63, 64, 95, 127]
+
+
+def test_report_ranks_sharing_a_device_is_labelled_a_test():
+    """--devices 0,0 (the N > 1 code on a one-GPU box): n_gpus counts DISTINCT devices, the ranks appear as contexts"""
+    a = argparse.Namespace(batch=64, steps=20, warmup=3)
+    res = [dict(_rank(0.024, 1.2, 6000.0, [0, 31, 63]), device=0), dict(_rank(0.025, 1.25, 6000.0, [64, 95, 127]), device=0)]
+    out, bad = bench.report(a, 2, res)
+    assert not bad and out["n_gpus"] == 1 and out["config"]["contexts"] == 2 and "not a scaling" in out["config"]["note"]
+    assert out["roofline"]["launch_ms_per_gpu"] == [1.2, 1.25]
+
+
+def test_report_carries_the_other_configs():
+    a = argparse.Namespace(batch=64, steps=20, warmup=3)
+    rec = {"metric": "m", "value": 1.0, "roofline": {"frac": 0.4}, "verified": "bit-exact vs the CPU oracle", "mismatched_frames": []}
+    r = dict(_rank(0.011, 0.55, 6000.0, [0, 31, 63]), other_configs={"4": dict(rec), "5": dict(rec, mismatched_frames=[7])})
+    out, bad = bench.report(a, 1, [r])
+    assert set(out["other_configs"]) == {"4", "5"} and bad == [7] and "mismatched_frames" not in out["other_configs"]["5"]
+
+
+def test_parse_defaults():
+    a = bench.parse([])
+    assert a.in_flight == 2 and a.batch == 64 and a.gpus == 1 and a.device_list is None
+    a = bench.parse(["--config", "5"])
+    assert a.in_flight == 1 and a.batch == 64
+    a = bench.parse(["--config", "4", "--in-flight", "2", "--gpus", "2", "--devices", "0,0"])
+    assert a.in_flight == 2 and a.batch == 32 and a.device_list == [0, 0]
 
 
 def test_report_takes_the_slowest_gpu_and_flags_mismatches():
@@ -48,10 +95,10 @@ def test_report_configs_4_and_5():
     r4.pop("copy_ceiling_gbs"), r4.pop("copy_ceiling_kernel")
     a = argparse.Namespace(batch=32, steps=50, warmup=5, config=4, unfused=False)
     out, bad = bench.report(a, 1, [r4])
-    assert not bad and out["metric"].startswith("Mpixels/sec on 8K warpAffine") and out["config"]["frames_per_gpu"] == 32
+    assert not bad and "8K warpAffine" in out["metric"] and out["config"]["frames_per_gpu"] == 32
     assert out["roofline"]["alg_bytes_per_launch"] == 32 * 1080 * 1920 * 30 and "frac_of_copy_ceiling" not in out["roofline"]
-    assert abs(out["value"] - 32 * 4320 * 7680 * 50 / 0.0355 / 1e6) < 1 and "fused" in out["config"]["path"]
-    assert abs(out["config"]["output_mpix_s"] - 32 * 1080 * 1920 * 50 / 0.0355 / 1e6) < 1
+    assert abs(out["value"] - 32 * 1080 * 1920 * 50 / 0.0355 / 1e6) < 1 and "fused" in out["config"]["path"] and "output pixels" in out["metric"]
+    assert abs(out["config"]["input_mpix_s"] - 32 * 4320 * 7680 * 50 / 0.0355 / 1e6) < 1
     a.unfused = True
     out, _ = bench.report(a, 1, [r4])
     assert out["roofline"]["alg_bytes_per_launch"] == 32 * (4320 * 7680 * 6 + 1080 * 1920 * 15) and "two launches" in out["config"]["path"]
