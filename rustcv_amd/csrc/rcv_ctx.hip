@@ -30,6 +30,8 @@ static void load_knobs()
     g_knobs.fr_wpc = env_int("RCV_FR_WPC", 0);
     g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
     g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
+    g_knobs.fr_chain = env_int("RCV_FR_CHAIN", -1);
+    g_knobs.fr_chain_rows = env_int("RCV_FR_CHAIN_ROWS", 0);
     g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
     g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
     g_knobs.fr_sob192 = env_int("RCV_FR_SOB192", 0);

@@ -78,6 +78,13 @@ struct FRArgs {
     long long tstart[4], tlen[4];
     unsigned long long* trace;   // (DBG & 1024, profiling builds) per-wave {start, end} of the 100 MHz counter
     size_t gstep, gfs;
+    // chained bands (k_filter_rows_chain, round 4): every XCD owns fpx whole frames cut into bpf bands each; wave (xcd, strip, g) of
+    // the ng band groups per XCD takes bands g, g + ng, g + 2 ng, ... of its XCD's list, one after the other, in ONE pipeline
+    int ng, bpf, fpx;
+    unsigned bmul;               // ceil(rows * 2^20 / bpf): band j of a frame = rows [(j * bmul) >> 20, ((j + 1) * bmul) >> 20)
+    unsigned long long inv_nstrips, inv_bpf;   // ceil(2^32 / nstrips), ceil(2^32 / bpf): exact quotients for the item counts of a launch
+    unsigned long long* tickets;     // 8 counters, 16 x 8 bytes apart (one 128-byte line each)
+    unsigned long long tbase[8];     // their values when this launch starts
 };
 
 // packed i16 arithmetic on two pixels (the Sobel stage of the SOB instantiation; same forms as rcv_harris_fused.hip)
@@ -547,6 +554,224 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     }
 }
 
+// ---- chained bands (round 4) ---------------------------------------------------------------------------------------------------
+// What the memory system wants (tools/ablate_walk*.py, ablate_bands.py): the strip-walker copy -- this
+// kernel's access pattern without the kernel -- runs 6-10 % faster when the bands are 16-32 rows instead of 103: what one XCD's 256
+// waves touch at a time is then a window of ~500 rows (6 MB) instead of a whole frame (25 MB).  The one-band-per-wave kernel cannot
+// use short bands: every band costs a wave launch, the weight tables, 2 * RAD halo rows and a pipeline fill (32-row bands: 0.587
+// against 0.574 ms while its memory-only variant GAINS 4 %).  Here a wave is PERSISTENT and CHAINS items: it draws (band, strip)
+// items from its XCD's ticket counter -- band-major, so the 256 waves of an XCD work on ~17 neighbouring bands, and dynamic, so a
+// slow wave simply takes fewer items (a STATIC assignment of bands to persistent waves was measured first: 6-9 % slower than hardware
+// dispatch even for the plain walker copy, and the EDGE strips' slower waves set the launch time) -- and walks them as ONE continuous
+// stream of row pairs through the register ring.  While the last rows of an item are computed, the first rows of the next one (its
+// halo included) are already in flight; tables and lane constants are set up once per wave.  Three cursors run over the same item
+// sequence: requests (RP - 1 pairs ahead), operand preparation (NP - 1 ahead), output.  The NP - 1 steps whose window straddles
+// two items compute garbage that is never stored.  The strip changes from item to item, so the border repair of the first / last
+// strip sits under a wave-uniform branch in `prepare` (VALU only) and every store is exec-masked by `byte offset < row bytes`.
+// Tickets: one 64-bit counter per XCD (ctx->kconst + RCV_KC_FR_TICKETS, 128 bytes apart), never reset: a launch hands its base
+// values over (tbase) and consumes exactly items + waves tickets per XCD (a wave draws one ticket ahead and ends on its first
+// ticket past the list), which the host adds up.
+struct FRItem {
+    int X;                     // byte offset of the strip in a destination row
+    int ys, ye, P;             // rows [ys, ye) of the frame, P = ceil(rows / 2) + NP - 1 pairs
+    bool edge, done;
+    const uint8_t* sf;
+    uint8_t* df;
+};
+
+template <int KS, int PP, int DBG>
+__global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
+{
+    constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
+    constexpr int RP = NP + PP;
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7;
+    const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
+    const int rb = a.cols * 3;
+    const int lane_cb = 48 * n - 12 + 48 * c, lane_so = 48 * n + 12 * q;
+    const int rv = ((a.cols & 15) + 4) & 15;
+    const unsigned nitems = (unsigned)(a.fpx * a.bpf * a.nstrips);   // of this XCD
+    unsigned long long* const tick = a.tickets + 16 * xcd;
+    const unsigned long long tbase = a.tbase[xcd];
+
+    v4i A[2][NP];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
+            A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+        }
+    v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+    asm volatile("" : "+v"(initv));
+
+    // A ticket is drawn with a SCALAR atomic (s_atomic_add_x2, returns the old value): its latency is counted by lgkmcnt, which
+    // nothing else in the loop uses, so waiting for it on the spot stalls this wave's issue for one L2 round trip per item (the other
+    // wave of the SIMD runs on) but leaves vmcnt alone -- the row pairs in flight stay in flight.  (A vector atomic drawn one item
+    // ahead was built first: the compiler's atomic optimizer broadcasts the result at the draw site behind an s_waitcnt vmcnt(0),
+    // which drains the prefetch ring once per item.)
+    auto draw = [&]() -> unsigned {
+        unsigned long long t = 1ull;
+        asm volatile("s_atomic_add_x2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tick) : "memory");
+        return (unsigned)(t - tbase);   // items per launch < 2^31 (host check)
+    };
+    auto make_item = [&](unsigned li, FRItem& it) {   // (scalar) item li of this XCD's list: band-major, strips of a band neighbours
+        if (li >= nitems) {
+            it.done = true;
+            return;
+        }
+        const unsigned band = (unsigned)(((unsigned long long)li * a.inv_nstrips) >> 32);
+        const unsigned strip = li - band * (unsigned)a.nstrips;
+        const unsigned f = (unsigned)(((unsigned long long)band * a.inv_bpf) >> 32);
+        const unsigned j = band - f * (unsigned)a.bpf;
+        const int frame = xcd * a.fpx + (int)f;
+        it.X = (int)strip * 768;
+        it.edge = it.X == 0 || it.X + 804 > rb;
+        it.ys = (int)(((unsigned long long)j * a.bmul) >> 20);
+        it.ye = (int)(((unsigned long long)(j + 1) * a.bmul) >> 20);
+        it.P = (it.ye - it.ys + 1) / 2 + NP - 1;
+        it.sf = a.src + (size_t)frame * a.sfs;
+        it.df = a.dst + (size_t)frame * a.dfs;
+        it.done = false;
+    };
+
+    // cursors: rc requests, pc prepares, oc computes / stores; `pend` is the item rc entered last (pc and oc follow within RP - 1 < P steps)
+    FRItem rc, pc, oc, pend;
+    int ri = 0, pi = 0, oi = 0;
+    rc.X = 0; rc.ys = 0; rc.ye = 0; rc.P = 1; rc.edge = false; rc.done = false; rc.sf = a.src; rc.df = a.dst;
+    make_item(draw(), rc);
+    if (rc.done) return;
+    pend = pc = oc = rc;                 // (every wave draws its items + 1 tickets: the host's accounting)
+
+    v4i W[RP][3];
+    auto request = [&](int slot) {
+        v4i(&dst)[3] = W[slot];
+        const int y0 = min(rc.ys - RAD + 2 * ri, rc.ye - 1 + RAD), y1 = min(rc.ys - RAD + 2 * ri + 1, rc.ye - 1 + RAD);
+        const int s0 = y0 < 0 ? -y0 : (y0 >= a.rows ? 2 * a.rows - 2 - y0 : y0), s1 = y1 < 0 ? -y1 : (y1 >= a.rows ? 2 * a.rows - 2 - y1 : y1);
+        const unsigned o0 = (unsigned)s0 * (unsigned)a.sstep, o1 = (unsigned)s1 * (unsigned)a.sstep;   // < 2^32 (host check)
+        const unsigned cbo = (unsigned)min(max(rc.X + lane_cb, 0), rb - 48);   // chunks that stick out of the row are read shifted into it
+        const unsigned off = (h ? o1 : o0) + cbo;
+        dst[0] = *(const v4i*)(rc.sf + off);
+        dst[1] = *(const v4i*)(rc.sf + off + 16);
+        dst[2] = *(const v4i*)(rc.sf + off + 32);
+        if (++ri == rc.P) {
+            if (!rc.done) make_item(draw(), pend);   // next item
+            if (pend.done) {                          // past the last one: keep re-reading its last pair (cache hits, never used)
+                rc.done = true;
+                ri = rc.P - 1;
+            } else {
+                rc = pend;
+                ri = 0;
+            }
+        }
+    };
+    auto prepare = [&](int slot) {
+        v4i(&w)[3] = W[slot];
+        uint32_t pb[4], pg[4], prr[4];
+        const uint32_t r[12] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3], (uint32_t)w[1][0], (uint32_t)w[1][1],
+                                (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
+        if (pc.edge) {   // (wave-uniform) first / last strip of the row
+            const int cb = pc.X + lane_cb;
+            const bool fl = cb < 0, fr = cb == rb - rv * 3;
+            if (fl) {   // the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
+                    pp[3] = pp[2];
+                    pp[2] = pp[1];
+                    pp[1] = pp[0];
+                    pp[0] = __builtin_amdgcn_perm(pp[0], pp[0], 0x01020300u);
+                }
+            }
+            if (fr) {   // the lane read pixels cols-16..cols-1 instead of cols-rv..: its rv valid pixels move to the front, then the mirror
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
+                    const uint32_t mir = __builtin_amdgcn_perm(pp[3], pp[3], 0x00000102u);
+                    if (rv == 4) {
+                        pp[0] = pp[3];
+                        pp[1] = mir;
+                    } else if (rv == 8) {
+                        pp[0] = pp[2];
+                        pp[1] = pp[3];
+                        pp[2] = mir;
+                    } else if (rv == 12) {
+                        pp[0] = pp[1];
+                        pp[1] = pp[2];
+                        pp[2] = pp[3];
+                        pp[3] = mir;
+                    } else {
+                        pp[0] = mir;
+                    }
+                }
+            }
+        }
+        w[0] = v4i{(int)(pb[0] ^ 0x80808080u), (int)(pb[1] ^ 0x80808080u), (int)(pb[2] ^ 0x80808080u), (int)(pb[3] ^ 0x80808080u)};
+        w[1] = v4i{(int)(pg[0] ^ 0x80808080u), (int)(pg[1] ^ 0x80808080u), (int)(pg[2] ^ 0x80808080u), (int)(pg[3] ^ 0x80808080u)};
+        w[2] = v4i{(int)(prr[0] ^ 0x80808080u), (int)(prr[1] ^ 0x80808080u), (int)(prr[2] ^ 0x80808080u), (int)(prr[3] ^ 0x80808080u)};
+        if (++pi == pc.P) {
+            pc = pend;
+            pi = 0;
+        }
+    };
+    auto store_row = [&](const v4i(&acc)[3], int y, bool ok) {
+        U3w o;
+        o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+        o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+        o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        const int so = oc.X + lane_so;
+        // non-temporal: the launch never reads its output back; windows past the row end (a partial last strip) are masked off
+        if (ok && so < rb) __builtin_nontemporal_store(v3i{(int)o.a, (int)o.b, (int)o.c}, (v3i*)(oc.df + (size_t)y * a.dstep + so));
+    };
+
+#pragma unroll
+    for (int i = 0; i < RP - 1; ++i) request(i);
+#pragma unroll
+    for (int i = 0; i < NP - 1; ++i) prepare(i);
+
+    for (;;) {
+#pragma unroll
+        for (int s = 0; s < RP; ++s) {
+            request((s + RP - 1) % RP);
+            const bool valid = oi <= oc.P - NP;          // the window's NP pairs belong to one item
+            const int y = oc.ys + 2 * oi;
+            if constexpr ((DBG & 256) != 0) {
+                // the chain's memory pattern alone: its loads, and its stores fed with loaded bytes
+                const v4i& w0 = W[s % RP][0];
+                const v4i& w1 = W[s % RP][1];
+                const int so = oc.X + lane_so;
+                if (valid && so < rb) __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(oc.df + (size_t)y * a.dstep + so));
+                if (valid && y + 1 < oc.ye && so < rb) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(oc.df + (size_t)(y + 1) * a.dstep + so));
+                if (++pi == pc.P) {
+                    pc = pend;
+                    pi = 0;
+                }
+            } else {
+                prepare((s + NP - 1) % RP);
+                if (valid) {   // (wave-uniform; the NP - 1 windows that straddle two items are skipped: no loads inside the branch)
+                    v4i acc[2][3];
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
+                    store_row(acc[0], y, true);
+                    store_row(acc[1], y + 1, y + 1 < oc.ye);
+                }
+            }
+            if (++oi == oc.P) {
+                if (pend.done) return;   // (rc found the list empty while oc was in this item: it was the wave's last one)
+                oc = pend;
+                oi = 0;
+            }
+        }
+    }
+}
+
 template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
 __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
 {
@@ -893,6 +1118,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).
     const int wpc = kn.fr_wpc > 0 ? (kn.fr_wpc > 12 ? 12 : kn.fr_wpc) : 10;
     const unsigned lds = kn.fr_wpc > 0 && wpc < 12 ? (unsigned)((163840 / wpc) & ~511) : 0u;
+    int small_plan = 0;
     // bands: the batch's frame-rows in equal parts, `rounds` x as many (band, strip) waves as the GPU holds (measured on 64 4K
     // frames: 4..16 rounds within 1-2 %, one round -- a static partition -- +20 %).  Each band boundary costs 2 * (ksize / 2)
     // halo rows of re-reads.
@@ -904,7 +1130,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         // launches of a few rounds: every SIMD the same number of equally long waves (rcv_plan_seg_rows with this kernel's own
         // figures: two waves per SIMD at most, a lone wave leaves its SIMD half idle; a band streams ksize - 1 halo rows and fills
         // its pipeline with a few more).  Whole bands per frame.
-        const int small = kn.fr_bpf > 0 ? 0 : rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 6, 2.3, 1.17, 2, 2);
+        const int small = small_plan = kn.fr_bpf > 0 ? 0 : rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 6, 2.3, 1.17, 2, 2);
         if (small > 0 || kn.fr_band_rows > 0) {
             const int br = kn.fr_band_rows > 0 ? kn.fr_band_rows : small;   // (knob: latency sweeps)
             nb = (long long)((s.rows + br - 1) / br) * s.n;
@@ -954,6 +1180,46 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     }
     a.shift = shift;
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
+    // Chained bands (k_filter_rows_chain): launches that fill the GPU, whole frames per XCD, the plain BGR instantiation.  Bands of
+    // ~chain_rows rows (at least 8: an item must hold more pairs than the ring), items = (band, strip) drawn from per-XCD ticket counters.
+    if (src_yuyv == 0 && !sob && dmask == 0 && (small_plan == 0 || kn.fr_chain == 1) && kn.fr_band_rows == 0 && kn.fr_chain != 0 && s.n >= 8 && s.n % 8 == 0 &&
+        s.rows >= 64) {
+        const int fpx = s.n / 8;
+        const int want_rows = kn.fr_chain_rows > 0 ? (kn.fr_chain_rows > 2048 ? 2048 : kn.fr_chain_rows) : 32;   // (bmul < 2^32)
+        int bpf = (s.rows + want_rows / 2) / want_rows;
+        bpf = bpf < 1 ? 1 : (bpf > s.rows / 8 ? s.rows / 8 : bpf);
+        const unsigned long long nitems = (unsigned long long)fpx * bpf * a.nstrips;
+        const int cwpc = kn.fr_wpc == 12 || kn.fr_wpc == 4 || kn.fr_wpc == 6 || kn.fr_wpc == 10 ? kn.fr_wpc : 8;   // (knob: waves per CU, sweeps)
+        const unsigned waves = (unsigned)(ctx->cu_count / 8 * cwpc);   // per XCD: cu_count / 8 CUs x 8 waves
+        if (nitems * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31)) {
+            a.ng = 0;
+            a.bpf = bpf;
+            a.fpx = fpx;
+            a.bmul = (unsigned)((((unsigned long long)s.rows << 20) + bpf - 1) / bpf);
+            a.inv_nstrips = ((1ull << 32) + a.nstrips - 1) / a.nstrips;
+            a.inv_bpf = ((1ull << 32) + bpf - 1) / bpf;
+            if (!ctx->fr_tickets_ready) {
+                RCV_HIP(hipMemsetAsync(ctx->kconst + RCV_KC_FR_TICKETS, 0, RCV_KC_FR_TICKETS_BYTES, ctx->stream));
+                for (int x = 0; x < 8; ++x) ctx->fr_ticket_base[x] = 0;
+                ctx->fr_tickets_ready = true;
+            }
+            a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS);
+            for (int x = 0; x < 8; ++x) {
+                a.tbase[x] = ctx->fr_ticket_base[x];
+                ctx->fr_ticket_base[x] += nitems + waves;   // what this launch draws from counter x: one ticket per item, one past the list per wave
+            }
+            const dim3 grid(8u * waves);
+            // EXACTLY 8 waves per CU, all resident from the start: the 7x7 instantiation's registers would let the dispatcher stack 12
+            // waves on some CUs and leave others short.  An untouched dynamic-LDS request of an eighth of the CU's 160 KB caps it.
+            const unsigned cap = (163840u / (unsigned)cwpc) & ~511u;
+            if (ksize == 7) {
+                if ((rcv_debug_flags & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
+                else RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+            } else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+            else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+            return rcv_launch_check(ctx);
+        }
+    }
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     a.wpb = kn.fr_wpb == 2 || kn.fr_wpb == 4 || kn.fr_wpb == 8 ? kn.fr_wpb : 1;
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)

@@ -12,13 +12,14 @@
 constexpr size_t RCV_KC_F7_TAB = 0, RCV_KC_F7_TAB_BYTES = 8192;          // strip kernel: 2 x 4 tables x 64 lanes x 16 B
 constexpr size_t RCV_KC_SOBEL_DUMP = 8192, RCV_KC_SOBEL_DUMP_BYTES = 4096;   // 256 lanes x 16 B
 constexpr size_t RCV_KC_F7_DUMP = 16384, RCV_KC_F7_DUMP_BYTES = 4096;    // strip kernel: 3 KiB
+constexpr size_t RCV_KC_FR_TICKETS = 20480, RCV_KC_FR_TICKETS_BYTES = 1024;   // chained row kernel: 8 ticket counters, one 128-byte line each
 constexpr size_t RCV_KC_FR_TAB = 32768, RCV_KC_FR_TAB_BYTES = 16384;     // row kernel: up to 2 x 2 x 4 tables x 1 KiB (two weight tables)
 constexpr size_t RCV_KC_BENCH = 49152, RCV_KC_BENCH_BYTES = 4096;        // rcv__membench read-only dump (256 threads x 16 B)
 constexpr size_t RCV_KC_PROBE = 57344, RCV_KC_PROBE_BYTES = 128;         // rcv__clock_probe: 8 x 2 counters
 constexpr size_t RCV_KC_FR_DUMP = 61440, RCV_KC_FR_DUMP_BYTES = 1024;    // row kernel: 64 lanes x 16 B
 constexpr size_t RCV_KC_BYTES = 65536;
 static_assert(RCV_KC_F7_TAB + RCV_KC_F7_TAB_BYTES <= RCV_KC_SOBEL_DUMP && RCV_KC_SOBEL_DUMP + RCV_KC_SOBEL_DUMP_BYTES <= RCV_KC_F7_DUMP &&
-              RCV_KC_F7_DUMP + RCV_KC_F7_DUMP_BYTES <= RCV_KC_FR_TAB && RCV_KC_FR_TAB + RCV_KC_FR_TAB_BYTES <= RCV_KC_BENCH &&
+              RCV_KC_F7_DUMP + RCV_KC_F7_DUMP_BYTES <= RCV_KC_FR_TICKETS && RCV_KC_FR_TICKETS + RCV_KC_FR_TICKETS_BYTES <= RCV_KC_FR_TAB && RCV_KC_FR_TAB + RCV_KC_FR_TAB_BYTES <= RCV_KC_BENCH &&
               RCV_KC_BENCH + RCV_KC_BENCH_BYTES <= RCV_KC_PROBE && RCV_KC_PROBE + RCV_KC_PROBE_BYTES <= RCV_KC_FR_DUMP &&
               RCV_KC_FR_DUMP + RCV_KC_FR_DUMP_BYTES <= RCV_KC_BYTES, "kconst regions overlap");
 
@@ -58,6 +59,8 @@ struct rcv_ctx {
         hipEvent_t uploaded;      // recorded behind the entry's last upload: its host copy may be rewritten once this has passed
         int8_t host[16384];
     } fr_tab[4];
+    bool fr_tickets_ready;        // the chained row kernel's ticket counters (kconst + RCV_KC_FR_TICKETS) have been zeroed
+    unsigned long long fr_ticket_base[8];   // ... and what they will read when the next launch starts (every launch draws a known number)
     uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
     unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
@@ -103,6 +106,8 @@ struct RcvKnobs {
     int fr_taper;         // RCV_FR_TAPER      0: equal bands; unset / 1: tapered tail of one round; n > 1: tail of n % of a round
     int fr_sob192;        // RCV_FR_SOB192     fused filter -> Sobel: 0 = 240-pixel strips with plain stores, 1 (default where the planes allow) = line-aligned 192-pixel strips, nt stores
     int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
+    int fr_chain;         // RCV_FR_CHAIN      0: never the chained-band kernel (k_filter_rows_chain); unset: launches that fill the GPU
+    int fr_chain_rows;    // RCV_FR_CHAIN_ROWS rows per chained band (0 = 32)
     int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
     int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
     int sobel_seg;        // RCV_SOBEL_SEG     rows per segment of the Sobel kernel (0 = plan)

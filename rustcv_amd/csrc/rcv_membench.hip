@@ -208,17 +208,21 @@ struct WalkArgs {
     uint8_t* dst;
     size_t step, fstride;
     int rows, nframes, nstrips, W, R, nbands, bands_per_xcd, halo, ntl;
+    int persist;   // ng > 0: ng band groups per XCD, wave (xcd, strip, g) walks bands g, g + ng, ... of its XCD itself (static, all waves resident)
+    int dup;       // 1: every byte is requested by two lanes (lane pairs share their 16 bytes: the MFMA kernel's overlapping windows), half the rows per request
 };
 template <int DEPTH>
 __global__ __launch_bounds__(64) void k_strip_walk(WalkArgs a)
 {
     const int lane = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3);
-    const int strip = slot % a.nstrips, bi = slot / a.nstrips;
-    if (bi >= a.bands_per_xcd) return;
+    const int strip = slot % a.nstrips;
+    int bi = slot / a.nstrips;
+    if (a.persist ? bi >= a.persist : bi >= a.bands_per_xcd) return;
+    const long long G = (long long)a.nframes * a.rows;
+  for (; bi < a.bands_per_xcd; bi += (a.persist ? a.persist : a.bands_per_xcd)) {
     const int band = xcd * a.bands_per_xcd + bi;
     if (band >= a.nbands) return;
-    const long long G = (long long)a.nframes * a.rows;
     long long g0 = G * band / a.nbands;
     const long long g1 = G * (band + 1) / a.nbands;
     const int spr = a.W >> 4;   // 16-byte slots per strip-row
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64) void k_strip_walk(WalkArgs a)
     int rowj[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int sidx = lane + 64 * j;
+        const int sidx = a.dup ? (lane >> 1) + 32 * j : lane + 64 * j;
         rowj[j] = sidx / spr;
         off[j] = (size_t)rowj[j] * a.step + (size_t)(sidx % spr) * 16 + (size_t)strip * a.W;
     }
@@ -260,12 +264,13 @@ __global__ __launch_bounds__(64) void k_strip_walk(WalkArgs a)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int y = yb + rowj[j];
-                    if (y >= ys && y < ye) __builtin_nontemporal_store(v[s][j], (u4v*)(df + (size_t)yb * a.step + off[j]));
+                    if (y >= ys && y < ye && !(a.dup && (lane & 1))) __builtin_nontemporal_store(v[s][j], (u4v*)(df + (size_t)yb * a.step + off[j]));
                 }
             }
         }
         g0 += ye - ys;
     }
+  }
 }
 
 __global__ __launch_bounds__(64) void k_nop(int* p)
@@ -346,10 +351,11 @@ extern "C" int rcv__storebench(rcv_ctx* ctx, void* p0, void* p1, int n, int rows
 // W % 16 == 0), `depth` requests of 3072 bytes in flight per wave (1, 2, 4), `rounds` bands per wave slot, wpc waves per CU (<= 8 ... 32),
 // halo rows re-read per band, nt loads or plain.  Asynchronous on the context's stream.
 extern "C" int rcv__stripwalk(rcv_ctx* ctx, void* dst, const void* src, int n, int rows, int row_bytes, size_t step, int W, int depth, int rounds, int wpc,
-                              int halo, int nt_loads)
+                              int halo, int flags)
 {
+    const int nt_loads = flags & 1, persist = (flags >> 1) & 1, dup = (flags >> 2) & 1;
     RCV_TRY(rcv_bind(ctx));
-    if (!dst || !src || n < 1 || rows < 1 || W < 16 || W % 16 || 3072 % W || row_bytes % W || step % 16 || rounds < 1 || wpc < 1 || wpc > 32) return RCV_ERR_ARG;
+    if (!dst || !src || n < 1 || rows < 1 || W < 16 || W % 16 || 1536 % W || row_bytes % W || step % 16 || rounds < 1 || wpc < 1 || wpc > 32) return RCV_ERR_ARG;
     WalkArgs a;
     a.src = (const uint8_t*)src;
     a.dst = (uint8_t*)dst;
@@ -358,7 +364,8 @@ extern "C" int rcv__stripwalk(rcv_ctx* ctx, void* dst, const void* src, int n, i
     a.rows = rows;
     a.nframes = n;
     a.W = W;
-    a.R = 3072 / W;
+    a.R = (dup ? 1536 : 3072) / W;
+    a.dup = dup;
     a.nstrips = row_bytes / W;
     a.halo = halo;
     a.ntl = nt_loads;
@@ -372,7 +379,9 @@ extern "C" int rcv__stripwalk(rcv_ctx* ctx, void* dst, const void* src, int n, i
     nb = nb < 8 ? 8 : nb;
     a.nbands = (int)nb;
     a.bands_per_xcd = (int)((nb + 7) / 8);
-    const dim3 grid((unsigned)((long long)a.bands_per_xcd * a.nstrips * 8));
+    a.persist = persist ? (int)(slots / 8 / a.nstrips) : 0;
+    if (persist && a.persist < 1) return RCV_ERR_ARG;
+    const dim3 grid((unsigned)((long long)(persist ? a.persist : a.bands_per_xcd) * a.nstrips * 8));
     const unsigned lds = wpc < 32 ? (unsigned)((163840 / wpc) & ~511) : 0u;
     if (lds > 65536u) {
         static bool once = false;

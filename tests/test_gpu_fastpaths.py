@@ -55,8 +55,8 @@ def test_fast_kernels_are_dispatched(ctx):
     M = np.array([0.9925, -0.1219, 300.0, 0.1219, 0.9925, -200.0], np.float32)
     # (name, call, substring of the kernel that must have been launched)
     cases = [
-        ("filter2D 7x7 BGR, 8 x 4K (row-streaming MFMA kernel)", lambda: device.filter2d(bgr, bgr2, k7, shift=6), "k_filter_rows_mfma<"),
-        ("GaussianBlur 5x5 int BGR, 8 x 4K (row-streaming MFMA kernel)", lambda: device.gaussian_blur(bgr, bgr2, 5, 0.0), "k_filter_rows_mfma<"),
+        ("filter2D 7x7 BGR, 8 x 4K (row-streaming MFMA kernel, chained bands)", lambda: device.filter2d(bgr, bgr2, k7, shift=6), "k_filter_rows_chain<7"),
+        ("GaussianBlur 5x5 int BGR, 8 x 4K (row-streaming MFMA kernel, chained bands)", lambda: device.gaussian_blur(bgr, bgr2, 5, 0.0), "k_filter_rows_chain<5"),
         ("filter2D 7x7 BGR, one 1080p frame (strip kernel, latency variant)", lambda: device.filter2d(one, one2, k7, shift=6), "k_filter7_mfma<0, 0, 0, true>"),
         ("filter2D 7x7 gray, 16 x 4K (row-streaming kernel, gray variant)", lambda: device.filter2d(gray16, gray16b, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 2>"),
         ("filter2D 7x7 gray, 8 x 4K (row-streaming kernel, gray variant, per-SIMD band plan)", lambda: device.filter2d(gray, gray2, k7, shift=6), "k_filter_rows_mfma<KS, 3, 0, 0, 2>"),
@@ -145,7 +145,11 @@ def test_row_streaming_kernel_by_size(ctx, knob):
     small_s, small_d = device.DeviceBatch(ctx, 1, 480, 640, 3), device.DeviceBatch(ctx, 1, 480, 640, 3)
     device.synth(big_s, 0, 1, 0)
     device.synth(small_s, 0, 2, 0)
+    assert "k_filter_rows_chain<" in _kernels_of(ctx, lambda: device.filter2d(big_s, big_d, k7, shift=6))   # (whole frames per XCD: chained bands)
+    c = big_d.download().copy()
+    knob("RCV_FR_CHAIN", 0)
     assert "k_filter_rows_mfma<" in _kernels_of(ctx, lambda: device.filter2d(big_s, big_d, k7, shift=6))
+    assert np.array_equal(c, big_d.download())
     assert "k_filter7_mfma<" in _kernels_of(ctx, lambda: device.filter2d(small_s, small_d, k7, shift=6))
     a = big_d.download().copy()
     knob("RCV_F7_ROWS", 0)

@@ -454,6 +454,53 @@ def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, taper)
         b.free()
 
 
+CHAIN_SHAPES = [(8, 64, 256), (8, 70, 272), (8, 97, 1084), (16, 131, 1040), (8, 200, 3840), (24, 66, 16), (8, 65, 772)]
+
+
+@pytest.mark.parametrize("n,rows,cols", CHAIN_SHAPES)
+@pytest.mark.parametrize("band_rows", [0, 8, 13])
+def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
+    """round 4: k_filter_rows_chain -- persistent waves that walk SHORT bands of their strip back to back through one register ring (the
+    next band's rows, halo included, are in flight while the last rows of the current one are computed; the steps whose window straddles
+    two bands store nothing).  Whole frames per XCD (n % 8 == 0); band heights 8 / 13 / 32 rows incl. odd heights and a last band that is
+    shorter; one strip, a partial last strip, widths with every residue of 4 mod 16; padded steps / frame strides with canaries; every
+    frame of the batch against the oracle for ksize 3 / 5 / 7 and the integer Gaussian 5x5 (the same launch path)."""
+    knob("RCV_FR_CHAIN", 1)
+    knob("RCV_F7_ROWS", 1)
+    knob("RCV_GAUSS_ROWS", 0)     # (small Gaussian launches would take the register-window kernel)
+    if band_rows:
+        knob("RCV_FR_CHAIN_ROWS", band_rows)
+    r = np.random.default_rng(9000 + 31 * rows + cols + band_rows + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    frames[1, : rows // 2] = 255
+    frames[2, :, : min(cols, 40)] = 0
+    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 16, frame_stride=rows * (cols * 3 + 16) + 64)
+    src.upload(frames)
+    L = _ffi.lib()
+    for ks, sh in ((7, 6), (5, 3), (3, 0)):
+        k = r.integers(-9, 10, size=(ks, ks)).astype(np.int8) if sh else r.integers(-128, 128, size=(ks, ks), dtype=np.int8)
+        dst = _canary_batch(ctx, n, rows, cols, 3, pad=32)
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, dst, k, shift=sh)
+        assert f"k_filter_rows_chain<{ks}" in L.rcv__debug_kernels().decode(), L.rcv__debug_kernels().decode()
+        got = dst.download()
+        for i in range(n):
+            want = oracle.filter2d_i8(frames[i], k, sh)
+            assert np.array_equal(got[i], want), (ks, i, np.argwhere(got[i] != want)[:4])
+        _assert_canaries(dst)
+        dst.free()
+    dst = _canary_batch(ctx, n, rows, cols, 3, pad=32)
+    L.rcv__debug_kernels_reset()
+    device.gaussian_blur(src, dst, 5, 0.0)
+    assert "k_filter_rows_chain<5" in L.rcv__debug_kernels().decode()
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.gaussian_blur(frames[i], 5, 0.0)), ("gauss", i)
+    _assert_canaries(dst)
+    dst.free()
+    src.free()
+
+
 def test_row_kernel_weight_table_cache(ctx, oracle, knob):
     """round 3: the row-streaming kernel caches the banded weight tables of FOUR kernels per context and uploads a
     new one stream-ordered without synchronising; a caller cycling through six kernels (more than the cache holds: entries are

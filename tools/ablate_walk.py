@@ -42,7 +42,7 @@ def main():
 
     # ---- F batches in flight ----
     inflight = {}
-    for F in (1, 2, 3, 4):
+    for F in (1, 2):
         g = multigpu.NativeGroup.in_flight(0, F)
         bufs = []
         for j in range(F):
@@ -112,21 +112,16 @@ def main():
 
     variants = [("filter (k_filter_rows_mfma)", filt), ("filter memory-only", "memonly"), ("copy sweep U=2 nt g=512", copy(21, 512)),
                 ("copy 2-region sweep", copy(40, 512 | (2 << 16)))]
-    for W in (768, 384, 256, 192, 128):
-        variants.append((f"walk W={W} depth=2 wpc=8 rounds=8 halo=6", walker(W, 2, 8, 8, 6)))
-    variants += [("walk W=768 depth=2 wpc=8 rounds=8 halo=0", walker(768, 2, 8, 8, 0)),
-                 ("walk W=768 depth=4 wpc=8 rounds=8 halo=6", walker(768, 4, 8, 8, 6)),
-                 ("walk W=384 depth=4 wpc=8 rounds=8 halo=6", walker(384, 4, 8, 8, 6)),
-                 ("walk W=384 depth=1 wpc=8 rounds=8 halo=6", walker(384, 1, 8, 8, 6)),
-                 ("walk W=768 depth=1 wpc=16 rounds=8 halo=6", walker(768, 1, 16, 8, 6)),
-                 ("walk W=384 depth=2 wpc=16 rounds=8 halo=6", walker(384, 2, 16, 8, 6)),
-                 ("walk W=384 depth=2 wpc=4 rounds=8 halo=6", walker(384, 2, 4, 8, 6)),
-                 ("walk W=768 depth=2 wpc=4 rounds=8 halo=6", walker(768, 2, 4, 8, 6)),
-                 ("walk W=384 depth=2 wpc=8 rounds=4 halo=6", walker(384, 2, 8, 4, 6)),
-                 ("walk W=384 depth=2 wpc=8 rounds=16 halo=6", walker(384, 2, 8, 16, 6)),
-                 ("walk W=256 depth=2 wpc=8 rounds=16 halo=6", walker(256, 2, 8, 16, 6)),
-                 ("walk W=768 depth=2 wpc=8 rounds=8 halo=6 nt loads", walker(768, 2, 8, 8, 6, 1)),
-                 ("walk W=384 depth=2 wpc=8 rounds=8 halo=6 nt loads", walker(384, 2, 8, 8, 6, 1))]
+    for W in (768, 384, 256, 128):
+        for rounds in (8, 16, 32):
+            variants.append((f"walk W={W} depth=2 wpc=8 rounds={rounds} halo=6", walker(W, 2, 8, rounds, 6)))
+    variants += [("walk W=768 depth=4 wpc=8 rounds=16 halo=6", walker(768, 4, 8, 16, 6)),
+                 ("walk W=384 depth=4 wpc=8 rounds=16 halo=6", walker(384, 4, 8, 16, 6)),
+                 ("walk W=384 depth=1 wpc=8 rounds=16 halo=6", walker(384, 1, 8, 16, 6)),
+                 ("walk W=384 depth=2 wpc=12 rounds=16 halo=6", walker(384, 2, 12, 16, 6)),
+                 ("walk W=384 depth=2 wpc=6 rounds=16 halo=6", walker(384, 2, 6, 16, 6)),
+                 ("walk W=256 depth=2 wpc=12 rounds=16 halo=6", walker(256, 2, 12, 16, 6)),
+                 ("walk W=768 depth=2 wpc=8 rounds=16 halo=0", walker(768, 2, 8, 16, 0))]
     res = {name: [] for name, _ in variants}
     for r in range(a.rot):
         for name, fn in variants:
