@@ -82,9 +82,10 @@ struct FRArgs {
     // the ng band groups per XCD takes bands g, g + ng, g + 2 ng, ... of its XCD's list, one after the other, in ONE pipeline
     int ng, bpf, fpx;
     unsigned bmul;               // ceil(rows * 2^20 / bpf): band j of a frame = rows [(j * bmul) >> 20, ((j + 1) * bmul) >> 20)
-    unsigned long long inv_nstrips, inv_bpf;   // ceil(2^32 / nstrips), ceil(2^32 / bpf): exact quotients for the item counts of a launch
-    unsigned long long* tickets;     // 8 counters, 16 x 8 bytes apart (one 128-byte line each)
-    unsigned long long tbase[8];     // their values when this launch starts
+    int n_edge, edge_waves;          // strips whose windows stick out of the row (the first + the last one or two); waves per XCD that start on them
+    unsigned long long inv_edge, inv_int, inv_bpf;   // ceil(2^32 / n_edge), ceil(2^32 / (nstrips - n_edge)), ceil(2^32 / bpf): exact quotients for a launch's item counts
+    unsigned long long* tickets;     // 16 counters (XCD x {interior, edge}), 16 x 8 bytes apart (one 128-byte line each)
+    unsigned long long tbase[16];    // their values when this launch starts
 };
 
 // packed i16 arithmetic on two pixels (the Sobel stage of the SOB instantiation; same forms as rcv_harris_fused.hip)
@@ -571,39 +572,34 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 // Tickets: one 64-bit counter per XCD (ctx->kconst + RCV_KC_FR_TICKETS, 128 bytes apart), never reset: a launch hands its base
 // values over (tbase) and consumes exactly items + waves tickets per XCD (a wave draws one ticket ahead and ends on its first
 // ticket past the list), which the host adds up.
-struct FRItem {
+struct FRItem {                // (all scalar)
     int X;                     // byte offset of the strip in a destination row
-    int ys, ye, P;             // rows [ys, ye) of the frame, P = ceil(rows / 2) + NP - 1 pairs
-    bool edge, done;
+    int ys, nrows, P;          // rows [ys, ys + nrows) of the frame, P = ceil(nrows / 2) + NP - 1 pairs
+    bool interior, done;       // no source row of the item needs mirroring; past the end of the list
     const uint8_t* sf;
     uint8_t* df;
 };
 
-template <int KS, int PP, int DBG>
-__global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
+// One queue of one XCD: the (band, strip) items of the EDGE strips (the first strip of a row and the last one or two, whose windows
+// stick out of the row) or of the interior strips, band-major.  EDGE is a compile-time property of the loop -- the border repair
+// and the masked stores exist in the edge loop only -- so a wave runs the loop of its own kind until that queue is empty and then
+// helps with the other one (kernel below).  Returns when the queue is empty.
+template <int KS, int PP, bool EDGE, int DBG>
+__device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, const int xcd, const v4i (&A)[2][(KS + 1) / 2], const v4i& initv)
 {
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;
-    const int lane = threadIdx.x;
-    const int xcd = blockIdx.x & 7;
     const int n = lane & 15, q = lane >> 4, h = q >> 1, c = q & 1;
     const int rb = a.cols * 3;
     const int lane_cb = 48 * n - 12 + 48 * c, lane_so = 48 * n + 12 * q;
     const int rv = ((a.cols & 15) + 4) & 15;
-    const unsigned nitems = (unsigned)(a.fpx * a.bpf * a.nstrips);   // of this XCD
-    unsigned long long* const tick = a.tickets + 16 * xcd;
-    const unsigned long long tbase = a.tbase[xcd];
-
-    v4i A[2][NP];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
-            A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
-        }
-    v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
-    asm volatile("" : "+v"(initv));
+    const unsigned sstep = (unsigned)a.sstep, dstep = (unsigned)a.dstep;   // (in-frame offsets are 32-bit: host check)
+    const int kstrips = EDGE ? a.n_edge : a.nstrips - a.n_edge;            // strips of this kind
+    const unsigned nitems = (unsigned)(a.fpx * a.bpf * kstrips);           // of this XCD and kind
+    if (nitems == 0) return;
+    unsigned long long* const tick = a.tickets + 16 * (2 * xcd + (EDGE ? 1 : 0));
+    const unsigned long long tbase = a.tbase[2 * xcd + (EDGE ? 1 : 0)];
+    const unsigned long long inv_k = EDGE ? a.inv_edge : a.inv_int;
 
     // A ticket is drawn with a SCALAR atomic (s_atomic_add_x2, returns the old value): its latency is counted by lgkmcnt, which
     // nothing else in the loop uses, so waiting for it on the spot stalls this wave's issue for one L2 round trip per item (the other
@@ -615,53 +611,101 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
         asm volatile("s_atomic_add_x2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tick) : "memory");
         return (unsigned)(t - tbase);   // items per launch < 2^31 (host check)
     };
-    auto make_item = [&](unsigned li, FRItem& it) {   // (scalar) item li of this XCD's list: band-major, strips of a band neighbours
+    auto make_item = [&](unsigned li, FRItem& it) {   // item li of this queue: band-major, the strips of a band neighbours
         if (li >= nitems) {
             it.done = true;
             return;
         }
-        const unsigned band = (unsigned)(((unsigned long long)li * a.inv_nstrips) >> 32);
-        const unsigned strip = li - band * (unsigned)a.nstrips;
+        const unsigned band = (unsigned)(((unsigned long long)li * inv_k) >> 32);
+        const unsigned ks = li - band * (unsigned)kstrips;
         const unsigned f = (unsigned)(((unsigned long long)band * a.inv_bpf) >> 32);
         const unsigned j = band - f * (unsigned)a.bpf;
         const int frame = xcd * a.fpx + (int)f;
-        it.X = (int)strip * 768;
-        it.edge = it.X == 0 || it.X + 804 > rb;
+        // edge strips: 0, then the trailing ones; interior strips: 1 .. nstrips - n_edge
+        const int strip = EDGE ? (ks == 0 ? 0 : a.nstrips - a.n_edge + (int)ks) : 1 + (int)ks;
+        it.X = strip * 768;
         it.ys = (int)(((unsigned long long)j * a.bmul) >> 20);
-        it.ye = (int)(((unsigned long long)(j + 1) * a.bmul) >> 20);
-        it.P = (it.ye - it.ys + 1) / 2 + NP - 1;
+        it.nrows = (int)(((unsigned long long)(j + 1) * a.bmul) >> 20) - it.ys;
+        it.P = (it.nrows + 1) / 2 + NP - 1;
+        it.interior = it.ys >= RAD && it.ys + it.nrows + RAD + 1 <= a.rows;   // (+ 1: an odd band's last pair holds one row more)
         it.sf = a.src + (size_t)frame * a.sfs;
         it.df = a.dst + (size_t)frame * a.dfs;
         it.done = false;
     };
 
-    // cursors: rc requests, pc prepares, oc computes / stores; `pend` is the item rc entered last (pc and oc follow within RP - 1 < P steps)
-    FRItem rc, pc, oc, pend;
-    int ri = 0, pi = 0, oi = 0;
-    rc.X = 0; rc.ys = 0; rc.ye = 0; rc.P = 1; rc.edge = false; rc.done = false; rc.sf = a.src; rc.df = a.dst;
-    make_item(draw(), rc);
-    if (rc.done) return;
-    pend = pc = oc = rc;                 // (every wave draws its items + 1 tickets: the host's accounting)
+    // Three cursors over the same item sequence: rc requests row pairs, pc prepares operands, oc computes / stores.  `pend` is the item
+    // rc entered last; pc and oc take it over when they reach the end of theirs (they follow within RP - 1 < P steps).  Per cursor,
+    // what the hot loop needs is kept as running values: a scalar row offset advanced per step and the lane's column offset as a
+    // register set once per item.
+    FRItem pend;
+    pend.X = 0; pend.ys = 0; pend.nrows = 0; pend.P = 1; pend.interior = false; pend.done = false; pend.sf = a.src; pend.df = a.dst;
+    make_item(draw(), pend);
+    if (pend.done) return;               // (every wave draws its items + 1 tickets of every queue it visits: the host's accounting)
+
+    // request cursor
+    const uint8_t* r_sf;
+    int ri, r_P, r_y;                    // pair ri of r_P; r_y = first row of the pair (may lie outside the frame: mirrored)
+    int r_last;                          // the item's last source row (ys + nrows - 1 + RAD): rows past it re-read it
+    unsigned r_off;                      // (interior items) r_y * sstep
+    bool r_int, r_done = false;
+    unsigned r_cb;                       // lane: clamped chunk offset
+    auto enter_rc = [&]() {
+        r_sf = pend.sf; ri = 0; r_P = pend.P; r_y = pend.ys - RAD; r_last = pend.ys + pend.nrows - 1 + RAD; r_int = pend.interior;
+        r_off = (unsigned)r_y * sstep;
+        // (EDGE: chunks that stick out of the row are read shifted into it)
+        r_cb = EDGE ? (unsigned)min(max(pend.X + lane_cb, 0), rb - 48) : (unsigned)(pend.X + lane_cb);
+    };
+    // prepare cursor
+    int pi, p_P;
+    bool p_fl = false, p_fr = false;
+    auto enter_pc = [&]() {
+        pi = 0; p_P = pend.P;
+        if (EDGE) {
+            const int cb = pend.X + lane_cb;
+            p_fl = cb < 0;
+            p_fr = cb == rb - rv * 3;
+        }
+    };
+    // output cursor
+    uint8_t* o_df;
+    int oi, o_P, o_nrows;
+    unsigned o_off;                      // row offset of the step's first output row
+    unsigned o_so;                       // lane: byte offset in the row
+    bool o_in = true;                    // lane: inside the row (a partial last strip)
+    auto enter_oc = [&]() {
+        o_df = pend.df; oi = 0; o_P = pend.P; o_nrows = pend.nrows; o_off = (unsigned)pend.ys * dstep;
+        o_so = (unsigned)(pend.X + lane_so);
+        if (EDGE) o_in = (int)o_so < rb;
+    };
+    enter_rc();
+    enter_pc();
+    enter_oc();
 
     v4i W[RP][3];
     auto request = [&](int slot) {
         v4i(&dst)[3] = W[slot];
-        const int y0 = min(rc.ys - RAD + 2 * ri, rc.ye - 1 + RAD), y1 = min(rc.ys - RAD + 2 * ri + 1, rc.ye - 1 + RAD);
-        const int s0 = y0 < 0 ? -y0 : (y0 >= a.rows ? 2 * a.rows - 2 - y0 : y0), s1 = y1 < 0 ? -y1 : (y1 >= a.rows ? 2 * a.rows - 2 - y1 : y1);
-        const unsigned o0 = (unsigned)s0 * (unsigned)a.sstep, o1 = (unsigned)s1 * (unsigned)a.sstep;   // < 2^32 (host check)
-        const unsigned cbo = (unsigned)min(max(rc.X + lane_cb, 0), rb - 48);   // chunks that stick out of the row are read shifted into it
-        const unsigned off = (h ? o1 : o0) + cbo;
-        dst[0] = *(const v4i*)(rc.sf + off);
-        dst[1] = *(const v4i*)(rc.sf + off + 16);
-        dst[2] = *(const v4i*)(rc.sf + off + 32);
-        if (++ri == rc.P) {
-            if (!rc.done) make_item(draw(), pend);   // next item
-            if (pend.done) {                          // past the last one: keep re-reading its last pair (cache hits, never used)
-                rc.done = true;
-                ri = rc.P - 1;
+        unsigned off;
+        if (r_int) {
+            off = r_off + (h ? sstep : 0u) + r_cb;
+        } else {   // items at the top / bottom of a frame: mirrored row indices (BORDER_REFLECT_101)
+            const int y0 = min(r_y, r_last), y1 = min(r_y + 1, r_last);
+            const int s0 = y0 < 0 ? -y0 : (y0 >= a.rows ? 2 * a.rows - 2 - y0 : y0), s1 = y1 < 0 ? -y1 : (y1 >= a.rows ? 2 * a.rows - 2 - y1 : y1);
+            off = (h ? (unsigned)s1 * sstep : (unsigned)s0 * sstep) + r_cb;
+        }
+        dst[0] = *(const v4i*)(r_sf + off);
+        dst[1] = *(const v4i*)(r_sf + off + 16);
+        dst[2] = *(const v4i*)(r_sf + off + 32);
+        r_y += 2;
+        r_off += 2 * sstep;
+        if (++ri == r_P) {
+            if (!r_done) make_item(draw(), pend);   // next item
+            if (pend.done) {                         // past the last one: keep re-reading its last pair (cache hits, never used)
+                r_done = true;
+                ri = r_P - 1;
+                r_y -= 2;
+                r_off -= 2 * sstep;
             } else {
-                rc = pend;
-                ri = 0;
+                enter_rc();
             }
         }
     };
@@ -672,10 +716,8 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
                                 (uint32_t)w[1][2], (uint32_t)w[1][3], (uint32_t)w[2][0], (uint32_t)w[2][1], (uint32_t)w[2][2], (uint32_t)w[2][3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) deint4w(r[3 * i], r[3 * i + 1], r[3 * i + 2], pb[i], pg[i], prr[i]);
-        if (pc.edge) {   // (wave-uniform) first / last strip of the row
-            const int cb = pc.X + lane_cb;
-            const bool fl = cb < 0, fr = cb == rb - rv * 3;
-            if (fl) {   // the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
+        if (EDGE) {
+            if (p_fl) {   // the lane read pixels 0..15 instead of -4..11: shift by one dword; pixels -3..-1 mirror 3, 2, 1
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
@@ -685,7 +727,7 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
                     pp[0] = __builtin_amdgcn_perm(pp[0], pp[0], 0x01020300u);
                 }
             }
-            if (fr) {   // the lane read pixels cols-16..cols-1 instead of cols-rv..: its rv valid pixels move to the front, then the mirror
+            if (p_fr) {   // the lane read pixels cols-16..cols-1 instead of cols-rv..: its rv valid pixels move to the front, then the mirror
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     uint32_t* pp = pl == 0 ? pb : (pl == 1 ? pg : prr);
@@ -711,64 +753,86 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
         w[0] = v4i{(int)(pb[0] ^ 0x80808080u), (int)(pb[1] ^ 0x80808080u), (int)(pb[2] ^ 0x80808080u), (int)(pb[3] ^ 0x80808080u)};
         w[1] = v4i{(int)(pg[0] ^ 0x80808080u), (int)(pg[1] ^ 0x80808080u), (int)(pg[2] ^ 0x80808080u), (int)(pg[3] ^ 0x80808080u)};
         w[2] = v4i{(int)(prr[0] ^ 0x80808080u), (int)(prr[1] ^ 0x80808080u), (int)(prr[2] ^ 0x80808080u), (int)(prr[3] ^ 0x80808080u)};
-        if (++pi == pc.P) {
-            pc = pend;
-            pi = 0;
-        }
     };
-    auto store_row = [&](const v4i(&acc)[3], int y, bool ok) {
+    auto store_row = [&](const v4i(&acc)[3], unsigned roff, bool ok) {
         U3w o;
         o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
         o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
         o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
-        const int so = oc.X + lane_so;
-        // non-temporal: the launch never reads its output back; windows past the row end (a partial last strip) are masked off
-        if (ok && so < rb) __builtin_nontemporal_store(v3i{(int)o.a, (int)o.b, (int)o.c}, (v3i*)(oc.df + (size_t)y * a.dstep + so));
+        // non-temporal: the launch never reads its output back; (EDGE) windows past the row end (a partial last strip) are masked off
+        if (ok && o_in) __builtin_nontemporal_store(v3i{(int)o.a, (int)o.b, (int)o.c}, (v3i*)(o_df + (size_t)(roff + o_so)));
     };
 
 #pragma unroll
     for (int i = 0; i < RP - 1; ++i) request(i);
 #pragma unroll
-    for (int i = 0; i < NP - 1; ++i) prepare(i);
+    for (int i = 0; i < NP - 1; ++i) {
+        prepare(i);
+        ++pi;
+    }
 
     for (;;) {
 #pragma unroll
         for (int s = 0; s < RP; ++s) {
             request((s + RP - 1) % RP);
-            const bool valid = oi <= oc.P - NP;          // the window's NP pairs belong to one item
-            const int y = oc.ys + 2 * oi;
+            const bool valid = oi <= o_P - NP;          // the window's NP pairs belong to one item
+            const bool two = 2 * oi + 1 < o_nrows;      // ... and its second output row exists (odd band heights)
             if constexpr ((DBG & 256) != 0) {
                 // the chain's memory pattern alone: its loads, and its stores fed with loaded bytes
                 const v4i& w0 = W[s % RP][0];
                 const v4i& w1 = W[s % RP][1];
-                const int so = oc.X + lane_so;
-                if (valid && so < rb) __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(oc.df + (size_t)y * a.dstep + so));
-                if (valid && y + 1 < oc.ye && so < rb) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(oc.df + (size_t)(y + 1) * a.dstep + so));
-                if (++pi == pc.P) {
-                    pc = pend;
-                    pi = 0;
-                }
-            } else {
+                if (valid && o_in) __builtin_nontemporal_store(v3i{w0[0], w0[1], w0[2]}, (v3i*)(o_df + (size_t)(o_off + o_so)));
+                if (valid && two && o_in) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(o_df + (size_t)(o_off + dstep + o_so)));
+            } else if (valid) {   // (wave-uniform)
                 prepare((s + NP - 1) % RP);
-                if (valid) {   // (wave-uniform; the NP - 1 windows that straddle two items are skipped: no loads inside the branch)
-                    v4i acc[2][3];
+                v4i acc[2][3];
 #pragma unroll
-                    for (int par = 0; par < 2; ++par)
+                for (int par = 0; par < 2; ++par)
 #pragma unroll
-                        for (int p = 0; p < NP; ++p)
+                    for (int p = 0; p < NP; ++p)
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl)
-                                acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
-                    store_row(acc[0], y, true);
-                    store_row(acc[1], y + 1, y + 1 < oc.ye);
-                }
+                        for (int pl = 0; pl < 3; ++pl)
+                            acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
+                store_row(acc[0], o_off, true);
+                store_row(acc[1], o_off + dstep, two);
+            } else {              // the NP - 1 windows that straddle two items: operands only
+                prepare((s + NP - 1) % RP);
             }
-            if (++oi == oc.P) {
+            o_off += 2 * dstep;
+            if (++pi == p_P) enter_pc();
+            if (++oi == o_P) {
                 if (pend.done) return;   // (rc found the list empty while oc was in this item: it was the wave's last one)
-                oc = pend;
-                oi = 0;
+                enter_oc();
             }
         }
+    }
+}
+
+template <int KS, int PP, int DBG>
+__global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
+{
+    constexpr int NP = (KS + 1) / 2;
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7;
+    const int slot = (int)(blockIdx.x >> 3);   // of this XCD
+    v4i A[2][NP];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
+            A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+        }
+    v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
+    asm volatile("" : "+v"(initv));
+    // the first edge_waves slots of every XCD start on the edge queue (their share of the work, a little more because they are the
+    // slower kind), the others on the interior queue; whoever finds its queue empty helps with the other one
+    bool edge = slot < a.edge_waves;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {   // (one copy of each loop in the binary)
+        if (edge) fr_chain_run<KS, PP, true, DBG>(a, lane, xcd, A, initv);
+        else fr_chain_run<KS, PP, false, DBG>(a, lane, xcd, A, initv);
+        edge = !edge;
     }
 }
 
@@ -1191,22 +1255,40 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         const unsigned long long nitems = (unsigned long long)fpx * bpf * a.nstrips;
         const int cwpc = kn.fr_wpc == 12 || kn.fr_wpc == 4 || kn.fr_wpc == 6 || kn.fr_wpc == 10 ? kn.fr_wpc : 8;   // (knob: waves per CU, sweeps)
         const unsigned waves = (unsigned)(ctx->cu_count / 8 * cwpc);   // per XCD: cu_count / 8 CUs x 8 waves
-        if (nitems * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31)) {
+        if (nitems * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31) &&
+            (unsigned long long)s.rows * d.step < (1ull << 32)) {
             a.ng = 0;
             a.bpf = bpf;
             a.fpx = fpx;
             a.bmul = (unsigned)((((unsigned long long)s.rows << 20) + bpf - 1) / bpf);
-            a.inv_nstrips = ((1ull << 32) + a.nstrips - 1) / a.nstrips;
+            // edge strips: strip 0 and every strip whose last window reaches past the row (the last one; the last two when the row ends
+            // within 36 bytes of a strip seam)
+            int n_edge = 0;
+            for (int st = 0; st < a.nstrips; ++st)
+                if (st == 0 || (long long)st * 768 + 804 > rb) ++n_edge;
+            const int n_int = a.nstrips - n_edge;
+            a.n_edge = n_edge;
+            a.inv_edge = ((1ull << 32) + n_edge - 1) / n_edge;
+            a.inv_int = n_int > 0 ? ((1ull << 32) + n_int - 1) / n_int : 0;
             a.inv_bpf = ((1ull << 32) + bpf - 1) / bpf;
+            // waves that start on the edge queue: its share of the strips, weighted 1.15 (border repair, masked stores)
+            {
+                const double wgt = kn.fr_rounds > 0 ? kn.fr_rounds / 100.0 : 1.15;   // (sweep: RCV_FR_ROUNDS = weight in %)
+                const double share = wgt * n_edge / (wgt * n_edge + n_int);
+                int ew = (int)(share * waves + 0.5);
+                a.edge_waves = n_int == 0 ? (int)waves : (ew < 1 ? 1 : ew);
+            }
             if (!ctx->fr_tickets_ready) {
                 RCV_HIP(hipMemsetAsync(ctx->kconst + RCV_KC_FR_TICKETS, 0, RCV_KC_FR_TICKETS_BYTES, ctx->stream));
-                for (int x = 0; x < 8; ++x) ctx->fr_ticket_base[x] = 0;
+                for (int x = 0; x < 16; ++x) ctx->fr_ticket_base[x] = 0;
                 ctx->fr_tickets_ready = true;
             }
             a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS);
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < 16; ++x) {
+                const unsigned long long items = (unsigned long long)fpx * bpf * ((x & 1) ? n_edge : n_int);
                 a.tbase[x] = ctx->fr_ticket_base[x];
-                ctx->fr_ticket_base[x] += nitems + waves;   // what this launch draws from counter x: one ticket per item, one past the list per wave
+                // what this launch draws from the counter: one ticket per item and one past the list per wave (a queue without items is never drawn from)
+                if (items) ctx->fr_ticket_base[x] += items + waves;
             }
             const dim3 grid(8u * waves);
             // EXACTLY 8 waves per CU, all resident from the start: the 7x7 instantiation's registers would let the dispatcher stack 12

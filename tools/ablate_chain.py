@@ -47,7 +47,7 @@ def main():
         assert rc == 0, rc
 
     res = {}
-    heights = (20, 24, 28, 32, 36, 40, 64)
+    heights = (24, 32, 40, 64)
     for r in range(3):
         os.environ["RCV_FR_CHAIN"] = "0"
         L.rcv__debug_reload_knobs()
