@@ -376,18 +376,17 @@ def run_rank(a, rank, world, device, fence, torch):
                 best, best_name = gbs, name
         res["copy_ceiling_gbs"] = best
         res["copy_ceiling_kernel"] = best_name
-        # the memory-only variant is selected by a PROCESS-WIDE flag: in the one-process form no rank may flip it while another one
-        # is still timing real launches -- everybody arrives, rank 0 sets it, everybody measures, everybody arrives, rank 0 clears it
-        fence(lanes, torch, device)
-        if rank == 0 or fence.tb is None:
-            L.rcv__debug_set(4)          # k_filter_rows_mfma<.., 260>: the launch's own loads and stores, no arithmetic
-        fence(lanes, torch, device)
-        settle(60.0, lane[0].step, lanes.sync)
-        res["memory_only_gbs"] = 2 * nbytes / (timed0(100) / 100) / 1e6
-        fence(lanes, torch, device)
-        if rank == 0 or fence.tb is None:
-            L.rcv__debug_set(0)
-        fence(lanes, torch, device)
+        # the kernel's own memory-only variant (k_filter_rows_chain<.., 256> / k_filter_rows_mfma<.., 260>: the launch's loads and stores,
+        # no arithmetic) lives in the measurement library, with the flag as an argument of the call: nothing process-wide to flip
+        tune = _ffi.rows_tune(dbg=4)
+        bs0, bd0, kp0 = lane[0].bs, lane[0].bd, lane[0].k.ctypes.data_as(C.POINTER(C.c_int8))
+
+        def memonly():
+            rc = BL.rcv__filter_rows_bench(ctx0.handle, C.byref(bs0), C.byref(bd0), kp0, 7, 6, tune, None)
+            if rc != 0:
+                raise SystemExit(f"rcv__filter_rows_bench failed: {rc}")
+        settle(60.0, memonly, lanes.sync)
+        res["memory_only_gbs"] = 2 * nbytes / (timed0(100, memonly) / 100) / 1e6
     for ln in lane:
         ln.free()
 

@@ -291,22 +291,6 @@ typedef struct rcv_import rcv_import;
 int  rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, size_t bytes, rcv_import** out, void** dev_ptr);
 void rcv_import_release(rcv_import* imp);
 
-/* ---- launch graphs -------------------------------------------------------------------------------------------------
- * The small configurations of the path (the reference's 640x480 convert + rectangle loop, examples/camera_demo.rs:50-76;
- * one 1080p blur) are bound by launch latency.  rcv_graph_begin .. rcv_graph_end records the rcv_*_batch calls (and
- * single-Mat calls on RCV_DEVICE mats) made on `ctx` instead of executing them; rcv_graph_launch replays the chain as
- * one submission on the context stream.  Replays use the same device pointers -- refresh the buffers' contents between
- * launches.  Entry points that have to synchronise (host mats, rcv_sync, rcv_free, rcv_upload/rcv_download, timers, the
- * ring) return RCV_ERR_UNSUPPORTED while recording.  A graph owns every constant table and every workspace its ops used
- * while they were recorded; it keeps its context alive (rcv_ctx_destroy on a context with live graphs or rings only drains
- * the stream; the memory goes when the last of them is destroyed).  EXPERIMENTAL: on ROCm 7.2 a replay measured slower
- * than the same calls made directly (profiles/graph_bench.json); nothing in the library uses graphs by itself. */
-typedef struct rcv_graph rcv_graph;
-int  rcv_graph_begin(rcv_ctx* ctx);
-int  rcv_graph_end(rcv_ctx* ctx, rcv_graph** out);
-int  rcv_graph_launch(rcv_ctx* ctx, rcv_graph* graph);
-void rcv_graph_destroy(rcv_graph* graph);
-
 #ifdef __cplusplus
 }
 #endif

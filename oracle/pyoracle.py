@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# (RCV_ORACLE_LIB: another build of the same source -- `make -C oracle asan-test` runs the CPU tests against the ASan / UBSan build)
+LIB_PATH = os.environ.get("RCV_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 _lib = None
 
 _u8p, _i8p, _i16p, _f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_int16), C.POINTER(C.c_float)

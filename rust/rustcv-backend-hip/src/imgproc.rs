@@ -531,32 +531,3 @@ impl<'c> Drop for StagingRing<'c> {
     }
 }
 
-// ---- launch graphs (experimental: a replay measured slower than direct calls on ROCm 7.2) ---------------------
-
-/// A recorded chain of device-resident calls, replayed as one `hipGraphLaunch`.
-pub struct Graph<'c> {
-    raw: *mut rcv_graph,
-    _ctx: PhantomData<&'c HipContext>,
-}
-unsafe impl<'c> Send for Graph<'c> {}
-
-impl<'c> Graph<'c> {
-    /// Record what `record` enqueues on `ctx` (device-resident batch calls only) into a graph.
-    pub fn capture<F: FnOnce(&HipContext) -> Result<()>>(ctx: &'c HipContext, record: F) -> Result<Self> {
-        status(unsafe { rcv_graph_begin(ctx.raw()) })?;
-        let recorded = record(ctx);
-        let mut raw = std::ptr::null_mut();
-        let ended = status(unsafe { rcv_graph_end(ctx.raw(), &mut raw) });
-        recorded?;
-        ended?;
-        Ok(Self { raw, _ctx: PhantomData })
-    }
-    pub fn launch(&self, ctx: &HipContext) -> Result<()> {
-        status(unsafe { rcv_graph_launch(ctx.raw(), self.raw) }).map(|_| ())
-    }
-}
-impl<'c> Drop for Graph<'c> {
-    fn drop(&mut self) {
-        unsafe { rcv_graph_destroy(self.raw) }
-    }
-}

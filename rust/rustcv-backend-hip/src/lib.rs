@@ -15,7 +15,7 @@ pub mod ffi;
 pub use ffi::*;
 
 /// Safe facade for the image operations and the device-resident batch path: `Mat`-shaped borrows, `DeviceBatch`, `StagingRing`,
-/// `Graph` and one wrapper per compute entry point (the Rust twin of include/rustcv.hpp).
+/// one wrapper per compute entry point (the Rust twin of include/rustcv.hpp).
 pub mod imgproc;
 
 /// Owning handle: one GPU + one HIP stream.  Not `Sync`; one thread per context (bridge.h:4-7).

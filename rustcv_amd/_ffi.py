@@ -67,10 +67,6 @@ _ring = C.c_void_p
 
 # name -> (restype, argtypes); the list every symbol in include/rustcv_hip.h must appear in
 SIGNATURES = {
-    "rcv_graph_begin": (_i, [_ctx]),
-    "rcv_graph_end": (_i, [_ctx, _P(C.c_void_p)]),
-    "rcv_graph_launch": (_i, [_ctx, C.c_void_p]),
-    "rcv_graph_destroy": (None, [C.c_void_p]),
     "rcv_ring_create": (_i, [_ctx, _i, _i, _i, _i, _i, _i, _i, _i, _i, _P(_ring)]),
     "rcv_ring_destroy": (None, [_ring]),
     "rcv_ring_in_flight": (_i, [_ring]),
@@ -139,12 +135,10 @@ SIGNATURES = {
 
 # test hooks inside the product library (not part of include/rustcv_hip.h): knob reload, dispatch trace, profiling-build flags
 DEBUG_SIGNATURES = {
-    "rcv__debug_set": (None, [_i]),
     "rcv__debug_reload_knobs": (None, []),
     "rcv__debug_kernels": (C.c_char_p, []),
     "rcv__debug_kernels_reset": (None, []),
     "rcv__debug_occupancy": (_i, []),
-    "rcv__debug_trace_buffer": (None, [C.c_void_p]),
 }
 
 # measurement kernels (plain copies / stores of every shape, launch floor, shader-clock probe): librustcv_hip_bench.so, a separate
@@ -155,7 +149,24 @@ BENCH_SIGNATURES = {
     "rcv__storebench": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i, _i]),
     "rcv__clock_probe": (_i, [_ctx, _i, C.POINTER(C.c_float)]),
     "rcv__stripwalk": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i]),
+    # the row-streaming filter with every plan parameter explicit + its measurement instantiations (tune: 14 ints, see ROWS_TUNE)
+    "rcv__filter_rows_bench": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i, _P(C.c_int), C.c_void_p]),
 }
+
+# order of the ints rcv__filter_rows_bench takes (defaults = the product's plan; dbg 4 = the kernel's memory-only variant)
+ROWS_TUNE = ("f7_rows", "dual_full", "chain", "chain_rows", "dbg", "wpc", "rounds", "pp", "order", "bpf", "band_rows", "taper", "wpb", "edge_pct")
+ROWS_TUNE_DEFAULTS = {"f7_rows": 1, "dual_full": 0, "chain": -1, "chain_rows": 0, "dbg": 0, "wpc": 0, "rounds": 0, "pp": 0, "order": 0, "bpf": 0,
+                      "band_rows": 0, "taper": -1, "wpb": 0, "edge_pct": 0}
+
+
+def rows_tune(**kw):
+    """ctypes int[14] for rcv__filter_rows_bench: rows_tune(dbg=4), rows_tune(chain=0, bpf=68), ..."""
+    bad = set(kw) - set(ROWS_TUNE)
+    if bad:
+        raise TypeError(f"unknown tune field(s) {sorted(bad)}")
+    v = dict(ROWS_TUNE_DEFAULTS, **kw)
+    return (C.c_int * len(ROWS_TUNE))(*[int(v[k]) for k in ROWS_TUNE])
+
 
 _lib = None
 

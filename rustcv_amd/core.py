@@ -100,10 +100,6 @@ class Context:
     def sync(self):
         _ffi.check(_ffi.lib().rcv_sync(self.handle), "rcv_sync")
 
-    def capture(self):
-        """`with ctx.capture() as g: <device-resident rcv calls>` records them into a launch graph; `g.launch()` replays."""
-        return Graph(self)
-
     def close(self):
         if self._h is not None:
             _ffi.lib().rcv_ctx_destroy(self._h)
@@ -120,46 +116,6 @@ class Context:
             self.close()
         except Exception:
             pass
-
-
-class Graph:
-    """`rcv_graph`: a recorded chain of device-resident calls, replayed as one hipGraph launch (include/rustcv_hip.h)."""
-
-    def __init__(self, ctx):
-        self._ctx, self._g = ctx, None
-
-    def __enter__(self):
-        _ffi.check(_ffi.lib().rcv_graph_begin(self._ctx.handle), "rcv_graph_begin")
-        return self
-
-    def __exit__(self, et, ev, tb):
-        g = C.c_void_p()
-        rc = _ffi.lib().rcv_graph_end(self._ctx.handle, C.byref(g))
-        if et is None:
-            _ffi.check(rc, "rcv_graph_end")
-            self._g = g
-        elif rc >= 0:
-            _ffi.lib().rcv_graph_destroy(g)   # the body failed: drop what was recorded
-        return False
-
-    def launch(self):
-        if self._g is None:
-            raise RuntimeError("graph was not recorded")
-        _ffi.check(_ffi.lib().rcv_graph_launch(self._ctx.handle, self._g), "rcv_graph_launch")
-
-    def close(self):
-        if self._g is not None:
-            _ffi.lib().rcv_graph_destroy(self._g)
-            self._g = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
-_default_ctx = None
 
 
 def device_count():

@@ -20,38 +20,18 @@ static int env_int(const char* name, int unset)
 }
 static void load_knobs()
 {
-    g_knobs.f7_seg_rows = env_int("RCV_F7_SEG_ROWS", 0);
-    g_knobs.f7_tps = env_int("RCV_F7_TPS", 0);
+    g_knobs.f7_rows = env_int("RCV_F7_ROWS", -1);
     g_knobs.f7_no_lat = getenv("RCV_F7_NO_LAT") != nullptr;
     g_knobs.f7_no_gray = getenv("RCV_F7_NO_GRAY") != nullptr;
     g_knobs.f7_dual_full = getenv("RCV_F7_DUAL_FULL") != nullptr;
-    g_knobs.f7_rows = env_int("RCV_F7_ROWS", -1);
-    g_knobs.fr_rounds = env_int("RCV_FR_ROUNDS", 0);
-    g_knobs.fr_wpc = env_int("RCV_FR_WPC", 0);
-    g_knobs.fr_pp = env_int("RCV_FR_PP", 0);
-    g_knobs.fr_order = env_int("RCV_FR_ORDER", -1);
     g_knobs.fr_chain = env_int("RCV_FR_CHAIN", -1);
     g_knobs.fr_chain_rows = env_int("RCV_FR_CHAIN_ROWS", 0);
-    g_knobs.fr_bpf = env_int("RCV_FR_BPF", 0);
-    g_knobs.fr_wpb = env_int("RCV_FR_WPB", 0);
-    g_knobs.fr_sob192 = env_int("RCV_FR_SOB192", 0);
-    g_knobs.fr_taper = env_int("RCV_FR_TAPER", -1);
     g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);
     g_knobs.gr_seg = env_int("RCV_GR_SEG", 0);
-    g_knobs.gr_plain = env_int("RCV_GR_PLAIN", 0);
-    g_knobs.fr_band_rows = env_int("RCV_FR_BAND_ROWS", 0);
-    g_knobs.xcd_order = env_int("RCV_XCD_ORDER", -1);
-    g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
+    g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
     g_knobs.warp_gray4 = env_int("RCV_WARP_GRAY4", -1);
-    g_knobs.warp_resize_lds = env_int("RCV_WARP_RESIZE_LDS", -1);
-    g_knobs.sobel_wgs = env_int("RCV_SOBEL_WGS", 0);
-    g_knobs.nms_seg = env_int("RCV_NMS_SEG", 0);
-    g_knobs.sobel_seg = env_int("RCV_SOBEL_SEG", 0);
-    g_knobs.sobel_plain = env_int("RCV_SOBEL_PLAIN", 0);
-    g_knobs.extra_lds = env_int("RCV_EXTRA_LDS", 0);
-    g_knobs.harris_seg_rows = env_int("RCV_HARRIS_SEG_ROWS", 0);
-    g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
+    g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
 }
 const RcvKnobs& rcv_knobs()
 {
@@ -154,7 +134,7 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
     if (!c) return;
     if (c->children > 0) {
         (void)hipSetDevice(c->device);
-        if (c->stream && !c->capturing) (void)hipStreamSynchronize(c->stream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
         c->zombie = true;
         return;
     }
@@ -171,7 +151,7 @@ void rcv_ctx_child_released(rcv_ctx* c)
 static void ctx_finalize(rcv_ctx* c)
 {
     (void)hipSetDevice(c->device);
-    if (c->stream && !c->capturing) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     if (c->tmp2) (void)hipFree(c->tmp2);
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
@@ -184,13 +164,6 @@ static void ctx_finalize(rcv_ctx* c)
     if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->capturing) {   // a capture was left open: close it and drop what it allocated
-        hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(c->stream, &g);
-        if (g) (void)hipGraphDestroy(g);
-        for (int i = 0; i < c->cap_nallocs; ++i) (void)hipFree(c->cap_allocs[i]);
-        (void)hipGetLastError();
-    }
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -211,7 +184,6 @@ int rcv_launch_check(rcv_ctx*)
 
 extern "C" int rcv_sync(rcv_ctx* ctx)
 {
-    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipStreamSynchronize(ctx->stream));
     return RCV_OK;
@@ -234,7 +206,6 @@ extern "C" int rcv_free(rcv_ctx* ctx, void* p)
 {
     RCV_TRY(rcv_bind(ctx));
     if (!p) return RCV_OK;
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // would synchronise the recording stream
     RCV_HIP(hipStreamSynchronize(ctx->stream));
     RCV_HIP(hipFree(p));
     return RCV_OK;
@@ -242,7 +213,6 @@ extern "C" int rcv_free(rcv_ctx* ctx, void* p)
 
 extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
-    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;   // pageable copies synchronise
     RCV_TRY(rcv_bind(ctx));
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
@@ -253,7 +223,6 @@ extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes
 
 extern "C" int rcv_download(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
-    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;   // pageable copies synchronise
     RCV_TRY(rcv_bind(ctx));
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
@@ -273,7 +242,6 @@ extern "C" int rcv_memset(rcv_ctx* ctx, void* dst, int value, size_t bytes)
 
 extern "C" int rcv_timer_start(rcv_ctx* ctx)
 {
-    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     return RCV_OK;
@@ -282,7 +250,6 @@ extern "C" int rcv_timer_start(rcv_ctx* ctx)
 extern "C" int rcv_timer_stop(rcv_ctx* ctx, float* ms)
 {
     if (!ms) return RCV_ERR_ARG;
-    if (ctx && ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     RCV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     RCV_HIP(hipEventSynchronize(ctx->ev1));
@@ -325,28 +292,9 @@ extern "C" int rcv_gaussian_taps_f32(int ksize, double sigma, float* taps)
 // ---- workspace ------------------------------------------------------------------------------
 // Kernel-internal temporaries (unfused intermediates).  rcv_ws_reserve(total) first, then carve.
 
-// While a graph is being recorded a workspace is a FRESH allocation owned by that graph (like its constant tables): replays
-// must never depend on the context's grow-only buffers, which a later, larger call frees and re-allocates.
-static int graph_owned_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out)
-{
-    if (ctx->cap_nallocs >= 64) return RCV_ERR_UNSUPPORTED;
-    void* p = nullptr;
-    RCV_HIP(hipMalloc(&p, bytes ? bytes : 16));
-    ctx->cap_allocs[ctx->cap_nallocs++] = p;
-    *out = (uint8_t*)p;
-    return RCV_OK;
-}
-
 int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
 {
     ctx->ws_off = 0;
-    if (ctx->capturing) {
-        ctx->ws_cur = nullptr;
-        ctx->ws_cur_cap = 0;
-        RCV_TRY(graph_owned_alloc(ctx, total, &ctx->ws_cur));
-        ctx->ws_cur_cap = total;
-        return RCV_OK;
-    }
     if (total > ctx->ws_cap) {
         RCV_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->ws) RCV_HIP(hipFree(ctx->ws));
@@ -355,14 +303,11 @@ int rcv_ws_reserve(rcv_ctx* ctx, size_t total)
         RCV_HIP(hipMalloc((void**)&ctx->ws, total));
         ctx->ws_cap = total;
     }
-    ctx->ws_cur = ctx->ws;
-    ctx->ws_cur_cap = ctx->ws_cap;
     return RCV_OK;
 }
 
 int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 {
-    if (ctx->capturing) return graph_owned_alloc(ctx, bytes, out);
     if (bytes > ctx->tmp2_cap) {
         RCV_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->tmp2) RCV_HIP(hipFree(ctx->tmp2));
@@ -378,8 +323,8 @@ int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out)
 {
     size_t off = (ctx->ws_off + 255) & ~(size_t)255;
-    if (!ctx->ws_cur || off + bytes > ctx->ws_cur_cap) return RCV_ERR_OOM;
-    *out = ctx->ws_cur + off;
+    if (!ctx->ws || off + bytes > ctx->ws_cap) return RCV_ERR_OOM;
+    *out = ctx->ws + off;
     ctx->ws_off = off + bytes;
     return RCV_OK;
 }
@@ -395,18 +340,8 @@ int rcv_upload_const(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset
 
 int rcv_const_table(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset, const uint8_t** dev)
 {
-    if (!ctx->capturing) {
-        RCV_TRY(rcv_upload_const(ctx, host, bytes, offset));
-        *dev = ctx->kconst + offset;
-        return RCV_OK;
-    }
-    if (ctx->cap_nallocs >= 64) return RCV_ERR_UNSUPPORTED;
-    void* p = nullptr;
-    RCV_HIP(hipMalloc(&p, bytes));
-    ctx->cap_allocs[ctx->cap_nallocs++] = p;
-    RCV_HIP(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->side));
-    RCV_HIP(hipStreamSynchronize(ctx->side));
-    *dev = (const uint8_t*)p;
+    RCV_TRY(rcv_upload_const(ctx, host, bytes, offset));
+    *dev = ctx->kconst + offset;
     return RCV_OK;
 }
 
@@ -470,7 +405,6 @@ int stage_begin(Stage* s, rcv_ctx* ctx)
 int stage_in(Stage* s, const rcv_mat* m, bool upload, bool copy_back, rcv_mat** dev_out)
 {
     if (!m || !dev_out) return RCV_ERR_ARG;
-    if (m->device == RCV_HOST && s->ctx->capturing) return RCV_ERR_UNSUPPORTED;   // host staging synchronises: device mats only
     if (s->count >= RCV_MAX_STAGE) return RCV_ERR_ARG;
     rcv_ctx* ctx = s->ctx;
     StagedMat* sm = &s->m[s->count];

@@ -40,8 +40,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-int rcv_debug_flags = 0;
-extern "C" void rcv__debug_set(int flags) { rcv_debug_flags = flags; }
 
 namespace {
 
@@ -92,7 +90,7 @@ __device__ __forceinline__ void deint4(uint32_t d0, uint32_t d1, uint32_t d2, ui
 struct U2 { uint32_t a, b; };
 struct U3 { uint32_t a, b, c; };
 
-// DBG: ablation bits for profiling builds (-DRCV_ABLATE): 1 skip global stores, 2 skip global loads, 4 skip MFMA,
+// DBG: ablation bits (instantiated by hand when profiling; the product launches DBG = 0 only): 1 skip global stores, 2 skip global loads, 4 skip MFMA,
 // 8 skip the staging realign/de-interleave, 16 skip the epilogue shift/saturate/pack
 // DUAL: weights beyond the i8 range (integer GaussianBlur 7x7: taps up to 324) are split K = 4*Q + R with Q, R in i8;
 // the same pixel operand feeds two MFMAs (tables A and A2) and the epilogue forms acc + (acc2 << 2).  LDS traffic is
@@ -650,15 +648,9 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         if (rc != RCV_ERR_UNSUPPORTED) return rc;
     }
 
-    // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered).  While a graph is
-    // being recorded the table goes into a buffer the graph owns, so that replays never depend on this cache.
+    // weight tables: rebuilt/uploaded only when the kernel changes (the upload is stream-ordered)
     const uint8_t* wtab = ctx->kconst + RCV_KC_F7_TAB;
-    if (ctx->capturing) {
-        int8_t tab[2 * 4 * 64 * 16];
-        build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
-        if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
-        RCV_TRY(rcv_const_table(ctx, tab, dual ? sizeof(tab) : sizeof(tab) / 2, RCV_KC_F7_TAB, &wtab));
-    } else if (!ctx->f7_valid || ctx->f7_ksize != ksize || ctx->f7_mode != mode || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
+    if (!ctx->f7_valid || ctx->f7_ksize != ksize || ctx->f7_mode != mode || memcmp(ctx->f7_k, k, (size_t)ksize * ksize * sizeof(int16_t)) != 0) {
         int8_t tab[2 * 4 * 64 * 16];
         build_wtab(k, ksize, mode == 0 ? 2 : (mode == 1 ? 0 : 3), tab);
         if (dual) build_wtab(k, ksize, mode == 1 ? 1 : 4, tab + 4096);
@@ -684,9 +676,8 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     a.cols = s.cols;
     a.ntiles_total = s.cols / 16;
     // strips of 256 px: line-aligned seams.  (240-px strips split widths such as 1920 evenly, but measured 3.5 % slower there
-    // than 7 full strips + one half strip; the kernel still takes tps = 15 through the tuning knob below.)
+    // than 7 full strips + one half strip.)
     a.tps = gray ? kTilesG : kTiles;
-    if (rcv_knobs().f7_tps == 15 && !gray) a.tps = 15;  // tuning knob (BGR strips)
     a.nstrips = (a.ntiles_total + a.tps - 1) / a.tps;
     // row segments: a few waves of 3 workgroups per CU with little tail (total close to a multiple of 3 * CUs), each
     // segment a multiple of 16 rows (>= 32); the per-segment constant models the prologue (two synchronous blocks).
@@ -694,8 +685,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
     int seg_rows;
     bool lat = false;
     const bool lat_ok = !src_yuyv && !dual && !rcv_knobs().f7_no_lat;
-    if (ctx->f7_plan_rows == s.rows && ctx->f7_plan_nstrips == a.nstrips && ctx->f7_plan_n == s.n && ctx->f7_plan_lat_ok == lat_ok &&
-        ctx->f7_plan_knob == rcv_knobs().f7_seg_rows) {
+    if (ctx->f7_plan_rows == s.rows && ctx->f7_plan_nstrips == a.nstrips && ctx->f7_plan_n == s.n && ctx->f7_plan_lat_ok == lat_ok) {
         seg_rows = ctx->f7_plan_seg_rows;
         lat = ctx->f7_plan_lat;
     } else {
@@ -712,7 +702,6 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
             double cost = (double)rounds * (sr + 6 + 40);
             if (cost < best) { best = cost; seg_rows = sr; }
         }
-        if (rcv_knobs().f7_seg_rows > 15) seg_rows = (rcv_knobs().f7_seg_rows + 15) / 16 * 16;   // tuning knob
         // small launches (everything resident in one round even with the shortest segments): the latency variant
         if (lat_ok) {
             for (int sr = 16; sr <= 32 && !lat; sr += 16) {
@@ -727,7 +716,6 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         ctx->f7_plan_nstrips = a.nstrips;
         ctx->f7_plan_n = s.n;
         ctx->f7_plan_lat_ok = lat_ok;
-        ctx->f7_plan_knob = rcv_knobs().f7_seg_rows;
         ctx->f7_plan_seg_rows = seg_rows;
         ctx->f7_plan_lat = lat;
     }
@@ -761,23 +749,7 @@ int rcv_filter_i16_fast(rcv_ctx* ctx, const View& s, const View& d, const int16_
         RCV_LAUNCH((k_filter7_mfma<0, 0, 0, true>), grid, block, 0, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
-#ifdef RCV_ABLATE  // profiling-only build: ablation bits 1 skip global stores, 2 skip global loads, 4 skip MFMA
-    switch (rcv_debug_flags & 31) {
-    case 8: RCV_LAUNCH((k_filter7_mfma<8, 0>), grid, block, 0, ctx->stream, a); break;
-    case 16: RCV_LAUNCH((k_filter7_mfma<16, 0>), grid, block, 0, ctx->stream, a); break;
-    case 24: RCV_LAUNCH((k_filter7_mfma<24, 0>), grid, block, 0, ctx->stream, a); break;
-    case 1: RCV_LAUNCH((k_filter7_mfma<1, 0>), grid, block, 0, ctx->stream, a); break;
-    case 2: RCV_LAUNCH((k_filter7_mfma<2, 0>), grid, block, 0, ctx->stream, a); break;
-    case 3: RCV_LAUNCH((k_filter7_mfma<3, 0>), grid, block, 0, ctx->stream, a); break;
-    case 4: RCV_LAUNCH((k_filter7_mfma<4, 0>), grid, block, 0, ctx->stream, a); break;
-    case 5: RCV_LAUNCH((k_filter7_mfma<5, 0>), grid, block, 0, ctx->stream, a); break;
-    case 6: RCV_LAUNCH((k_filter7_mfma<6, 0>), grid, block, 0, ctx->stream, a); break;
-    case 7: RCV_LAUNCH((k_filter7_mfma<7, 0>), grid, block, 0, ctx->stream, a); break;
-    default: RCV_LAUNCH((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a); break;
-    }
-#else
     RCV_LAUNCH((k_filter7_mfma<0, 0>), grid, block, 0, ctx->stream, a);
-#endif
     return rcv_launch_check(ctx);
 }
 

@@ -281,7 +281,7 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
     const unsigned gy = (unsigned)((s.rows + seg - 1) / seg);
     {
         const long long nb = (long long)gx * gy * s.n;
-        const bool xcd = rcv_knobs().xcd_order != 0 && nb < (1LL << 30);
+        const bool xcd = nb < (1LL << 30);
         const int bpx = xcd ? (int)((nb + 7) / 8) : 0;
         const dim3 grid = xcd ? dim3((unsigned)bpx * 8u) : dim3(gx, gy, s.n);
         RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);

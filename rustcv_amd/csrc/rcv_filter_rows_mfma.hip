@@ -47,9 +47,29 @@
 #include "rcv_device_utils.h"
 #include <string.h>
 
-extern int rcv_debug_flags;
-void* rcv_debug_trace = nullptr;   // device buffer for the per-wave timeline of profiling builds (rcv__debug_trace_buffer)
-extern "C" void rcv__debug_trace_buffer(void* p) { rcv_debug_trace = p; }
+// This file is compiled TWICE: into librustcv_hip.so (the product: the plain instantiations and the launch plan below, nothing else)
+// and, with -DRCV_ROWS_BENCH, into librustcv_hip_bench.so, where every plan parameter is an argument of rcv__filter_rows_bench
+// (RowsTune) and the measurement instantiations exist -- memory-only variants, ablations, the per-wave timeline.  bench.py's
+// memory_only leg and tools/ablate_*.py call that entry; the product library carries no experiment and reads no tuning knob here
+// beyond the four dispatch overrides its tests need (RCV_F7_ROWS, RCV_F7_DUAL_FULL, RCV_FR_CHAIN, RCV_FR_CHAIN_ROWS).
+struct RowsTune {
+    int f7_rows = -1;     // 1 every eligible shape, 0 never, -1 by size
+    int dual_full = 0;    // large weights: K = 4Q + R even where the centre split applies
+    int chain = -1;       // chained-band kernel: 0 never, 1 every eligible launch, -1 launches that fill the GPU
+    int chain_rows = 0;   // rows per chained band (0 = 32)
+    // ---- measurement builds only (the product passes the defaults) ----
+    int dbg = 0;          // instantiation: 4 memory-only, 1 / 2 / ... ablations (launch_rows_dbg), 24 wave timeline
+    int wpc = 0;          // waves per CU the bands are planned for / (chain) resident per CU
+    int rounds = 0;       // bands per wave slot (0 = 8)
+    int pp = 0;           // row pairs in flight (0 = 3)
+    int order = 0;        // 1: bands dealt round-robin to the XCDs
+    int bpf = 0;          // bands per frame
+    int band_rows = 0;    // rows per band on launches of a few frames
+    int taper = -1;       // 0 equal bands, -1 / 1 tapered tail, n > 1: n % of a round
+    int wpb = 0;          // waves per workgroup (2 / 4 / 8)
+    int edge_pct = 0;     // (chain) weight of an edge strip against an interior one, % (0 = 115)
+    void* trace = nullptr;   // device buffer of the per-wave timeline
+};
 
 namespace {
 
@@ -66,7 +86,6 @@ struct FRArgs {
     int nstrips, nframes;
     int nbands, bands_per_xcd;   // the n * rows frame-rows of the batch are cut into nbands equal bands; a wave = (band, strip)
     int order;                   // 0: a contiguous eighth of the bands per XCD (default); 1: bands dealt round-robin to the XCDs
-    int sob192;                  // SOB: 1 = line-aligned 192-pixel strips with non-temporal stores (SOB = 2 instantiation)
     int wpb;                     // waves per workgroup (1, 2, 4 or 8): independent waves, neighbouring strips of a band on one CU
     int shift, acc_init;
     int dual_shift;              // DMASK != 0: result = acc + (acc2 << dual_shift), the second tables follow the first 2 x NP
@@ -127,7 +146,7 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
     pr = __builtin_amdgcn_perm(d2, t, 0x07040100u);  // + r2(d2.0) r3(d2.3)
 }
 
-// DBG (profiling builds, make EXTRA=-DRCV_ABLATE): 1 skip stores, 2 skip loads, 4 skip MFMAs, 8 plain instead of non-temporal stores
+// DBG (measurement build of this file, -DRCV_ROWS_BENCH): 1 skip stores, 2 skip loads, 4 skip MFMAs, 8 plain instead of non-temporal stores
 // DMASK: weights beyond the i8 range are split K = M + (S << dual_shift) with M, S inside i8 (integer GaussianBlur 7x7: taps up to
 // 324 = K1 + 2 * T2 with T2 confined to the centre rows; any |w| <= 511 as 4Q + R).  The same data operand feeds a second MFMA
 // with the S table into a second accumulator set; bit (parity * NP + p) of DMASK says which row pairs have a non-zero S table
@@ -392,9 +411,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // lane has both lanes' dx and the odd lane both lanes' dy: ONE 16-byte store per lane and row.  Pair-local validity: tile
     // pixels 8 .. 247 (strip 0: from 0), inside the row; a width that is not a multiple of 8 ends on a half pair.
     const int tp2 = 16 * n + 8 * (q >> 1), gp2 = X / 3 + tp2;
-    // SOB = 2: strips 192 pixels apart (384 bytes = three whole lines of an i16 plane per wave and row: non-temporal stores); the tile
-    // starts 16 pixels left of the strip (strip 0: at pixel 0) and stores tile pixels 16 .. 207 (strip 0: 0 .. 191)
-    const bool pair_ok = SOB == 2 ? (tp2 >= (X == 0 ? 0 : 16) && tp2 < (X == 0 ? 192 : 208)) : (SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248);
+    const bool pair_ok = SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248;
     const bool g_full = pair_ok && gp2 + 8 <= a.cols, g_half = pair_ok && gp2 + 8 > a.cols && gp2 + 4 <= a.cols;
     uint8_t* const gplane = (q & 1) ? dyf : dxf;
     typedef uint32_t fr_u2 __attribute__((ext_vector_type(2)));
@@ -408,11 +425,6 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         uint8_t* const o = gplane + (size_t)gy * a.gstep + 2 * (size_t)gp2;
         // plain stores: the 480-byte row pieces of neighbouring strips share lines, which the L2 merges (non-temporal: 1.05
         // instead of 0.78 ms on 64 4K frames)
-        if constexpr (SOB == 2) {   // (row pieces are whole lines: no other wave writes into them)
-            if (g_full) __builtin_nontemporal_store(fr_u4{x0, x1, y0, y1}, (fr_u4*)o);
-            else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
-            return;
-        }
         if (g_full) *(fr_u4*)o = fr_u4{x0, x1, y0, y1};
         else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
     };
@@ -866,9 +878,8 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     if (bi >= a.bands_per_xcd) return;
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (a.tn == 0 && band >= a.nbands) return;
-    // byte offset of the strip's TILE in a destination row (gray: also the pixel offset; SOB = 1: tiles 240 pixels apart; SOB = 2: 192
-    // apart, starting 16 pixels left of the pixels they store)
-    const int X = SOB == 2 ? (strip == 0 ? 0 : strip * 576 - 48) : strip * (SOB ? 720 : 768);
+    // byte offset of the strip's TILE in a destination row (gray: also the pixel offset; SOB = 1: tiles 240 pixels apart)
+    const int X = strip * (SOB ? 720 : 768);
     // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
     const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
@@ -909,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
 
 // host: A tables.  Table (parity, p): lane (m, qa) holds k = 16 qa + i: row half h = qa >> 1, window pixel j = 16 (qa & 1) + i
 // (the window starts 4 pixels left of the tile).  parity 0: pair p carries kernel rows 2p, 2p + 1; parity 1: 2p - 1, 2p.
-void build_rows_wtab(const int8_t* k, int ksize, int8_t* tab)
+static void build_rows_wtab(const int8_t* k, int ksize, int8_t* tab)
 {
     const int rad = ksize / 2, np = (ksize + 1) / 2;
     for (int par = 0; par < 2; ++par)
@@ -924,10 +935,10 @@ void build_rows_wtab(const int8_t* k, int ksize, int8_t* tab)
 }
 
 template <int KS, int PP>
-void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t st)
+void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t st, int dbg)
 {
-#ifdef RCV_ABLATE
-    switch (rcv_debug_flags & 255) {
+#ifdef RCV_ROWS_BENCH
+    switch (dbg & 255) {
     case 32: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 32>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 96: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 96>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 128: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 128>), grid, dim3(64 * a.wpb), lds, st, a); return;
@@ -952,27 +963,21 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     default: break;
     }
 #endif
-    // the kernel's own memory-only variant (its loads and its stores, nothing in between): bench.py times it next to the plain
-    // copies as the ceiling of THIS access pattern (rcv__debug_set(4); the output is not a filtered image)
-#ifdef RCV_ABLATE
-    constexpr bool kMemOnly = KS == 7;
-#else
-    constexpr bool kMemOnly = KS == 7 && PP == 3;
-#endif
-#ifdef RCV_ABLATE
+    // the kernel's own memory-only variant (its loads and its stores, nothing in between): the ceiling of THIS access pattern (the
+    // output is not a filtered image); 7: the same with two waves per (band, strip): twice the workgroups for the same band plan
+#ifdef RCV_ROWS_BENCH
     if constexpr (KS == 7) {
-        if ((rcv_debug_flags & 255) == 7) {   // memory-only, two waves per (band, strip): twice the workgroups for the same band plan
+        if ((dbg & 255) == 7) {
             RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 772>), dim3(grid.x * 2), dim3(64 * a.wpb), lds, st, a);
             return;
         }
-    }
-#endif
-    if constexpr (kMemOnly) {
-        if ((rcv_debug_flags & 255) == 4) {
+        if ((dbg & 255) == 4) {
             RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 260>), grid, dim3(64 * a.wpb), lds, st, a);
             return;
         }
     }
+#endif
+    (void)dbg;
     RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64 * a.wpb), lds, st, a);
 }
 
@@ -992,12 +997,11 @@ constexpr int rows_dmask(int ksize, int lo, int hi)
 constexpr int kCentre7 = rows_dmask(7, 2, 4);   // second table in kernel rows 2..4 (the integer 7x7 Gaussian): 2 of 4 pairs per parity
 
 template <int KS>
-void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st)
+void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv, hipStream_t st, int dbg)
 {
     const dim3 grid((unsigned)(((long long)a.bands_per_xcd * a.nstrips + a.wpb - 1) / a.wpb * 8));
     if (a.gdx) {   // filter2D -> gray -> Sobel (BGR source, one weight table: the caller checked)
-        if (a.sob192) RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 2>), grid, dim3(64 * a.wpb), lds, st, a);
-        else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
+        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (src_yuyv == 1) {   // (one weight table only: the caller checked)
@@ -1020,15 +1024,15 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
         else RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, kAll>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
-#ifdef RCV_ABLATE   // profiling builds: prefetch depth selectable at run time (RCV_FR_PP)
-    if (KS == 7 && pp == 2) return launch_rows_dbg<7, 2>(a, grid, lds, st);
-    if (KS == 7 && pp == 4) return launch_rows_dbg<7, 4>(a, grid, lds, st);
-    if (KS == 7 && pp == 5) return launch_rows_dbg<7, 5>(a, grid, lds, st);
-    if (KS == 7 && pp == 6) return launch_rows_dbg<7, 6>(a, grid, lds, st);
-    if (KS == 7 && pp == 8) return launch_rows_dbg<7, 8>(a, grid, lds, st);
+#ifdef RCV_ROWS_BENCH   // measurement builds: prefetch depth selectable at run time
+    if (KS == 7 && pp == 2) return launch_rows_dbg<7, 2>(a, grid, lds, st, dbg);
+    if (KS == 7 && pp == 4) return launch_rows_dbg<7, 4>(a, grid, lds, st, dbg);
+    if (KS == 7 && pp == 5) return launch_rows_dbg<7, 5>(a, grid, lds, st, dbg);
+    if (KS == 7 && pp == 6) return launch_rows_dbg<7, 6>(a, grid, lds, st, dbg);
+    if (KS == 7 && pp == 8) return launch_rows_dbg<7, 8>(a, grid, lds, st, dbg);
 #endif
     (void)pp;
-    launch_rows_dbg<KS, 3>(a, grid, lds, st);
+    launch_rows_dbg<KS, 3>(a, grid, lds, st, dbg);
 }
 
 } // namespace
@@ -1039,23 +1043,50 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 // gx, gy (both or neither): the i16 gradient planes of the fused filter2D -> BGR2GRAY -> Sobel launch; `d` is not written then
 // (BGR source with 4-byte aligned rows and a width that is a multiple of 4, |weights| <= 127, 8-byte aligned gradient rows).
 static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size, const View* gx,
-                       const View* gy);
+                       const View* gy, const RowsTune& kn);
 
+#ifndef RCV_ROWS_BENCH
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size,
                         const View* gx, const View* gy)
 {
     // (Round 3 experiments, removed: the batch as consecutive launches of 2 ... 32 frames -- 0.59 ... 0.82 ms against 0.55 for the one
     //  launch -- and its two halves as concurrent launches on two streams, forked and joined per call: 0.615 against 0.582 ms;
     //  profiles/r03_ablate_chunked_launches.txt.)
-    return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy);
+    const RcvKnobs& g = rcv_knobs();
+    RowsTune t;
+    t.f7_rows = g.f7_rows;
+    t.dual_full = g.f7_dual_full;
+    t.chain = g.fr_chain;
+    t.chain_rows = g.fr_chain_rows;
+    return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy, t);
 }
+#else
+// Measurement entry (librustcv_hip_bench.so): the BGR -> BGR filter of a device-resident batch with every plan parameter explicit.
+// tune: 14 ints {f7_rows, dual_full, chain, chain_rows, dbg, wpc, rounds, pp, order, bpf, band_rows, taper, wpb, edge_pct}; trace: the
+// per-wave timeline buffer (dbg 24) or NULL.  With dbg != 0 the output is NOT a filtered image.
+extern "C" int rcv__filter_rows_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift, const int* tune, void* trace)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dst || !k || !tune || (ksize != 3 && ksize != 5 && ksize != 7) || shift < 0 || shift > 24) return RCV_ERR_ARG;
+    View s, d;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (s.rows != d.rows || s.cols != d.cols || s.n != d.n || s.ch != 3 || d.ch != 3) return RCV_ERR_ARG;
+    int16_t k16[49];
+    for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+    RowsTune t;
+    t.f7_rows = tune[0]; t.dual_full = tune[1]; t.chain = tune[2]; t.chain_rows = tune[3]; t.dbg = tune[4]; t.wpc = tune[5]; t.rounds = tune[6];
+    t.pp = tune[7]; t.order = tune[8]; t.bpf = tune[9]; t.band_rows = tune[10]; t.taper = tune[11]; t.wpb = tune[12]; t.edge_pct = tune[13];
+    t.trace = trace;
+    return rows_launch(ctx, s, d, k16, ksize, shift, 0, true, nullptr, nullptr, t);
+}
+#endif
 
 static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size, const View* gx,
-                       const View* gy)
+                       const View* gy, const RowsTune& kn)
 {
     const bool sob = gx != nullptr;
     if (sob != (gy != nullptr)) return RCV_ERR_ARG;
-    const RcvKnobs& kn = rcv_knobs();
     if (kn.f7_rows == 0) return RCV_ERR_UNSUPPORTED;
     if (ksize != 3 && ksize != 5 && ksize != 7) return RCV_ERR_UNSUPPORTED;
     // src_yuyv: 0 BGR, 1 packed YUYV source, 2 one-channel (gray) source and destination
@@ -1084,13 +1115,10 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     const long long rb = (long long)s.cols * (gray ? 1 : 3);
     // in-frame source offsets are 32-bit
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // (the weight-table cache below is not graph-owned)
-    // (sob: strips 240 pixels apart, each storing 240 pixels -- strip 0: 248)
-    // SOB: 240-pixel strips with plain stores, or (gradient rows that start on 128-byte lines, width > 192; knob RCV_FR_SOB192) 192-pixel
-    // strips whose row pieces are whole lines -> non-temporal stores, at 33 % instead of 7 % redundant matrix work
-    const bool sob192 = sob && kn.fr_sob192 != 0 && s.cols > 192 && (uintptr_t)gx->p % 128 == 0 && gx->step % 128 == 0 && (gx->n <= 1 || gx->fstride % 128 == 0) &&
-                        (uintptr_t)gy->p % 128 == 0;
-    const int nstrips = sob192 ? (s.cols + 191) / 192 : (sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768));
+    // (sob: strips 240 pixels apart, each storing 240 pixels -- strip 0: 248 -- with plain stores.  Line-aligned 192-pixel strips with
+    //  non-temporal stores were built in round 3 and measured 7 % slower -- 33 % instead of 7 % redundant matrix work --; removed in round 4,
+    //  profiles/ops_table.md keeps the A/B)
+    const int nstrips = sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768);
     const long long G = (long long)s.n * s.rows;
     // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
     //  streaming VALU kernel: 4-7x slower even on one frame)
@@ -1108,7 +1136,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         if (k[i] > 127 + 2 * 127 || k[i] < -128 - 2 * 128) split2 = false;
         ksum += k[i];
     }
-    if (dual && kn.f7_dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
+    if (dual && kn.dual_full) split2 = false;   // (the knob keeps the 4Q + R split testable)
     if (dual && (src_yuyv == 1 || src_yuyv == 2 || sob)) return RCV_ERR_UNSUPPORTED;   // (two tables: BGR -> BGR only)
 
     // weight tables: a small cache keyed by the kernel (see rcv_ctx::fr_tab)
@@ -1175,28 +1203,27 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.gdy = sob ? gy->p : nullptr;
     a.gstep = sob ? gx->step : 0;
     a.gfs = sob ? gx->fstride : 0;
-    a.sob192 = sob192 ? 1 : 0;
-    a.trace = (unsigned long long*)rcv_debug_trace;
+    a.trace = (unsigned long long*)kn.trace;
     // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
     // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob
     // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).
-    const int wpc = kn.fr_wpc > 0 ? (kn.fr_wpc > 12 ? 12 : kn.fr_wpc) : 10;
-    const unsigned lds = kn.fr_wpc > 0 && wpc < 12 ? (unsigned)((163840 / wpc) & ~511) : 0u;
+    const int wpc = kn.wpc > 0 ? (kn.wpc > 12 ? 12 : kn.wpc) : 10;
+    const unsigned lds = kn.wpc > 0 && wpc < 12 ? (unsigned)((163840 / wpc) & ~511) : 0u;
     int small_plan = 0;
     // bands: the batch's frame-rows in equal parts, `rounds` x as many (band, strip) waves as the GPU holds (measured on 64 4K
     // frames: 4..16 rounds within 1-2 %, one round -- a static partition -- +20 %).  Each band boundary costs 2 * (ksize / 2)
     // halo rows of re-reads.
     {
         const long long slots = (long long)wpc * ctx->cu_count;
-        const int rounds = kn.fr_rounds > 0 ? kn.fr_rounds : 8;
+        const int rounds = kn.rounds > 0 ? kn.rounds : 8;
         const long long want = rounds * slots / a.nstrips;   // bands for `rounds` fills of the wave slots
         long long nb;
         // launches of a few rounds: every SIMD the same number of equally long waves (rcv_plan_seg_rows with this kernel's own
         // figures: two waves per SIMD at most, a lone wave leaves its SIMD half idle; a band streams ksize - 1 halo rows and fills
         // its pipeline with a few more).  Whole bands per frame.
-        const int small = small_plan = kn.fr_bpf > 0 ? 0 : rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 6, 2.3, 1.17, 2, 2);
-        if (small > 0 || kn.fr_band_rows > 0) {
-            const int br = kn.fr_band_rows > 0 ? kn.fr_band_rows : small;   // (knob: latency sweeps)
+        const int small = small_plan = kn.bpf > 0 ? 0 : rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, ksize + 5 + (sob ? 2 : 0), 6, 2.3, 1.17, 2, 2);
+        if (small > 0 || kn.band_rows > 0) {
+            const int br = kn.band_rows > 0 ? kn.band_rows : small;   // (knob: latency sweeps)
             nb = (long long)((s.rows + br - 1) / br) * s.n;
         } else if (s.n >= 8) {
             // a whole number of bands per FRAME: no band straddles a frame (one segment, one pipeline fill per wave), and with
@@ -1204,7 +1231,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             // (5 rounds) 0.646, 15.75 / 18.4 (6 / 7 rounds) 0.592
             long long bpf = (want + s.n / 2) / s.n;
             long long most = (s.rows + 31) / 32;             // at least 32 rows per band
-            if (kn.fr_bpf > 0) bpf = kn.fr_bpf, most = (s.rows + 3) / 4;   // tuning knob (sweep-order ablation: bands down to 4 rows)
+            if (kn.bpf > 0) bpf = kn.bpf, most = (s.rows + 3) / 4;   // tuning knob (sweep-order ablation: bands down to 4 rows)
             bpf = bpf < 1 ? 1 : (bpf > most ? most : bpf);
             nb = bpf * s.n;
         } else {
@@ -1216,17 +1243,17 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         }
         a.nbands = (int)nb;
         a.bands_per_xcd = (int)((nb + 7) / 8);
-        a.order = kn.fr_order == 1 ? 1 : 0;
+        a.order = kn.order == 1 ? 1 : 0;
         a.tn = 0;
         // Tapered bands (round 3, tools/wave_timeline.py): with equal bands the launch's LAST round of waves starts spread over
         // one wave duration (56 us at 103-row bands) and the slots then drain for as long -- occupancy below 90 % for the last 60 us
         // of a 605-us launch.  So the tail of every XCD's list -- about one round of its wave slots -- is cut finer: the first half
         // into half-height bands, the second half into quarter-height ones; the last waves to start are the shortest.
-        if (small == 0 && kn.fr_band_rows == 0 && a.order == 0 && s.n >= 8 && s.n % 8 == 0 && kn.fr_taper != 0 && nb >= 64) {
+        if (small == 0 && kn.band_rows == 0 && a.order == 0 && s.n >= 8 && s.n % 8 == 0 && kn.taper != 0 && nb >= 64) {
             const long long Lx = G / 8;
             const double H = (double)G / (double)nb;                              // rows per (big) band
             const double cb = 8.0 * ctx->cu_count / 8.0 / a.nstrips;             // bands one XCD has in flight (8 waves per CU)
-            const int pct = kn.fr_taper > 1 ? kn.fr_taper : 100;                // (knob: the tapered part in % of one round)
+            const int pct = kn.taper > 1 ? kn.taper : 100;                // (knob: the tapered part in % of one round)
             long long T = (long long)(cb * H * pct / 100.0 + 0.5);
             if (T > Lx / 2) T = Lx / 2;
             if (T >= (long long)(4 * H)) {
@@ -1246,14 +1273,14 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     // Chained bands (k_filter_rows_chain): launches that fill the GPU, whole frames per XCD, the plain BGR instantiation.  Bands of
     // ~chain_rows rows (at least 8: an item must hold more pairs than the ring), items = (band, strip) drawn from per-XCD ticket counters.
-    if (src_yuyv == 0 && !sob && dmask == 0 && (small_plan == 0 || kn.fr_chain == 1) && kn.fr_band_rows == 0 && kn.fr_chain != 0 && s.n >= 8 && s.n % 8 == 0 &&
+    if (src_yuyv == 0 && !sob && dmask == 0 && (small_plan == 0 || kn.chain == 1) && kn.band_rows == 0 && kn.chain != 0 && s.n >= 8 && s.n % 8 == 0 &&
         s.rows >= 64) {
         const int fpx = s.n / 8;
-        const int want_rows = kn.fr_chain_rows > 0 ? (kn.fr_chain_rows > 2048 ? 2048 : kn.fr_chain_rows) : 32;   // (bmul < 2^32)
+        const int want_rows = kn.chain_rows > 0 ? (kn.chain_rows > 2048 ? 2048 : kn.chain_rows) : 32;   // (bmul < 2^32)
         int bpf = (s.rows + want_rows / 2) / want_rows;
         bpf = bpf < 1 ? 1 : (bpf > s.rows / 8 ? s.rows / 8 : bpf);
         const unsigned long long nitems = (unsigned long long)fpx * bpf * a.nstrips;
-        const int cwpc = kn.fr_wpc == 12 || kn.fr_wpc == 4 || kn.fr_wpc == 6 || kn.fr_wpc == 10 ? kn.fr_wpc : 8;   // (knob: waves per CU, sweeps)
+        const int cwpc = kn.wpc == 12 || kn.wpc == 4 || kn.wpc == 6 || kn.wpc == 10 ? kn.wpc : 8;   // (knob: waves per CU, sweeps)
         const unsigned waves = (unsigned)(ctx->cu_count / 8 * cwpc);   // per XCD: cu_count / 8 CUs x 8 waves
         if (nitems * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31) &&
             (unsigned long long)s.rows * d.step < (1ull << 32)) {
@@ -1273,7 +1300,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             a.inv_bpf = ((1ull << 32) + bpf - 1) / bpf;
             // waves that start on the edge queue: its share of the strips, weighted 1.15 (border repair, masked stores)
             {
-                const double wgt = kn.fr_rounds > 0 ? kn.fr_rounds / 100.0 : 1.15;   // (sweep: RCV_FR_ROUNDS = weight in %)
+                const double wgt = kn.edge_pct > 0 ? kn.edge_pct / 100.0 : 1.15;   // (tools/ablate_chain_edge.py: 80 ... 200 %, best 115)
                 const double share = wgt * n_edge / (wgt * n_edge + n_int);
                 int ew = (int)(share * waves + 0.5);
                 a.edge_waves = n_int == 0 ? (int)waves : (ew < 1 ? 1 : ew);
@@ -1295,19 +1322,22 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             // waves on some CUs and leave others short.  An untouched dynamic-LDS request of an eighth of the CU's 160 KB caps it.
             const unsigned cap = (163840u / (unsigned)cwpc) & ~511u;
             if (ksize == 7) {
-                if ((rcv_debug_flags & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
-                else RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+#ifdef RCV_ROWS_BENCH
+                if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
+                else
+#endif
+                    RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             } else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             return rcv_launch_check(ctx);
         }
     }
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
-    a.wpb = kn.fr_wpb == 2 || kn.fr_wpb == 4 || kn.fr_wpb == 8 ? kn.fr_wpb : 1;
+    a.wpb = kn.wpb == 2 || kn.wpb == 4 || kn.wpb == 8 ? kn.wpb : 1;
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)
-    const int pp = kn.fr_pp > 0 ? kn.fr_pp : 3;
-    if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
-    else if (ksize == 5) launch_rows<5>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
-    else launch_rows<3>(a, pp, ldsw, dmask, src_yuyv, ctx->stream);
+    const int pp = kn.pp > 0 ? kn.pp : 3;
+    if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream, kn.dbg);
+    else if (ksize == 5) launch_rows<5>(a, pp, ldsw, dmask, src_yuyv, ctx->stream, kn.dbg);
+    else launch_rows<3>(a, pp, ldsw, dmask, src_yuyv, ctx->stream, kn.dbg);
     return rcv_launch_check(ctx);
 }

@@ -246,7 +246,7 @@ int rcv_gauss_int_rows(rcv_ctx* ctx, const View& s, const View& d, int ksize)
     a.rows = s.rows;
     a.rb = (int)rb;
     a.seg_rows = seg;
-    a.plain_stores = kn.gr_plain;
+    a.plain_stores = 0;
     a.nsegs = nsegs;
     const long long waves = (long long)a.nstrips * a.nsegs * s.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;

@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float sc
 #endif
 constexpr int kBoxTileW = RCV_BOX_TW, kBoxTileH = 256 / RCV_BOX_TW;   // output tile of one workgroup (4 waves of 16 x 4)
 
-// One wave's share of k_warp_resize_box: output pixel (x, y) of frame `frame` (also the per-tile fallback of k_warp_resize_lds).
+// One wave's share of k_warp_resize_box: output pixel (x, y) of frame `frame` .
 template <int S>
 __device__ __forceinline__ void warp_resize_box_px(const View& s, const View& d, const Affine& A, const int frame, const int x, const int y)
 {
@@ -1260,137 +1260,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     warp_resize_box_px<S>(s, d, A, (int)blockIdx.z, x, y);
 }
 
-// ---- fused warpAffine -> exact 4x down-scale through an LDS-staged source patch (round 3) ------------------------------------
-// k_warp_resize_box pays ~290 VALU instructions and eight 12-byte tap gathers per output pixel and, to keep its HBM over-fetch in
-// check, cannot use the XCD-contiguous tile order.  Here a workgroup owns a 16 x 16 OUTPUT tile = a 64 x 64 tile of the
-// (never materialised) intermediate image; its source patch -- the bounding box of the mapped tile -- is copied to LDS once per frame
-// with coalesced 12-byte loads, one {b g r x} dword per pixel (the scheme of k_warp_affine_lds: same staging plan, same double
-// buffer, same pitch planner), and each thread interpolates the four centre samples of its output pixel from LDS: a tap pair is
-// one ds_read2_b32, the coordinates / weights / LDS offsets of the four samples are computed once per group of frames.  Same f32
-// operations in the same order as every other warp path; a tile whose patch does not fit, touches the source border or lies
-// outside runs warp_resize_box_px.
-// MEASURED (profiles/r03_warp_resize_lds.txt): bit-exact, but 0.91 ms against the gather kernel's 0.715 ms on 32 x 8K -> 1080p.
-// The samples sit 4 pixels apart, so at most 9 of every 16 staged pixels are ever read (the gather kernel never touches the
-// rest beyond the cache line), a thread stages 5.3 chunks per frame for ONE output pixel (k_warp_affine_lds: 3.5 for eight),
-// and the 4-dword lane stride of the tap reads is a 4-way bank conflict whatever the pitch.  Kept selectable
-// (RCV_WARP_RESIZE_LDS=1) as the record of that experiment; the gather kernel stays the default.
-constexpr int kWrTile = 16;   // output tile edge (x 4 = 64 intermediate pixels)
-
-__global__ __launch_bounds__(kBlock) void k_warp_resize_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
-                                                            int tiles_per_xcd)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t wr_lds[];
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_per_xcd > 0) {   // XCD-contiguous raster order: overlapping patches of neighbouring tiles meet in one L2
-        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
-        if (t >= ntiles) return;
-        bz = t / (gx * gy);
-        const int rem = t - bz * gx * gy;
-        by = rem / gx;
-        bx = rem - by * gx;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = bx * kWrTile + (lane & 15), y = by * kWrTile + 4 * wave + (lane >> 4);   // d.cols % 4 == 0: quads never straddle the row end
-    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
-    // the tile's source patch from the four corners of its SAMPLE grid (intermediate pixels 4X + 1 .. 4X + 2): sx and sy are
-    // monotonic in x and in y
-    const float cx0 = (float)(4 * min(bx * kWrTile, d.cols - 1) + 1), cx1 = (float)(4 * min(bx * kWrTile + kWrTile - 1, d.cols - 1) + 2);
-    const float cy0 = (float)(4 * min(by * kWrTile, d.rows - 1) + 1), cy1 = (float)(4 * min(by * kWrTile + kWrTile - 1, d.rows - 1) + 2);
-    const float t0 = fmaf(A.m[1], cy0, A.m[2]), t1 = fmaf(A.m[1], cy1, A.m[2]), u0 = fmaf(A.m[4], cy0, A.m[5]), u1 = fmaf(A.m[4], cy1, A.m[5]);
-    const float xa = fmaf(A.m[0], cx0, t0), xb = fmaf(A.m[0], cx1, t0), xc = fmaf(A.m[0], cx0, t1), xd = fmaf(A.m[0], cx1, t1);
-    const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
-    const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
-    const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
-    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
-              ((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0 && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-              (unsigned long long)s.rows * s.step < (1ull << 32);
-    int ix0 = 0, iy0 = 0;
-    if (ok) {
-        ix0 = (int)xmin & ~3;
-        iy0 = (int)ymin;
-        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
-    }
-    if (!__builtin_amdgcn_readfirstlane((int)ok)) {
-        for (int f = f0; f < f1; ++f) warp_resize_box_px<4>(s, d, A, f, x, y);
-        return;
-    }
-    ix0 = __builtin_amdgcn_readfirstlane(ix0);
-    iy0 = __builtin_amdgcn_readfirstlane(iy0);
-    // ---- frame-invariant per-thread state: the four samples' lerp weights and LDS offsets ----
-    const int xq = min(x, d.cols - 1), yq = min(y, d.rows - 1);
-    f2 fxy[4];
-    unsigned la[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float fxx = (float)(4 * xq + 1 + (i & 1)), fyy = (float)(4 * yq + 1 + (i >> 1));
-        const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-        fxy[i] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
-        la[i] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
-    }
-    // ---- staging plan (as k_warp_affine_lds): chunk c = 4 pixels (12 source bytes -> 16 LDS bytes); thread t copies chunks t, t + 256, ...
-    const int nchunks = prow * cpr;
-    const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
-    const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * 3) - 12u) & ~3u;
-    unsigned goff[kWlMaxG], loff[kWlMaxG];
-    bool gval[kWlMaxG];
-#pragma unroll
-    for (int g = 0; g < kWlMaxG; ++g) {
-        const int c = (int)threadIdx.x + kBlock * g;
-        gval[g] = c < nchunks;
-        const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
-        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(3 * (ix0 + 4 * col)), frame_lim);
-        loff[g] = (unsigned)(row * pitch + 16 * col);
-    }
-    const int ng = (nchunks + kBlock - 1) / kBlock;
-    typedef const __attribute__((address_space(1))) uint8_t* cgp;
-    typedef uint32_t u3v __attribute__((ext_vector_type(3)));
-    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(1))) u3v gU3;
-    u3v G[kWlMaxG];
-    auto gload = [&](int f) {
-        cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
-        asm("" : "+s"(sf));
-#pragma unroll
-        for (int g = 0; g < kWlMaxG; ++g)
-            if (g < ng) {   // uniform
-                unsigned o = goff[g];
-                asm("" : "+v"(o));
-                G[g] = *(const gU3*)(sf + o);
-            }
-    };
-    const unsigned bufbytes = (unsigned)(pitch * prow);
-    gload(f0);
-    for (int f = f0; f < f1; ++f) {
-        uint8_t* buf = wr_lds + ((f - f0) & 1) * bufbytes;
-#pragma unroll
-        for (int g = 0; g < kWlMaxG; ++g)
-            if (gval[g]) {   // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
-                const uint32_t c0 = G[g].x, c1 = G[g].y, c2 = G[g].z;
-                *(u4v*)(buf + loff[g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
-            }
-        __syncthreads();
-        if (f + 1 < f1) gload(f + 1);
-        uint32_t p[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t* pa = (const uint32_t*)(buf + la[i]);
-            const uint32_t* pb = (const uint32_t*)(buf + la[i] + pitch);
-            p[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[i]);
-        }
-        // (a+b+c+d+2)>>2 per channel: B and R ride in the two 16-bit halves of one dword, G in another
-        const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
-        const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
-        const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
-        const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
-        const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
-        const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
-        if ((threadIdx.x & 3) == 0 && x < d.cols && y < d.rows) {
-            struct U3 { uint32_t a, b, c; };
-            *(U3*)(d.p + (size_t)f * d.fstride + (size_t)y * d.step + (size_t)x * 3) =
-                U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
-        }
-    }
-}
+// (Round 3 built the fused warp -> 4x down-scale on an LDS-staged source patch as well -- k_warp_resize_lds: 16 x 16 output tiles, the warp
+//  kernel's staging plan and double buffer; bit-exact, 0.91 ms against this gather kernel's 0.715 ms on 32 x 8K -> 1080p because the samples
+//  sit 4 pixels apart: <= 9 of 16 staged pixels are ever read and the tap reads are a 4-way bank conflict for every pitch.  Removed from the
+//  product in round 4; the measurement is profiles/r03_warp_resize_lds.txt, the source is in the history at commit e87cdfd.)
 
 // ---- RCV_32F images (SURVEY.md 8-A "warp_affine (u8/f32 ...)"; the cornerHarris response map) --------------------------------
 // The same sampling rules and the same f32 operations in the same order as the u8 kernels (top = fma(fx, p01 - p00, p00), bot
@@ -1715,13 +1588,11 @@ extern "C" int rcv_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* d
 // pitch is the one -- of the multiples of 16 bytes that keep both buffers within 64 KB -- for which the 32 lanes of a tap read
 // (ds_read_b32 groups, bank = dword index mod 32) collide least: the lanes of a wave walk along a source row and step to the
 // next row every 1 / |m3| pixels, so the best row pitch depends on the matrix.  A model of the first wave of two tiles decides.
-// fused4: the plan of k_warp_resize_lds instead (a 16 x 16 tile of output pixels = the centre samples of 16 x 16 blocks of 4 x 4
-// intermediate pixels; lane = 16 * row + column).
-static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cpr_out, bool fused4 = false)
+static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cpr_out)
 {
     for (int i = 0; i < 6; ++i)
         if (!(fabsf(M[i]) <= 3.0e38f)) return false;   // NaN, inf
-    const int ew = fused4 ? 4 * kWrTile - 3 : kWlTW - 1, eh = fused4 ? 4 * kWrTile - 3 : kWlTH - 1;   // extent of the tile's sample grid
+    const int ew = kWlTW - 1, eh = kWlTH - 1;   // extent of the tile's sample grid
     const double wx = fabs((double)M[0]) * ew + fabs((double)M[1]) * eh;
     const double wy = fabs((double)M[3]) * ew + fabs((double)M[4]) * eh;
     if (!(wx < 2048.0 && wy < 2048.0)) return false;
@@ -1735,11 +1606,11 @@ static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cp
         long long cost = 0;
         for (int tile = 0; tile < 2; ++tile) {
             const double ox = tile ? 7.0 * kWlTW : 0.0, oy = tile ? 3.0 * kWlTH : 0.0;
-            for (int r = 0; r < (fused4 ? 4 : kWarpRows); ++r)   // (fused4: r = the sample of the 2 x 2 centre)
+            for (int r = 0; r < kWarpRows; ++r)
                 for (int half = 0; half < 2; ++half) {
                     int cnt[32] = {0}, seen[32][8];
                     for (int l = 32 * half; l < 32 * half + 32; ++l) {
-                        const double px = fused4 ? 4 * (l & 15) + 1 + (r & 1) : l, py = fused4 ? 4 * (l >> 4) + 1 + (r >> 1) : r;
+                        const double px = l, py = r;
                         const double sx = M[0] * (ox + px) + M[1] * (oy + py) + (M[2] - floor(M[2])) + 4096.0;
                         const double sy = M[3] * (ox + px) + M[4] * (oy + py) + (M[5] - floor(M[5])) + 4096.0;
                         const long long dw = (long long)floor(sy) * (pitch / 4) + (long long)floor(sx);   // dword index up to a constant
@@ -1791,7 +1662,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
                 const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
                 const unsigned long long tiles = t1 * gz;
-                const bool xcd = rcv_knobs().xcd_order > 0 && tiles < (1ull << 30);
+                const bool xcd = false;   // (plain raster order measured better for one-channel tiles)
                 const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
                 const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
                 RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
@@ -1829,7 +1700,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
             const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;
             const bool rags = (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4);   // byte-aligned source rows
-            const bool xcd = rcv_knobs().xcd_order != 0 && tiles < (1ull << 30);
+            const bool xcd = tiles < (1ull << 30);
             const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
@@ -1841,7 +1712,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
                 const unsigned long long tq = t1 * gzq;
                 // (plain raster order unless RCV_XCD_ORDER=1 asks for the XCD-contiguous one: measured 0.849 against 0.888 ms on 32 x 8K)
-                const bool xq = rcv_knobs().xcd_order > 0 && tq < (1ull << 30);
+                const bool xq = false;   // (plain raster order)
                 const int tpq = xq ? (int)((tq + 7) / 8) : 0;
                 const dim3 gridq = xq ? dim3((unsigned)tpq * 8) : dim3(lgx, lgy, gzq);
                 if (prow * cpr <= 4 * kBlock) RCV_LAUNCH(k_warp_gray_lds4<4>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
@@ -1884,29 +1755,6 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            // S = 4: the LDS-staged kernel when the source patch of a 64 x 64 block of `mid` fits (rotations / shears / scales near 1)
-            if (S == 4 && rcv_knobs().warp_resize_lds > 0 && s.cols >= 8 && s.rows >= 4) {   // (measured slower than the gather kernel: off by default)
-                if (!ctx->wr_valid || memcmp(ctx->wr_M, M, sizeof(ctx->wr_M)) != 0) {
-                    ctx->wr_ok = warp_lds_plan(M, &ctx->wr_pitch, &ctx->wr_prow, &ctx->wr_cpr, true);
-                    memcpy(ctx->wr_M, M, sizeof(ctx->wr_M));
-                    ctx->wr_valid = true;
-                }
-                if (ctx->wr_ok) {
-                    const unsigned lgx = (unsigned)((d.cols + kWrTile - 1) / kWrTile), lgy = (unsigned)((d.rows + kWrTile - 1) / kWrTile);
-                    const unsigned long long wgs = (unsigned long long)lgx * lgy * d.n;
-                    int fpg = wgs / 8 >= 8192 ? 8 : (wgs / 4 >= 8192 ? 4 : (wgs / 2 >= 8192 ? 2 : 1));
-                    if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
-                    const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
-                    const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
-                    const unsigned lds = 2u * (unsigned)ctx->wr_pitch * (unsigned)ctx->wr_prow;
-                    const bool xcd = rcv_knobs().xcd_order != 0 && tiles < (1ull << 30);
-                    const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
-                    const dim3 lgrid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
-                    RCV_LAUNCH(k_warp_resize_lds, lgrid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, ctx->wr_pitch, ctx->wr_prow, ctx->wr_cpr, (int)lgx,
-                               (int)lgy, (int)tiles, tpx);
-                    return rcv_launch_check(ctx);
-                }
-            }
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
             // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)

@@ -85,7 +85,6 @@ extern "C" int rcv_group_timer_stop(rcv_group* g, float* elapsed_ms)
 {
     if (!g || !elapsed_ms) return RCV_ERR_ARG;
     for (rcv_ctx* c : g->ctxs) {
-        if (c->capturing) return RCV_ERR_UNSUPPORTED;
         RCV_TRY(rcv_bind(c));
         RCV_HIP(hipEventRecord(c->ev1, c->stream));
     }

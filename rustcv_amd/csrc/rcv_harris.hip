@@ -235,12 +235,11 @@ int nms_launch(rcv_ctx* ctx, const View& r, const View& m, float thr)
         // (launches that fill the GPU: 16-row segments -- round 3, tools/ablate_segs.py on 64 4K frames: 16 rows 0.509 ms, 32 rows 0.538,
         //  64 rows 0.554: with the XCD-contiguous block order short segments keep what one XCD reads at a time compact)
         int seg = small > 0 && small < 64 ? small : 16;
-        if (rcv_knobs().nms_seg > 0) seg = rcv_knobs().nms_seg;   // (tuning knob)
         dim3 grid((unsigned)gx0, (unsigned)((r.rows + seg - 1) / seg), r.n);
         const int gx = (int)grid.x, gy = (int)grid.y;
         const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
         int bpx = 0;
-        if (rcv_knobs().xcd_order != 0 && nb < (1ull << 30)) {
+        if (nb < (1ull << 30)) {
             bpx = (int)((nb + 7) / 8);
             grid = dim3((unsigned)bpx * 8);
         }

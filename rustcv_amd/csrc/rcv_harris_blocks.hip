@@ -695,7 +695,7 @@ int rcv_harris_resp_rows(rcv_ctx* ctx, const View& ix, const View& iy, const Vie
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const long long nblocks = (waves + 3) / 4;
-    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     const double s = 1.0 / (4.0 * (double)block * 255.0);   // 2^(aperture-1) * blockSize * 255, aperture = 3
     a.s2 = (float)(s * s);
@@ -748,7 +748,7 @@ int rcv_harris_blocks_fused(rcv_ctx* ctx, const View& s, const View* r, const Vi
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const long long nblocks = (waves + 3) / 4;
-    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     const double sc = 1.0 / (4.0 * (double)block * 255.0);
     a.s2 = (float)(sc * sc);

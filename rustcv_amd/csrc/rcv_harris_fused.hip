@@ -457,7 +457,6 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
         const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, 13, 16);
         if (small > 0) seg = small;
     }
-    if (rcv_knobs().harris_seg_rows > 0) seg = rcv_knobs().harris_seg_rows;
     a.seg_rows = seg;
     a.nsegs = (s.rows + seg - 1) / seg;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
@@ -470,7 +469,7 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     // response-only launches (cornerHarris: 4 of 5 bytes per pixel are stores): 3 workgroups per CU measured 0.698 against 0.803 ms
     constexpr unsigned kRespOnlyLds = 54272;
     const long long nblocks = (waves + 3) / 4;
-    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     if (rag) {
         if (s.ch == 1) {

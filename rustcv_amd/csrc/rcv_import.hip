@@ -26,7 +26,6 @@ extern "C" int rcv_import_dmabuf(rcv_ctx* ctx, int dmabuf_fd, size_t offset, siz
     if (dmabuf_fd < 0 || bytes == 0) return RCV_ERR_ARG;
     if (offset + bytes < offset) return RCV_ERR_SIZE;   // offset + bytes wraps size_t
     RCV_TRY(rcv_bind(ctx));
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;
     rcv_import* im = new (std::nothrow) rcv_import();
     if (!im) return RCV_ERR_OOM;
     im->ctx = ctx;
@@ -81,7 +80,7 @@ extern "C" void rcv_import_release(rcv_import* im)
     rcv_ctx* ctx = im->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        if (ctx->stream && !ctx->capturing) (void)hipStreamSynchronize(ctx->stream);   // kernels may still read the mapping
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // kernels may still read the mapping
     }
     if (im->ext) (void)hipDestroyExternalMemory(im->ext);
     if (im->fd >= 0) close(im->fd);

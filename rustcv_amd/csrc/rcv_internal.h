@@ -33,8 +33,6 @@ struct rcv_ctx {
     // workspace for kernel-internal temporaries (reserve once per call, then carve)
     uint8_t* ws;
     size_t ws_cap, ws_off;
-    uint8_t* ws_cur;     // what rcv_ws_alloc carves: ws, or (while a graph is recorded) a buffer owned by that graph
-    size_t ws_cur_cap;
     uint8_t* tmp2;       // second grow-only temporary (an intermediate image of a two-stage fallback whose second stage uses ws)
     size_t tmp2_cap;
     // small device scratch for per-call constants (filter taps, weight tables)
@@ -46,7 +44,7 @@ struct rcv_ctx {
     int f7_mode;         // 0 one table, 1 K = 4Q + R, 2 K = K1 + 2*T2 (which tables the cache holds)
     int16_t f7_k[49];
     // cached launch plan of the strip kernel (segment height, latency variant) for the last geometry
-    int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_knob, f7_plan_seg_rows;
+    int f7_plan_rows, f7_plan_nstrips, f7_plan_n, f7_plan_seg_rows;
     bool f7_plan_lat_ok, f7_plan_lat;
     // cached banded-weight tables of the row-streaming MFMA filter (rcv_filter_rows_mfma.hip): four entries, least recently used
     // replaced, each with its own 16-KiB device region (fr_tabs) and a persistent host copy, so that a caller alternating between
@@ -67,60 +65,33 @@ struct rcv_ctx {
     bool wl_valid = false, wl_ok = false;
     float wl_M[6] = {0, 0, 0, 0, 0, 0};
     int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
-    // ... and of the fused warp -> 4x down-scale kernel (k_warp_resize_lds)
-    bool wr_valid = false, wr_ok = false;
-    float wr_M[6] = {0, 0, 0, 0, 0, 0};
-    int wr_pitch = 0, wr_prow = 0, wr_cpr = 0;
-    // stream capture (rcv_graph.hip): while `capturing`, entry points may only enqueue on `stream`; per-call constant
-    // tables are placed in device buffers owned by the graph being recorded instead of the shared kconst cache
-    bool capturing;
-    hipStream_t side;            // upload stream for graph-owned constants (never captured)
-    void* cap_allocs[64];
-    int cap_nallocs;
+    hipStream_t side;            // second stream of the context (the measurement library's clock probe runs beside the main one)
     // grow-only pinned staging for small per-call host tables that outlive the call (rcv_text_blend.hip)
     uint8_t* pin;
     size_t pin_cap;
     hipEvent_t pin_ev;           // recorded after the H2D that reads `pin`
-    int children;                // live graphs / staging rings that use this context's device and stream
+    int children;                // live staging rings that use this context's device and stream
     bool zombie;                 // rcv_ctx_destroy was called while children were alive: freed when the last one goes
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
-// Environment knobs (tuning sweeps and tests only; nothing needs them in production).  Read ONCE per process -- a launch-bound
-// call (a single 1080p frame: 6 us) must not pay for getenv -- and again on rcv__debug_reload_knobs() (tests, after setenv).
+// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), twelve in all; nothing
+// needs them in production and no tuning parameter is among them (those are arguments of the measurement entries in
+// librustcv_hip_bench.so).  Read ONCE per process -- a launch-bound call (a single 1080p frame: 6 us) must not pay for getenv -- and
+// again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 lists each with the test that uses it.
 struct RcvKnobs {
-    int f7_seg_rows;      // RCV_F7_SEG_ROWS   row-segment height of the MFMA strip kernel (0 = cost model)
-    int f7_tps;           // RCV_F7_TPS        15: 240-pixel strips
+    int f7_rows;          // RCV_F7_ROWS       row-streaming MFMA kernel: 1 every eligible shape, 0 never, -1 (unset) by size
     int f7_no_lat;        // RCV_F7_NO_LAT     small launches take the pipelined strip kernel instead of its latency variant
     int f7_no_gray;       // RCV_F7_NO_GRAY    one-channel images take the dot4 streaming kernel
     int f7_dual_full;     // RCV_F7_DUAL_FULL  large-weight kernels use K = 4Q + R even where the centre split applies
-    int f7_rows;          // RCV_F7_ROWS       row-streaming MFMA kernel: 1 every eligible shape, 0 never, -1 (unset) by size
-    int fr_rounds;        // RCV_FR_ROUNDS     bands per wave slot of the row-streaming kernel (0 = 8)
-    int fr_wpc;           // RCV_FR_WPC        its waves per CU (0 = 10)
-    int fr_pp;            // RCV_FR_PP         its row pairs in flight (profiling builds; 0 = 3)
-    int fr_bpf;           // RCV_FR_BPF        bands per frame (batches of >= 8 frames; 0 = from RCV_FR_ROUNDS)
-    int fr_band_rows;     // RCV_FR_BAND_ROWS  rows per band of the row-streaming kernel on launches of fewer than 8 frames (0 = per-SIMD plan)
-    int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian (rcv_gauss_rows.hip): 1 every eligible shape, 0 never, -1 (unset) small launches
-    int gr_plain;         // RCV_GR_PLAIN      its stores plain instead of non-temporal (ablation)
-    int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan)
-    int fr_taper;         // RCV_FR_TAPER      0: equal bands; unset / 1: tapered tail of one round; n > 1: tail of n % of a round
-    int fr_sob192;        // RCV_FR_SOB192     fused filter -> Sobel: 0 = 240-pixel strips with plain stores, 1 (default where the planes allow) = line-aligned 192-pixel strips, nt stores
-    int fr_wpb;           // RCV_FR_WPB        its waves per workgroup (1 / 2 / 4 / 8: neighbouring strips of a band on one CU)
-    int fr_chain;         // RCV_FR_CHAIN      0: never the chained-band kernel (k_filter_rows_chain); unset: launches that fill the GPU
-    int fr_chain_rows;    // RCV_FR_CHAIN_ROWS rows per chained band (0 = 32)
-    int fr_order;         // RCV_FR_ORDER      1: bands dealt round-robin to the XCDs instead of a contiguous eighth each (ablation)
-    int extra_lds;        // RCV_EXTRA_LDS     experiment: untouched dynamic LDS added to EVERY launch (caps workgroups per CU)
-    int sobel_seg;        // RCV_SOBEL_SEG     rows per segment of the Sobel kernel (0 = plan)
-    int sobel_plain;      // RCV_SOBEL_PLAIN   1: plain instead of non-temporal stores (A/B)
-    int nms_seg;          // RCV_NMS_SEG       rows per segment of the NMS kernel (0 = plan)
-    int sobel_wgs;        // RCV_SOBEL_WGS     workgroups per CU of the Sobel kernel (0 = default)
-    int warp_resize_lds;  // RCV_WARP_RESIZE_LDS 1: the fused warp -> 4x resize on the LDS-staged kernel (slower: experiment record)
-    int warp_gray4;       // RCV_WARP_GRAY4    0: one-channel warpAffine never on the four-frames-per-pass kernel (k_warp_gray_lds4)
-    int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (ablation / tests of the gather kernel)
-    int warp_fpg;         // RCV_WARP_FPG      frames per workgroup in the warpAffine kernel (default: up to 8 while >= 8192 workgroups remain)
-    int xcd_order;        // RCV_XCD_ORDER     0: plain block order in the register-window kernels (ablation; default XCD-contiguous)
-    int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too (A/B against the dedicated one, tests)
-    int harris_seg_rows;  // RCV_HARRIS_SEG_ROWS
+    int fr_chain;         // RCV_FR_CHAIN      chained-band kernel: 0 never, 1 every eligible launch, -1 (unset) launches that fill the GPU
+    int fr_chain_rows;    // RCV_FR_CHAIN_ROWS rows per chained band (0 = 32): band seams at other rows
+    int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian: 1 every eligible shape, 0 never, -1 (unset) small launches
+    int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan): segment seams at every height
+    int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too
+    int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (the gather kernel on the same maps)
+    int warp_gray4;       // RCV_WARP_GRAY4    0: one-channel warpAffine never on the four-frames-per-pass kernel
+    int warp_fpg;         // RCV_WARP_FPG      frames per workgroup of the warp kernels (an incomplete last group)
 };
 const RcvKnobs& rcv_knobs();
 
@@ -130,12 +101,11 @@ void rcv_note_kernel(const char* name);
 #define RCV_LAUNCH(kernelName, grid_, block_, lds_, ...)                                                   \
     do {                                                                                                   \
         rcv_note_kernel(#kernelName);                                                                      \
-        hipLaunchKernelGGL(kernelName, grid_, block_, (lds_) + (unsigned)rcv_knobs().extra_lds, __VA_ARGS__); \
+        hipLaunchKernelGGL(kernelName, grid_, block_, (lds_), __VA_ARGS__);                                  \
     } while (0)
 
-// Device copy of a small per-call constant table, valid for the kernel about to be enqueued.  Outside capture: the
-// shared 64-KiB kconst area at `offset`, uploaded stream-ordered.  During capture: a fresh device buffer owned by the
-// graph, uploaded immediately on a side stream, so that replays do not depend on later contents of kconst.
+// Device copy of a small per-call constant table, valid for the kernel about to be enqueued: the shared 64-KiB kconst area at
+// `offset`, uploaded stream-ordered.
 int rcv_const_table(rcv_ctx* ctx, const void* host, size_t bytes, size_t offset, const uint8_t** dev);
 
 // Kernel-facing description of a (batch of) strided image(s).

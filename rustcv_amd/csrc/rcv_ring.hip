@@ -155,7 +155,6 @@ extern "C" int rcv_ring_submit(rcv_ring* r, const rcv_mat* host_in, rcv_ring_op 
     if (!r || !op) return RCV_ERR_ARG;
     if (r->head - r->tail >= (unsigned long long)r->depth) return RCV_ERR_BUSY;
     rcv_ctx* ctx = r->ctx;
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;
     RCV_TRY(rcv_bind(ctx));
     rcv_ring::Slot& s = r->slots[r->head % r->depth];
     if (host_in) {

@@ -24,7 +24,6 @@
 #include "rcv_device_utils.h"
 #include <type_traits>
 
-extern int rcv_debug_flags;
 
 namespace {
 
@@ -66,7 +65,7 @@ struct __attribute__((packed, aligned(2))) U4u { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(2))) U2h { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) U1h { uint32_t a; };
 
-// DBG (profiling builds, -DRCV_ABLATE): 1 skip global stores, 2 skip global loads
+// DBG (instantiated by hand when profiling; the product launches DBG = 0 only): 1 skip global stores, 2 skip global loads
 // BGR = true: the source is a BGR image and the gradient is taken of its gray conversion (the fixed-point BT.601 of
 // RCV_BGR2GRAY, two v_dot4 per pixel) -- cvtColor + Sobel in one launch, 7 instead of 9 bytes per pixel and no gray image.
 template <int DBG, bool BGR, bool RAG = false>
@@ -335,18 +334,17 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
     // rows 0.439, 90 rows 0.445 -- with the XCD-contiguous block order shorter segments keep what one XCD has in flight more
     // compact; a BGR source likes them shorter still: 12-20 rows 0.614-0.617 against 0.648 at 68).
     int seg = s.ch == 3 ? 16 : 24;
-    if (rcv_knobs().sobel_seg > 0) seg = rcv_knobs().sobel_seg;   // (tuning knob)
     a.seg_rows = seg;
     a.nsegs = s.rows >= 2 * seg ? (s.rows + seg / 2) / seg : 1;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
     if (waves > 0x3fffffff) return RCV_ERR_UNSUPPORTED;
     a.total_waves = (int)waves;
     const long long nblocks = (waves + 3) / 4;
-    a.blocks_per_xcd = rcv_knobs().xcd_order == 0 ? 0 : (int)((nblocks + 7) / 8);
+    a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     const dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     // occupancy cap (workgroups per CU) through an untouched dynamic-LDS request; 0 = what the registers allow
     // measured on 64 4K frames: 5 (registers) / 4 workgroups per CU 0.519 ms, 3 workgroups 0.474 ms (gray); 0.638 / 0.625 (BGR source)
-    const int wgs = rcv_knobs().sobel_wgs > 0 ? rcv_knobs().sobel_wgs : 3;
+    const int wgs = 3;
     const unsigned lds = wgs < 5 ? (unsigned)((163840 / wgs) & ~511) : 0u;
     if (rag) {
         if (s.ch == 3) RCV_LAUNCH((k_sobel_rows<0, true, true>), grid, dim3(256), lds, ctx->stream, a);
@@ -357,17 +355,6 @@ int rcv_sobel_tiled(rcv_ctx* ctx, const View& s, const View& dx, const View& dy)
         RCV_LAUNCH((k_sobel_rows<0, true>), grid, dim3(256), lds, ctx->stream, a);
         return rcv_launch_check(ctx);
     }
-#ifdef RCV_ABLATE
-    switch (rcv_debug_flags & 7) {
-    case 4: RCV_LAUNCH((k_sobel_rows<4, false>), grid, dim3(256), lds, ctx->stream, a); break;
-    case 1: RCV_LAUNCH((k_sobel_rows<1, false>), grid, dim3(256), lds, ctx->stream, a); break;
-    case 2: RCV_LAUNCH((k_sobel_rows<2, false>), grid, dim3(256), lds, ctx->stream, a); break;
-    case 3: RCV_LAUNCH((k_sobel_rows<3, false>), grid, dim3(256), lds, ctx->stream, a); break;
-    default: RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a); break;
-    }
-#else
-    if (rcv_knobs().sobel_plain) RCV_LAUNCH((k_sobel_rows<4, false>), grid, dim3(256), lds, ctx->stream, a);   // (plain instead of non-temporal stores: A/B knob)
-    else RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a);
-#endif
+    RCV_LAUNCH((k_sobel_rows<0, false>), grid, dim3(256), lds, ctx->stream, a);
     return rcv_launch_check(ctx);
 }

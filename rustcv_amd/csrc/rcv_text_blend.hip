@@ -84,7 +84,6 @@ extern "C" int rcv_blend_glyphs_batch(rcv_ctx* ctx, rcv_batch* mats, const rcv_g
 {
     if (!mats || n_glyphs < 0 || (n_glyphs > 0 && !glyphs)) return RCV_ERR_ARG;
     RCV_TRY(rcv_bind(ctx));
-    if (ctx->capturing) return RCV_ERR_UNSUPPORTED;   // the glyph data is per call: nothing a replay could reuse
     if (mats->frame0.device != RCV_DEVICE) return RCV_ERR_ARG;
     if (mats->frame0.channels != 3) return RCV_ERR_UNSUPPORTED;   // drawing.rs:132 hard-codes 3
     View m;

@@ -217,7 +217,7 @@ def test_rust_ffi_declares_the_whole_header():
     for name in hf:
         assert rf[name] == hf[name], (name, rf[name], hf[name])
     opaque = {k for k, v in rs.items() if not v}             # zero-sized handles (only a private field)
-    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_graph", "rcv_import", "rcv_group"}
+    assert opaque == {"rcv_ctx", "rcv_ring", "rcv_import", "rcv_group"}
     for name, fields in hs.items():
         assert rs[name] == fields, (name, rs[name], fields)
     assert rc == hc and len(hc) >= 29
@@ -264,7 +264,7 @@ def _rust_calls(src):
 def test_rust_facade_wraps_every_entry_point():
     """round 3: the Rust crate is at parity with include/rustcv.hpp -- lib.rs + imgproc.rs together call EVERY
     non-debug function of include/rustcv_hip.h from a safe wrapper, each call with the header's number of arguments; the facade has
-    the Mat-shaped borrows (rustcv/src/core/mat.rs:6-15), the owning DeviceBatch / StagingRing / Graph handles with Drop, and
+    the Mat-shaped borrows (rustcv/src/core/mat.rs:6-15), the owning DeviceBatch / StagingRing handles with Drop, and
     rgb_to_bgr (rustcv-camera/src/decode.rs:213)"""
     hf, _, _ = _parse_header()
     base = os.path.join(ROOT, "rust", "rustcv-backend-hip", "src")
@@ -277,17 +277,41 @@ def test_rust_facade_wraps_every_entry_point():
             assert got == len(params), (name, got, len(params))
     assert not [n for n in calls if n not in hf and not n.startswith(("rcv_mat", "rcv_batch", "rcv_glyph", "rcv_ring_op"))], "call of an undeclared function"
     assert "pub mod imgproc;" in lib_rs
-    for item in ("pub struct MatRef<", "pub struct MatMut<", "pub struct DeviceBatch<", "pub struct StagingRing<", "pub struct Graph<", "pub enum HipError",
+    for item in ("pub struct MatRef<", "pub struct MatMut<", "pub struct DeviceBatch<", "pub struct StagingRing<", "pub enum HipError",
                  "pub fn rgb_to_bgr(", "pub fn harris_pipeline_batch(", "pub fn filter2d_i8_batch(", "pub fn warp_affine_resize_batch("):
         assert item in img_rs, item
     assert "pub struct DeviceGroup" in lib_rs and "impl Drop for DeviceGroup" in lib_rs and "pub fn frame_range(" in lib_rs
-    for handle in ("DeviceBatch", "StagingRing", "Graph"):
+    for handle in ("DeviceBatch", "StagingRing"):
         assert re.search(r"impl<'c> Drop for %s<'c>" % handle, img_rs), handle
     # every safe wrapper of a compute entry point exists under the C name minus its prefix
     for name in hf:
-        if name.startswith(("rcv_ring_", "rcv_graph_", "rcv_import_", "rcv_ctx_", "rcv_timer_", "rcv_group_")) or name in (
+        if name.startswith(("rcv_ring_", "rcv_import_", "rcv_ctx_", "rcv_timer_", "rcv_group_")) or name in (
                 "rcv_malloc", "rcv_free", "rcv_upload", "rcv_download", "rcv_memset", "rcv_sync", "rcv_strerror", "rcv_synth_batch", "rcv_shard_range"):
             continue
         assert re.search(r"pub fn %s\(" % name[4:], lib_rs + img_rs), name
     assert img_rs.count("{") == img_rs.count("}") and img_rs.count("(") == img_rs.count(")")   # (no compiler here: at least balanced)
     assert lib_rs.count("{") == lib_rs.count("}") and lib_rs.count("(") == lib_rs.count(")")
+
+
+def test_product_library_is_slim():
+    """round 4: the product library reads twelve environment knobs -- dispatch overrides for the tests, no tuning
+    parameter -- exports no measurement entry (those live in librustcv_hip_bench.so) and carries no launch-graph API any more"""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "rustcv_amd", "csrc", "rcv_ctx.hip")).read()
+    knobs = set(re.findall(r'"(RCV_[A-Z0-9_]+)"', src[src.index("static void load_knobs()"):src.index("const RcvKnobs& rcv_knobs()")]))
+    assert len(knobs) == 12, sorted(knobs)
+    others = set()
+    for f in os.listdir(os.path.join(ROOT, "rustcv_amd", "csrc")):
+        if f.endswith((".hip", ".h")) and f not in ("rcv_ctx.hip", "rcv_membench.hip"):
+            others |= set(re.findall(r'getenv\("(RCV_[A-Z0-9_]+)"\)', open(os.path.join(ROOT, "rustcv_amd", "csrc", f)).read()))
+    assert not others, others                      # (no file reads the environment behind the table's back)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for k in knobs:
+        assert k in design, f"{k} is not documented in DESIGN.md"
+    syms = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rcv_\w+)", syms))
+    assert {s for s in exported if s.startswith("rcv__")} == {"rcv__debug_kernels", "rcv__debug_kernels_reset", "rcv__debug_occupancy", "rcv__debug_reload_knobs"}
+    assert not [s for s in exported if "graph" in s or "bench" in s or "stripwalk" in s]
+    bench = subprocess.run(["nm", "-D", "--defined-only", _ffi.BENCH_LIB_PATH], capture_output=True, text=True).stdout
+    assert {"rcv__filter_rows_bench", "rcv__membench", "rcv__stripwalk", "rcv__storebench", "rcv__clock_probe"} <= set(re.findall(r" T (rcv_\w+)", bench))

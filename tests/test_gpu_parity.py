@@ -401,15 +401,15 @@ def test_filter2d_i8_mfma_path(ctx, oracle, rng, knob, rows, cols, ksize, shift,
 
 
 @pytest.mark.parametrize("variant", ["bgr", "gray", "yuyv", "sobel", "dual"])
-@pytest.mark.parametrize("taper", [None, 0, 200])
-def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, taper):
+@pytest.mark.parametrize("chain", [None, 0])
+def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, chain):
     """round 3: launches that fill the GPU several times over cut the tail of every XCD's band list into half- and quarter-height
-    bands (tapered bands; RCV_FR_TAPER=0: equal bands, 200: a tapered part twice as long).  32 frames of 1080p -- the smallest
-    BASELINE-shaped batch that takes this path -- EVERY frame against the oracle, for each source flavour of the row kernel (BGR,
-    one-channel, packed YUYV, the fused filter -> gray -> Sobel launch, two weight tables); band seams fall on different rows in each
-    setting, frame boundaries inside XCD ranges included (n % 8 == 0: four frames per XCD)"""
-    if taper is not None:
-        knob("RCV_FR_TAPER", taper)
+    bands (tapered bands).  32 frames of 1080p -- the smallest BASELINE-shaped batch that takes this path -- EVERY frame against the
+    oracle, for each source flavour of the row kernel (BGR, one-channel, packed YUYV, the fused filter -> gray -> Sobel launch, two
+    weight tables); frame boundaries inside XCD ranges included (n % 8 == 0: four frames per XCD).  Round 4: the plain BGR launch of this
+    size takes the chained-band kernel by default; RCV_FR_CHAIN=0 keeps the tapered one-band-per-wave kernel covered"""
+    if chain is not None:
+        knob("RCV_FR_CHAIN", chain)
     knob("RCV_GAUSS_ROWS", 0)
     n, rows, cols = 32, 1080, 1920
     r = np.random.default_rng(991 + _SOAK_SEED)
@@ -449,7 +449,8 @@ def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, taper)
                 want = oracle.filter2d_i8(frames[i], k, 6)
             assert np.array_equal(got[i], want.reshape(got[i].shape)), (variant, i, np.argwhere(got[i] != want.reshape(got[i].shape))[:3])
         outs = [dst]
-    assert "k_filter_rows_mfma<" in L.rcv__debug_kernels().decode()
+    launched = L.rcv__debug_kernels().decode()
+    assert ("k_filter_rows_chain<" if variant == "bgr" and chain is None else "k_filter_rows_mfma<") in launched, launched
     for b in outs + [src]:
         b.free()
 
@@ -1132,40 +1133,6 @@ def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
         b.free()
 
 
-@pytest.mark.parametrize("rows,cols", [(9, 196), (12, 208), (33, 380), (40, 384), (31, 388), (37, 400), (21, 572), (18, 576), (26, 580), (70, 768),
-                                       (19, 1000), (130, 1920), (5, 3840), (66, 192 * 7 + 4)])
-@pytest.mark.parametrize("ksize", [3, 5, 7])
-def test_filter2d_sobel_fused_line_aligned_strips(ctx, oracle, knob, rows, cols, ksize):
-    """round 3: the SOB = 2 instantiation -- strips 192 pixels apart whose row pieces are whole 128-byte lines of the i16 planes
-    (non-temporal stores), tiles starting 16 pixels left of the pixels they store; taken when the planes' rows start on lines.
-    Widths around the multiples of 192 put the row's end into every place of a tile; batch of 3, canaries in the row padding."""
-    knob("RCV_FR_SOB192", 1)
-    n = 3
-    r = np.random.default_rng(rows * 2003 + cols * 11 + ksize + _SOAK_SEED)
-    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
-    frames[1] = (r.integers(0, 2, size=(rows, cols, 1)) * 255).astype(np.uint8)
-    k = r.integers(-8, 9, size=(ksize, ksize)).astype(np.int8)
-    k[ksize // 2, ksize // 2] = 40
-    src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 12)
-    src.upload(frames)
-    gstep = (cols * 2 + 127) // 128 * 128 + 128
-    dx = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=gstep, frame_stride=rows * gstep + 512)
-    dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=gstep, frame_stride=rows * gstep + 512)
-    dx.memset(0xCD)
-    dy.memset(0xCD)
-    launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, 6))
-    assert "k_filter_rows_mfma<KS, 3, 0, 0, 0, 2>" in launched, launched
-    gx, gy = dx.download(), dy.download()
-    for i in range(n):
-        wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, 6)))
-        assert np.array_equal(gx[i].reshape(rows, cols), wx.reshape(rows, cols)), ("dx", i, np.argwhere(gx[i].reshape(rows, cols) != wx.reshape(rows, cols))[:4])
-        assert np.array_equal(gy[i].reshape(rows, cols), wy.reshape(rows, cols)), ("dy", i, np.argwhere(gy[i].reshape(rows, cols) != wy.reshape(rows, cols))[:4])
-    _assert_canaries(dx)
-    _assert_canaries(dy)
-    for b in (src, dx, dy):
-        b.free()
-
-
 def test_filter2d_sobel_fused_unequal_plane_layouts(ctx, oracle):
     """gradient planes with different row steps, or rows that are not 8-byte aligned, take the two-launch path: same bytes"""
     n, rows, cols = 2, 40, 512
@@ -1330,17 +1297,15 @@ def test_warp_affine_resize_fused(ctx, oracle, rng, scale, dshape, M):
     dst.free()
 
 
-@pytest.mark.parametrize("n,fpg,kernel", [(4, 0, "quad"), (5, 0, "quad"), (9, 4, "quad"), (9, 8, "quad-xcd"), (17, 0, "quad"), (19, 16, "quad-xcd"), (6, 0, "single")])
+@pytest.mark.parametrize("n,fpg,kernel", [(4, 0, "quad"), (5, 0, "quad"), (9, 4, "quad"), (9, 8, "quad"), (17, 0, "quad"), (19, 16, "quad"), (6, 0, "single")])
 @pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "shift", "flip", "big"])
 @pytest.mark.parametrize("dshape", [(70, 200), (33, 131)])
 def test_warp_affine_gray_four_frames_per_pass(ctx, oracle, rng, knob, n, fpg, kernel, M, dshape):
     """round 3: one-channel warpAffine with the SAME pixel of four consecutive frames in one LDS dword (k_warp_gray_lds4): frame
     counts that are not a multiple of 4, groups with a short last pass, ragged destination widths (131), tiles at the source border
-    and outside (gather path), both tile orders, against the one-frame kernel's results (RCV_WARP_GRAY4=0) and the oracle"""
+    and outside (gather path), against the one-frame kernel's results (RCV_WARP_GRAY4=0) and the oracle"""
     if kernel == "single":
         knob("RCV_WARP_GRAY4", 0)
-    if kernel == "quad-xcd":
-        knob("RCV_XCD_ORDER", 1)
     if fpg:
         knob("RCV_WARP_FPG", fpg)
     dr, dc = dshape
@@ -1365,16 +1330,11 @@ def test_warp_affine_gray_four_frames_per_pass(ctx, oracle, rng, knob, n, fpg, k
     dst.free()
 
 
-@pytest.mark.parametrize("kernel,fpg", [("lds", 0), ("lds", 3), ("lds-raster", 2), ("box", 0)])
+@pytest.mark.parametrize("kernel,fpg", [("box", 0)])
 @pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "ident", "flip", "grow", "big"])
 def test_warp_affine_resize_fused_lds_tiles(ctx, oracle, rng, knob, kernel, fpg, M):
-    """the LDS-staged fused warp -> 4x kernel (16 x 16 output tiles: staged interior tiles, gather tiles at the source border and
-    outside, ragged last tile row / column, groups of frames with a short last group, both tile orders) and the gather kernel
-    it replaces produce the oracle's resize(warp_affine(.)) bit for bit"""
-    if kernel != "box":
-        knob("RCV_WARP_RESIZE_LDS", 1)   # (off by default: the gather kernel is faster)
-    if kernel == "lds-raster":
-        knob("RCV_XCD_ORDER", 0)
+    """the fused warp -> 4x gather kernel (interior tiles, tiles at the source border and outside, ragged last tile row / column) produces
+    the oracle's resize(warp_affine(.)) bit for bit.  (Round 3's LDS-staged variant of this launch was removed in round 4: slower.)"""
     if fpg:
         knob("RCV_WARP_FPG", fpg)
     dr, dc = 52, 100                  # 4 x 7 tiles, the last row / column of tiles ragged (dc % 4 == 0)
@@ -2697,15 +2657,15 @@ def test_geometry_f32_random_shapes(ctx, oracle):
 
 
 def test_row_kernel_random_batches(ctx, oracle, knob):
-    """RCV_SOAK random launches of the row-streaming MFMA kernel in its LARGE-launch regime (tapered bands when the batch is a
-    multiple of 8, plain bands otherwise, 1 / 2 / 4 waves per workgroup): 8..24 frames of 16k-aligned widths, ksize 3 / 5 / 7,
+    """RCV_SOAK random launches of the row-streaming MFMA kernel in its LARGE-launch regime (chained or tapered bands when the batch is a
+    multiple of 8, plain bands otherwise): 8..24 frames of 16k-aligned widths, ksize 3 / 5 / 7,
     random i8 weights and shifts; three frames of each launch against the oracle"""
     r = np.random.default_rng(0x7A9E + _SOAK_SEED)
     L = _ffi.lib()
     for case in range(max(2, _SOAK // 2)):
         knob("RCV_F7_ROWS")
-        knob("RCV_FR_WPB", int(r.choice([1, 2, 4])))
-        knob("RCV_FR_TAPER", int(r.choice([0, 1, 1])))
+        knob("RCV_FR_CHAIN", int(r.choice([-1, 0, 1])))
+        knob("RCV_FR_CHAIN_ROWS", int(r.choice([0, 9, 21, 64])))
         ksize = int(r.choice([3, 5, 7]))
         n = int(r.choice([8, 9, 16, 17, 24]))
         rows, cols = int(r.integers(300, 700)), 16 * int(r.integers(60, 130))
@@ -2716,7 +2676,7 @@ def test_row_kernel_random_batches(ctx, oracle, knob):
         device.synth(src, 1, 0x5EED0100 + case + _SOAK_SEED, 0)
         L.rcv__debug_kernels_reset()
         device.filter2d(src, dst, k, shift=shift)
-        assert "k_filter_rows_mfma" in L.rcv__debug_kernels().decode()
+        assert "k_filter_rows_" in L.rcv__debug_kernels().decode()
         frames = src.download()
         got = dst.download()
         for i in sorted({0, n // 2, n - 1}):
@@ -2755,8 +2715,6 @@ def test_warp_affine_f32_lds_kernel(ctx, oracle, rng, knob, fpg, xcd, M):
     (expected: bit-exact) and identical to the per-pixel kernel (RCV_WARP_LDS=0)"""
     if fpg:
         knob("RCV_WARP_FPG", fpg)
-    if xcd:
-        knob("RCV_XCD_ORDER", 1)
     n, sr, sc, dr, dc = 5, 150, 300, 131, 259
     Ms = {"rot7": _rot(7.0, dc / 2, dr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, dc / 2, dr / 2, 20.0, 12.0),
           "shear": np.array([1, 0.25, 3.5, -0.125, 1, 18.25], np.float32), "shift": np.array([1, 0, 7.5, 0, 1, 3.25], np.float32),

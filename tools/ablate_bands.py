@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/ablate_bands.py -- (round 4) band height: the north-star kernel, its memory-only variant and the strip-walker copy at the
-SAME bands per frame (RCV_FR_BPF; 21 = the default plan, 103-row bands).  The walker says short bands (a compact window per XCD)
+SAME bands per frame (tune bpf; 21 = the default plan, 103-row bands).  The walker says short bands (a compact window per XCD)
 are worth 6-10 %; the kernel does not show it -- is that its per-band prologue (tables, halo rows, pipeline fill)?
 Same process, three rotations, medians."""
 import ctypes as C
@@ -43,31 +43,22 @@ def main():
         L.rcv_timer_stop(ctx.handle, C.byref(ms))
         return ms.value / launches
 
-    def filt():
-        rc = L.rcv_filter2d_i8_batch(ctx.handle, C.byref(bs), C.byref(bd), kp, 7, 6)
-        assert rc == 0, rc
+    from tools._rows import Rows
+    rows = Rows(ctx, src, dst, k)
 
     bpfs = (0, 27, 34, 45, 68, 90, 135)
     res = {}
     for r in range(3):
         for bpf in bpfs:
             for taper in ((1, 0) if bpf else (1,)):
-                os.environ["RCV_FR_BPF"] = str(bpf)
-                os.environ["RCV_FR_TAPER"] = str(taper)
-                L.rcv__debug_reload_knobs()
-                res.setdefault((bpf, taper, "filter"), []).append(timed(filt))
-                L.rcv__debug_set(4)
-                res.setdefault((bpf, taper, "memonly"), []).append(timed(filt))
-                L.rcv__debug_set(0)
+                res.setdefault((bpf, taper, "filter"), []).append(timed(rows.fn(chain=0, bpf=bpf, taper=taper)))
+                res.setdefault((bpf, taper, "memonly"), []).append(timed(rows.fn(chain=0, bpf=bpf, taper=taper, dbg=4)))
             rounds = max(1, round((bpf or 21) * 64 * 15 / 2048))
 
             def walk():
                 rc = BL.rcv__stripwalk(ctx.handle, dst.ptr, src.ptr, n, ROWS, COLS * 3, COLS * 3, 768, 2, rounds, 8, 6, 0)
                 assert rc == 0, rc
             res.setdefault((bpf, rounds, "walker"), []).append(timed(walk))
-    os.environ.pop("RCV_FR_BPF")
-    os.environ.pop("RCV_FR_TAPER")
-    L.rcv__debug_reload_knobs()
     print("bands per frame (0 = default plan: 21, tapered) | taper / walker rounds | what | median ms | frac of 8 TB/s | samples")
     for key in sorted(res, key=lambda t: (t[0], t[2], t[1])):
         m = statistics.median(res[key])

@@ -45,35 +45,25 @@ def main():
     def filt():
         rc = L.rcv_filter2d_i8_batch(ctx.handle, C.byref(bs), C.byref(bd), kp, 7, 6)
         assert rc == 0, rc
+    from tools._rows import Rows
+    rows = Rows(ctx, src, dst, k)
 
     res = {}
     heights = (24, 32, 40, 64)
     for r in range(3):
-        os.environ["RCV_FR_CHAIN"] = "0"
-        L.rcv__debug_reload_knobs()
-        res.setdefault(("one band per wave (103 rows, tapered)", "filter"), []).append(timed(filt))
-        L.rcv__debug_set(4)
-        res.setdefault(("one band per wave (103 rows, tapered)", "memonly"), []).append(timed(filt))
-        L.rcv__debug_set(0)
-        os.environ["RCV_FR_CHAIN"] = "1"
+        res.setdefault(("one band per wave (103 rows, tapered)", "filter"), []).append(timed(rows.fn(chain=0)))
+        res.setdefault(("one band per wave (103 rows, tapered)", "memonly"), []).append(timed(rows.fn(chain=0, dbg=4)))
         for hgt in heights:
-            os.environ["RCV_FR_CHAIN_ROWS"] = str(hgt)
-            L.rcv__debug_reload_knobs()
             L.rcv__debug_kernels_reset()
-            res.setdefault((f"chained {hgt:3d} rows", "filter"), []).append(timed(filt))
+            res.setdefault((f"chained {hgt:3d} rows", "filter"), []).append(timed(rows.fn(chain=1, chain_rows=hgt)))
             assert "k_filter_rows_chain" in L.rcv__debug_kernels().decode()
-            L.rcv__debug_set(4)
-            res.setdefault((f"chained {hgt:3d} rows", "memonly"), []).append(timed(filt))
-            L.rcv__debug_set(0)
+            res.setdefault((f"chained {hgt:3d} rows", "memonly"), []).append(timed(rows.fn(chain=1, chain_rows=hgt, dbg=4)))
             rounds = max(1, round(ROWS / hgt * 64 * 15 / 2048))
 
             def walk():
                 rc = BL.rcv__stripwalk(ctx.handle, dst.ptr, src.ptr, n, ROWS, COLS * 3, COLS * 3, 768, 4, rounds, 8, 6, 4)   # kernel-like: dup lanes, 2 rows per request, 4 in flight
                 assert rc == 0, rc
             res.setdefault((f"chained {hgt:3d} rows", "walker"), []).append(timed(walk))
-    os.environ.pop("RCV_FR_CHAIN")
-    os.environ.pop("RCV_FR_CHAIN_ROWS")
-    L.rcv__debug_reload_knobs()
     # the default plan, as shipped
     L.rcv__debug_kernels_reset()
     t = timed(filt, 200)

@@ -28,10 +28,10 @@ def main():
     device.synth(src, 0, 0x5EED0003, 0)
     bs, bd = src.as_rcv(), dst.as_rcv()
 
-    def timed(launches=60):
-        def fn():
-            rc = L.rcv_filter2d_i8_batch(ctx.handle, C.byref(bs), C.byref(bd), kp, 7, 6)
-            assert rc == 0, rc
+    from tools._rows import Rows
+    rows = Rows(ctx, src, dst, k)
+
+    def timed(fn, launches=60):
         t = time.perf_counter()
         while time.perf_counter() - t < 0.04:
             for _ in range(8):
@@ -46,20 +46,11 @@ def main():
 
     res = {}
     for r in range(3):
-        os.environ["RCV_FR_CHAIN"] = "0"
-        os.environ.pop("RCV_FR_WPC", None)
-        L.rcv__debug_reload_knobs()
-        res.setdefault(("one band per wave", 8, 103, "filter"), []).append(timed())
-        os.environ["RCV_FR_CHAIN"] = "1"
+        res.setdefault(("one band per wave", 8, 103, "filter"), []).append(timed(rows.fn(chain=0)))
         for wpc in (6, 8, 10, 12):
             for hgt in (24, 32, 48, 64):
-                os.environ["RCV_FR_WPC"] = str(wpc)
-                os.environ["RCV_FR_CHAIN_ROWS"] = str(hgt)
-                L.rcv__debug_reload_knobs()
-                res.setdefault(("chained", wpc, hgt, "filter"), []).append(timed())
-                L.rcv__debug_set(4)
-                res.setdefault(("chained", wpc, hgt, "memonly"), []).append(timed())
-                L.rcv__debug_set(0)
+                res.setdefault(("chained", wpc, hgt, "filter"), []).append(timed(rows.fn(chain=1, chain_rows=hgt, wpc=wpc)))
+                res.setdefault(("chained", wpc, hgt, "memonly"), []).append(timed(rows.fn(chain=1, chain_rows=hgt, wpc=wpc, dbg=4)))
     for key in res:
         m = statistics.median(res[key])
         print(f"  {key[0]:18s} wpc {key[1]:2d} rows {key[2]:3d} {key[3]:8s} {m:.4f} ms  {2 * nbytes / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[key]]}")

@@ -98,6 +98,9 @@ def main():
         rc = L.rcv_filter2d_i8_batch(ctx.handle, C.byref(bs), C.byref(bd), kp, 7, 6)
         assert rc == 0, rc
 
+    from tools._rows import Rows
+    memonly = Rows(ctx, src, dst, k).fn(dbg=4)
+
     def walker(W, depth, wpc, rounds, halo, ntl=0):
         def fn():
             rc = BL.rcv__stripwalk(ctx.handle, dst.ptr, src.ptr, n, ROWS, COLS * 3, COLS * 3, W, depth, rounds, wpc, halo, ntl)
@@ -126,9 +129,7 @@ def main():
     for r in range(a.rot):
         for name, fn in variants:
             if fn == "memonly":
-                L.rcv__debug_set(4)
-                ms = timed(filt, a.launches)
-                L.rcv__debug_set(0)
+                ms = timed(memonly, a.launches)
             else:
                 ms = timed(fn, a.launches)
             res[name].append(ms)
