@@ -651,7 +651,10 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     // register set once per item.
     FRItem pend;
     pend.X = 0; pend.ys = 0; pend.nrows = 0; pend.P = 1; pend.interior = false; pend.done = false; pend.sf = a.src; pend.df = a.dst;
-    make_item(draw(), pend);
+    // (one item per ticket: two / four neighbouring strips per ticket -- fewer draws -- measured 6 / 12 % SLOWER, tools/ablate_chain_misc.py:
+    //  the strips of a band must be in flight together)
+    auto next_item = [&]() { make_item(draw(), pend); };
+    next_item();
     if (pend.done) return;               // (every wave draws its items + 1 tickets of every queue it visits: the host's accounting)
 
     // request cursor
@@ -710,7 +713,7 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
         r_y += 2;
         r_off += 2 * sstep;
         if (++ri == r_P) {
-            if (!r_done) make_item(draw(), pend);   // next item
+            if (!r_done) next_item();
             if (pend.done) {                         // past the last one: keep re-reading its last pair (cache hits, never used)
                 r_done = true;
                 ri = r_P - 1;
@@ -1324,6 +1327,8 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             if (ksize == 7) {
 #ifdef RCV_ROWS_BENCH
                 if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
+                else if (kn.pp == 4) RCV_LAUNCH((k_filter_rows_chain<7, 4, 0>), grid, dim3(64), cap, ctx->stream, a);
+                else if (kn.pp == 2) RCV_LAUNCH((k_filter_rows_chain<7, 2, 0>), grid, dim3(64), cap, ctx->stream, a);
                 else
 #endif
                     RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
