@@ -314,7 +314,8 @@ pub struct DeviceBatch<'c> {
     pub step: usize,
     pub frame_stride: usize,
 }
-unsafe impl<'c> Send for DeviceBatch<'c> {}
+// (NOT `Send`: a batch borrows its `HipContext`, which is deliberately `!Sync` -- one thread per context, bridge.h:4-7; moving a batch to another
+//  thread would let two threads drive one rcv_ctx.  Create batches on the thread that owns the context.)
 
 impl<'c> DeviceBatch<'c> {
     /// Packed rows (`step = cols * channels * sample bytes`), frames 256-byte aligned.
@@ -476,7 +477,7 @@ pub struct StagingRing<'c> {
     raw: *mut rcv_ring,
     _ctx: PhantomData<&'c HipContext>,
 }
-unsafe impl<'c> Send for StagingRing<'c> {}
+// (NOT `Send`, for the same reason as DeviceBatch: the ring borrows a `!Sync` context.)
 
 /// Shape of the ring's input or output frames.
 #[derive(Debug, Clone, Copy)]

@@ -124,7 +124,8 @@ class ImportedBuffer:
         imp._views -= 1
 
     def release(self):
-        """unmap; refuses while views made by as_batch are alive (they would be dangling device pointers)"""
+        """unmap.  CONTRACT (since round 3): raises RuntimeError while views made by as_batch are alive -- they would be dangling device
+        pointers -- so drop (or `del`) the views first: `view = imp.as_batch(...); ...; del view; imp.release()`."""
         if self._h is not None and getattr(self, "_views", 0) > 0:
             raise RuntimeError(f"ImportedBuffer.release(): {self._views} view(s) of the mapping are still alive")
         if self._h is not None:

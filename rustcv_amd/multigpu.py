@@ -147,6 +147,8 @@ class NativeGroup:
         _ffi.check(_ffi.lib().rcv_group_sync(self._h), "rcv_group_sync")
 
     def close(self):
+        """destroys the group's contexts.  Free the DeviceBatches allocated on them FIRST: a batch freed afterwards cannot call rcv_free
+        any more (its context handle is gone) and its device memory stays allocated until the process ends."""
         from . import _ffi
         if self._h is not None:
             for c in self.ctxs:
