@@ -57,6 +57,22 @@ __device__ __forceinline__ uint32_t shl1(uint32_t v) { return __builtin_amdgcn_u
 __device__ __forceinline__ float shr1f(float v) { return __builtin_bit_cast(float, shr1(__builtin_bit_cast(uint32_t, v))); }
 __device__ __forceinline__ float shl1f(float v) { return __builtin_bit_cast(float, shl1(__builtin_bit_cast(uint32_t, v))); }
 
+// The NMS maxima as the instructions themselves: through fmaxf the compiler first canonicalises every operand it cannot prove quiet (a
+// v_max_f32 x, x per pixel: values extracted from packed-f32 results, DPP moves); the hardware maxima give the same result for the values
+// that occur here (finite responses and -inf) without it.  Round 4, from the ISA: 1 of 29 instructions per pixel.
+__device__ __forceinline__ float vmax2(float a, float b)
+{
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 struct Row6 { uint32_t d[6]; };
 struct U2 { uint32_t a, b; };
 // global-address-space views: a pointer laundered through an SGPR constraint would otherwise decay to a flat pointer
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     const int xc = min(max(x, 0), a.cols - 8);
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
+    const bool has_edge = strip == 0 || (strip + 1) * kStripPx + 8 > a.cols;   // (wave-uniform) the strip holds the lane left of x = 0 / the lane at x = cols
     // RAG: the lane's 8 logical pixels x .. x+7 (right of the image: their mirror images) as byte selectors into the gray run it
     // gets from the clamped position xc; identity wherever the run lies inside the image (and for the left halo lane, which
     // keeps its own fix-up below)
@@ -119,6 +136,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
+    const float thr_v = a.thr_up;
 
     auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
         v = min(v, ye + 1);
@@ -166,10 +184,12 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         // TQ (aligned BGR / YUYV sources): the weights times 4 -- 7472, 38468, 19596 = 256*{29,150,76} + {48,68,140}, rounding term
         // 4*8192 -- put the gray value (sum >> 14) into bits 16..23, a whole byte that the Sobel's byte permutes read in place:
         // no shift, and no packing of the eight values
-        auto gray_of = [](uint32_t px) -> uint32_t {
+        // (up = true: the pixel sits in bytes 1..3 of its dword -- pixels 3 and 7 of a 24-byte run -- and the weights move up instead
+        //  of the data moving down: no v_alignbyte for those two)
+        auto gray_of = [](uint32_t px, bool up = false) -> uint32_t {
             if constexpr (TQ) {
-                const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x004c961du, 0u, false);
-                const uint32_t lo8 = __builtin_amdgcn_udot4(px, 0x008c4430u, 32768u, false);
+                const uint32_t hi8 = __builtin_amdgcn_udot4(px, up ? 0x4c961d00u : 0x004c961du, 0u, false);
+                const uint32_t lo8 = __builtin_amdgcn_udot4(px, up ? 0x8c443000u : 0x008c4430u, 32768u, false);
                 return (hi8 << 8) + lo8;
             } else {
                 const uint32_t hi8 = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);   // 7*B + 37*G + 19*R
@@ -193,7 +213,8 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k0 = 3 * j, w0 = k0 >> 2, sh = k0 & 3;   // pixel j = bytes k0..k0+2 of the 24-byte run
-                g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
+                if (TQ && sh == 1) g[j] = gray_of(q.d[w0], true);
+                else g[j] = gray_of(sh == 0 ? q.d[w0] : __builtin_amdgcn_alignbyte(q.d[w0 + 1 < 6 ? w0 + 1 : 5], q.d[w0], sh));
             }
         }
         // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
@@ -201,8 +222,13 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         if constexpr (TQ) {
             // the gray values sit in byte 2 of their dwords: the pairs are picked straight from there, the eight bytes are
             // never packed into two dwords
-            if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
-            if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
+            // (the two mirror lanes exist in the first / last strip only: a wave-uniform branch around the selects -- 13 of 15 strips
+            //  of a 4K row skip them; the volatile asm keeps the compiler from turning it back into selects)
+            if (has_edge) {
+                asm volatile("; strip with a mirror lane");
+                if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
+                if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
+            }
             const uint32_t lf = shr1(g[7]), rt = shl1(g[0]);
             constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
             L[0] = pk(g[0], lf, kPair);
@@ -269,12 +295,14 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         }
         // `mirrored` is a scalar condition (rows outside the image only): a uniform branch between the product and its exact
         // negation (a free source modifier) instead of one v_cndmask per pixel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * iy2[j];
         if (mirrored) {
+            // (the volatile asm keeps this a BRANCH: if-converted, the two arms met in register copies -- four v_mov_b64 on every row of
+            //  the image for the sake of the two rows outside it; round 4, from the ISA)
+            asm volatile("; row outside the image: dy changes sign");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * (-iy2[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * iy2[j];
+            for (int j = 0; j < 4; ++j) pxy[j] = -pxy[j];   // exact
         }
         // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
         const float exx = edgeL ? pxx[1].x : pxx[3].y, exy = edgeL ? pxy[1].x : pxy[3].y, eyy = edgeL ? pyy[1].x : pyy[3].y;
@@ -332,6 +360,10 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         // image belong to whole lanes (cols % 8 == 0: the lane left of x = 0, lanes right of the last column) that never
         // store; only the values they hand to their neighbours matter, and those are replaced right here.
         if (u < 0 || u >= a.rows) {
+            // (a branch, not eight selects on every row: the compiler had if-converted this into a v_cndmask per pixel AND, no longer
+            //  knowing the selected value canonical, a v_max_f32 x, x per pixel in front of the maxima below -- 2 of 29 instructions per
+            //  pixel; round 4, from the ISA)
+            asm volatile("; row outside the image: every response is -inf");
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] = NEG_INF;
         }
@@ -349,12 +381,12 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             // The threshold rides in the neighbour maxima: rc > thr <=> rc >= thr_up (the next float above thr, set by the host;
             // denormals are preserved in this kernel), and keep = (rc >= max(neighbours, thr_up)) -- one compare per pixel
             // instead of two; that thr_up also enters the row maxima of the rows above / below changes nothing (a max of maxima).
-            const float lrmax = fmaxf(fmaxf(left, right), a.thr_up);
-            const float m3 = fmaxf(lrmax, r[j]);
+            const float lrmax = vmax3(left, right, thr_v);
+            const float m3 = vmax2(lrmax, r[j]);
             // output row w = u-1: centre rc, neighbours = rowmax3(u-2), left/right of u-1, rowmax3(u)
-            const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);
+            const float m8 = vmax3(m3a[j], mlr[j], m3);
             const bool keep = rc[j] >= m8;
-            mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+            mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;   // (an SDWA select with a byte destination was tried: same count)
             m3a[j] = m3b[j];
             m3b[j] = m3;
             rc[j] = r[j];
