@@ -1334,7 +1334,11 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                     RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             } else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
-            return rcv_launch_check(ctx);
+            const int rc = rcv_launch_check(ctx);
+            // a launch that did not start drew nothing: the host's count of the counters would be ahead of them from here on (items of
+            // later launches skipped) -- start over from zeroed counters next time
+            if (rc != RCV_OK) ctx->fr_tickets_ready = false;
+            return rc;
         }
     }
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;

@@ -502,6 +502,47 @@ def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
     src.free()
 
 
+def test_filter_rows_chain_ticket_accounting(oracle, knob):
+    """the chained-band kernel's ticket counters are never reset: every launch gets their base values from the host, which adds up what
+    each launch draws (items + waves per queue).  Sixty launches of four different geometries (different item counts, one / three edge
+    strips, a single-strip image whose interior queue is empty) and three kernel sizes queued back to back WITHOUT a sync on a fresh
+    context, every result against the oracle: a counter / base mismatch would make later launches skip or repeat items"""
+    import rustcv_amd as rcv
+    knob("RCV_FR_CHAIN", 1)
+    knob("RCV_F7_ROWS", 1)
+    c = rcv.Context(0)
+    r = np.random.default_rng(4711 + _SOAK_SEED)
+    shapes = [(8, 64, 256), (8, 90, 1040), (16, 72, 772), (8, 130, 2304)]
+    srcs, frames = [], []
+    for n, rows, cols in shapes:
+        f = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+        b = device.DeviceBatch(c, n, rows, cols, 3)
+        b.upload(f)
+        srcs.append(b)
+        frames.append(f)
+    L = _ffi.lib()
+    jobs = []
+    for it in range(60):
+        si = int(r.integers(0, len(shapes)))
+        ks = int(r.choice([3, 5, 7]))
+        k = r.integers(-9, 10, size=(ks, ks)).astype(np.int8)
+        n, rows, cols = shapes[si]
+        dst = device.DeviceBatch(c, n, rows, cols, 3)
+        L.rcv__debug_kernels_reset()
+        device.filter2d(srcs[si], dst, k, shift=5)            # no sync: the queue holds launches of every geometry
+        assert "k_filter_rows_chain<" in L.rcv__debug_kernels().decode()
+        jobs.append((si, k, dst))
+    c.sync()
+    for si, k, dst in jobs:
+        got = dst.download()
+        for i in (0, shapes[si][0] - 1):
+            assert np.array_equal(got[i], oracle.filter2d_i8(frames[si][i], k, 5)), (si, k.shape, i)
+        dst.free()
+    for b in srcs:
+        b.free()
+    c.close()
+
+
 def test_row_kernel_weight_table_cache(ctx, oracle, knob):
     """round 3: the row-streaming kernel caches the banded weight tables of FOUR kernels per context and uploads a
     new one stream-ordered without synchronising; a caller cycling through six kernels (more than the cache holds: entries are
