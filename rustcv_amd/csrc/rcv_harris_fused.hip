@@ -73,6 +73,14 @@ __device__ __forceinline__ float vmax3(float a, float b, float c)
     return d;
 }
 
+// byte 2 of a dword as f32 in ONE instruction (as C the compiler pulls the conversion through the Sobel's additions and does those in integer)
+__device__ __forceinline__ float cvb2(uint32_t w)
+{
+    float f;
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
+
 struct Row6 { uint32_t d[6]; };
 struct U2 { uint32_t a, b; };
 // global-address-space views: a pointer laundered through an SGPR constraint would otherwise decay to a flat pointer
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
     constexpr bool YUYV = SRCK == 1, GRAY = SRCK == 2;
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
+    constexpr bool FSOB = TQ && !WANT_RESP;   // (same box, same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel)   // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD)
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
     const float thr_v = a.thr_up;
@@ -165,12 +174,16 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
 
     // ---- pipeline state --------------------------------------------------------------------------------------
     uint32_t h1a[4], h1b[4], h2a[4], h2b[4];      // Sobel horizontal parts of gray rows v-2, v-1 (packed i16 pairs)
+    f2 f1a[4], f1b[4], f2a[4], f2b[4];            // ... the same as packed f32 pairs {pixel j, pixel j + 4} (FSOB)
     f2 hsxx[4], hsxy[4], hsyy[4];                 // horizontal box sums of product row u-1 -- kept in f32: every product
                                                   // (<= 1020^2) and every 2x2 sum (< 2^24) is an exactly representable
                                                   // integer, so f32 adds/muls are exact and can use the packed f32 ALU
     float m3a[8], m3b[8], rc[8], mlr[8];          // NMS: rowmax3 of rows u-2, u-1; response and left/right max of row u-1
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
+    for (int j = 0; j < 4; ++j) {
+        h1a[j] = h1b[j] = h2a[j] = h2b[j] = 0;
+        f1a[j] = f1b[j] = f2a[j] = f2b[j] = f2{0.0f, 0.0f};
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         hsxx[j & 3] = hsxy[j & 3] = hsyy[j & 3] = f2{0.0f, 0.0f};
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         }
         // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
         uint32_t L[5], Cc[4];   // zero-extended gray pairs (g[2j-1], g[2j]) and (g[2j], g[2j+1])
+        f2 fix[4], fiy[4];      // (FSOB) Ix, Iy of row u as f32 pairs
         if constexpr (TQ) {
             // the gray values sit in byte 2 of their dwords: the pairs are picked straight from there, the eight bytes are
             // never packed into two dwords
@@ -230,6 +244,29 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
                 if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
             }
             const uint32_t lf = shr1(g[7]), rt = shl1(g[0]);
+            if constexpr (FSOB) {
+                // Round 4: the Sobel in PACKED F32 on the pairs {pixel j, pixel j + 4} the later stages use anyway.  v_cvt_f32_ubyte2 takes
+                // the gray value straight out of byte 2 of its dword (one instruction per value, twelve per row with the two neighbour
+                // pairs), every intermediate is a small integer, so the f32 arithmetic is exact and Ix, Iy come out as the SAME f32 values
+                // the integer path converts to -- without its nine byte permutes and sixteen i16 -> f32 conversions (-13 per row of 8 px).
+                f2 P[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[j] = f2{cvb2(g[j]), cvb2(g[j + 4])};
+                const f2 Pm = f2{cvb2(lf), cvb2(g[3])};   // pixels {-1, 3}
+                const f2 Pp = f2{cvb2(g[4]), cvb2(rt)};   // pixels {4, 8}
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f2 lft = j ? P[j - 1] : Pm, rgt = j < 3 ? P[j + 1] : Pp;
+                    const f2 h1 = rgt - lft;
+                    const f2 h2 = __builtin_elementwise_fma(P[j], f2{2.0f, 2.0f}, lft + rgt);
+                    fix[j] = __builtin_elementwise_fma(f1b[j], f2{2.0f, 2.0f}, f1a[j] + h1);
+                    fiy[j] = h2 - f2a[j];
+                    f1a[j] = f1b[j];
+                    f1b[j] = h1;
+                    f2a[j] = f2b[j];
+                    f2b[j] = h2;
+                }
+            } else {
             constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
             L[0] = pk(g[0], lf, kPair);
             L[1] = pk(g[2], g[1], kPair);
@@ -238,6 +275,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
             L[4] = pk(rt, g[7], kPair);
 #pragma unroll
             for (int j = 0; j < 4; ++j) Cc[j] = pk(g[2 * j + 1], g[2 * j], kPair);
+            }
         } else {
             uint32_t lo = GRAY ? q.d[0] : g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), hi = GRAY ? q.d[1] : g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
             if (edgeL) hi = pk(lo, hi, 0x05020100u);   // x = -1 mirrors x = 1
@@ -266,6 +304,13 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         // every neighbour pair {2j-1, 2j} straddling two registers, and the compiler rebuilds it with ~3 v_mov per pixel
         f2 ix2[4], iy2[4];
         float ixs[8], iys[8];
+        if constexpr (FSOB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ix2[j] = fix[j];
+                iy2[j] = fiy[j];
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t h1 = pk_sub(L[j + 1], L[j]);
@@ -285,6 +330,7 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
         for (int j = 0; j < 4; ++j) {
             ix2[j] = f2{ixs[j], ixs[j + 4]};
             iy2[j] = f2{iys[j], iys[j + 4]};
+        }
         }
         // ---- products and 2x2 box sums: S(u) = Hs(u-1) + Hs(u), Hs(x) = P(x-1) + P(x) -------------------------------
         f2 pxx[4], pxy[4], pyy[4];
