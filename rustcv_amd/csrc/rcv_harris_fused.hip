@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
     constexpr bool YUYV = SRCK == 1, GRAY = SRCK == 2;
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
-    constexpr bool FSOB = TQ && !WANT_RESP;   // (same box, same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel)   // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD)
+    // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD); same box,
+    // same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel
+    constexpr bool FSOB = TQ && !WANT_RESP;
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
     const float thr_v = a.thr_up;

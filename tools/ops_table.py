@@ -10,7 +10,7 @@ d = json.load(open(src))
 # what bounds each op: ops whose fixed arithmetic exceeds what the vector ALU can issue at HBM rate are VALU-bound by
 # construction; for those the HBM percentage is information, not the target (rocprofv3 issue-slot figures: profiles/r02_op_*.txt)
 BOUND = [("filter2D 7x7 f32", "VALU (49 dependent fmaf per sample)"), ("sigma=1.5", "VALU (14 fmaf per sample)"),
-         ("cornerHarris blockSize 3", "VALU / stores"), ("blockSize 3", "VALU (46 instr/px: 95 % of issue slots)"), ("Harris pipeline", "VALU (30 instr/px: 83 % of issue slots)"), ("cornerHarris", "VALU / stores"),
+         ("cornerHarris blockSize 3", "VALU / stores"), ("blockSize 3", "VALU (46 instr/px: 95 % of issue slots)"), ("Harris pipeline", "VALU (28 instr/px)"), ("cornerHarris", "VALU / stores"),
          ("warpAffine + resize", "instruction issue + gather path (traffic x1.31 of the source is not the limiter: DESIGN 9)"), ("warpAffine bilinear f32", "HBM (LDS-staged f32 patch, no conversions)"), ("(rot 7deg) on a GRAY", "load latency + per-workgroup set-up (four frames per LDS pass: VALU 47 %, 2.5 of 4 waves per SIMD)"), ("warpAffine", "instruction issue (VALU 70-78 %, LDS 25 %; LDS-staged taps)"),
          ("rectangle", "launch latency"), ("text blend", "launch latency"), ("batch=1", "launch latency (L3-resident)"),
          ("640x480", "launch latency"), ("resize 8K -> 1080p", "HBM (line granularity: 56 MB/frame must be fetched for 31 MB used)")]
