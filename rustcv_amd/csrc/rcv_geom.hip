@@ -591,6 +591,62 @@ __device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint
     return pack_floor3(v01.x, v01.y, v2);
 }
 
+// bilerp_bgrx on TWO pixels whose weights arrive as the pairs fxp = {fx of pixel 0, fx of pixel 1}, fyp likewise (round 4).
+// Channels b, g of a pixel ride in one packed pair as before (the pixel's weight broadcast out of its half of fxp / fyp);
+// channel r -- which bilerp_bgrx finishes with three unpacked operations -- pairs with the OTHER pixel's channel r through
+// the whole chain: 3.5 instead of 5 instructions per pixel for that channel, the same f32 operations in the same order.
+__device__ __forceinline__ void bilerp_bgrx_pair(const uint32_t (&p)[2][4], f2 fxp, f2 fyp, uint32_t& o0, uint32_t& o1)
+{
+    const f2 half2 = {0.5f, 0.5f};
+    f2 v01[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f2 a0 = {ub<0>(p[k][0]), ub<1>(p[k][0])}, a1 = {ub<0>(p[k][1]), ub<1>(p[k][1])};
+        const f2 b0 = {ub<0>(p[k][2]), ub<1>(p[k][2])}, b1 = {ub<0>(p[k][3]), ub<1>(p[k][3])};
+        const f2 top = k ? pk_fma_bc<1>(fxp, a1 - a0, a0) : pk_fma_bc<0>(fxp, a1 - a0, a0);
+        const f2 bot = k ? pk_fma_bc<1>(fxp, b1 - b0, b0) : pk_fma_bc<0>(fxp, b1 - b0, b0);
+        v01[k] = (k ? pk_fma_bc<1>(fyp, bot - top, top) : pk_fma_bc<0>(fyp, bot - top, top)) + half2;
+    }
+    const f2 c00 = {ub<2>(p[0][0]), ub<2>(p[1][0])}, c01 = {ub<2>(p[0][1]), ub<2>(p[1][1])};
+    const f2 c10 = {ub<2>(p[0][2]), ub<2>(p[1][2])}, c11 = {ub<2>(p[0][3]), ub<2>(p[1][3])};
+    const f2 topc = __builtin_elementwise_fma(fxp, c01 - c00, c00);
+    const f2 botc = __builtin_elementwise_fma(fxp, c11 - c10, c10);
+    const f2 vc = __builtin_elementwise_fma(fyp, botc - topc, topc) + half2;
+    o0 = pack_floor3(v01[0].x, v01[0].y, vc.x);
+    o1 = pack_floor3(v01[1].x, v01[1].y, vc.y);
+}
+
+// quad_transpose4 in 8 instead of 16 VALU instructions (round 4): v_cndmask_b32 is a VOP2 instruction, so its first source
+// takes the DPP quad permutation itself -- d = vcc ? own : neighbour's -- and the v_mov_b32_dpp in front of every select goes.
+// The four lane masks (even / odd lane, lower / upper pair of a quad) are wave constants in SGPR pairs.  s_nop 1 in front:
+// a DPP source needs two wait states after the VALU write of that register, and the compiler's hazard recogniser does not
+// look inside an asm block (inside the block every DPP source was written at least three instructions earlier).
+template <int N> struct IntC { static constexpr int value = N; };
+struct QuadMasks { uint64_t even, odd, lo, hi; };
+__device__ __forceinline__ QuadMasks quad_masks() { return QuadMasks{0x5555555555555555ull, 0xaaaaaaaaaaaaaaaaull, 0x3333333333333333ull, 0xccccccccccccccccull}; }
+__device__ __forceinline__ void quad_transpose4_dpp(uint32_t (&a)[4], const QuadMasks& m)
+{
+    uint32_t b0, b1, b2, b3, c0, c1, c2, c3;
+    asm("s_nop 1\n\t"
+        "s_mov_b64 vcc, %12\n\t"
+        "v_cndmask_b32_dpp %0, %9, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // even ? a0 : a1 of lane ^ 1
+        "v_cndmask_b32_dpp %2, %11, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   // even ? a2 : a3 of lane ^ 1
+        "s_mov_b64 vcc, %13\n\t"
+        "v_cndmask_b32_dpp %1, %8, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // odd ? a1 : a0 of lane ^ 1
+        "v_cndmask_b32_dpp %3, %10, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   // odd ? a3 : a2 of lane ^ 1
+        "s_mov_b64 vcc, %14\n\t"
+        "v_cndmask_b32_dpp %4, %2, %0, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // lower pair ? b0 : b2 of lane ^ 2
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %5, %3, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // lower pair ? b1 : b3 of lane ^ 2
+        "s_mov_b64 vcc, %15\n\t"
+        "v_cndmask_b32_dpp %6, %0, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // upper pair ? b2 : b0 of lane ^ 2
+        "v_cndmask_b32_dpp %7, %1, %3, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"           // upper pair ? b3 : b1 of lane ^ 2
+        : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(m.even), "s"(m.odd), "s"(m.lo), "s"(m.hi)
+        : "vcc");
+    a[0] = c0; a[1] = c1; a[2] = c2; a[3] = c3;
+}
+
 // RAGS: source rows of any alignment (an odd width of a packed image): a chunk's 12 bytes are fetched as the 16 aligned bytes
 // that contain them and shifted into place with v_alignbyte when they are written to LDS.
 // CH = 1 (one-channel images): the same tiles, patch geometry and LDS layout (one dword per patch pixel).  A chunk's 4 pixels are
@@ -600,7 +656,7 @@ __device__ __forceinline__ void warp_gray_frame(const View& s, const View& d, co
 
 template <int CH, bool RAGS>
 __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
-                                                            int tiles_per_xcd)
+                                                            int tiles_per_xcd, int strip)
 {
     constexpr bool AL = RAGS || CH == 1;   // chunks are fetched as aligned dwords and shifted into place
     extern __shared__ __attribute__((aligned(16))) uint8_t wl_lds[];
@@ -614,8 +670,14 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
         if (t >= ntiles) return;
         bz = t / (gx * gy);
         const int rem = t - bz * gx * gy;
-        by = rem / gx;
-        bx = rem - by * gx;
+        if (strip > 0) {   // vertical strips of `strip` tile columns, each walked row by row (the last one may be narrower)
+            const int per = strip * gy, sidx = rem / per, r2 = rem - sidx * per, w = min(strip, gx - sidx * strip);
+            by = r2 / w;
+            bx = sidx * strip + r2 - by * w;
+        } else {
+            by = rem / gx;
+            bx = rem - by * gx;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
@@ -650,16 +712,28 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     iy0 = __builtin_amdgcn_readfirstlane(iy0);
 
     // ---- frame-invariant per-thread state: lerp weights and the LDS offset of each pixel's upper-left tap ----
+    // (round 4) the weights of rows 2k and 2k+1 as the pairs fxp[k] = {fx, fx'}, fyp[k] = {fy, fy'}: a pixel's b / g lerps
+    // broadcast its half, the r lerps of the two pixels share packed operations (bilerp_bgrx_pair); the LDS offsets for BOTH
+    // patch buffers (the frame loop is unrolled by two, so neither the buffer base nor a select is added per frame)
     const bool ragd = (d.cols & 3) || ((uintptr_t)d.p & 3) || (d.step & 3) || (d.fstride & 3);   // ragged destination (uniform)
     const float fxx = (float)min(x, d.cols - 1);
-    f2 fxy[kWarpRows];
-    unsigned la[kWarpRows];
+    const unsigned bufbytes = (unsigned)(pitch * prow);
+    typedef __attribute__((address_space(3))) uint8_t* lp;
+    typedef const __attribute__((address_space(3))) uint32_t* lcu;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lp)wl_lds;   // (the LDS base folded into every precomputed offset: no add per access)
+    f2 fxp[kWarpRows / 2], fyp[kWarpRows / 2];
+    unsigned la[2][kWarpRows], lb[2][kWarpRows];   // upper / lower tap row
 #pragma unroll
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
-        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        fxp[r >> 1][r & 1] = __builtin_amdgcn_fractf(sxy.x);   // sx, sy >= 0: exact sx - floor(sx)
+        fyp[r >> 1][r & 1] = __builtin_amdgcn_fractf(sxy.y);
+        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        la[1][r] = la[0][r] + bufbytes;
+        lb[0][r] = la[0][r] + (unsigned)pitch;
+        lb[1][r] = la[1][r] + (unsigned)pitch;
+        asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]), "+v"(lb[0][r]), "+v"(lb[1][r]));   // (registers, not sums re-formed at every use)
     }
     const int xq = x & ~3, yi = ybase + (lane & 3);
     unsigned so[kWarpRows / 4];
@@ -670,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot             // <= kWlMaxG * 256 (host)
     // (a frame's last row ends at (rows - 1) * step + cols * CH: a padded LAST row need not be allocated -- rcv_view guarantees no more)
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * CH) - (CH == 1 ? 8u : (RAGS ? 16u : 12u))) & (AL ? ~0u : ~3u);
-    unsigned goff[kWlMaxG], loff[kWlMaxG];
+    unsigned goff[kWlMaxG], loff[2][kWlMaxG];
     bool gval[kWlMaxG];
 #pragma unroll
     for (int g = 0; g < kWlMaxG; ++g) {
@@ -679,7 +753,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
         // rows below the source and a chunk past the frame's end are read from a clamped position: no tap lies in them
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(CH * (ix0 + 4 * col)), frame_lim);
-        loff[g] = (unsigned)(row * pitch + 16 * col);
+        loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
+        loff[1][g] = loff[0][g] + bufbytes;
+        asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
     }
     const int ng = (nchunks + kBlock - 1) / kBlock;
     typedef const __attribute__((address_space(1))) uint8_t* cgp;
@@ -688,7 +764,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) u3v gU3;
     typedef __attribute__((address_space(1))) u4v gU4;
-    u4v G[kWlMaxG];          // (RAGS: 16 aligned bytes; else 12 bytes in .xyz)
+    typedef __attribute__((address_space(3))) u4v* lU4;
+    u4v G[kWlMaxG];          // (RAGS / one channel: the aligned bytes that contain the chunk)
+    u3v G3[kWlMaxG];         // (aligned BGR: the chunk's 12 bytes)
     unsigned gmis[kWlMaxG];  // RAGS: byte position of the chunk inside them
     auto gload = [&](int f) {
         const uint8_t* fb = s.p + (size_t)f * s.fstride;
@@ -698,93 +776,147 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (g < ng) {   // uniform
-                unsigned o = goff[g] + fmis;
-                asm("" : "+v"(o));
                 if constexpr (CH == 1) {
+                    unsigned o = goff[g] + fmis;
+                    asm("" : "+v"(o));
                     typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
                     typedef __attribute__((address_space(1))) u2v_ gU2;
                     gmis[g] = o & 3u;
                     const u2v_ t = *(const gU2*)(sf + (o & ~3u));
                     G[g] = u4v{t.x, t.y, 0u, 0u};
                 } else if constexpr (RAGS) {
+                    unsigned o = goff[g] + fmis;
+                    asm("" : "+v"(o));
                     gmis[g] = o & 3u;
                     G[g] = *(const gU4*)(sf + (o & ~3u));
                 } else {
-                    const u3v t = *(const gU3*)(sf + o);
-                    G[g] = u4v{t.x, t.y, t.z, 0u};
+                    // (the in-place barrier keeps the zero-extension of the offset in this block: scalar frame base + 32-bit
+                    //  thread offset is then ONE instruction with no address arithmetic and no copy)
+                    asm volatile("" : "+v"(goff[g]));
+                    G3[g] = *(const gU3*)(sf + goff[g]);
                 }
             }
     };
-    const unsigned bufbytes = (unsigned)(pitch * prow);
-    gload(f0);
-    for (int f = f0; f < f1; ++f) {
-        uint8_t* buf = wl_lds + ((f - f0) & 1) * bufbytes;
+    const QuadMasks qm = quad_masks();
+    // the patch of the frame whose chunks G / G3 hold goes to LDS buffer B
+    auto stage = [&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (gval[g]) {
                 if constexpr (CH == 1) {   // pixels x .. x+4 -> four dwords {g(x+i) g(x+i+1) . .}
                     const uint32_t e0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]), e1 = __builtin_amdgcn_alignbyte(0u, G[g].y, gmis[g]);
-                    *(u4v*)(buf + loff[g]) = u4v{e0, __builtin_amdgcn_alignbyte(e1, e0, 1), __builtin_amdgcn_alignbyte(e1, e0, 2), __builtin_amdgcn_alignbyte(e1, e0, 3)};
+                    *(lU4)(loff[B][g]) = u4v{e0, __builtin_amdgcn_alignbyte(e1, e0, 1), __builtin_amdgcn_alignbyte(e1, e0, 2), __builtin_amdgcn_alignbyte(e1, e0, 3)};
                     continue;
                 }
                 // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
-                uint32_t c0 = G[g].x, c1 = G[g].y, c2 = G[g].z;
+                uint32_t c0, c1, c2;
                 if constexpr (RAGS) {
                     c0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]);
                     c1 = __builtin_amdgcn_alignbyte(G[g].z, G[g].y, gmis[g]);
                     c2 = __builtin_amdgcn_alignbyte(G[g].w, G[g].z, gmis[g]);
+                } else {
+                    c0 = G3[g].x; c1 = G3[g].y; c2 = G3[g].z;
                 }
-                *(u4v*)(buf + loff[g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
+                *(lU4)(loff[B][g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
             }
-        __syncthreads();
-        if (f + 1 < f1) gload(f + 1);
+    };
+    // the tile of frame f from LDS buffer B.  INNER (a tile that lies inside an aligned destination: every lane stores) has NO
+    // branch around its two stores -- see the loop below.
+    auto compute = [&](const int f, auto Bc, auto Ic) {
+        constexpr int B = decltype(Bc)::value;
+        constexpr bool INNER = decltype(Ic)::value != 0;
         gp dfr = (gp)(d.p + (size_t)f * d.fstride);
         asm("" : "+s"(dfr));
 #pragma unroll
         for (int h = 0; h < kWarpRows / 4; ++h) {
             uint32_t t[4];
+            if constexpr (CH == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * h + i;
-                const uint32_t* pa = (const uint32_t*)(buf + la[r]);
-                const uint32_t* pb = (const uint32_t*)(buf + la[r] + pitch);
-                if constexpr (CH == 1) {
-                    const uint32_t a = pa[0], b = pb[0];
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * h + i;
+                    const uint32_t a = *(lcu)(la[B][r]), b = *(lcu)(lb[B][r]);
                     const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
-                    const f2 tb2 = pk_fma_bc<0>(fxy[r], p1 - p0, p0);
-                    t[i] = trunc_u32(fmaf(fxy[r].y, tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
-                } else {
-                    t[i] = bilerp_bgrx(pa[0], pa[1], pb[0], pb[1], fxy[r]);
+                    const f2 tb2 = (r & 1) ? pk_fma_bc<1>(fxp[r >> 1], p1 - p0, p0) : pk_fma_bc<0>(fxp[r >> 1], p1 - p0, p0);
+                    t[i] = trunc_u32(fmaf(fyp[r >> 1][r & 1], tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = 4 * h + 2 * i;
+                    uint32_t p[2][4];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const lcu pa = (lcu)(la[B][r + k]), pb = (lcu)(lb[B][r + k]);
+                        p[k][0] = pa[0]; p[k][1] = pa[1]; p[k][2] = pb[0]; p[k][3] = pb[1];
+                    }
+                    bilerp_bgrx_pair(p, fxp[r >> 1], fyp[r >> 1], t[2 * i], t[2 * i + 1]);
                 }
             }
             // quad transpose, then lane 4q+i stores the 12 bytes of pixels 4q..4q+3 of row 4h+i
             // (the same transpose through LDS -- four dword writes and one ds_read_b128 per wave instead of 16 VALU
             //  instructions -- timed the same: 1.655 against 1.645 ms)
-            quad_transpose4(t, lane);
+            quad_transpose4_dpp(t, qm);
             if constexpr (CH == 1) {
-                if (xq < d.cols && yi + 4 * h < d.rows) {   // lane 4q+i: pixels 4q .. 4q+3 of row 4h+i as one dword
+                if (INNER || (xq < d.cols && yi + 4 * h < d.rows)) {   // lane 4q+i: pixels 4q .. 4q+3 of row 4h+i as one dword
                     typedef uint32_t u1m __attribute__((aligned(1)));
-                    uint8_t* q = d.p + (size_t)f * d.fstride + so[h];
                     const uint32_t v = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
-                    if (d.cols - xq >= 4) *(u1m*)q = v;
-                    else
-                        for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(v >> (8 * j));
+                    if constexpr (INNER) {
+                        typedef __attribute__((address_space(1))) u1m gU1m;
+                        asm volatile("" : "+v"(so[h]));
+                        *(gU1m*)(dfr + so[h]) = v;
+                    } else {
+                        uint8_t* q = d.p + (size_t)f * d.fstride + so[h];
+                        if (d.cols - xq >= 4) *(u1m*)q = v;
+                        else
+                            for (int j = 0; j < d.cols - xq; ++j) q[j] = (uint8_t)(v >> (8 * j));
+                    }
                 }
                 continue;
             }
-            if (xq < d.cols && yi + 4 * h < d.rows) {
-                unsigned o = so[h];
-                asm("" : "+v"(o));
-                const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
-                // (one store instruction for aligned and for byte-aligned rows -- the hardware takes either; only the row's last,
-                //  partial quad of a width that is not a multiple of 4 goes out byte by byte)
-                typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
-                typedef __attribute__((address_space(1))) u3m gU3m;
-                if (ragd && d.cols - xq < 4) store_quad_ragged(d.p + (size_t)f * d.fstride + o, val.x, val.y, val.z, d.cols - xq);
-                else *(gU3m*)(dfr + o) = val;
+            const u3v val = {__builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u), __builtin_amdgcn_perm(t[3], t[2], 0x06050402u)};
+            // (one store instruction for aligned and for byte-aligned rows -- the hardware takes either; only the row's last,
+            //  partial quad of a width that is not a multiple of 4 goes out byte by byte)
+            typedef uint32_t u3m __attribute__((ext_vector_type(3), aligned(1)));
+            typedef __attribute__((address_space(1))) u3m gU3m;
+            if constexpr (INNER) {
+                asm volatile("" : "+v"(so[h]));   // (as goff above)
+                *(gU3m*)(dfr + so[h]) = val;
+            } else if (xq < d.cols && yi + 4 * h < d.rows) {
+                asm volatile("" : "+v"(so[h]));
+                if (ragd && d.cols - xq < 4) store_quad_ragged(d.p + (size_t)f * d.fstride + so[h], val.x, val.y, val.z, d.cols - xq);
+                else *(gU3m*)(dfr + so[h]) = val;
             }
         }
-    }
+    };
+    // The frame loop, rotated: compute(f) | stage(f + 1) | barrier | loads of f + 2.  The chunk registers are next touched in
+    // stage(f + 1), and between their loads and that point every path issues the same vector-memory instructions -- the two
+    // output stores of compute(f), unconditional for INNER tiles -- so the compiler's wait there is vmcnt(2): the wave waits for
+    // its chunk loads, NOT for the stores it has just issued.  With a branch around the stores (or the wait at the head of the
+    // loop, where the prologue's path has no stores) that wait is vmcnt(0) and every wave sits out the write latency of its own
+    // stores once per frame: 1.65 -> 1.22 ms with the stores removed, against 1.13 ms for the arithmetic alone.
+    // One barrier per frame: stage(f + 1) overwrites the buffer compute(f - 1) read, which every wave left before barrier f.
+    auto run = [&](auto Ic) {
+        gload(f0);
+        stage(IntC<0>{});
+        __syncthreads();
+        if (f0 + 1 < f1) gload(f0 + 1);
+        for (int f = f0;; f += 2) {
+            compute(f, IntC<0>{}, Ic);
+            if (f + 1 >= f1) break;
+            stage(IntC<1>{});
+            __syncthreads();
+            if (f + 2 < f1) gload(f + 2);
+            compute(f + 1, IntC<1>{}, Ic);
+            if (f + 2 >= f1) break;
+            stage(IntC<0>{});
+            __syncthreads();
+            if (f + 3 < f1) gload(f + 3);
+        }
+    };
+    const bool inner = !ragd && bx * kWlTW + kWlTW <= d.cols && by * kWlTH + kWlTH <= d.rows;   // (uniform)
+    if (inner) run(IntC<1>{});
+    else run(IntC<0>{});
 }
 
 // ---- one-channel warpAffine, FOUR FRAMES per LDS pass (round 3) ---------------------------------------------------------------
@@ -848,14 +980,20 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     ix0 = __builtin_amdgcn_readfirstlane(ix0);
     iy0 = __builtin_amdgcn_readfirstlane(iy0);
     const float fxx = (float)min(x, d.cols - 1);
+    typedef __attribute__((address_space(3))) uint8_t* lp;
+    typedef const __attribute__((address_space(3))) uint32_t* lcu;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lp)wg_lds;   // (the LDS base folded into every precomputed offset)
+    const unsigned bufbytes = (unsigned)(pitch * prow);
     f2 fxy[kWarpRows];
-    unsigned la[kWarpRows];
+    unsigned la[2][kWarpRows];   // (per patch buffer: the pass loop is unrolled by two)
 #pragma unroll
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
         fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};
-        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        la[1][r] = la[0][r] + bufbytes;
+        asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]));
     }
     const int xq = x & ~3, yi = ybase + (lane & 3);
     unsigned so[kWarpRows / 4];
@@ -865,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     const int nchunks = prow * cpr;
     const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)s.cols - 4u) & ~3u;
-    unsigned goff[NG], loff[NG];
+    unsigned goff[NG], loff[2][NG];
     bool gval[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -873,12 +1011,16 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
         gval[g] = c < nchunks;
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(ix0 + 4 * col), frame_lim);
-        loff[g] = (unsigned)(row * pitch + 16 * col);
+        loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
+        loff[1][g] = loff[0][g] + bufbytes;
+        asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
     }
     const int ng = (nchunks + kBlock - 1) / kBlock;
     typedef const __attribute__((address_space(1))) uint8_t* cgp;
+    typedef __attribute__((address_space(1))) uint8_t* gp;
     typedef __attribute__((address_space(1))) uint32_t gU1;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4v* lU4;
     uint32_t G[NG][4];
     auto gload = [&](int fb) {   // frames fb .. fb + 3 (past the group's last frame: that frame again, never stored)
 #pragma unroll
@@ -888,35 +1030,34 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 if (g < ng) {   // uniform
-                    unsigned o = goff[g];
-                    asm("" : "+v"(o));
-                    G[g][k] = *(const gU1*)(sf + o);
+                    asm volatile("" : "+v"(goff[g]));   // (scalar frame base + 32-bit thread offset in one instruction: see k_warp_affine_lds)
+                    G[g][k] = *(const gU1*)(sf + goff[g]);
                 }
         }
     };
-    const unsigned bufbytes = (unsigned)(pitch * prow);
     const bool ragd = (d.cols & 3) != 0;
-    gload(f0);
-    int pass = 0;
-    for (int fb = f0; fb < f1; fb += 4, ++pass) {
-        uint8_t* buf = wg_lds + (pass & 1) * bufbytes;
+    const QuadMasks qm = quad_masks();
+    auto stage = [&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             if (gval[g]) {
                 uint32_t v[4] = {G[g][0], G[g][1], G[g][2], G[g][3]};   // frame k: pixels x .. x+3
                 bytes4x4_transpose(v);                                  // pixel j: frames 0 .. 3
-                *(u4v*)(buf + loff[g]) = u4v{v[0], v[1], v[2], v[3]};
+                *(lU4)(loff[B][g]) = u4v{v[0], v[1], v[2], v[3]};
             }
-        __syncthreads();
-        if (fb + 4 < f1) gload(fb + 4);
+    };
+    // INNER: a tile inside the destination, whose width is a multiple of 4, in a group of whole passes -- eight unconditional stores
+    auto compute = [&](const int fb, auto Bc, auto Ic) {
+        constexpr int B = decltype(Bc)::value;
+        constexpr bool INNER = decltype(Ic)::value != 0;
 #pragma unroll
         for (int h = 0; h < kWarpRows / 4; ++h) {
             uint32_t w[4];   // row 4h + i, this lane's pixel: {frame 0, 1, 2, 3}
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * h + i;
-                const uint32_t* pa = (const uint32_t*)(buf + la[r]);
-                const uint32_t* pb = (const uint32_t*)(buf + la[r] + pitch);
+                const lcu pa = (lcu)(la[B][r]), pb = (lcu)(la[B][r] + (unsigned)pitch);
                 const uint32_t a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                 const f2 half2 = {0.5f, 0.5f};
                 // frames 0 and 1, frames 2 and 3: per frame top = fma(fx, p01 - p00, p00), bot = fma(fx, p11 - p10, p10),
@@ -930,9 +1071,19 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
                 asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(v23.y));
                 w[i] = px;
             }
-            quad_transpose4(w, lane);   // lane 4q + i: row 4h + i, pixels 4q .. 4q+3, each {frame 0 .. 3}
-            bytes4x4_transpose(w);      // w[k]: frame k, pixels 4q .. 4q+3
-            if (xq < d.cols && yi + 4 * h < d.rows) {
+            quad_transpose4_dpp(w, qm);   // lane 4q + i: row 4h + i, pixels 4q .. 4q+3, each {frame 0 .. 3}
+            bytes4x4_transpose(w);        // w[k]: frame k, pixels 4q .. 4q+3
+            if constexpr (INNER) {
+                asm volatile("" : "+v"(so[h]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gp dfr = (gp)(d.p + (size_t)(fb + k) * d.fstride);
+                    asm("" : "+s"(dfr));
+                    typedef uint32_t u1m __attribute__((aligned(1)));
+                    typedef __attribute__((address_space(1))) u1m gU1m;
+                    *(gU1m*)(dfr + so[h]) = w[k];
+                }
+            } else if (xq < d.cols && yi + 4 * h < d.rows) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (fb + k < f1) {   // uniform
@@ -944,7 +1095,30 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
                     }
             }
         }
-    }
+    };
+    // the pass loop, rotated as in k_warp_affine_lds: compute(pass) | stage(pass + 1) | barrier | loads of pass + 2 -- the wait
+    // in front of stage() then covers the chunk loads only, not the stores compute() has just issued
+    auto run = [&](auto Ic) {
+        gload(f0);
+        stage(IntC<0>{});
+        __syncthreads();
+        if (f0 + 4 < f1) gload(f0 + 4);
+        for (int fb = f0;; fb += 8) {
+            compute(fb, IntC<0>{}, Ic);
+            if (fb + 4 >= f1) break;
+            stage(IntC<1>{});
+            __syncthreads();
+            if (fb + 8 < f1) gload(fb + 8);
+            compute(fb + 4, IntC<1>{}, Ic);
+            if (fb + 8 >= f1) break;
+            stage(IntC<0>{});
+            __syncthreads();
+            if (fb + 12 < f1) gload(fb + 12);
+        }
+    };
+    const bool inner = !ragd && ((f1 - f0) & 3) == 0 && bx * kWlTW + kWlTW <= d.cols && by * kWlTH + kWlTH <= d.rows;   // (uniform)
+    if (inner) run(IntC<1>{});
+    else run(IntC<0>{});
 }
 
 // One-channel images: the scheme of k_warp_affine_bgr with 2-byte tap pairs.  One thread per output column and kWarpRows
@@ -1438,20 +1612,26 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     ix0 = __builtin_amdgcn_readfirstlane(ix0);
     iy0 = __builtin_amdgcn_readfirstlane(iy0);
     const float fxx = (float)min(x, d.cols - 1);
+    typedef __attribute__((address_space(3))) uint8_t* lp;
+    typedef const __attribute__((address_space(3))) float* lcf;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lp)wf_lds;   // (the LDS base folded into every precomputed offset)
+    const unsigned bufbytes = (unsigned)(pitch * prow);
     f2 fxy[kWarpRows];
-    unsigned la[kWarpRows];
+    unsigned la[2][kWarpRows];   // (per patch buffer: the frame loop is unrolled by two)
 #pragma unroll
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
         fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
-        la[r] = __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        la[1][r] = la[0][r] + bufbytes;
+        asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]));
     }
     // ---- staging plan: chunk c = 4 samples = 16 source bytes (rows are 4-byte aligned) -> 16 LDS bytes ----
     const int nchunks = prow * cpr;
     const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = (unsigned)(s.rows - 1) * (unsigned)s.step + 4u * (unsigned)s.cols - 16u;
-    unsigned goff[kWlMaxG], loff[kWlMaxG];
+    unsigned goff[kWlMaxG], loff[2][kWlMaxG];
     bool gval[kWlMaxG];
 #pragma unroll
     for (int g = 0; g < kWlMaxG; ++g) {
@@ -1459,13 +1639,17 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
         gval[g] = c < nchunks;
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
         goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + 4u * (unsigned)(ix0 + 4 * col), frame_lim);
-        loff[g] = (unsigned)(row * pitch + 16 * col);
+        loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
+        loff[1][g] = loff[0][g] + bufbytes;
+        asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
     }
     const int ng = (nchunks + kBlock - 1) / kBlock;
     typedef const __attribute__((address_space(1))) uint8_t* cgp;
+    typedef __attribute__((address_space(1))) uint8_t* gp;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
     typedef __attribute__((address_space(1))) u4a gU4a;
+    typedef __attribute__((address_space(3))) u4v* lU4;
     u4v G[kWlMaxG];
     auto gload = [&](int f) {
         cgp sf = (cgp)(s.p + (size_t)f * s.fstride);
@@ -1473,33 +1657,62 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (g < ng) {   // uniform
-                unsigned o = goff[g];
-                asm("" : "+v"(o));
-                const u4a t = *(const gU4a*)(sf + o);
+                asm volatile("" : "+v"(goff[g]));   // (scalar frame base + 32-bit thread offset in one instruction: see k_warp_affine_lds)
+                const u4a t = *(const gU4a*)(sf + goff[g]);
                 G[g] = u4v{t.x, t.y, t.z, t.w};
             }
     };
-    const unsigned bufbytes = (unsigned)(pitch * prow);
     const bool inx = x < d.cols;
-    gload(f0);
-    for (int f = f0; f < f1; ++f) {
-        uint8_t* buf = wf_lds + ((f - f0) & 1) * bufbytes;
+    unsigned so[kWarpRows];   // in-frame offset of the thread's pixel in each of its rows (INNER tiles: d.rows * d.step < 2^32 checked below)
+#pragma unroll
+    for (int r = 0; r < kWarpRows; ++r) so[r] = (unsigned)(ybase + r) * (unsigned)d.step + 4u * (unsigned)x;
+    auto stage = [&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
-            if (gval[g]) *(u4v*)(buf + loff[g]) = G[g];
-        __syncthreads();
-        if (f + 1 < f1) gload(f + 1);
+            if (gval[g]) *(lU4)(loff[B][g]) = G[g];
+    };
+    auto compute = [&](const int f, auto Bc, auto Ic) {
+        constexpr int B = decltype(Bc)::value;
+        constexpr bool INNER = decltype(Ic)::value != 0;
         uint8_t* dcol = d.p + (size_t)f * d.fstride + 4 * (size_t)x;
+        gp dfr = (gp)(d.p + (size_t)f * d.fstride);
+        asm("" : "+s"(dfr));
 #pragma unroll
         for (int r = 0; r < kWarpRows; ++r) {
-            const float* pa = (const float*)(buf + la[r]);
-            const float* pb = (const float*)(buf + la[r] + pitch);
+            const lcf pa = (lcf)(la[B][r]), pb = (lcf)(la[B][r] + (unsigned)pitch);
             const f2 p0 = {pa[0], pb[0]}, p1 = {pa[1], pb[1]};
             const f2 tb = pk_fma_bc<0>(fxy[r], p1 - p0, p0);                     // {top, bottom}: fma(fx, p01 - p00, p00), fma(fx, p11 - p10, p10)
             const float v = fmaf(fxy[r].y, tb.y - tb.x, tb.x);
-            if (inx && ybase + r < d.rows) *(float*)(dcol + (size_t)(ybase + r) * d.step) = v;
+            if constexpr (INNER) {
+                asm volatile("" : "+v"(so[r]));
+                *(__attribute__((address_space(1))) float*)(dfr + so[r]) = v;
+            } else if (inx && ybase + r < d.rows) *(float*)(dcol + (size_t)(ybase + r) * d.step) = v;
         }
-    }
+    };
+    // the frame loop, rotated as in k_warp_affine_lds: compute(f) | stage(f + 1) | barrier | loads of f + 2 -- the wait in
+    // front of stage() covers the chunk loads only, not the eight stores compute() has just issued (INNER tiles: no branch)
+    auto run = [&](auto Ic) {
+        gload(f0);
+        stage(IntC<0>{});
+        __syncthreads();
+        if (f0 + 1 < f1) gload(f0 + 1);
+        for (int f = f0;; f += 2) {
+            compute(f, IntC<0>{}, Ic);
+            if (f + 1 >= f1) break;
+            stage(IntC<1>{});
+            __syncthreads();
+            if (f + 2 < f1) gload(f + 2);
+            compute(f + 1, IntC<1>{}, Ic);
+            if (f + 2 >= f1) break;
+            stage(IntC<0>{});
+            __syncthreads();
+            if (f + 3 < f1) gload(f + 3);
+        }
+    };
+    const bool inner = bx * kWlTW + kWlTW <= d.cols && by * kWlTH + kWlTH <= d.rows && (unsigned long long)d.rows * d.step < (1ull << 32);   // (uniform)
+    if (inner) run(IntC<1>{});
+    else run(IntC<0>{});
 }
 
 // views of an RCV_32F source / destination pair: 1, 3 or 4 channels, 4-byte aligned rows and frames
@@ -1685,6 +1898,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         // frames per workgroup (the coordinate arithmetic is shared inside a group): as many of 8 / 4 / 2 as still leave >= 8192 workgroups
         const unsigned long long wgs = (unsigned long long)gx * gy * d.n;
         int fpg = wgs / 8 >= 8192 ? 8 : (wgs / 4 >= 8192 ? 4 : (wgs / 2 >= 8192 ? 2 : 1));
+        if (s.ch == 3 && d.n % 16 == 0 && wgs / 16 >= 8192) fpg = 16;   // (32 x 8K: 1.479 -> 1.459 ms; 32 per group: 1.546)
         if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
         const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
         // the LDS-staged kernel when the source patch of a 64 x 32 tile is small enough (rotations, shears and scales near 1)
@@ -1702,6 +1916,14 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const bool rags = (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4);   // byte-aligned source rows
             const bool xcd = tiles < (1ull << 30);
             const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
+            // tile order inside an XCD's run: vertical strips of 6 tile columns walked row by row, so that the ~96 tiles an XCD has
+            // in flight form a block whose patches overlap on all four sides inside ONE L2 (plain raster order: 0.8 of a tile row
+            // in flight, the rows shared with the tiles above / below come from HBM again): same process, sustained: 1.497 -> 1.465 ms, strips of 6 .. 16 alike (tools/ablate_warp_order.py)
+#ifdef RCV_WARP_TUNE
+            const int strip = getenv("RCV_WARP_STRIP") ? atoi(getenv("RCV_WARP_STRIP")) : 6;   // (tools/ablate_warp_order.py)
+#else
+            const int strip = 6;
+#endif
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
                 // four frames per LDS pass: one pass per workgroup, two for the largest launches (tools/ablate_gray4.py: 16 x 4K 0.125 ms
@@ -1719,9 +1941,9 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 else RCV_LAUNCH(k_warp_gray_lds4<kWlMaxG>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
                 return rcv_launch_check(ctx);
             }
-            if (s.ch == 1) RCV_LAUNCH((k_warp_affine_lds<1, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
-            else if (rags) RCV_LAUNCH((k_warp_affine_lds<3, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
-            else RCV_LAUNCH((k_warp_affine_lds<3, false>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+            if (s.ch == 1) RCV_LAUNCH((k_warp_affine_lds<1, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);
+            else if (rags) RCV_LAUNCH((k_warp_affine_lds<3, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);
+            else RCV_LAUNCH((k_warp_affine_lds<3, false>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);
             return rcv_launch_check(ctx);
         }
         if (s.ch == 3) {

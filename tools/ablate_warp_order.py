@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""tools/ablate_warp_order.py -- (round 4) BGR warpAffine 32 x 8K, same process, rotations + medians: tile order inside an XCD's run
+(RCV_WARP_STRIP: 0 = raster, n = vertical strips of n tile columns; read by the host code when built with -DRCV_WARP_TUNE) and frames
+per workgroup (RCV_WARP_FPG).
+
+    make -C rustcv_amd/csrc EXTRA=-DRCV_WARP_TUNE && python tools/ablate_warp_order.py [--rot 5] [--launches 40]
+"""
+import argparse, ctypes as C, os, statistics, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rustcv_amd as rcv
+from rustcv_amd import _ffi, device
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rot", type=int, default=5)
+ap.add_argument("--launches", type=int, default=40)
+ap.add_argument("--deg", type=float, default=7.0)
+ap.add_argument("--strips", default="0,4,6,8,12,16,24")
+ap.add_argument("--fpgs", default="")
+a = ap.parse_args()
+L = _ffi.lib(); ctx = rcv.Context(0)
+n, rows, cols = 32, 4320, 7680
+s = device.DeviceBatch(ctx, n, rows, cols, 3); d = device.DeviceBatch(ctx, n, rows, cols, 3)
+device.synth(s, 0, 0x5EED0007, 0)
+t = np.deg2rad(a.deg); c, sn = np.cos(t), np.sin(t); cx, cy = cols / 2, rows / 2
+M = np.array([c, -sn, cx - c * cx + sn * cy + 13.25, sn, c, cy - sn * cx - c * cy - 8.5], np.float32)
+
+def timed(launches):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.25:
+        for _ in range(4): device.warp_affine(s, d, M)
+        ctx.sync()
+    ms = C.c_float(); L.rcv_timer_start(ctx.handle)
+    for _ in range(launches): device.warp_affine(s, d, M)
+    L.rcv_timer_stop(ctx.handle, C.byref(ms)); return ms.value / launches
+
+variants = [{"RCV_WARP_STRIP": x} for x in a.strips.split(",") if x] + [{"RCV_WARP_FPG": x} for x in a.fpgs.split(",") if x]
+res = {i: [] for i in range(len(variants))}
+for r in range(a.rot):
+    for i, env in enumerate(variants):
+        for k in ("RCV_WARP_STRIP", "RCV_WARP_FPG"): os.environ.pop(k, None)
+        os.environ.update(env); L.rcv__debug_reload_knobs()
+        res[i].append(timed(a.launches))
+px = n * rows * cols
+print(f"32 x 8K BGR warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = 6 B/px / ms / 8 TB/s")
+for i, env in enumerate(variants):
+    m = statistics.median(res[i])
+    print(f"  {str(env):32s} {m:.4f} ms  frac {px * 6 / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
