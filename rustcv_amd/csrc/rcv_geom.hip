@@ -1872,7 +1872,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
                 const unsigned long long t1 = (unsigned long long)lgx * lgy;
                 int fpg = t1 * ((d.n + 7) / 8) >= 4096 ? 8 : (t1 * ((d.n + 3) / 4) >= 4096 ? 4 : (t1 * ((d.n + 1) / 2) >= 4096 ? 2 : 1));
-                if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
+                if ((rcv_knobs().warp_fpg & 255) > 0) fpg = min(rcv_knobs().warp_fpg & 255, d.n);
                 const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
                 const unsigned long long tiles = t1 * gz;
                 const bool xcd = false;   // (plain raster order measured better for one-channel tiles)
@@ -1899,7 +1899,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         const unsigned long long wgs = (unsigned long long)gx * gy * d.n;
         int fpg = wgs / 8 >= 8192 ? 8 : (wgs / 4 >= 8192 ? 4 : (wgs / 2 >= 8192 ? 2 : 1));
         if (s.ch == 3 && d.n % 16 == 0 && wgs / 16 >= 8192) fpg = 16;   // (32 x 8K: 1.479 -> 1.459 ms; 32 per group: 1.546)
-        if (rcv_knobs().warp_fpg > 0) fpg = min(rcv_knobs().warp_fpg, d.n);
+        if ((rcv_knobs().warp_fpg & 255) > 0) fpg = min(rcv_knobs().warp_fpg & 255, d.n);
         const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
         // the LDS-staged kernel when the source patch of a 64 x 32 tile is small enough (rotations, shears and scales near 1)
         int pitch = 0, prow = 0, cpr = 0;
@@ -1919,18 +1919,14 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             // tile order inside an XCD's run: vertical strips of 6 tile columns walked row by row, so that the ~96 tiles an XCD has
             // in flight form a block whose patches overlap on all four sides inside ONE L2 (plain raster order: 0.8 of a tile row
             // in flight, the rows shared with the tiles above / below come from HBM again): same process, sustained: 1.497 -> 1.465 ms, strips of 6 .. 16 alike (tools/ablate_warp_order.py)
-#ifdef RCV_WARP_TUNE
-            const int strip = getenv("RCV_WARP_STRIP") ? atoi(getenv("RCV_WARP_STRIP")) : 6;   // (tools/ablate_warp_order.py)
-#else
-            const int strip = 6;
-#endif
+            const int strip = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1 : 6;   // (RCV_WARP_FPG = fpg + 256 * (strip + 1): tools/ablate_warp_order.py)
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
                 // four frames per LDS pass: one pass per workgroup, two for the largest launches (tools/ablate_gray4.py: 16 x 4K 0.125 ms
                 // with groups of 4 against 0.142 with 8, 64 x 1080p 0.139 / 0.151, 8 x 8K 0.233 / 0.246; 32 x 8K 0.861 / 0.850)
                 const unsigned long long t1 = (unsigned long long)lgx * lgy;
                 int fq = t1 * ((d.n + 7) / 8) >= 32768 ? 8 : 4;
-                if (rcv_knobs().warp_fpg > 0) fq = max(4, min(rcv_knobs().warp_fpg, d.n) & ~3);
+                if ((rcv_knobs().warp_fpg & 255) > 0) fq = max(4, min(rcv_knobs().warp_fpg & 255, d.n) & ~3);
                 const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
                 const unsigned long long tq = t1 * gzq;
                 // (plain raster order unless RCV_XCD_ORDER=1 asks for the XCD-contiguous one: measured 0.849 against 0.888 ms on 32 x 8K)

@@ -91,7 +91,7 @@ struct RcvKnobs {
     int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (the gather kernel on the same maps)
     int warp_gray4;       // RCV_WARP_GRAY4    0: one-channel warpAffine never on the four-frames-per-pass kernel
-    int warp_fpg;         // RCV_WARP_FPG      frames per workgroup of the warp kernels (an incomplete last group)
+    int warp_fpg;         // RCV_WARP_FPG      frames per workgroup of the warp kernels (an incomplete last group); + 256 * (s + 1): tile strips of s columns
 };
 const RcvKnobs& rcv_knobs();
 

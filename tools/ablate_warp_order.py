@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """tools/ablate_warp_order.py -- (round 4) BGR warpAffine 32 x 8K, same process, rotations + medians: tile order inside an XCD's run
-(RCV_WARP_STRIP: 0 = raster, n = vertical strips of n tile columns; read by the host code when built with -DRCV_WARP_TUNE) and frames
-per workgroup (RCV_WARP_FPG).
+(0 = raster, n = vertical strips of n tile columns) and frames per workgroup, both through the test knob
+RCV_WARP_FPG = fpg + 256 * (strip + 1)  (fpg 0: the default; no strip part: the default of 6).
 
-    make -C rustcv_amd/csrc EXTRA=-DRCV_WARP_TUNE && python tools/ablate_warp_order.py [--rot 5] [--launches 40]
+    python tools/ablate_warp_order.py [--rot 5] [--launches 40]
 """
 import argparse, ctypes as C, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,15 +34,16 @@ def timed(launches):
     for _ in range(launches): device.warp_affine(s, d, M)
     L.rcv_timer_stop(ctx.handle, C.byref(ms)); return ms.value / launches
 
-variants = [{"RCV_WARP_STRIP": x} for x in a.strips.split(",") if x] + [{"RCV_WARP_FPG": x} for x in a.fpgs.split(",") if x]
+variants = [{"RCV_WARP_FPG": str(256 * (int(x) + 1))} for x in a.strips.split(",") if x] + [{"RCV_WARP_FPG": x} for x in a.fpgs.split(",") if x]
+names = ["strip %s" % x for x in a.strips.split(",") if x] + ["frames per workgroup %s" % x for x in a.fpgs.split(",") if x]
 res = {i: [] for i in range(len(variants))}
 for r in range(a.rot):
     for i, env in enumerate(variants):
-        for k in ("RCV_WARP_STRIP", "RCV_WARP_FPG"): os.environ.pop(k, None)
+        os.environ.pop("RCV_WARP_FPG", None)
         os.environ.update(env); L.rcv__debug_reload_knobs()
         res[i].append(timed(a.launches))
 px = n * rows * cols
 print(f"32 x 8K BGR warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = 6 B/px / ms / 8 TB/s")
 for i, env in enumerate(variants):
     m = statistics.median(res[i])
-    print(f"  {str(env):32s} {m:.4f} ms  frac {px * 6 / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
+    print(f"  {names[i]:32s} {m:.4f} ms  frac {px * 6 / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
