@@ -621,6 +621,30 @@ __device__ __forceinline__ void bilerp_bgrx_pair(const uint32_t (&p)[2][4], f2 f
 // The four lane masks (even / odd lane, lower / upper pair of a quad) are wave constants in SGPR pairs.  s_nop 1 in front:
 // a DPP source needs two wait states after the VALU write of that register, and the compiler's hazard recogniser does not
 // look inside an asm block (inside the block every DPP source was written at least three instructions earlier).
+// Tile order of the LDS-staged warp kernels: hardware places block b on XCD b % 8.  With tiles_per_xcd > 0 every XCD works through
+// its own contiguous run of the tile list, so that tiles whose patches overlap (the bounding box of a rotated tile is ~1.5x the
+// tile; a one-channel tile row is half a 128-byte line) run on the same L2 shortly after one another.  The list order is (frame
+// group, strip, tile row, tile column inside the strip): vertical strips of `strip` tile columns walked row by row, so that the
+// ~100 tiles an XCD has in flight form a block whose patches overlap on all four sides inside that L2; strip = 0: plain raster.
+__device__ __forceinline__ bool wl_tile(int tiles_per_xcd, int strip, int gx, int gy, int ntiles, int& bx, int& by, int& bz)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (tiles_per_xcd <= 0) return true;
+    const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= ntiles) return false;
+    bz = t / (gx * gy);
+    const int rem = t - bz * gx * gy;
+    if (strip > 0) {   // (the last strip may be narrower)
+        const int per = strip * gy, sidx = rem / per, r2 = rem - sidx * per, w = min(strip, gx - sidx * strip);
+        by = r2 / w;
+        bx = sidx * strip + r2 - by * w;
+    } else {
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    return true;
+}
+
 template <int N> struct IntC { static constexpr int value = N; };
 struct QuadMasks { uint64_t even, odd, lo, hi; };
 __device__ __forceinline__ QuadMasks quad_masks() { return QuadMasks{0x5555555555555555ull, 0xaaaaaaaaaaaaaaaaull, 0x3333333333333333ull, 0xccccccccccccccccull}; }
@@ -660,25 +684,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
 {
     constexpr bool AL = RAGS || CH == 1;   // chunks are fetched as aligned dwords and shifted into place
     extern __shared__ __attribute__((aligned(16))) uint8_t wl_lds[];
-    // Tile order: hardware places block b on XCD b % 8.  With tiles_per_xcd > 0 every XCD works through its own contiguous run
-    // of the (frame group, tile row, tile column) list in raster order: the patches of neighbouring tiles overlap (the bounding
-    // box of a rotated tile is ~1.5x the tile), and only tiles that run on the same XCD shortly after one another find the
-    // shared source rows in its L2.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_per_xcd > 0) {
-        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
-        if (t >= ntiles) return;
-        bz = t / (gx * gy);
-        const int rem = t - bz * gx * gy;
-        if (strip > 0) {   // vertical strips of `strip` tile columns, each walked row by row (the last one may be narrower)
-            const int per = strip * gy, sidx = rem / per, r2 = rem - sidx * per, w = min(strip, gx - sidx * strip);
-            by = r2 / w;
-            bx = sidx * strip + r2 - by * w;
-        } else {
-            by = rem / gx;
-            bx = rem - by * gx;
-        }
-    }
+    int bx, by, bz;
+    if (!wl_tile(tiles_per_xcd, strip, gx, gy, ntiles, bx, by, bz)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
     const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
@@ -942,18 +949,11 @@ __device__ __forceinline__ void bytes4x4_transpose(uint32_t (&v)[4])
 // NG: chunk slots per thread (prow * cpr <= 256 NG): 4 covers rotations up to ~10 degrees and keeps 8 registers of prefetch state free
 template <int NG>
 __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
-                                                           int tiles_per_xcd)
+                                                           int tiles_per_xcd, int strip)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_per_xcd > 0) {   // XCD-contiguous raster order (see k_warp_affine_lds)
-        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
-        if (t >= ntiles) return;
-        bz = t / (gx * gy);
-        const int rem = t - bz * gx * gy;
-        by = rem / gx;
-        bx = rem - by * gx;
-    }
+    int bx, by, bz;
+    if (!wl_tile(tiles_per_xcd, strip, gx, gy, ntiles, bx, by, bz)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
     const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
@@ -1569,18 +1569,11 @@ __device__ __forceinline__ float warp_px_f32_1(const uint8_t* sf, const View& s,
 }
 
 __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine A, int fpg, int pitch, int prow, int cpr, int gx, int gy, int ntiles,
-                                                         int tiles_per_xcd)
+                                                         int tiles_per_xcd, int strip)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t wf_lds[];
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (tiles_per_xcd > 0) {
-        const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
-        if (t >= ntiles) return;
-        bz = t / (gx * gy);
-        const int rem = t - bz * gx * gy;
-        by = rem / gx;
-        bx = rem - by * gx;
-    }
+    int bx, by, bz;
+    if (!wl_tile(tiles_per_xcd, strip, gx, gy, ntiles, bx, by, bz)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = bx * kWlTW + lane, ybase = by * kWlTH + wave * kWarpRows;
     const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
@@ -1875,11 +1868,15 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 if ((rcv_knobs().warp_fpg & 255) > 0) fpg = min(rcv_knobs().warp_fpg & 255, d.n);
                 const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
                 const unsigned long long tiles = t1 * gz;
-                const bool xcd = false;   // (plain raster order measured better for one-channel tiles)
+                // (RCV_WARP_FPG >= 256: XCD-contiguous runs in strips of (value >> 8) - 1 tile columns, 0 = raster: tools/ablate_warp_order.py)
+                // 8 x 8K rot 7: plain grid order 0.464 ms, XCD runs in raster order 0.473, strips of 2 / 4 / 8 / 16: 0.489 / 0.483 / 0.477 / 0.455
+                // (kept on the plain grid order: the best strip width gains 2 % here and small launches lose)
+                const bool xcd = rcv_knobs().warp_fpg >= 256 && tiles < (1ull << 30);
+                const int strip = xcd ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
                 const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
                 const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
                 RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
-                           ctx->wl_prow, ctx->wl_cpr, (int)lgx, (int)lgy, (int)tiles, tpx);
+                           ctx->wl_prow, ctx->wl_cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);
                 return rcv_launch_check(ctx);
             }
         }
@@ -1929,12 +1926,14 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 if ((rcv_knobs().warp_fpg & 255) > 0) fq = max(4, min(rcv_knobs().warp_fpg & 255, d.n) & ~3);
                 const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
                 const unsigned long long tq = t1 * gzq;
-                // (plain raster order unless RCV_XCD_ORDER=1 asks for the XCD-contiguous one: measured 0.849 against 0.888 ms on 32 x 8K)
-                const bool xq = false;   // (plain raster order)
+                // 32 x 8K rot 7: plain grid order 0.826 ms, XCD runs in raster order 0.868, strips of 2 / 4 / 8 / 16: 0.832 / 0.815 / 0.787 / 0.791
+                // (kept on the plain grid order: strips of 8 gain 5 % on 32 x 8K in one process and lose 3 ... 17 % on 4 / 8 frames)
+                const bool xq = rcv_knobs().warp_fpg >= 256 && tq < (1ull << 30);
+                const int stripq = xq ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
                 const int tpq = xq ? (int)((tq + 7) / 8) : 0;
                 const dim3 gridq = xq ? dim3((unsigned)tpq * 8) : dim3(lgx, lgy, gzq);
-                if (prow * cpr <= 4 * kBlock) RCV_LAUNCH(k_warp_gray_lds4<4>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
-                else RCV_LAUNCH(k_warp_gray_lds4<kWlMaxG>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq);
+                if (prow * cpr <= 4 * kBlock) RCV_LAUNCH(k_warp_gray_lds4<4>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq, stripq);
+                else RCV_LAUNCH(k_warp_gray_lds4<kWlMaxG>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq, stripq);
                 return rcv_launch_check(ctx);
             }
             if (s.ch == 1) RCV_LAUNCH((k_warp_affine_lds<1, true>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);

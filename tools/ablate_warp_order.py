@@ -17,11 +17,16 @@ ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--deg", type=float, default=7.0)
 ap.add_argument("--strips", default="0,4,6,8,12,16,24")
 ap.add_argument("--fpgs", default="")
+ap.add_argument("--kind", default="bgr", help="bgr | gray | f32")
 a = ap.parse_args()
 L = _ffi.lib(); ctx = rcv.Context(0)
-n, rows, cols = 32, 4320, 7680
-s = device.DeviceBatch(ctx, n, rows, cols, 3); d = device.DeviceBatch(ctx, n, rows, cols, 3)
-device.synth(s, 0, 0x5EED0007, 0)
+n, rows, cols = (8 if a.kind == "f32" else 32), 4320, 7680
+ch = 3 if a.kind == "bgr" else 1
+if a.kind == "f32":
+    s = device.DeviceBatch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F); d = device.DeviceBatch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F); s.memset(0x3C)
+else:
+    s = device.DeviceBatch(ctx, n, rows, cols, ch); d = device.DeviceBatch(ctx, n, rows, cols, ch)
+    device.synth(s, 0, 0x5EED0007, 0)
 t = np.deg2rad(a.deg); c, sn = np.cos(t), np.sin(t); cx, cy = cols / 2, rows / 2
 M = np.array([c, -sn, cx - c * cx + sn * cy + 13.25, sn, c, cy - sn * cx - c * cy - 8.5], np.float32)
 
@@ -43,7 +48,8 @@ for r in range(a.rot):
         os.environ.update(env); L.rcv__debug_reload_knobs()
         res[i].append(timed(a.launches))
 px = n * rows * cols
-print(f"32 x 8K BGR warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = 6 B/px / ms / 8 TB/s")
+bpp = {"bgr": 6, "gray": 2, "f32": 8}[a.kind]
+print(f"{n} x 8K {a.kind} warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = {bpp} B/px / ms / 8 TB/s; for gray / f32 any strip value also switches the XCD-contiguous runs on")
 for i, env in enumerate(variants):
     m = statistics.median(res[i])
-    print(f"  {names[i]:32s} {m:.4f} ms  frac {px * 6 / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
+    print(f"  {names[i]:32s} {m:.4f} ms  frac {px * bpp / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
