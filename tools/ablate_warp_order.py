@@ -18,9 +18,12 @@ ap.add_argument("--deg", type=float, default=7.0)
 ap.add_argument("--strips", default="0,4,6,8,12,16,24")
 ap.add_argument("--fpgs", default="")
 ap.add_argument("--kind", default="bgr", help="bgr | gray | f32")
+ap.add_argument("--shape", default="", help="n,rows,cols (default: 32 (f32: 8) x 8K)")
 a = ap.parse_args()
 L = _ffi.lib(); ctx = rcv.Context(0)
 n, rows, cols = (8 if a.kind == "f32" else 32), 4320, 7680
+if a.shape:
+    n, rows, cols = (int(v) for v in a.shape.split(","))
 ch = 3 if a.kind == "bgr" else 1
 if a.kind == "f32":
     s = device.DeviceBatch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F); d = device.DeviceBatch(ctx, n, rows, cols, 1, depth=_ffi.RCV_32F); s.memset(0x3C)
@@ -49,7 +52,7 @@ for r in range(a.rot):
         res[i].append(timed(a.launches))
 px = n * rows * cols
 bpp = {"bgr": 6, "gray": 2, "f32": 8}[a.kind]
-print(f"{n} x 8K {a.kind} warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = {bpp} B/px / ms / 8 TB/s; for gray / f32 any strip value also switches the XCD-contiguous runs on")
+print(f"{n} x {cols}x{rows} {a.kind} warpAffine rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = {bpp} B/px / ms / 8 TB/s; for gray / f32 any strip value also switches the XCD-contiguous runs on")
 for i, env in enumerate(variants):
     m = statistics.median(res[i])
     print(f"  {names[i]:32s} {m:.4f} ms  frac {px * bpp / m / 1e6 / 8000:.4f}   {['%.4f' % x for x in res[i]]}")
