@@ -2748,14 +2748,50 @@ def test_geometry_f32_at_8k(ctx, oracle):
         b.free()
 
 
+@pytest.mark.parametrize("kind", ["bgr", "gray", "f32"])
+@pytest.mark.parametrize("strip", [None, 0, 1, 5, 6, 7, 23, 40])
+def test_warp_affine_tile_orders(ctx, oracle, rng, knob, kind, strip):
+    """tile orders of the LDS-staged warp kernels (round 4): XCD-contiguous runs walked in vertical strips of `strip` tile columns --
+    a grid of 23 x 9 tiles (the last strip narrower, wider than the grid, one column) x 3 frame groups, 17 frames in groups of 16 / 8 /
+    the default; every tile written exactly once with the oracle's bytes (canaries around the destination)"""
+    n, sr, sc, dr, dc = 17, 300, 1500, 270, 1460   # 23 x 9 tiles of 64 x 32
+    M = _rot(7.0, dc / 2, dr / 2, 13.25, 9.5)
+    if kind == "f32":
+        frames = rng.standard_normal((n, sr, sc)).astype(np.float32)
+        src = device.DeviceBatch(ctx, n, sr, sc, 1, _ffi.RCV_32F)
+        dst = _canary_batch(ctx, n, dr, dc, 1, _ffi.RCV_32F, pad=20)
+        src.upload(frames[..., None])
+        want = [oracle.warp_affine_f32(frames[i], M, dr, dc) for i in range(n)]
+    else:
+        ch = 3 if kind == "bgr" else 1
+        frames = rng.integers(0, 256, size=(n, sr, sc, ch), dtype=np.uint8)
+        src = device.DeviceBatch(ctx, n, sr, sc, ch)
+        dst = _canary_batch(ctx, n, dr, dc, ch, pad=20)
+        src.upload(frames)
+        want = [oracle.warp_affine(frames[i] if ch == 3 else frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, ch) for i in range(n)]
+    for fpg in (0, 8, 16):
+        if strip is not None or fpg:
+            knob("RCV_WARP_FPG", fpg + (256 * (strip + 1) if strip is not None else 0))
+        dst.memset(0xCD)
+        launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, M))
+        assert {"bgr": "k_warp_affine_lds<3", "gray": "k_warp_gray_lds4", "f32": "k_warp_f32_lds"}[kind] in launched, launched
+        got = dst.download()
+        for i in range(n):
+            if kind == "f32":
+                assert np.array_equal(got[i].reshape(dr, dc).view(np.uint32), want[i].view(np.uint32)), (kind, strip, fpg, i)
+            else:
+                assert np.array_equal(got[i].reshape(want[i].shape), want[i]), (kind, strip, fpg, i)
+        _assert_canaries(dst)
+
+
 @pytest.mark.parametrize("fpg,xcd", [(0, 0), (2, 1), (8, 0), (3, 1)])
 @pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "shift", "flip", "big"])
 def test_warp_affine_f32_lds_kernel(ctx, oracle, rng, knob, fpg, xcd, M):
     """one-channel RCV_32F warpAffine on the LDS-staged kernel (k_warp_f32_lds): interior tiles from LDS, border / outside tiles through
     the per-pixel code, frame groups with a short last group, both tile orders, ragged widths, padded steps -- within 1 ULP of the oracle
     (expected: bit-exact) and identical to the per-pixel kernel (RCV_WARP_LDS=0)"""
-    if fpg:
-        knob("RCV_WARP_FPG", fpg)
+    if fpg or xcd:
+        knob("RCV_WARP_FPG", fpg + (256 * (1 + fpg) if xcd else 0))   # xcd: XCD-contiguous runs, strips of `fpg` tile columns
     n, sr, sc, dr, dc = 5, 150, 300, 131, 259
     Ms = {"rot7": _rot(7.0, dc / 2, dr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, dc / 2, dr / 2, 20.0, 12.0),
           "shear": np.array([1, 0.25, 3.5, -0.125, 1, 18.25], np.float32), "shift": np.array([1, 0, 7.5, 0, 1, 3.25], np.float32),
