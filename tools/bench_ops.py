@@ -255,7 +255,7 @@ def main():
     device.synth(s, 0, SEED + 4, 0)
     M = rot_matrix(7.0, 7680 / 2, 4320 / 2, 13.25, -8.5)
     frac = warp_touched_fraction(M.astype(np.float64), 4320, 7680, 4320, 7680) if not a.only or "warpAffine bil" in a.only.replace("_", " ") or "GRAY" in a.only or "f32" in a.only else 1.0
-    record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 3 + 3 * frac, lambda: device.warp_affine(s, d, M), valu=38,
+    record("warpAffine bilinear (rot 7deg)", "8K batch=32/GPU", s.n, 7680 * 4320, 3 + 3 * frac, lambda: device.warp_affine(s, d, M), valu=32,
            note=f"3 B written per output px + 3 B per DISTINCT in-bounds source px touched ({frac:.4f} per output px, counted on the host; upper bound 6)",
            cpu=lambda: cpu_time(lambda orc: orc.warp_affine(np.zeros((4320, 7680, 3), np.uint8), M, 4320, 7680), 7680 * 4320, 6.0))
     d.free()
