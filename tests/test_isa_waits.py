@@ -1,0 +1,52 @@
+"""The wait in front of the staging writes of the LDS-staged warp kernels, read from the compiler's output (CPU test: hipcc
+cross-compiles gfx950 without a GPU).
+
+gfx9 counts loads and stores in one in-order counter; the frame loops of these kernels are arranged (rcv_geom.hip: `run`) so that for
+tiles inside the destination the compiler can leave the stores of the frame just computed outstanding -- `s_waitcnt vmcnt(N)` with
+N = the number of those stores -- instead of `vmcnt(0)`.  That property is worth 5-25 % of the kernels' time
+(profiles/r04_warp_store_wait_ablation.txt) and silently depends on control flow the next edit or compiler may change: pin it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def geom_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "rcv_geom.s"
+    flags = open(os.path.join(ROOT, "rustcv_amd", "csrc", "build", "flags.stamp")).read().split() if os.path.exists(
+        os.path.join(ROOT, "rustcv_amd", "csrc", "build", "flags.stamp")) else "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math".split()
+    flags = [f for f in flags if f not in ("-fPIC",)]
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), os.path.join(ROOT, "rustcv_amd", "csrc", "rcv_geom.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def _body(asm, mangled_part):
+    i0 = next(i for i, l in enumerate(asm) if re.match(r"^_Z\S*" + re.escape(mangled_part) + r"\S*:", l))
+    i1 = next(i for i in range(i0, len(asm)) if asm[i].startswith(".Lfunc_end"))   # (a kernel has several s_endpgm)
+    return [l.strip().split(";")[0].strip() for l in asm[i0:i1]]
+
+
+@pytest.mark.parametrize("kernel,store,nstores", [("17k_warp_affine_ldsILi3ELb0E", "global_store_dwordx3", 2),
+                                                  ("16k_warp_gray_lds4ILi4E", "global_store_dword", 8),
+                                                  ("14k_warp_f32_lds", "global_store_dword", 8)])
+def test_staging_wait_leaves_the_stores_outstanding(geom_asm, kernel, store, nstores):
+    body = [l for l in _body(geom_asm, kernel) if l.startswith(("global_", "s_waitcnt vmcnt", "ds_write", "s_barrier"))]
+    # a run of exactly `nstores` unconditional stores, then the wait, then the LDS staging writes of the next frame
+    hits = 0
+    for i in range(len(body) - nstores - 1):
+        run = body[i:i + nstores]
+        if all(l.startswith(store + " ") for l in run) and (i == 0 or not body[i - 1].startswith("global_store")):
+            nxt = body[i + nstores]
+            if nxt.startswith("s_waitcnt vmcnt(") and body[i + nstores + 1].startswith("ds_write_b128"):
+                assert nxt == "s_waitcnt vmcnt(%d)" % nstores, (kernel, nxt)
+                hits += 1
+    assert hits >= 2, (kernel, hits)   # both halves of the loop unrolled by two
