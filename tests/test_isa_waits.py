@@ -42,11 +42,13 @@ def test_staging_wait_leaves_the_stores_outstanding(geom_asm, kernel, store, nst
     body = [l for l in _body(geom_asm, kernel) if l.startswith(("global_", "s_waitcnt vmcnt", "ds_write", "s_barrier", "s_cbranch", "s_and_saveexec"))]   # (with the branches: a store behind a bounds test is not part of a run)
     # a run of exactly `nstores` unconditional stores, then the wait, then the LDS staging writes of the next frame
     hits = 0
-    for i in range(len(body) - nstores - 1):
+    flow = ("s_cbranch", "s_and_saveexec")
+    for i in range(1, len(body) - nstores - 1):
         run = body[i:i + nstores]
-        if all(l.startswith(store + " ") for l in run) and (i == 0 or not body[i - 1].startswith("global_store")):
-            nxt = body[i + nstores]
-            if nxt.startswith("s_waitcnt vmcnt(") and body[i + nstores + 1].startswith("ds_write_b128"):
-                assert nxt == "s_waitcnt vmcnt(%d)" % nstores, (kernel, nxt)
-                hits += 1
+        if not all(l.startswith(store + " ") for l in run) or body[i - 1].startswith("global_store"):
+            continue   # (a store behind a bounds test has a branch in front of it and is not part of such a run)
+        rest = [l for l in body[i + nstores:] if not l.startswith(flow)]   # (the loop's exit test sits between the stores and the wait)
+        if rest[0].startswith("s_waitcnt vmcnt(") and rest[1].startswith("ds_write_b128"):   # the wait guards the next frame's staging writes
+            assert rest[0] == "s_waitcnt vmcnt(%d)" % nstores, (kernel, rest[0])
+            hits += 1
     assert hits >= 2, (kernel, hits)   # both halves of the loop unrolled by two
