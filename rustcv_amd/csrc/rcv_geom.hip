@@ -1802,8 +1802,12 @@ static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cp
     const double wx = fabs((double)M[0]) * ew + fabs((double)M[1]) * eh;
     const double wy = fabs((double)M[3]) * ew + fabs((double)M[4]) * eh;
     if (!(wx < 2048.0 && wy < 2048.0)) return false;
-    const int cpr = ((int)ceil(wx) + 3 + 3 + 3) / 4;     // pixels: extent + floor slack + right tap, + up to 3 for the aligned start
-    const int prow = (int)ceil(wy) + 3;
+    // Columns a tile needs: floor(xmax) - floor(xmin) + 2 (the right tap) <= floor(wx) + 3, + up to 3 for the patch's 4-pixel aligned
+    // start; rows: floor(wy) + 3.  1/64 of slack for the kernel's f32 coordinates (a tile that needs more than the plan holds fails
+    // the kernel's own test and takes the gather path: slower, never wrong).  Round 4: exact instead of generous bounds -- 7 degrees:
+    // 19 x 42 -> 18 x 41 chunks, which is 3 instead of 4 chunk slots per thread (738 <= 768).
+    const int cpr = ((int)floor(wx + 1.0 / 64) + 6 + 3) / 4;
+    const int prow = (int)floor(wy + 1.0 / 64) + 3;
     if ((long long)cpr * prow > (long long)kWlMaxG * kBlock) return false;
     int best = 0;
     long long best_cost = -1;
@@ -1915,8 +1919,12 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
             // tile order inside an XCD's run: vertical strips of 6 tile columns walked row by row, so that the ~96 tiles an XCD has
             // in flight form a block whose patches overlap on all four sides inside ONE L2 (plain raster order: 0.8 of a tile row
-            // in flight, the rows shared with the tiles above / below come from HBM again): same process, sustained: 1.497 -> 1.465 ms, strips of 6 .. 16 alike (tools/ablate_warp_order.py)
-            const int strip = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1 : 6;   // (RCV_WARP_FPG = fpg + 256 * (strip + 1): tools/ablate_warp_order.py)
+            // in flight, the rows shared with the tiles above / below come from HBM again) -- when the map tilts the patch enough
+            // for that overlap to matter: 8 x 8K, raster / strips of 6: 0 deg 0.381 / 0.432 ms, 1 deg 0.384 / 0.400, 3 deg 0.383 / 0.391,
+            // 5 deg 0.389 / 0.383, 10 deg 0.394 / 0.372, 20 deg 0.431 / 0.390, 45 deg 0.443 / 0.416, 90 deg 0.378 / 0.409
+            // (tools/ablate_warp_order.py --deg; strips of 6 .. 16 alike at 7 deg, 32 x 8K: 1.497 -> 1.465 ms)
+            const int strip = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1
+                              : (fabsf(M[3]) >= 0.07f && fabsf(M[4]) >= 0.5f * fabsf(M[3]) ? 6 : 0);   // (RCV_WARP_FPG = fpg + 256 * (strip + 1): the tool's override)
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
                 // four frames per LDS pass: one pass per workgroup, two for the largest launches (tools/ablate_gray4.py: 16 x 4K 0.125 ms
