@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
             if (gval[g]) {
                 if constexpr (CH == 1) {   // pixels x .. x+4 -> four dwords {g(x+i) g(x+i+1) . .}
                     const uint32_t e0 = __builtin_amdgcn_alignbyte(G[g].y, G[g].x, gmis[g]), e1 = __builtin_amdgcn_alignbyte(0u, G[g].y, gmis[g]);
-                    *(lU4)(loff[B][g]) = u4v{e0, __builtin_amdgcn_alignbyte(e1, e0, 1), __builtin_amdgcn_alignbyte(e1, e0, 2), __builtin_amdgcn_alignbyte(e1, e0, 3)};
+                    *(lU4)(uintptr_t)(loff[B][g]) = u4v{e0, __builtin_amdgcn_alignbyte(e1, e0, 1), __builtin_amdgcn_alignbyte(e1, e0, 2), __builtin_amdgcn_alignbyte(e1, e0, 3)};
                     continue;
                 }
                 // 12 bytes {b g r b | g r b g | r b g r} -> four {b g r x} dwords
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
                 } else {
                     c0 = G3[g].x; c1 = G3[g].y; c2 = G3[g].z;
                 }
-                *(lU4)(loff[B][g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
+                *(lU4)(uintptr_t)(loff[B][g]) = u4v{c0, __builtin_amdgcn_alignbyte(c1, c0, 3), __builtin_amdgcn_alignbyte(c2, c1, 2), c2 >> 8};
             }
     };
     // the tile of frame f from LDS buffer B.  INNER (a tile that lies inside an aligned destination: every lane stores) has NO
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * h + i;
-                    const uint32_t a = *(lcu)(la[B][r]), b = *(lcu)(lb[B][r]);
+                    const uint32_t a = *(lcu)(uintptr_t)(la[B][r]), b = *(lcu)(uintptr_t)(lb[B][r]);
                     const f2 p0 = {ub<0>(a), ub<0>(b)}, p1 = {ub<1>(a), ub<1>(b)};
                     const f2 tb2 = (r & 1) ? pk_fma_bc<1>(fxp[r >> 1], p1 - p0, p0) : pk_fma_bc<0>(fxp[r >> 1], p1 - p0, p0);
                     t[i] = trunc_u32(fmaf(fyp[r >> 1][r & 1], tb2.y - tb2.x, tb2.x) + 0.5f);   // every tap inside the source: an integer in [0, 255]
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
                     uint32_t p[2][4];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const lcu pa = (lcu)(la[B][r + k]), pb = (lcu)(lb[B][r + k]);
+                        const lcu pa = (lcu)(uintptr_t)(la[B][r + k]), pb = (lcu)(uintptr_t)(lb[B][r + k]);
                         p[k][0] = pa[0]; p[k][1] = pa[1]; p[k][2] = pb[0]; p[k][3] = pb[1];
                     }
                     bilerp_bgrx_pair(p, fxp[r >> 1], fyp[r >> 1], t[2 * i], t[2 * i + 1]);
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
             if (gval[g]) {
                 uint32_t v[4] = {G[g][0], G[g][1], G[g][2], G[g][3]};   // frame k: pixels x .. x+3
                 bytes4x4_transpose(v);                                  // pixel j: frames 0 .. 3
-                *(lU4)(loff[B][g]) = u4v{v[0], v[1], v[2], v[3]};
+                *(lU4)(uintptr_t)(loff[B][g]) = u4v{v[0], v[1], v[2], v[3]};
             }
     };
     // INNER: a tile inside the destination, whose width is a multiple of 4, in a group of whole passes -- eight unconditional stores
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * h + i;
-                const lcu pa = (lcu)(la[B][r]), pb = (lcu)(la[B][r] + (unsigned)pitch);
+                const lcu pa = (lcu)(uintptr_t)(la[B][r]), pb = (lcu)(uintptr_t)(la[B][r] + (unsigned)pitch);
                 const uint32_t a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                 const f2 half2 = {0.5f, 0.5f};
                 // frames 0 and 1, frames 2 and 3: per frame top = fma(fx, p01 - p00, p00), bot = fma(fx, p11 - p10, p10),
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
         constexpr int B = decltype(Bc)::value;
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
-            if (gval[g]) *(lU4)(loff[B][g]) = G[g];
+            if (gval[g]) *(lU4)(uintptr_t)(loff[B][g]) = G[g];
     };
     auto compute = [&](const int f, auto Bc, auto Ic) {
         constexpr int B = decltype(Bc)::value;
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
         asm("" : "+s"(dfr));
 #pragma unroll
         for (int r = 0; r < kWarpRows; ++r) {
-            const lcf pa = (lcf)(la[B][r]), pb = (lcf)(la[B][r] + (unsigned)pitch);
+            const lcf pa = (lcf)(uintptr_t)(la[B][r]), pb = (lcf)(uintptr_t)(la[B][r] + (unsigned)pitch);
             const f2 p0 = {pa[0], pb[0]}, p1 = {pa[1], pb[1]};
             const f2 tb = pk_fma_bc<0>(fxy[r], p1 - p0, p0);                     // {top, bottom}: fma(fx, p01 - p00, p00), fma(fx, p11 - p10, p10)
             const float v = fmaf(fxy[r].y, tb.y - tb.x, tb.x);
