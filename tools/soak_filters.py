@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak_filters.py [N] -- N seeded random (shape, alignment, batch, kernel) cases of the integer filter2D / GaussianBlur on BGR and
-gray images against the oracle with the library's own dispatch (no knobs): every width (multiples of 16, of 4, odd), packed and
+gray images against the oracle with the library's own dispatch (no knobs except RCV_FR_CHAIN=1 on every fifth BGR case: a batch of 8 / 16 / 24 frames of >= 64 rows:
+k_filter_rows_chain, launch after launch on one context = its ticket accounting): every width (multiples of 16, of 4, odd), packed and
 padded rows, weights inside and beyond the i8 range.  Prints the kernels used and the number of mismatches.  Run on a GPU box."""
 import os
 import sys
@@ -25,6 +26,12 @@ for case in range(N):
     cols = int(16 * rng.integers(1, 130)) if kind == 0 else (int(4 * rng.integers(4, 520)) if kind == 1 else int(rng.integers(16, 2100)))
     rows = int(rng.integers(4, 260))
     n = int(rng.integers(1, 5))
+    if ch == 3 and case % 5 == 4:   # (round 4) shapes the persistent ticket-queue row kernel takes: batches of 8k frames, >= 64 rows
+        n, rows = 8 * int(rng.integers(1, 4)), int(rng.integers(64, 420))
+    os.environ.pop("RCV_FR_CHAIN", None)
+    if ch == 3 and case % 5 == 4:
+        os.environ["RCV_FR_CHAIN"] = "1"   # (every eligible launch, not only the ones that fill the GPU)
+    L.rcv__debug_reload_knobs()
     ks = int(rng.choice([3, 5, 7]))
     pad = int(rng.choice([0, 0, 4, 16, 1]))
     step = cols * ch + pad
