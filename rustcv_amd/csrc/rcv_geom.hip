@@ -567,8 +567,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
 // cache lines, and the texture-address path spends ~32 cycles on each such wave instruction whatever its width (4 / 8 / 12 /
 // 16-byte tap loads time the same) -- 512 of them per wave and frame against ~330 cycles of arithmetic.  Here a
 // workgroup (4 waves, an output tile of 64 columns x 32 rows: near-square, so the rotated source patch is only ~1.4x the
-// tile) copies the patch into LDS with coalesced 12-byte loads of 4 pixels each -- about four per thread and frame instead of
-// sixteen gathers -- unpacked to one dword per pixel {b g r x}: a pixel's two taps of a row are then two consecutive dwords
+// tile) copies the patch into LDS with coalesced 12-byte loads of 4 pixels each -- three per thread and frame at 7 degrees instead
+// of sixteen gathers -- unpacked to one dword per pixel {b g r x}: a pixel's two taps of a row are then two consecutive dwords
 // (one ds_read2_b32, no byte alignment work), and with a row pitch chosen by the host for the matrix (warp_lds_plan) the 32
 // lanes of a read land on 32 different banks.  Two LDS buffers: the next frame's patch is in flight while this frame's 8
 // pixels per thread are computed, one barrier per frame.  pitch / prow / cpr: bytes per staged row (a multiple of 16), staged
@@ -576,24 +576,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
 // warp_bgr_wave (direct gathers) instead.  Same f32 operations in the same order as every other path.
 constexpr int kWlTW = 64, kWlTH = 32, kWlMaxG = 6;
 
-// bilerp_bgr on unpacked pixels: p00, p01 = {b g r x} of the upper tap pair, p10, p11 of the lower
-__device__ __forceinline__ uint32_t bilerp_bgrx(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, f2 fxy)
-{
-    const f2 a0 = {ub<0>(p00), ub<1>(p00)}, a1 = {ub<0>(p01), ub<1>(p01)};
-    const f2 b0 = {ub<0>(p10), ub<1>(p10)}, b1 = {ub<0>(p11), ub<1>(p11)};
-    const f2 c0 = {ub<2>(p00), ub<2>(p10)}, c1 = {ub<2>(p01), ub<2>(p11)};
-    const f2 half2 = {0.5f, 0.5f};
-    const f2 top = pk_fma_bc<0>(fxy, a1 - a0, a0);
-    const f2 bot = pk_fma_bc<0>(fxy, b1 - b0, b0);
-    const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
-    const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
-    const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
-    return pack_floor3(v01.x, v01.y, v2);
-}
-
-// bilerp_bgrx on TWO pixels whose weights arrive as the pairs fxp = {fx of pixel 0, fx of pixel 1}, fyp likewise (round 4).
-// Channels b, g of a pixel ride in one packed pair as before (the pixel's weight broadcast out of its half of fxp / fyp);
-// channel r -- which bilerp_bgrx finishes with three unpacked operations -- pairs with the OTHER pixel's channel r through
+// bilerp_bgr on TWO unpacked pixels (p[k] = {p00, p01, p10, p11} of pixel k, each {b g r x}: the upper and the lower tap pair)
+// whose weights arrive as the pairs fxp = {fx of pixel 0, fx of pixel 1}, fyp likewise (round 4).
+// Channels b, g of a pixel ride in one packed pair as in bilerp_bgr (the pixel's weight broadcast out of its half of fxp / fyp);
+// channel r -- which bilerp_bgr finishes with three unpacked operations -- pairs with the OTHER pixel's channel r through
 // the whole chain: 3.5 instead of 5 instructions per pixel for that channel, the same f32 operations in the same order.
 __device__ __forceinline__ void bilerp_bgrx_pair(const uint32_t (&p)[2][4], f2 fxp, f2 fyp, uint32_t& o0, uint32_t& o1)
 {
