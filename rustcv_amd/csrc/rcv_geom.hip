@@ -684,17 +684,25 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
     const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
     const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
-    // every tap of the tile inside the source, one more row of slack below (the last 12-byte chunk of a patch row may read past
-    // the row's end into the next row), 32-bit in-frame offsets, 4-byte aligned rows in every frame
-    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
+    // INSIDE: every tap of the tile inside the source, one more row of slack below (the last 12-byte chunk of a patch row may read
+    // past the row's end into the next row).  Round 4, aligned BGR sources whose width is a multiple of 4: a tile whose patch
+    // leaves the source is staged as well -- a 4-pixel chunk is then wholly inside or wholly outside the source, outside chunks
+    // are staged as zeros, and a tap of value 0 is exactly the specification's constant border (orc_warp_affine: every tap outside
+    // the source contributes 0.0f; a sample with all four taps outside is 0 whatever its weights).  The per-pixel gather code these
+    // tiles used to run made them 8 % of the tiles and 12 % (one channel: 25 %) of the launch's time, most of it as its tail.
+    // Common to both: 32-bit in-frame offsets, 4-byte aligned rows in every frame.
+    const bool inside = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2);   // NaN -> false
+    const bool edge_ok = CH == 3 && !RAGS && (s.cols & 3) == 0 && xmin > -1.0e6f && xmax < 1.0e6f && ymin > -1.0e6f && ymax < 1.0e6f;   // NaN -> false
+    bool ok = (inside || edge_ok) &&
               (AL || (((uintptr_t)s.p & 3) == 0 && (s.fstride & 3) == 0 && (s.step & 3) == 0)) && s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) &&
               (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) && d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
     int ix0 = 0, iy0 = 0;
     if (ok) {
-        ix0 = (int)xmin & ~3;   // patch columns start at a multiple of 4 pixels = 12 bytes: 4-byte aligned chunk loads
-        iy0 = (int)ymin;
-        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+        ix0 = (int)floorf(xmin) & ~3;   // patch columns start at a multiple of 4 pixels = 12 bytes: 4-byte aligned chunk loads
+        iy0 = (int)floorf(ymin);
+        ok = (int)floorf(xmax) + 2 - ix0 <= 4 * cpr && (int)floorf(ymax) + 2 - iy0 <= prow;
     }
+    const bool border = __builtin_amdgcn_readfirstlane((int)!inside) != 0;   // (uniform) the patch leaves the source: some chunks are zeros
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {   // (the same value in every lane of the workgroup)
         if constexpr (CH == 3) warp_bgr_wave(s, d, A, f0, f1, x, ybase);
         else
@@ -720,9 +728,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-        fxp[r >> 1][r & 1] = __builtin_amdgcn_fractf(sxy.x);   // sx, sy >= 0: exact sx - floor(sx)
-        fyp[r >> 1][r & 1] = __builtin_amdgcn_fractf(sxy.y);
-        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        const f2 fl = __builtin_elementwise_floor(sxy);
+        fxp[r >> 1][r & 1] = sxy.x - fl.x;   // (the specification's sx - floor(sx): exact; also right of / below zero)
+        fyp[r >> 1][r & 1] = sxy.y - fl.y;
+        la[0][r] = lds0 + __umul24((unsigned)((int)fl.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)fl.x - ix0);
         la[1][r] = la[0][r] + bufbytes;
         lb[0][r] = la[0][r] + (unsigned)pitch;
         lb[1][r] = la[1][r] + (unsigned)pitch;
@@ -738,6 +747,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     // (a frame's last row ends at (rows - 1) * step + cols * CH: a padded LAST row need not be allocated -- rcv_view guarantees no more)
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)(s.cols * CH) - (CH == 1 ? 8u : (RAGS ? 16u : 12u))) & (AL ? ~0u : ~3u);
     unsigned goff[kWlMaxG], loff[2][kWlMaxG];
+    unsigned gzero = 0;   // bit g: chunk slot g lies outside the source (border tiles: staged as zeros)
     bool gval[kWlMaxG];
 #pragma unroll
     for (int g = 0; g < kWlMaxG; ++g) {
@@ -745,7 +755,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
         gval[g] = c < nchunks;
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;   // (other threads re-read the patch's first chunk: a cache hit)
         // rows below the source and a chunk past the frame's end are read from a clamped position: no tap lies in them
-        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(CH * (ix0 + 4 * col)), frame_lim);
+        const int ry = iy0 + row, px = ix0 + 4 * col;   // (border tiles: either may lie outside the source)
+        gzero |= (unsigned)(ry < 0 || ry >= s.rows || px < 0 || px + 4 > s.cols) << g;
+        goff[g] = min(__umul24((unsigned)min(max(ry, 0), s.rows - 1), (unsigned)s.step) + (unsigned)(CH * max(px, 0)), frame_lim);
         loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
         loff[1][g] = loff[0][g] + bufbytes;
         asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
@@ -794,6 +806,14 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_lds(View s, View d, Affi
     // the patch of the frame whose chunks G / G3 hold goes to LDS buffer B
     auto stage = [&](auto Bc) {
         constexpr int B = decltype(Bc)::value;
+        if constexpr (CH == 3 && !RAGS) {
+            if (border) {   // (uniform; the volatile asm keeps it a branch: if-converted it is three selects per chunk on EVERY tile)
+                asm volatile("; tile whose patch leaves the source: chunks outside are zeros");
+#pragma unroll
+                for (int g = 0; g < kWlMaxG; ++g)
+                    if ((gzero >> g) & 1u) G3[g] = u3v{0u, 0u, 0u};
+            }
+        }
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (gval[g]) {
