@@ -970,15 +970,20 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
     const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
     const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
-    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
+    // (inside / border tiles: as in k_warp_affine_lds -- a patch that leaves a source whose width is a multiple of 4 is staged with
+    //  zeros for the chunks outside)
+    const bool inside = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2);   // NaN -> false
+    const bool edge_ok = (s.cols & 3) == 0 && xmin > -1.0e6f && xmax < 1.0e6f && ymin > -1.0e6f && ymax < 1.0e6f;   // NaN -> false
+    bool ok = (inside || edge_ok) &&
               s.step >= 16 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32) && d.step < (1u << 24) &&
               d.rows < (1 << 24) && (unsigned long long)d.rows * d.step < (1ull << 32);
     int ix0 = 0, iy0 = 0;
     if (ok) {
-        ix0 = (int)xmin & ~3;
-        iy0 = (int)ymin;
-        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+        ix0 = (int)floorf(xmin) & ~3;
+        iy0 = (int)floorf(ymin);
+        ok = (int)floorf(xmax) + 2 - ix0 <= 4 * cpr && (int)floorf(ymax) + 2 - iy0 <= prow;
     }
+    const bool border = __builtin_amdgcn_readfirstlane((int)!inside) != 0;   // (uniform)
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {
         for (int f = f0; f < f1; ++f) warp_gray_frame(s, d, A, f, x, ybase);
         return;
@@ -996,8 +1001,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};
-        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        const f2 fl = __builtin_elementwise_floor(sxy);
+        fxy[r] = sxy - fl;   // (the specification's sx - floor(sx): exact; also left of / above zero)
+        la[0][r] = lds0 + __umul24((unsigned)((int)fl.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)fl.x - ix0);
         la[1][r] = la[0][r] + bufbytes;
         asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]));
     }
@@ -1010,13 +1016,16 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = ((unsigned)(s.rows - 1) * (unsigned)s.step + (unsigned)s.cols - 4u) & ~3u;
     unsigned goff[NG], loff[2][NG];
+    unsigned gzero = 0;   // bit g: chunk slot g lies outside the source (border tiles: staged as zeros)
     bool gval[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
-        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + (unsigned)(ix0 + 4 * col), frame_lim);
+        const int ry = iy0 + row, px = ix0 + 4 * col;   // (border tiles: either may lie outside the source)
+        gzero |= (unsigned)(ry < 0 || ry >= s.rows || px < 0 || px + 4 > s.cols) << g;
+        goff[g] = min(__umul24((unsigned)min(max(ry, 0), s.rows - 1), (unsigned)s.step) + (unsigned)max(px, 0), frame_lim);
         loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
         loff[1][g] = loff[0][g] + bufbytes;
         asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
@@ -1045,6 +1054,12 @@ __global__ __launch_bounds__(kBlock) void k_warp_gray_lds4(View s, View d, Affin
     const QuadMasks qm = quad_masks();
     auto stage = [&](auto Bc) {
         constexpr int B = decltype(Bc)::value;
+        if (border) {   // (uniform; kept a branch by the volatile asm)
+            asm volatile("; tile whose patch leaves the source: chunks outside are zeros");
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if ((gzero >> g) & 1u) G[g][0] = G[g][1] = G[g][2] = G[g][3] = 0u;
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             if (gval[g]) {
@@ -1590,14 +1605,18 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     const float ya = fmaf(A.m[3], cx0, u0), yb = fmaf(A.m[3], cx1, u0), yc = fmaf(A.m[3], cx0, u1), yd = fmaf(A.m[3], cx1, u1);
     const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
     const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
-    bool ok = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2) &&   // NaN -> false
-              s.step >= 64 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
+    // (inside / border tiles: as in k_warp_affine_lds -- a patch that leaves a source whose width is a multiple of 4 is staged with
+    //  zeros for the chunks outside: a tap of 0.0f is the specification's border, orc_warp_affine_f32)
+    const bool inside = xmin >= 0.0f && xmax < (float)(s.cols - 1) && ymin >= 0.0f && ymax < (float)(s.rows - 2);   // NaN -> false
+    const bool edge_ok = (s.cols & 3) == 0 && xmin > -1.0e6f && xmax < 1.0e6f && ymin > -1.0e6f && ymax < 1.0e6f;   // NaN -> false
+    bool ok = (inside || edge_ok) && s.step >= 64 && s.step < (1u << 24) && s.rows < (1 << 24) && (unsigned long long)s.rows * s.step < (1ull << 32);
     int ix0 = 0, iy0 = 0;
     if (ok) {
-        ix0 = (int)xmin & ~3;
-        iy0 = (int)ymin;
-        ok = (int)xmax + 2 - ix0 <= 4 * cpr && (int)ymax + 2 - iy0 <= prow;
+        ix0 = (int)floorf(xmin) & ~3;
+        iy0 = (int)floorf(ymin);
+        ok = (int)floorf(xmax) + 2 - ix0 <= 4 * cpr && (int)floorf(ymax) + 2 - iy0 <= prow;
     }
+    const bool border = __builtin_amdgcn_readfirstlane((int)!inside) != 0;   // (uniform)
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {
         if (x < d.cols)
             for (int f = f0; f < f1; ++f) {
@@ -1621,8 +1640,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     for (int r = 0; r < kWarpRows; ++r) {
         const float fyy = (float)min(ybase + r, d.rows - 1);
         const f2 sxy = __builtin_elementwise_fma(f2{A.m[0], A.m[3]}, f2{fxx, fxx}, __builtin_elementwise_fma(f2{A.m[1], A.m[4]}, f2{fyy, fyy}, f2{A.m[2], A.m[5]}));
-        fxy[r] = f2{__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)};   // sx, sy >= 0: exact sx - floor(sx)
-        la[0][r] = lds0 + __umul24((unsigned)((int)sxy.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)sxy.x - ix0);
+        const f2 fl = __builtin_elementwise_floor(sxy);
+        fxy[r] = sxy - fl;   // (the specification's sx - floor(sx): exact; also left of / above zero)
+        la[0][r] = lds0 + __umul24((unsigned)((int)fl.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)fl.x - ix0);
         la[1][r] = la[0][r] + bufbytes;
         asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]));
     }
@@ -1631,13 +1651,16 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     const unsigned cpr_magic = (1u << 20) / (unsigned)cpr + 1u;   // c / cpr == (c * cpr_magic) >> 20 for every c < 1536 and cpr <= 755 (here cpr * prow <= 1536, prow >= 3): one division instead of one per chunk slot
     const unsigned frame_lim = (unsigned)(s.rows - 1) * (unsigned)s.step + 4u * (unsigned)s.cols - 16u;
     unsigned goff[kWlMaxG], loff[2][kWlMaxG];
+    unsigned gzero = 0;   // bit g: chunk slot g lies outside the source (border tiles: staged as zeros)
     bool gval[kWlMaxG];
 #pragma unroll
     for (int g = 0; g < kWlMaxG; ++g) {
         const int c = (int)threadIdx.x + kBlock * g;
         gval[g] = c < nchunks;
         const int row = gval[g] ? (int)(((unsigned)c * cpr_magic) >> 20) : 0, col = gval[g] ? c - row * cpr : 0;
-        goff[g] = min(__umul24((unsigned)min(iy0 + row, s.rows - 1), (unsigned)s.step) + 4u * (unsigned)(ix0 + 4 * col), frame_lim);
+        const int ry = iy0 + row, px = ix0 + 4 * col;   // (border tiles: either may lie outside the source)
+        gzero |= (unsigned)(ry < 0 || ry >= s.rows || px < 0 || px + 4 > s.cols) << g;
+        goff[g] = min(__umul24((unsigned)min(max(ry, 0), s.rows - 1), (unsigned)s.step) + 4u * (unsigned)max(px, 0), frame_lim);
         loff[0][g] = lds0 + (unsigned)(row * pitch + 16 * col);
         loff[1][g] = loff[0][g] + bufbytes;
         asm volatile("" : "+v"(loff[0][g]), "+v"(loff[1][g]));
@@ -1667,6 +1690,12 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     for (int r = 0; r < kWarpRows; ++r) so[r] = (unsigned)(ybase + r) * (unsigned)d.step + 4u * (unsigned)x;
     auto stage = [&](auto Bc) {
         constexpr int B = decltype(Bc)::value;
+        if (border) {   // (uniform; kept a branch by the volatile asm)
+            asm volatile("; tile whose patch leaves the source: chunks outside are zeros");
+#pragma unroll
+            for (int g = 0; g < kWlMaxG; ++g)
+                if ((gzero >> g) & 1u) G[g] = u4v{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int g = 0; g < kWlMaxG; ++g)
             if (gval[g]) *(lU4)(uintptr_t)(loff[B][g]) = G[g];

@@ -43,12 +43,24 @@ def test_staging_wait_leaves_the_stores_outstanding(geom_asm, kernel, store, nst
     # a run of exactly `nstores` unconditional stores, then the wait, then the LDS staging writes of the next frame
     hits = 0
     flow = ("s_cbranch", "s_and_saveexec")
-    for i in range(1, len(body) - nstores - 1):
-        run = body[i:i + nstores]
-        if not all(l.startswith(store + " ") for l in run) or body[i - 1].startswith("global_store"):
-            continue   # (a store behind a bounds test has a branch in front of it and is not part of such a run)
-        rest = [l for l in body[i + nstores:] if not l.startswith(flow)]   # (the loop's exit test sits between the stores and the wait)
-        if rest[0].startswith("s_waitcnt vmcnt(") and rest[1].startswith("ds_write_b128"):   # the wait guards the next frame's staging writes
-            assert rest[0] == "s_waitcnt vmcnt(%d)" % nstores, (kernel, rest[0])
+    i = 1
+    while i < len(body) - nstores:
+        if not body[i].startswith(store + " ") or body[i - 1].startswith("global_store"):
+            i += 1
+            continue
+        # a run of unconditional stores (a store behind a bounds test has a branch in front of it and ends the run), the waits
+        # inside / behind it, then the staging writes of the next frame: every wait must leave the stores issued so far outstanding
+        j, seen, waits = i, 0, []
+        while j < len(body) and (body[j].startswith((store + " ", "s_waitcnt vmcnt(") + flow)):
+            if body[j].startswith(store + " "):
+                if seen and body[j - 1].startswith(flow):
+                    break
+                seen += 1
+            elif body[j].startswith("s_waitcnt"):
+                waits.append((seen, body[j]))
+            j += 1
+        if seen == nstores and waits and j < len(body) and body[j].startswith("ds_write_b128"):
+            assert all(w == "s_waitcnt vmcnt(%d)" % k for k, w in waits), (kernel, waits)
             hits += 1
+        i = max(j, i + 1)
     assert hits >= 2, (kernel, hits)   # both halves of the loop unrolled by two
