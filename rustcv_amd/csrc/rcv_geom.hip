@@ -1644,6 +1644,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
         fxy[r] = sxy - fl;   // (the specification's sx - floor(sx): exact; also left of / above zero)
         la[0][r] = lds0 + __umul24((unsigned)((int)fl.y - iy0), (unsigned)pitch) + 4u * (unsigned)((int)fl.x - ix0);
         la[1][r] = la[0][r] + bufbytes;
+        // A sample the specification sets to 0 without reading a tap (sx <= -1, sx >= cols, likewise sy): zero taps give the same 0
+        // -- except at sx == -1 (sy == -1) exactly, where the tap at column (row) 0 is data with weight 0, and 0 * inf is NaN.  Such
+        // pixels read their four taps from a zeroed area behind the two patch buffers (pitch + 16 bytes: the host adds them).
+        if (border && !(sxy.x > -1.0f && sxy.x < (float)s.cols && sxy.y > -1.0f && sxy.y < (float)s.rows)) la[0][r] = la[1][r] = lds0 + 2u * bufbytes;
         asm volatile("" : "+v"(la[0][r]), "+v"(la[1][r]));
     }
     // ---- staging plan: chunk c = 4 samples = 16 source bytes (rows are 4-byte aligned) -> 16 LDS bytes ----
@@ -1720,6 +1724,8 @@ __global__ __launch_bounds__(kBlock) void k_warp_f32_lds(View s, View d, Affine 
     };
     // the frame loop, rotated as in k_warp_affine_lds: compute(f) | stage(f + 1) | barrier | loads of f + 2 -- the wait in
     // front of stage() covers the chunk loads only, not the eight stores compute() has just issued (INNER tiles: no branch)
+    if (border)   // (the zeroed area: written once, before the first barrier)
+        for (unsigned o = 4u * threadIdx.x; o < (unsigned)pitch + 16u; o += 4u * kBlock) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(lds0 + 2u * bufbytes + o) = 0u;
     auto run = [&](auto Ic) {
         gload(f0);
         stage(IntC<0>{});
@@ -1847,7 +1853,7 @@ static bool warp_lds_plan(const float* M, int* pitch_out, int* prow_out, int* cp
     int best = 0;
     long long best_cost = -1;
     for (int pitch = 16 * cpr; pitch < 16 * cpr + 128; pitch += 16) {   // (the bank pattern repeats every 128 bytes of pitch)
-        if (2LL * pitch * prow > 65536) break;
+        if (2LL * pitch * prow + pitch + 16 > 65536) break;   // (+ the f32 kernel's zeroed row)
         long long cost = 0;
         for (int tile = 0; tile < 2; ++tile) {
             const double ox = tile ? 7.0 * kWlTW : 0.0, oy = tile ? 3.0 * kWlTH : 0.0;
@@ -1914,7 +1920,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 const int strip = xcd ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
                 const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
                 const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
-                RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
+                RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow + (unsigned)ctx->wl_pitch + 16u, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
                            ctx->wl_prow, ctx->wl_cpr, (int)lgx, (int)lgy, (int)tiles, tpx, strip);
                 return rcv_launch_check(ctx);
             }

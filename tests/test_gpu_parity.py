@@ -2749,6 +2749,42 @@ def test_geometry_f32_at_8k(ctx, oracle):
 
 
 @pytest.mark.parametrize("kind", ["bgr", "gray", "f32"])
+@pytest.mark.parametrize("M", ["rot30", "shift-out", "zoom-out", "corner", "far-out", "edge-exact"])
+def test_warp_affine_border_tiles_staged(ctx, oracle, rng, kind, M):
+    """(round 4) tiles whose source patch leaves the source run on the LDS-staged kernels too when the source width is a multiple
+    of 4: chunks outside the source are staged as zeros, which is the specification's constant border tap by tap.  Maps that put
+    much of the destination outside the source, on its edges (coordinates of exactly -1, 0, cols - 1, cols) and wholly outside;
+    f32 sources carry inf / NaN next to the border; the result is the oracle's, and no launch falls back to the gather kernels"""
+    n, sr, sc, dr, dc = 5, 200, 360, 230, 412
+    Ms = {"rot30": _rot(30.0, sc / 2, sr / 2, 11.25, -7.5), "shift-out": np.array([1, 0, -77.25, 0, 1, 51.5], np.float32),
+          "zoom-out": np.array([1.3, 0.02, -40.0, -0.03, 1.3, -35.0], np.float32), "corner": _rot(-12.0, 0.0, 0.0, -20.5, 160.25),
+          "far-out": np.array([1, 0, 5000.0, 0, 1, 3.0], np.float32), "edge-exact": np.array([1, 0, -1.0, 0, 1, -1.0], np.float32)}[M]
+    if kind == "f32":
+        frames = rng.standard_normal((n, sr, sc)).astype(np.float32)
+        frames[:, 0, :7] = np.inf; frames[:, -1, -5:] = np.nan; frames[:, 3:6, 0] = -np.inf
+        src = device.DeviceBatch(ctx, n, sr, sc, 1, _ffi.RCV_32F)
+        dst = _canary_batch(ctx, n, dr, dc, 1, _ffi.RCV_32F, pad=20)
+        src.upload(frames[..., None])
+        want = [oracle.warp_affine_f32(frames[i], Ms, dr, dc) for i in range(n)]
+    else:
+        ch = 3 if kind == "bgr" else 1
+        frames = rng.integers(1, 256, size=(n, sr, sc, ch), dtype=np.uint8)   # (no zeros inside: a border tap mistaken for data shows)
+        src = device.DeviceBatch(ctx, n, sr, sc, ch)
+        dst = _canary_batch(ctx, n, dr, dc, ch, pad=20)
+        src.upload(frames)
+        want = [oracle.warp_affine(frames[i] if ch == 3 else frames[i, :, :, 0], Ms, dr, dc).reshape(dr, dc, ch) for i in range(n)]
+    launched = _kernels_launched(ctx, lambda: device.warp_affine(src, dst, Ms))
+    assert {"bgr": "k_warp_affine_lds<3", "gray": "k_warp_gray_lds4", "f32": "k_warp_f32_lds"}[kind] in launched, launched
+    got = dst.download()
+    for i in range(n):
+        if kind == "f32":
+            assert int(_ulp_distance(got[i].reshape(dr, dc), want[i]).max()) == 0, (kind, M, i)   # (NaN == NaN, whatever its payload)
+        else:
+            assert np.array_equal(got[i].reshape(want[i].shape), want[i]), (kind, M, i)
+    _assert_canaries(dst)
+
+
+@pytest.mark.parametrize("kind", ["bgr", "gray", "f32"])
 @pytest.mark.parametrize("strip", [None, 0, 1, 5, 6, 7, 23, 40])
 def test_warp_affine_tile_orders(ctx, oracle, rng, knob, kind, strip):
     """tile orders of the LDS-staged warp kernels (round 4): XCD-contiguous runs walked in vertical strips of `strip` tile columns --
