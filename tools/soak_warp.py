@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak_warp.py [N] [CH] -- N seeded random (shape, map, batch, frames-per-workgroup) cases of the BGR (CH = 1: one-channel) warpAffine against the oracle,
+"""tools/soak_warp.py [N] [CH | f32] -- N seeded random (shape, map, batch, frames-per-workgroup) cases of the BGR (CH = 1: one-channel) warpAffine against the oracle,
 run from the repo root on a GPU box; prints how many launches took the LDS-staged kernel and the number of mismatches (round 2: 400 cases,
 676 launches on the LDS kernel, 0 mismatches)."""
 import os, sys
@@ -20,7 +20,8 @@ bad = 0
 nlds = 0
 nquad = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-CH = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+F32 = len(sys.argv) > 2 and sys.argv[2] == "f32"   # (round 4) one-channel RCV_32F frames: k_warp_f32_lds, inf / NaN next to the source border
+CH = 1 if F32 else (int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 for case in range(N):
     rng = np.random.default_rng(0xABCD00 + case)
     sr, sc = int(rng.integers(40, 700)), int(rng.integers(40, 900))
@@ -38,9 +39,17 @@ for case in range(N):
     elif kind == 6: M = rot(float(rng.uniform(-180, 180)), sc / 2, sr / 2, 0, 0) * np.float32(rng.uniform(0.5, 1.6))
     else: M = np.array([float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 800)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-100, 600))], np.float32)
     M = np.asarray(M, np.float32)
-    frames = rng.integers(0, 256, size=(n, sr, sc, CH), dtype=np.uint8)
-    src = device.DeviceBatch(ctx, n, sr, sc, CH, step=sc * CH + (int(rng.integers(0, 4)) if CH == 1 and case % 2 else 0))
-    dst = device.DeviceBatch(ctx, n, dr, dc, CH)
+    if F32:
+        if case % 2: sc = (sc + 3) & ~3   # (every second case: a width the border tiles can be staged for)
+        frames = (rng.standard_normal((n, sr, sc, 1)) * rng.choice([1e-3, 1.0, 3e4])).astype(np.float32)
+        if case % 3 == 0:
+            frames[:, 0, : sc // 3] = np.inf; frames[:, -1, sc // 2:] = -np.inf; frames[:, sr // 3: sr // 2, 0] = np.nan; frames[:, :, -1] = np.float32(1e-41)
+        src = device.DeviceBatch(ctx, n, sr, sc, 1, _ffi.RCV_32F)
+        dst = device.DeviceBatch(ctx, n, dr, dc, 1, _ffi.RCV_32F)
+    else:
+        frames = rng.integers(0, 256, size=(n, sr, sc, CH), dtype=np.uint8)
+        src = device.DeviceBatch(ctx, n, sr, sc, CH, step=sc * CH + (int(rng.integers(0, 4)) if CH == 1 and case % 2 else 0))
+        dst = device.DeviceBatch(ctx, n, dr, dc, CH)
     src.upload(frames)
     for fpg in (0, int(rng.integers(1, 9))):
         os.environ.pop("RCV_WARP_FPG", None)
@@ -55,6 +64,14 @@ for case in range(N):
         nquad += "k_warp_gray_lds4" in k
         got = dst.download()
         for i in range(n):
+            if F32:
+                want = oracle.warp_affine_f32(frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, 1)
+                g, w = got[i].reshape(dr, dc, 1), want
+                same = np.array_equal(g.view(np.uint32)[~np.isnan(w)], w.view(np.uint32)[~np.isnan(w)]) and np.array_equal(np.isnan(g), np.isnan(w))
+                if same: continue
+                bad += 1
+                print("MISMATCH", case, fpg, i, k, M.tolist(), (sr, sc, dr, dc, n), flush=True)
+                break
             want = oracle.warp_affine(frames[i] if CH == 3 else frames[i, :, :, 0], M, dr, dc).reshape(dr, dc, CH)
             if not np.array_equal(got[i].reshape(dr, dc, CH), want):
                 bad += 1
