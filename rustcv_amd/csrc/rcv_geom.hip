@@ -1915,9 +1915,11 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                 const unsigned long long tiles = t1 * gz;
                 // (RCV_WARP_FPG >= 256: XCD-contiguous runs in strips of (value >> 8) - 1 tile columns, 0 = raster: tools/ablate_warp_order.py)
                 // 8 x 8K rot 7: plain grid order 0.464 ms, XCD runs in raster order 0.473, strips of 2 / 4 / 8 / 16: 0.489 / 0.483 / 0.477 / 0.455
-                // (kept on the plain grid order: the best strip width gains 2 % here and small launches lose)
-                const bool xcd = rcv_knobs().warp_fpg >= 256 && tiles < (1ull << 30);
-                const int strip = xcd ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
+                // tile order (re-measured after the border tiles went onto the staged path, tools/ablate_warp_order.py --kind f32; plain grid /
+                // XCD-contiguous raster / strips of 6): 8 x 8K 0.417 / 0.447 / 0.443 ms, 2 x 8K 0.113 / 0.118 / 0.114, 4 x 4K 0.058 / 0.042 / 0.043,
+                // 1 x 1080p 0.0073 all: contiguous runs for launches of up to 16K tiles, the plain order above
+                const bool xcd = rcv_knobs().warp_fpg >= 256 ? tiles < (1ull << 30) : tiles <= 16384;
+                const int strip = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
                 const int tpx = xcd ? (int)((tiles + 7) / 8) : 0;
                 const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
                 RCV_LAUNCH(k_warp_f32_lds, grid, dim3(kBlock), 2u * (unsigned)ctx->wl_pitch * (unsigned)ctx->wl_prow + (unsigned)ctx->wl_pitch + 16u, ctx->stream, s, d, Af, fpg, ctx->wl_pitch,
@@ -1968,17 +1970,23 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
                               : (fabsf(M[3]) >= 0.07f && fabsf(M[4]) >= 0.5f * fabsf(M[3]) ? 6 : 0);   // (RCV_WARP_FPG = fpg + 256 * (strip + 1): the tool's override)
             const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
-                // four frames per LDS pass: one pass per workgroup, two for the largest launches (tools/ablate_gray4.py: 16 x 4K 0.125 ms
-                // with groups of 4 against 0.142 with 8, 64 x 1080p 0.139 / 0.151, 8 x 8K 0.233 / 0.246; 32 x 8K 0.861 / 0.850)
+                // four frames per LDS pass, up to four passes per workgroup (the per-workgroup set-up is 0.12 of a 0.70-ms launch at two
+                // passes).  Frames per workgroup x tile order, tools/ablate_warp_order.py --kind gray --combos, after the border tiles went
+                // onto the staged path (before, more passes per workgroup only lengthened the tail of slow border tiles): 32 x 8K fq 8 / 16
+                // raster 0.729 / 0.750, strips of 8 0.667 / 0.661 ms; 64 x 4K 0.376 / 0.368, 0.337 / 0.330; 16 x 4K 0.069 / 0.065, 0.070 /
+                // 0.064 (fq 4: 0.087); 64 x 1080p 0.070 / 0.062, 0.072 / 0.064 (fq 4: 0.088)
                 const unsigned long long t1 = (unsigned long long)lgx * lgy;
-                int fq = t1 * ((d.n + 7) / 8) >= 32768 ? 8 : 4;
+                int fq = d.n >= 16 ? 16 : (d.n >= 8 ? 8 : 4);
                 if ((rcv_knobs().warp_fpg & 255) > 0) fq = max(4, min(rcv_knobs().warp_fpg & 255, d.n) & ~3);
                 const unsigned gzq = (unsigned)((d.n + fq - 1) / fq);
                 const unsigned long long tq = t1 * gzq;
-                // 32 x 8K rot 7: plain grid order 0.826 ms, XCD runs in raster order 0.868, strips of 2 / 4 / 8 / 16: 0.832 / 0.815 / 0.787 / 0.791
-                // (kept on the plain grid order: strips of 8 gain 5 % on 32 x 8K in one process and lose 3 ... 17 % on 4 / 8 frames)
-                const bool xq = rcv_knobs().warp_fpg >= 256 && tq < (1ull << 30);
-                const int stripq = xq ? (rcv_knobs().warp_fpg >> 8) - 1 : 0;
+                // tile order (re-measured after the border tiles went onto the staged path -- before, contiguous runs concentrated the slow
+                // border tiles and lost 3 ... 17 % on small launches; tools/ablate_warp_order.py --kind gray; plain grid / XCD-contiguous raster /
+                // strips of 8): 32 x 8K 0.671 / 0.675 / 0.640 ms, 8 x 8K 0.192 / 0.191 / 0.191, 16 x 4K 0.0985 / 0.0876 / 0.0893, 4 x 4K
+                // 0.0296 / 0.0251 / 0.0257: contiguous runs always, in strips of 8 for a tilted map (the rule of the BGR kernel)
+                const bool xq = tq < (1ull << 30);
+                const int stripq = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1
+                                   : (fabsf(M[3]) >= 0.07f && fabsf(M[4]) >= 0.5f * fabsf(M[3]) ? 8 : 0);
                 const int tpq = xq ? (int)((tq + 7) / 8) : 0;
                 const dim3 gridq = xq ? dim3((unsigned)tpq * 8) : dim3(lgx, lgy, gzq);
                 if (prow * cpr <= 4 * kBlock) RCV_LAUNCH(k_warp_gray_lds4<4>, gridq, dim3(kBlock), lds, ctx->stream, s, d, A, fq, pitch, prow, cpr, (int)lgx, (int)lgy, (int)tq, tpq, stripq);

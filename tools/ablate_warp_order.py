@@ -18,6 +18,7 @@ ap.add_argument("--deg", type=float, default=7.0)
 ap.add_argument("--strips", default="0,4,6,8,12,16,24")
 ap.add_argument("--fpgs", default="")
 ap.add_argument("--kind", default="bgr", help="bgr | gray | f32")
+ap.add_argument("--combos", default="", help="fpg:strip pairs, e.g. 8:0,16:8")
 ap.add_argument("--shape", default="", help="n,rows,cols (default: 32 (f32: 8) x 8K)")
 a = ap.parse_args()
 L = _ffi.lib(); ctx = rcv.Context(0)
@@ -44,6 +45,10 @@ def timed(launches):
 
 variants = [{"RCV_WARP_FPG": str(256 * (int(x) + 1))} for x in a.strips.split(",") if x] + [{"RCV_WARP_FPG": x} for x in a.fpgs.split(",") if x]
 names = ["strip %s" % x for x in a.strips.split(",") if x] + ["frames per workgroup %s" % x for x in a.fpgs.split(",") if x]
+for c in [c for c in a.combos.split(",") if c]:
+    f, st = (int(v) for v in c.split(":"))
+    variants.append({"RCV_WARP_FPG": str(f + 256 * (st + 1))})
+    names.append("frames per workgroup %d, strip %d" % (f, st))
 res = {i: [] for i in range(len(variants))}
 for r in range(a.rot):
     for i, env in enumerate(variants):
