@@ -1909,7 +1909,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             if (ctx->wl_ok) {
                 const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
                 const unsigned long long t1 = (unsigned long long)lgx * lgy;
-                int fpg = t1 * ((d.n + 7) / 8) >= 4096 ? 8 : (t1 * ((d.n + 3) / 4) >= 4096 ? 4 : (t1 * ((d.n + 1) / 2) >= 4096 ? 2 : 1));
+                int fpg = min(d.n, 4);   // (sharing the per-workgroup state beats the number of workgroups; groups of 1 / 2 / 4 / 8: 8 x 8K 0.486 / 0.416 / 0.399 / 0.419 ms, 8 x 1080p 0.0336 / 0.0237 / 0.0219 / 0.0235, 4 x 4K 0.0615 / 0.0419 / 0.0450)
                 if ((rcv_knobs().warp_fpg & 255) > 0) fpg = min(rcv_knobs().warp_fpg & 255, d.n);
                 const unsigned gz = (unsigned)((d.n + fpg - 1) / fpg);
                 const unsigned long long tiles = t1 * gz;
@@ -1955,7 +1955,16 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
         pitch = ctx->wl_pitch; prow = ctx->wl_prow; cpr = ctx->wl_cpr;
         if (rcv_knobs().warp_lds != 0 && s.cols >= 8 && s.rows >= 4 && ctx->wl_ok) {
             const unsigned lgx = (unsigned)((d.cols + kWlTW - 1) / kWlTW), lgy = (unsigned)((d.rows + kWlTH - 1) / kWlTH);
-            const unsigned long long tiles = (unsigned long long)lgx * lgy * gz;
+            // frames per workgroup of the staged kernels: sharing the coordinates, weights and the staging plan is worth more than the
+            // number of workgroups -- groups of min(n, 8), 16 on frames of 4K and up (tools/ablate_warp_order.py --combos, BGR, after the
+            // border tiles went onto the staged path; groups of 1 / 2 / 4 / 8 / 16): 4 x 4K 0.094 / 0.061 / 0.050 ms, 8 x 1080p 0.049 /
+            // 0.033 / 0.028 / 0.029, 16 x 1080p 0.094 / 0.061 / 0.051 / 0.047 / 0.051, 16 x 4K 0.389 / 0.256 / 0.212 / 0.192 / 0.185,
+            // 8 x 8K 0.764 / 0.503 / 0.415 / 0.374; the old rule (at least 8192 workgroups) ran 4 x 4K and 8 x 1080p in groups of 1
+            fpg = min(d.n, 8);
+            if (d.n % 16 == 0 && (unsigned long long)lgx * lgy >= 4000) fpg = 16;
+            if ((rcv_knobs().warp_fpg & 255) > 0) fpg = min(rcv_knobs().warp_fpg & 255, d.n);
+            const unsigned gzl = (unsigned)((d.n + fpg - 1) / fpg);
+            const unsigned long long tiles = (unsigned long long)lgx * lgy * gzl;
             const unsigned lds = 2u * (unsigned)pitch * (unsigned)prow;
             const bool rags = (uintptr_t)s.p % 4 || s.step % 4 || (s.n > 1 && s.fstride % 4);   // byte-aligned source rows
             const bool xcd = tiles < (1ull << 30);
@@ -1968,7 +1977,7 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
             // (tools/ablate_warp_order.py --deg; strips of 6 .. 16 alike at 7 deg, 32 x 8K: 1.497 -> 1.465 ms)
             const int strip = rcv_knobs().warp_fpg >= 256 ? (rcv_knobs().warp_fpg >> 8) - 1
                               : (fabsf(M[3]) >= 0.07f && fabsf(M[4]) >= 0.5f * fabsf(M[3]) ? 6 : 0);   // (RCV_WARP_FPG = fpg + 256 * (strip + 1): the tool's override)
-            const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gz);
+            const dim3 grid = xcd ? dim3((unsigned)tpx * 8) : dim3(lgx, lgy, gzl);
             if (s.ch == 1 && d.n >= 4 && rcv_knobs().warp_gray4 != 0 && (uintptr_t)s.p % 4 == 0 && s.step % 4 == 0 && s.fstride % 4 == 0) {
                 // four frames per LDS pass, up to four passes per workgroup (the per-workgroup set-up is 0.12 of a 0.70-ms launch at two
                 // passes).  Frames per workgroup x tile order, tools/ablate_warp_order.py --kind gray --combos, after the border tiles went
