@@ -124,6 +124,9 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+_default_ctx = None
+
+
 def default_context():
     """Lazily created process-wide context on device $LOCAL_RANK (or 0)."""
     global _default_ctx

@@ -1,32 +1,11 @@
 // rcv_geom.hip -- bilinear resize and warpAffine (u8 and f32, channels 1/3/4).  Not in the reference
 // (SURVEY.md F1); semantics SURVEY.md 8-A == oracle/rcv_oracle.c orc_resize / orc_warp_affine.
 // f32 evaluation order is fixed and spelled out op by op; built with -ffp-contract=off.
-#include "rcv_internal.h"
-#include <math.h>
-#include <string.h>
+#include "rcv_geom_dev.h"
 
 namespace {
 
 constexpr int kBlock = 256;
-
-__device__ __forceinline__ uint8_t round_half_up_u8(float v)
-{
-    int iv = (int)floorf(v + 0.5f);
-    return (uint8_t)min(max(iv, 0), 255);
-}
-
-// Two horizontally adjacent BGR taps (6 bytes at byte offset 3*x0 of a row) fetched with ONE 8-byte load instead of
-// six byte loads.  The load window is clamped into the row (rows are >= 8 bytes here), then shifted into place;
-// x0 may be -1 (left tap outside: its bytes are garbage and masked by the caller).
-__device__ __forceinline__ uint64_t load_taps6(const uint8_t* row, int x0, int rowbytes)
-{
-    const int off = 3 * x0;
-    const int offc = min(max(off, 0), rowbytes - 8);
-    uint64_t raw;
-    __builtin_memcpy(&raw, row + offc, 8);   // unaligned 8-byte global load
-    const int sh = (off - offc) * 8;         // -24 .. +56 bits
-    return sh >= 0 ? (raw >> sh) : (raw << (-sh));
-}
 
 // Exact integer down-scale by S in {2,4} (both axes), 3 channels: with half-pixel centres the bilinear sample point
 // falls exactly between the centre 2x2 pixels of each SxS block with weights 1/2, and the general f32 path
@@ -153,64 +132,6 @@ __global__ __launch_bounds__(kBlock) void k_resize(View s, View d, float scx, fl
     }
 }
 
-struct Affine { float m[6]; };
-
-// One output pixel, any channel count, byte-granular taps: the reference formulation every fast path below must match.
-template <int CH>
-__device__ __forceinline__ void warp_px(const uint8_t* sf, const View& s, const Affine& A, float fxx, float fyy, uint8_t* o)
-{
-    float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-    float sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-    if (!(sx > -1.0f && sx < (float)s.cols && sy > -1.0f && sy < (float)s.rows)) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) o[c] = 0;
-        return;
-    }
-    float x0f = floorf(sx), y0f = floorf(sy);
-    int x0 = (int)x0f, y0 = (int)y0f;
-    float fx = sx - x0f, fy = sy - y0f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    bool vx0 = x0 >= 0, vx1 = x1 < s.cols, vy0 = y0 >= 0, vy1 = y1 < s.rows;
-    const uint8_t* ra = sf + (size_t)(vy0 ? y0 : 0) * s.step;
-    const uint8_t* rb = sf + (size_t)(vy1 ? y1 : 0) * s.step;
-    size_t xa = (size_t)(vx0 ? x0 : 0) * CH, xb = (size_t)(vx1 ? x1 : 0) * CH;
-    uint64_t ta = 0, tb = 0;
-    const bool wide = CH == 3 && s.cols >= 3;
-    if (wide) {
-        ta = load_taps6(ra, x0, s.cols * 3);
-        tb = load_taps6(rb, x0, s.cols * 3);
-    }
-    // four channels on 4-byte aligned rows: a tap is one dword (taps outside the source read a clamped position and count as 0)
-    const bool quad = CH == 4 && ((((uintptr_t)ra | (uintptr_t)rb) & 3) == 0);
-    uint32_t q00 = 0, q01 = 0, q10 = 0, q11 = 0;
-    if (quad) {
-        q00 = (vx0 && vy0) ? *(const uint32_t*)(ra + xa) : 0u; q01 = (vx1 && vy0) ? *(const uint32_t*)(ra + xb) : 0u;
-        q10 = (vx0 && vy1) ? *(const uint32_t*)(rb + xa) : 0u; q11 = (vx1 && vy1) ? *(const uint32_t*)(rb + xb) : 0u;
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        float p00, p01, p10, p11;
-        if (quad) {
-            p00 = (float)((q00 >> (8 * c)) & 0xff); p01 = (float)((q01 >> (8 * c)) & 0xff);
-            p10 = (float)((q10 >> (8 * c)) & 0xff); p11 = (float)((q11 >> (8 * c)) & 0xff);
-        } else if (wide) {
-            p00 = (vx0 && vy0) ? (float)(uint32_t)((ta >> (8 * c)) & 0xff) : 0.0f;
-            p01 = (vx1 && vy0) ? (float)(uint32_t)((ta >> (24 + 8 * c)) & 0xff) : 0.0f;
-            p10 = (vx0 && vy1) ? (float)(uint32_t)((tb >> (8 * c)) & 0xff) : 0.0f;
-            p11 = (vx1 && vy1) ? (float)(uint32_t)((tb >> (24 + 8 * c)) & 0xff) : 0.0f;
-        } else {
-            p00 = (vx0 && vy0) ? (float)ra[xa + c] : 0.0f;
-            p01 = (vx1 && vy0) ? (float)ra[xb + c] : 0.0f;
-            p10 = (vx0 && vy1) ? (float)rb[xa + c] : 0.0f;
-            p11 = (vx1 && vy1) ? (float)rb[xb + c] : 0.0f;
-        }
-        float top = fmaf(fx, p01 - p00, p00);
-        float bot = fmaf(fx, p11 - p10, p10);
-        float v = fmaf(fy, bot - top, top);
-        o[c] = round_half_up_u8(v);
-    }
-}
-
 template <int CH>
 __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A)
 {
@@ -231,7 +152,6 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine(View s, View d, Affine A
 // v_cvt_f32_ubyteN straight from the tap dwords, invalid taps zeroed once per pixel instead of once per channel, and
 // the three result bytes of four neighbouring lanes gathered with DPP so that every fourth lane stores 12 bytes.
 // Same f32 operations in the same order as k_warp_affine<3>.
-typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kWarpRows = 8;
 #ifndef RCV_WARP_WW
 #define RCV_WARP_WW 64
@@ -240,80 +160,6 @@ constexpr int kWarpRows = 8;
 #define RCV_WARP_TW 256
 #endif
 constexpr int kWarpWW = RCV_WARP_WW, kWarpTW = RCV_WARP_TW;   // wave / workgroup width in pixels
-
-// byte N of a dword -> f32 in one instruction (the compiler otherwise mixes shifts, masks and integer subtracts in)
-template <int N>
-__device__ __forceinline__ float ub(uint32_t v)
-{
-    float f;
-    if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v));
-    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v));
-    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v));
-    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v));
-    return f;
-}
-
-// Bilinear sample of one BGR pixel from its two tap dwords per row {b0 g0 r0 b1 | g1 r1 . .} (upper row a, lower row b),
-// packed {b, g, r, 0}.  The f32 operations and their order are those of warp_px<3> / resize_px<3>: per channel
-// top = fma(fx, p01 - p00, p00), bot = fma(fx, p11 - p10, p10), v = fma(fy, bot - top, top), floor(v + 0.5).  Channels 0 and 1
-// ride in packed-f32 pairs, channel 2 pairs its top and bottom row (v_pk_add / v_pk_fma: two IEEE operations per
-// instruction, bit-identical to the scalar ops).  All taps must be valid (interior), so the result is an exact integer in
-// [0, 255] and v_cvt_pk_u8_f32 converts, saturates and packs it.
-// PIN = true pins each byte conversion to one v_cvt_f32_ubyteN (fewer instructions: -2 % in the 8-row warp / 4-row resize
-// kernels); the fused down-scale kernel, which interleaves four pixels, schedules better with the compiler's own choice.
-// d = fma({w, w}, a, b) with w = the low (HI = 0) or the high (HI = 1) half of the register pair wp: op_sel broadcasts the
-// half, so the {fx, fy} pair the coordinate arithmetic leaves behind feeds all four lerps without a v_mov to duplicate it
-template <int HI>
-__device__ __forceinline__ f2 pk_fma_bc(f2 wp, f2 a, f2 b)
-{
-    f2 d;
-    if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(wp), "v"(a), "v"(b));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(wp), "v"(a), "v"(b));
-    return d;
-}
-
-// {floor(b), floor(g), floor(r), 0} of three values in [0, 256): v_cvt_u32_f32 truncates (= floor for these non-negative values)
-// and its SDWA form writes the low byte of the result straight into byte 0 / 1 / 2 of the destination, the other bytes kept --
-// three instructions for what v_floor_f32 + v_cvt_pk_u8_f32 need six (the interpolated value + 0.5 lies in [0.5, 255.5]: every
-// lerp result is between its two end points, so neither the saturation nor the rounding of v_cvt_pk_u8_f32 is ever used)
-__device__ __forceinline__ uint32_t pack_floor3(float b, float g, float r)
-{
-    uint32_t d;
-    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(b));
-    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(g));
-    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r));
-    return d;
-}
-
-// floor of a value in [0, 256) as an integer: one v_cvt_u32_f32 (truncation) instead of v_floor_f32 + v_cvt_i32_f32
-__device__ __forceinline__ uint32_t trunc_u32(float v)
-{
-    uint32_t d;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(d) : "v"(v));
-    return d;
-}
-
-template <bool PIN>
-__device__ __forceinline__ uint32_t bilerp_bgr(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, f2 fxy)
-{
-    f2 a0, a1, b0, b1, c0, c1;
-    if constexpr (PIN) {
-        a0 = f2{ub<0>(alo), ub<1>(alo)}; a1 = f2{ub<3>(alo), ub<0>(ahi)};
-        b0 = f2{ub<0>(blo), ub<1>(blo)}; b1 = f2{ub<3>(blo), ub<0>(bhi)};
-        c0 = f2{ub<2>(alo), ub<2>(blo)}; c1 = f2{ub<1>(ahi), ub<1>(bhi)};
-    } else {
-        a0 = f2{(float)(alo & 0xff), (float)((alo >> 8) & 0xff)}; a1 = f2{(float)(alo >> 24), (float)(ahi & 0xff)};
-        b0 = f2{(float)(blo & 0xff), (float)((blo >> 8) & 0xff)}; b1 = f2{(float)(blo >> 24), (float)(bhi & 0xff)};
-        c0 = f2{(float)((alo >> 16) & 0xff), (float)((blo >> 16) & 0xff)}; c1 = f2{(float)((ahi >> 8) & 0xff), (float)((bhi >> 8) & 0xff)};
-    }
-    const f2 half2 = {0.5f, 0.5f};
-    const f2 top = pk_fma_bc<0>(fxy, a1 - a0, a0);
-    const f2 bot = pk_fma_bc<0>(fxy, b1 - b0, b0);
-    const f2 tb2 = pk_fma_bc<0>(fxy, c1 - c0, c0);
-    const f2 v01 = pk_fma_bc<1>(fxy, bot - top, top) + half2;
-    const float v2 = fmaf(fxy.y, tb2.y - tb2.x, tb2.x) + 0.5f;
-    return pack_floor3(v01.x, v01.y, v2);
-}   // output rows per thread: fewer, longer-lived workgroups and 16 tap loads in flight per lane
 
 // 4 x 4 transpose of dwords inside every quad of lanes: on return lane 4q+i holds in a[j] what lane 4q+j held in a[i].
 // Two butterfly stages (lane distance 1, then 2), each a select between a register and a quad-permuted neighbour register:
@@ -607,30 +453,6 @@ __device__ __forceinline__ void bilerp_bgrx_pair(const uint32_t (&p)[2][4], f2 f
 // The four lane masks (even / odd lane, lower / upper pair of a quad) are wave constants in SGPR pairs.  s_nop 1 in front:
 // a DPP source needs two wait states after the VALU write of that register, and the compiler's hazard recogniser does not
 // look inside an asm block (inside the block every DPP source was written at least three instructions earlier).
-// Tile order of the LDS-staged warp kernels: hardware places block b on XCD b % 8.  With tiles_per_xcd > 0 every XCD works through
-// its own contiguous run of the tile list, so that tiles whose patches overlap (the bounding box of a rotated tile is ~1.5x the
-// tile; a one-channel tile row is half a 128-byte line) run on the same L2 shortly after one another.  The list order is (frame
-// group, strip, tile row, tile column inside the strip): vertical strips of `strip` tile columns walked row by row, so that the
-// ~100 tiles an XCD has in flight form a block whose patches overlap on all four sides inside that L2; strip = 0: plain raster.
-__device__ __forceinline__ bool wl_tile(int tiles_per_xcd, int strip, int gx, int gy, int ntiles, int& bx, int& by, int& bz)
-{
-    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-    if (tiles_per_xcd <= 0) return true;
-    const int t = (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3);
-    if (t >= ntiles) return false;
-    bz = t / (gx * gy);
-    const int rem = t - bz * gx * gy;
-    if (strip > 0) {   // (the last strip may be narrower)
-        const int per = strip * gy, sidx = rem / per, r2 = rem - sidx * per, w = min(strip, gx - sidx * strip);
-        by = r2 / w;
-        bx = sidx * strip + r2 - by * w;
-    } else {
-        by = rem / gx;
-        bx = rem - by * gx;
-    }
-    return true;
-}
-
 template <int N> struct IntC { static constexpr int value = N; };
 struct QuadMasks { uint64_t even, odd, lo, hi; };
 __device__ __forceinline__ QuadMasks quad_masks() { return QuadMasks{0x5555555555555555ull, 0xaaaaaaaaaaaaaaaaull, 0x3333333333333333ull, 0xccccccccccccccccull}; }
@@ -1362,104 +1184,6 @@ __global__ __launch_bounds__(kBlock) void k_resize_gray(View s, View d, float sc
     }
 }
 
-// ---- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR ("next" row f1) ---------------------
-// resize(warp_affine(src -> mid), dst) with mid = S * dst.  For an exact integer factor the bilinear resize reads only
-// the centre 2x2 of every SxS block of `mid` (k_resize_box above), so the fused kernel evaluates just those four warped
-// pixels per output pixel -- bit for bit what the warp kernels produce (same f32 ops, same order, same rounding) -- and
-// averages them with (a+b+c+d+2)>>2.  `mid` never exists: 1/4 (S=2: all) of the warp arithmetic of the unfused pair and
-// none of its 2 x 3 B/px intermediate traffic.  One thread per output pixel, four lanes share a 12-byte store.
-#ifndef RCV_BOX_TW
-#define RCV_BOX_TW 64
-#endif
-constexpr int kBoxTileW = RCV_BOX_TW, kBoxTileH = 256 / RCV_BOX_TW;   // output tile of one workgroup (4 waves of 16 x 4)
-
-// One wave's share of k_warp_resize_box: output pixel (x, y) of frame `frame` .
-template <int S>
-__device__ __forceinline__ void warp_resize_box_px(const View& s, const View& d, const Affine& A, const int frame, const int x, const int y)
-{
-    const uint8_t* sf = s.p + (size_t)frame * s.fstride;
-    uint8_t* dfr = d.p + (size_t)frame * d.fstride;
-    // A workgroup owns a 32 x 8 tile of output pixels, each wave a 16 x 4 sub-tile (lane = 16 * row + column): the taps of
-    // a wave then fall into a compact source patch (64 x 16 px for S = 4, plus the rotation's drift) that its eight tap loads
-    // reuse out of L1.  With one output ROW segment per wave (64 x 1) the same loads walked across 30 source rows at 7 degrees,
-    // every line was used by two lanes only and fetched again by the waves of the neighbouring rows (1.66x the algorithmic
-    // bytes from HBM; 64 % of the wave cycles waiting on memory).
-    const int xq = min(x, d.cols - 1), yq = min(y, d.rows - 1);
-    constexpr int o = S / 2 - 1;
-    float sx[4], sy[4];
-    bool inter = true;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
-        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
-    }
-    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-                       (unsigned long long)s.rows * s.step < (1ull << 32);
-    uint32_t p[4];
-    if (small && __all(inter)) {   // wave-uniform: every tap of every lane inside the source (see k_warp_affine_bgr)
-        struct U3 { uint32_t a, b, c; };
-        U3 ta[4], tb[4];
-        unsigned sh[4];
-        float fx[4], fy[4];
-        const unsigned sstep = (unsigned)s.step;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
-            fx[i] = sx[i] - x0f;
-            fy[i] = sy[i] - y0f;
-            const unsigned off = __umul24((unsigned)(int)y0f, sstep) + 3u * (unsigned)(int)x0f;
-            sh[i] = off & 3u;
-            ta[i] = *(const U3*)(sf + (off & ~3u));
-            tb[i] = *(const U3*)(sf + ((off & ~3u) + sstep));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].b, ta[i].a, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].c, ta[i].b, sh[i]);
-            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].b, tb[i].a, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].c, tb[i].b, sh[i]);
-            p[i] = bilerp_bgr<false>(alo, ahi, blo, bhi, f2{fx[i], fy[i]});
-        }
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            uint8_t o3[3];
-            warp_px<3>(sf, s, A, (float)(S * xq + o + (i & 1)), (float)(S * yq + o + (i >> 1)), o3);
-            p[i] = (uint32_t)o3[0] | ((uint32_t)o3[1] << 8) | ((uint32_t)o3[2] << 16);
-        }
-    }
-    // (a+b+c+d+2)>>2 per channel: B and R ride in the two 16-bit halves of one dword, G in another
-    const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
-    const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
-    const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
-    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
-    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
-    const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
-    if ((threadIdx.x & 3) == 0 && x < d.cols && y < d.rows) {
-        struct U3 { uint32_t a, b, c; };
-        *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) =
-            U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
-    }
-}
-
-#ifndef RCV_BOX_WW
-#define RCV_BOX_WW 32
-#endif
-template <int S>
-__global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affine A)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int WW = RCV_BOX_WW, WH = 64 / WW;   // wave sub-tile
-    const int x = blockIdx.x * kBoxTileW + (wave % (kBoxTileW / WW)) * WW + (lane % WW);   // d.cols % 4 == 0: quads never straddle the row end
-    const int y = blockIdx.y * kBoxTileH + (wave / (kBoxTileW / WW)) * WH + (lane / WW);
-    warp_resize_box_px<S>(s, d, A, (int)blockIdx.z, x, y);
-}
-
-// (Round 3 built the fused warp -> 4x down-scale on an LDS-staged source patch as well -- k_warp_resize_lds: 16 x 16 output tiles, the warp
-//  kernel's staging plan and double buffer; bit-exact, 0.91 ms against this gather kernel's 0.715 ms on 32 x 8K -> 1080p because the samples
-//  sit 4 pixels apart: <= 9 of 16 staged pixels are ever read and the tap reads are a 4-way bank conflict for every pitch.  Removed from the
-//  product in round 4; the measurement is profiles/r03_warp_resize_lds.txt, the source is in the history at commit e87cdfd.)
-
 // ---- RCV_32F images (SURVEY.md 8-A "warp_affine (u8/f32 ...)"; the cornerHarris response map) --------------------------------
 // The same sampling rules and the same f32 operations in the same order as the u8 kernels (top = fma(fx, p01 - p00, p00), bot
 // likewise, v = fma(fy, bot - top, top); oracle: orc_resize_f32 / orc_warp_affine_f32) with f32 taps and the unrounded v as the
@@ -1763,17 +1487,6 @@ int check_geom_f32(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
     return RCV_OK;
 }
 
-int check_geom(const rcv_batch* src, rcv_batch* dst, View* s, View* d)
-{
-    if (!src || !dst) return RCV_ERR_ARG;
-    RCV_TRY(rcv_view_batch(src, RCV_8U, s));
-    RCV_TRY(rcv_view_batch(dst, RCV_8U, d));
-    if (s->ch != d->ch || s->n != d->n) return RCV_ERR_ARG;
-    if (s->ch != 1 && s->ch != 3 && s->ch != 4) return RCV_ERR_UNSUPPORTED;
-    if (d->rows > 65535 || d->n > 65535) return RCV_ERR_UNSUPPORTED;
-    return RCV_OK;
-}
-
 inline dim3 px_grid(const View& d)
 {
     unsigned gx = (unsigned)((d.cols + kBlock - 1) / kBlock);
@@ -2021,57 +1734,6 @@ extern "C" int rcv_warp_affine_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_bat
     else if (s.ch == 3) RCV_LAUNCH(k_warp_affine<3>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     else RCV_LAUNCH(k_warp_affine<4>, px_grid(d), dim3(kBlock), 0, ctx->stream, s, d, A);
     return rcv_launch_check(ctx);
-}
-
-// resize(warp_affine(src -> mid_rows x mid_cols), dst) without materialising `mid` when mid = S * dst, S in {2, 4};
-// any other shape runs the two ordinary kernels through the context workspace (same results either way).
-extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int mid_rows, int mid_cols)
-{
-    RCV_TRY(rcv_bind(ctx));
-    if (!M || mid_rows < 0 || mid_cols < 0) return RCV_ERR_ARG;
-    View s, d;
-    RCV_TRY(check_geom(src, dst, &s, &d));
-    if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
-    if (mid_rows == 0 || mid_cols == 0) return RCV_ERR_ARG;
-    Affine A;
-    for (int i = 0; i < 6; ++i) A.m[i] = M[i];
-    for (int S = 2; S <= 4; S += 2) {
-        if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
-            d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
-            // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
-            // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)
-            constexpr unsigned kLds = 27136;
-            if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A);
-            else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A);
-            return rcv_launch_check(ctx);
-        }
-    }
-    const size_t tstep = ((size_t)mid_cols * s.ch + 15) & ~(size_t)15, tfs = tstep * mid_rows;
-    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
-    uint8_t* tmp;
-    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
-    rcv_batch tb = *dst;
-    tb.frame0.data = tmp;
-    tb.frame0.cap = tfs;
-    tb.frame0.step = tstep;
-    tb.frame0.rows = mid_rows;
-    tb.frame0.cols = mid_cols;
-    tb.frame_stride = tfs;
-    RCV_TRY(rcv_warp_affine_batch(ctx, src, &tb, M));
-    return rcv_resize_batch(ctx, &tb, dst);
-}
-
-extern "C" int rcv_warp_affine_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M, int mid_rows, int mid_cols)
-{
-    if (!src || !dst) return RCV_ERR_ARG;
-    Stage st;
-    RCV_TRY(stage_begin(&st, ctx));
-    rcv_mat *ds, *dd;
-    RCV_TRY(stage_in(&st, src, true, false, &ds));
-    RCV_TRY(stage_in(&st, dst, true, true, &dd));
-    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
-    return stage_finish(&st, rcv_warp_affine_resize_batch(ctx, &bs, &bd, M, mid_rows, mid_cols));
 }
 
 extern "C" int rcv_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst)

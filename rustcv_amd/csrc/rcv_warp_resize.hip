@@ -1,0 +1,407 @@
+// rcv_warp_resize.hip -- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR: SURVEY.md 8(f) row f1, BASELINE config 4
+// (8K warpAffine + resize -> 1080p).  Not in the reference; semantics = resize(warp_affine(.)) of SURVEY.md 8-A ==
+// oracle/rcv_oracle.c orc_resize(orc_warp_affine(.)), bit for bit.
+#include "rcv_geom_dev.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- fused warpAffine -> exact SxS down-scale (S in {2, 4}), BGR ("next" row f1) ---------------------
+// resize(warp_affine(src -> mid), dst) with mid = S * dst.  For an exact integer factor the bilinear resize reads only
+// the centre 2x2 of every SxS block of `mid` (k_resize_box above), so the fused kernel evaluates just those four warped
+// pixels per output pixel -- bit for bit what the warp kernels produce (same f32 ops, same order, same rounding) -- and
+// averages them with (a+b+c+d+2)>>2.  `mid` never exists: 1/4 (S=2: all) of the warp arithmetic of the unfused pair and
+// none of its 2 x 3 B/px intermediate traffic.  One thread per output pixel, four lanes share a 12-byte store.
+#ifndef RCV_BOX_TW
+#define RCV_BOX_TW 64
+#endif
+constexpr int kBoxTileW = RCV_BOX_TW, kBoxTileH = 256 / RCV_BOX_TW;   // output tile of one workgroup (4 waves of 16 x 4)
+
+// Tile order of the fused launches.  Hardware places block b on XCD b % 8.
+//  per_xcd == 0: the 3-D grid as launched (x fastest: raster order, neighbouring tiles on different XCDs);
+//  per_xcd > 0:  wl_tile's order -- the whole tile list (frame group, strip, tile row, tile column) cut into eight contiguous runs, one
+//                per XCD: neighbouring tiles share an L2, but the eight XCDs stream eight distant regions (other frame groups) at once;
+//  per_xcd < 0:  SYNCHRONOUS STRIPES (round 5): every frame group's tile list (strip, tile row, tile column) is cut into eight runs of
+//                -per_xcd tiles, XCD k takes run k of group 0, then run k of group 1, ...: with vertical strips each XCD walks its own
+//                stripe of the image from top to bottom while all eight work on the same rows of the same frames -- a tile's lines
+//                shared with the tile below (a rotated tile's row pieces end in lines that continue in its vertical neighbours:
+//                x1.3 of the source at 7 degrees) are L2 hits a few workgroups later, and DRAM sees one band of one frame group.
+__device__ __forceinline__ bool wr_tile(int per_xcd, int strip, int gx, int gy, int ngroups, int& bx, int& by, int& bz)
+{
+    if (per_xcd >= 0) return wl_tile(per_xcd, strip, gx, gy, gx * gy * ngroups, bx, by, bz);
+    const int pg = -per_xcd, q = (int)(blockIdx.x >> 3);
+    bz = q / pg;
+    const int rem = (int)(blockIdx.x & 7) * pg + (q - bz * pg);
+    if (bz >= ngroups || rem >= gx * gy) return false;
+    if (strip > 0) {   // (the last strip may be narrower)
+        const int per = strip * gy, sidx = rem / per, r2 = rem - sidx * per, w = min(strip, gx - sidx * strip);
+        by = r2 / w;
+        bx = sidx * strip + r2 - by * w;
+    } else {
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    return true;
+}
+
+// One wave's share of k_warp_resize_box: output pixel (x, y) of frame `frame` .
+template <int S>
+__device__ __forceinline__ void warp_resize_box_px(const View& s, const View& d, const Affine& A, const int frame, const int x, const int y)
+{
+    const uint8_t* sf = s.p + (size_t)frame * s.fstride;
+    uint8_t* dfr = d.p + (size_t)frame * d.fstride;
+    // A workgroup owns a 32 x 8 tile of output pixels, each wave a 16 x 4 sub-tile (lane = 16 * row + column): the taps of
+    // a wave then fall into a compact source patch (64 x 16 px for S = 4, plus the rotation's drift) that its eight tap loads
+    // reuse out of L1.  With one output ROW segment per wave (64 x 1) the same loads walked across 30 source rows at 7 degrees,
+    // every line was used by two lanes only and fetched again by the waves of the neighbouring rows (1.66x the algorithmic
+    // bytes from HBM; 64 % of the wave cycles waiting on memory).
+    const int xq = min(x, d.cols - 1), yq = min(y, d.rows - 1);
+    constexpr int o = S / 2 - 1;
+    float sx[4], sy[4];
+    bool inter = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
+        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
+    }
+    const bool small = ((uintptr_t)sf & 3) == 0 && (s.step & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+                       (unsigned long long)s.rows * s.step < (1ull << 32);
+    uint32_t p[4];
+    if (small && __all(inter)) {   // wave-uniform: every tap of every lane inside the source (see k_warp_affine_bgr)
+        struct U3 { uint32_t a, b, c; };
+        U3 ta[4], tb[4];
+        unsigned sh[4];
+        float fx[4], fy[4];
+        const unsigned sstep = (unsigned)s.step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
+            fx[i] = sx[i] - x0f;
+            fy[i] = sy[i] - y0f;
+            const unsigned off = __umul24((unsigned)(int)y0f, sstep) + 3u * (unsigned)(int)x0f;
+            sh[i] = off & 3u;
+            ta[i] = *(const U3*)(sf + (off & ~3u));
+            tb[i] = *(const U3*)(sf + ((off & ~3u) + sstep));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].b, ta[i].a, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].c, ta[i].b, sh[i]);
+            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].b, tb[i].a, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].c, tb[i].b, sh[i]);
+            p[i] = bilerp_bgr<false>(alo, ahi, blo, bhi, f2{fx[i], fy[i]});
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            uint8_t o3[3];
+            warp_px<3>(sf, s, A, (float)(S * xq + o + (i & 1)), (float)(S * yq + o + (i >> 1)), o3);
+            p[i] = (uint32_t)o3[0] | ((uint32_t)o3[1] << 8) | ((uint32_t)o3[2] << 16);
+        }
+    }
+    // (a+b+c+d+2)>>2 per channel: B and R ride in the two 16-bit halves of one dword, G in another
+    const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
+    const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
+    const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
+    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, px, 0x101, 0xf, 0xf, true);
+    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, px, 0x102, 0xf, 0xf, true);
+    const uint32_t p3 = __builtin_amdgcn_update_dpp(0u, px, 0x103, 0xf, 0xf, true);
+    if ((threadIdx.x & 3) == 0 && x < d.cols && y < d.rows) {
+        struct U3 { uint32_t a, b, c; };
+        *(U3*)(dfr + (size_t)y * d.step + (size_t)x * 3) =
+            U3{__builtin_amdgcn_perm(p1, px, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+    }
+}
+
+#ifndef RCV_BOX_WW
+#define RCV_BOX_WW 32
+#endif
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affine A, int per_xcd, int strip, int gx, int gy)
+{
+    int bx, by, bz;
+    if (!wr_tile(per_xcd, strip, gx, gy, d.n, bx, by, bz)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WW = RCV_BOX_WW, WH = 64 / WW;   // wave sub-tile
+    const int x = bx * kBoxTileW + (wave % (kBoxTileW / WW)) * WW + (lane % WW);   // d.cols % 4 == 0: quads never straddle the row end
+    const int y = by * kBoxTileH + (wave / (kBoxTileW / WW)) * WH + (lane / WW);
+    warp_resize_box_px<S>(s, d, A, bz, x, y);
+}
+
+// ---- the same launch as a FRAME LOOP (round 5) -----------------------------------------------------------------------------------
+// One affine map serves every frame of a batch, so everything k_warp_resize_box computes before its first load -- the four sample
+// coordinates, the interior test, floor / fraction, the tap offsets and alignment shifts: ~150 of its 278 VALU instructions per
+// output pixel -- is the same for all frames.  Here a wave keeps one 64-pixel sub-tile and walks the frames [f0, f1) of its frame
+// group: that state is computed once (18 registers), a frame costs its eight tap gathers (saddr form: the frame base is an SGPR
+// pair, the lane offset never changes), 4 x 31 instructions of exact bilinear arithmetic and one dword store per lane.  The loop is
+// software-pipelined by hand, two frames deep with two register sets (A, B): the gathers of frame f + 2 are issued before the
+// arithmetic of frame f + 1, so a wave always has 8-16 gathers in flight and does not depend on occupancy to hide their latency
+// (round 4's frame groups without the pipeline lost: 0.81-1.18 against 0.70 ms).
+// Counting rules of gfx9's one in-order vmcnt the loop is shaped by (tests/test_isa_waits.py pins the numbers):
+//  * no load or store of the loop sits behind a lane-dependent branch: every lane stores one dword of its quad's 12 bytes (lane 3
+//    repeats lane 2's dword), coordinates are clamped into the image by whole quads (a clamped quad recomputes and rewrites its
+//    neighbour's bytes with the same values), so ragged tiles need no bounds test;
+//  * the prologue issues one store to the context's dump line between its two gather sets, so that the loop head sees the same
+//    count of younger operations on the entry edge as on the back edge (set B's 8 gathers + 1 store) and waits with vmcnt(9+),
+//    not for the stores just issued.
+// Waves whose taps are not all inside the source (8 % at 7 degrees) run k_warp_resize_box's per-frame path.
+// DBG (measurement build, -DRCV_WRL_BENCH): 1 = gathers and stores only (the taps are OR-ed into the stored dword), 2 = arithmetic and stores only
+template <int S, int WW, int DBG = 0>
+__global__ __launch_bounds__(kBlock) void k_warp_resize_loop(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int tiles_per_xcd, int strip,
+                                                             uint32_t* dump)
+{
+    int bx, by, bz;
+    if (!wr_tile(tiles_per_xcd, strip, gx, gy, ngroups, bx, by, bz)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WH = 64 / WW;   // wave sub-tile WW x WH, workgroup tile 2 x 2 of them
+    const int x = bx * (2 * WW) + (wave & 1) * WW + (lane % WW);
+    const int y = by * (2 * WH) + (wave >> 1) * WH + (lane / WW);
+    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
+    // whole quads clamped into the image (d.cols % 4 == 0, d.cols >= 4)
+    const int xq = min(x & ~3, d.cols - 4) + (x & 3), yq = min(y, d.rows - 1);
+    constexpr int o = S / 2 - 1;
+    float sx[4], sy[4];
+    bool inter = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
+        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
+    }
+    if (!__all(inter)) {   // wave-uniform
+        if (__all(x >= d.cols || y >= d.rows)) return;
+        for (int f = f0; f < f1; ++f) warp_resize_box_px<S>(s, d, A, f, x, y);
+        return;
+    }
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    unsigned off[4], sh[4];
+    f2 fxy[4];
+    const unsigned sstep = (unsigned)s.step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
+        fxy[i] = f2{sx[i] - x0f, sy[i] - y0f};
+        const unsigned ob = __umul24((unsigned)(int)y0f, sstep) + 3u * (unsigned)(int)x0f;
+        sh[i] = ob & 3u;
+        off[i] = ob & ~3u;
+    }
+    if constexpr (DBG == 3) {   // the shared footprint: rows ymin .. ymin + 3 from column xmin, 16 aligned bytes each
+        const float xm = floorf(fminf(fminf(sx[0], sx[1]), fminf(sx[2], sx[3]))), ym = floorf(fminf(fminf(sy[0], sy[1]), fminf(sy[2], sy[3])));
+        const unsigned ob = __umul24((unsigned)(int)ym, sstep) + 3u * (unsigned)(int)xm;
+        off[0] = ob & ~3u;
+    }
+    // lane k of a quad stores dword min(k, 2) of the quad's 12 bytes {b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3}: it needs the pixels
+    // k' = min(k, 2) and k' + 1 of its quad (two quad_perm moves) and one v_perm with a per-lane selector
+    const int kq = min(lane & 3, 2);
+    const unsigned doff = (unsigned)yq * (unsigned)d.step + (unsigned)(xq & ~3) * 3u + 4u * (unsigned)kq;
+    const uint32_t psel = kq == 0 ? 0x04020100u : (kq == 1 ? 0x05040201u : 0x06050402u);
+    const uint8_t* sf = s.p + (size_t)f0 * s.fstride;
+    uint8_t* df = d.p + (size_t)f0 * d.fstride;
+    // raw buffer resources (base in SGPRs, the lane's offset in one VGPR, the second tap row through the scalar offset operand):
+    // no per-frame address arithmetic on the VALU
+    constexpr int kRsrc = 0x00020000;
+    auto gather = [&](const uint8_t* base, u3 (&ta)[4], u3 (&tb)[4]) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, kRsrc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (DBG == 2) {
+                asm volatile("" : "=v"(ta[i]), "=v"(tb[i]));   // whatever the registers hold
+                continue;
+            }
+            if constexpr (DBG == 3) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off[0], (unsigned)i * sstep, 0);
+                ta[i] = u3{v.x, v.y, v.z};
+                tb[i] = u3{v.w, v.w, v.w};
+                continue;
+            }
+            ta[i] = __builtin_amdgcn_raw_buffer_load_b96(r, off[i], 0, 0);
+            tb[i] = __builtin_amdgcn_raw_buffer_load_b96(r, off[i], sstep, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto finish = [&](const u3 (&ta)[4], const u3 (&tb)[4], uint8_t* dbase) {
+        uint32_t p[4];
+        if constexpr (DBG == 1 || DBG == 3) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v |= ta[i].x | ta[i].y | ta[i].z | tb[i].x | tb[i].y | tb[i].z;
+            __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0xffffffff, kRsrc), doff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t alo = __builtin_amdgcn_alignbyte(ta[i].y, ta[i].x, sh[i]), ahi = __builtin_amdgcn_alignbyte(ta[i].z, ta[i].y, sh[i]);
+            const uint32_t blo = __builtin_amdgcn_alignbyte(tb[i].y, tb[i].x, sh[i]), bhi = __builtin_amdgcn_alignbyte(tb[i].z, tb[i].y, sh[i]);
+            p[i] = bilerp_bgr<true>(alo, ahi, blo, bhi, fxy[i]);
+        }
+        // (a+b+c+d+2)>>2 per channel: B and R ride in the two 16-bit halves of one dword, G in another
+        const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
+        const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
+        const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
+        const uint32_t pa = __builtin_amdgcn_update_dpp(0u, px, 0xA4, 0xf, 0xf, true);   // quad_perm [0,1,2,2]
+        const uint32_t pb = __builtin_amdgcn_update_dpp(0u, px, 0xF9, 0xf, 0xf, true);   // quad_perm [1,2,3,3]
+        const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0xffffffff, kRsrc);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(pb, pa, psel), w, doff, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    u3 ta[4], tb[4], ua[4], ub_[4];
+    const size_t sfs = s.fstride, dfs = d.fstride;
+    gather(sf, ta, tb);
+    __builtin_amdgcn_raw_buffer_store_b32(psel, __builtin_amdgcn_make_buffer_rsrc((void*)dump, 0, 0xffffffff, kRsrc), 4u * threadIdx.x, 0, 0);   // (see the counting rules above)
+    __builtin_amdgcn_sched_barrier(0);
+    gather(f0 + 1 < f1 ? sf + sfs : sf, ua, ub_);
+    int f = f0;
+#pragma unroll 1
+    while (f + 3 < f1) {   // set A = frame f, set B = frame f + 1; frames f + 2 and f + 3 exist
+        finish(ta, tb, df);
+        gather(sf + 2 * sfs, ta, tb);
+        finish(ua, ub_, df + dfs);
+        gather(sf + 3 * sfs, ua, ub_);
+        sf += 2 * sfs;
+        df += 2 * dfs;
+        f += 2;
+    }
+    // 1, 2 or 3 frames left: A = f, B = f + 1 (when it exists)
+    finish(ta, tb, df);
+    if (f + 1 < f1) {
+        if (f + 2 < f1) gather(sf + 2 * sfs, ta, tb);
+        finish(ua, ub_, df + dfs);
+        if (f + 2 < f1) finish(ta, tb, df + 2 * dfs);
+    }
+}
+
+// (Round 3 built the fused warp -> 4x down-scale on an LDS-staged source patch as well -- k_warp_resize_lds: 16 x 16 output tiles, the warp
+//  kernel's staging plan and double buffer; bit-exact, 0.91 ms against this gather kernel's 0.715 ms on 32 x 8K -> 1080p because the samples
+//  sit 4 pixels apart: <= 9 of 16 staged pixels are ever read and the tap reads are a 4-way bank conflict for every pitch.  Removed from the
+//  product in round 4; the measurement is profiles/r03_warp_resize_lds.txt, the source is in the history at commit e87cdfd.)
+
+// ---- host side of the frame-loop kernel ---------------------------------------------------------------------------------------
+// fpg: frames per wave (0: by batch size); ww: wave sub-tile width; xcd: contiguous run of the tile list per XCD; strip: tile columns per
+// vertical strip of that list (0: raster); lds: dynamic-LDS request that caps the workgroups per CU (0: none)
+struct WrlPlan { int fpg = 0, ww = 32, xcd = 1, strip = 0; unsigned lds = 0; int dbg = 0; };
+
+bool wrl_ok(const View& s, const View& d)
+{
+    return ((uintptr_t)s.p & 3) == 0 && (s.step & 3) == 0 && (s.fstride & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+           (unsigned long long)s.rows * s.step < (1ull << 32) && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
+}
+
+int wrl_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S, WrlPlan p)
+{
+    const int ww = p.ww == 16 ? 16 : (p.ww == 64 ? 64 : 32), wh = 64 / ww;
+    const int gx = (d.cols + 2 * ww - 1) / (2 * ww), gy = (d.rows + 2 * wh - 1) / (2 * wh);
+    int fpg = p.fpg > 0 ? min(p.fpg, d.n) : min(d.n, 16);
+    const int groups = (d.n + fpg - 1) / fpg;
+    const unsigned long long tiles = (unsigned long long)gx * gy * groups;
+    if (tiles >= (1ull << 28)) return RCV_ERR_UNSUPPORTED;
+    // xcd 1: contiguous runs of the whole list; 2: synchronous stripes (runs of every frame group's list)
+    const int pg = (gx * gy + 7) / 8;
+    const int tpx = p.xcd == 1 ? (int)((tiles + 7) / 8) : (p.xcd == 2 ? -pg : 0);
+    const dim3 grid = p.xcd == 1 ? dim3((unsigned)(8 * tpx)) : (p.xcd == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
+    uint32_t* dump = (uint32_t*)(ctx->kconst + RCV_KC_SOBEL_DUMP);
+#ifdef RCV_WRL_BENCH
+    if (p.dbg == 1) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 1>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
+    if (p.dbg == 3) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 3>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
+    if (p.dbg == 2) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 2>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
+#endif
+#define WRL_GO(S_, W_) RCV_LAUNCH((k_warp_resize_loop<S_, W_>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump)
+    if (S == 2) { if (ww == 16) WRL_GO(2, 16); else if (ww == 64) WRL_GO(2, 64); else WRL_GO(2, 32); }
+    else { if (ww == 16) WRL_GO(4, 16); else if (ww == 64) WRL_GO(4, 64); else WRL_GO(4, 32); }
+#undef WRL_GO
+    return rcv_launch_check(ctx);
+}
+
+} // namespace
+
+#ifndef RCV_WRL_BENCH
+// resize(warp_affine(src -> mid_rows x mid_cols), dst) without materialising `mid` when mid = S * dst, S in {2, 4};
+// any other shape runs the two ordinary kernels through the context workspace (same results either way).
+extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int mid_rows, int mid_cols)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!M || mid_rows < 0 || mid_cols < 0) return RCV_ERR_ARG;
+    View s, d;
+    RCV_TRY(check_geom(src, dst, &s, &d));
+    if (d.rows == 0 || d.cols == 0 || d.n == 0) return RCV_OK;
+    if (mid_rows == 0 || mid_cols == 0) return RCV_ERR_ARG;
+    Affine A;
+    for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    for (int S = 2; S <= 4; S += 2) {
+        if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
+            d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
+            if (rcv_knobs().warp_resize_loop > 0 && d.n > 1 && wrl_ok(s, d))   // (measured slower than the per-frame launch on 32 x 8K: DESIGN.md 9; tests only)
+                return wrl_launch(ctx, s, d, A, S, WrlPlan{});
+            dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
+            // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
+            // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)
+            constexpr unsigned kLds = 27136;
+            if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A, 0, 0, (int)grid.x, (int)grid.y);
+            else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A, 0, 0, (int)grid.x, (int)grid.y);
+            return rcv_launch_check(ctx);
+        }
+    }
+    const size_t tstep = ((size_t)mid_cols * s.ch + 15) & ~(size_t)15, tfs = tstep * mid_rows;
+    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
+    uint8_t* tmp;
+    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
+    rcv_batch tb = *dst;
+    tb.frame0.data = tmp;
+    tb.frame0.cap = tfs;
+    tb.frame0.step = tstep;
+    tb.frame0.rows = mid_rows;
+    tb.frame0.cols = mid_cols;
+    tb.frame_stride = tfs;
+    RCV_TRY(rcv_warp_affine_batch(ctx, src, &tb, M));
+    return rcv_resize_batch(ctx, &tb, dst);
+}
+
+extern "C" int rcv_warp_affine_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M, int mid_rows, int mid_cols)
+{
+    if (!src || !dst) return RCV_ERR_ARG;
+    Stage st;
+    RCV_TRY(stage_begin(&st, ctx));
+    rcv_mat *ds, *dd;
+    RCV_TRY(stage_in(&st, src, true, false, &ds));
+    RCV_TRY(stage_in(&st, dst, true, true, &dd));
+    rcv_batch bs = rcv_single(ds), bd = rcv_single(dd);
+    return stage_finish(&st, rcv_warp_affine_resize_batch(ctx, &bs, &bd, M, mid_rows, mid_cols));
+}
+#endif
+
+#ifdef RCV_WRL_BENCH
+// Measurement entry (librustcv_hip_bench.so only): the fused warp -> down-scale launch with every plan parameter as an argument.
+// variant 0: k_warp_resize_box (one launch per frame tile), 1: k_warp_resize_loop.
+extern "C" int rcv__warp_resize_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int S, int variant, int fpg, int ww, int xcd,
+                                      int strip, int lds)
+{
+    RCV_TRY(rcv_bind(ctx));
+    View s, d;
+    RCV_TRY(check_geom(src, dst, &s, &d));
+    if (!M || (S != 2 && S != 4) || s.ch != 3 || d.cols % 4 || d.n == 0) return RCV_ERR_ARG;
+    if (xcd & 256) s.fstride = 0;   // every frame reads frame 0: the launch without its HBM reads
+    xcd &= 255;
+    Affine A;
+    for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    if (variant == 0) {
+        dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
+        const int bgx = (int)grid.x, bgy = (int)grid.y, pg = (bgx * bgy + 7) / 8;
+        const int ord = xcd & 3;
+        const int per = ord == 1 ? (int)(((long long)bgx * bgy * d.n + 7) / 8) : (ord == 2 ? -pg : 0);
+        if (ord == 1) grid = dim3((unsigned)(8 * per));
+        if (ord == 2) grid = dim3((unsigned)(8 * pg * d.n));
+        const unsigned l = lds < 0 ? 27136u : (unsigned)lds;
+        if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), l, ctx->stream, s, d, A, per, strip, bgx, bgy);
+        else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), l, ctx->stream, s, d, A, per, strip, bgx, bgy);
+        return rcv_launch_check(ctx);
+    }
+    if (!wrl_ok(s, d)) return RCV_ERR_UNSUPPORTED;
+    WrlPlan p;
+    p.fpg = fpg; p.ww = ww; p.xcd = xcd & 3; p.dbg = (xcd >> 4) & 15; p.strip = strip; p.lds = lds < 0 ? 0u : (unsigned)lds;   // (xcd + 16 * dbg)
+    return wrl_launch(ctx, s, d, A, S, p);
+}
+#endif

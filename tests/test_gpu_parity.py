@@ -221,6 +221,22 @@ def test_rectangle(ctx, oracle, rng, rect, thick, pad):
     assert np.array_equal(m.data, want)
 
 
+def test_calls_without_ctx_use_the_default_context(oracle, rng):
+    # imgproc.* / videoio.* without ctx= go through core.default_context()
+    rows, cols = 48, 64
+    base = rng.integers(0, 256, size=rows * cols * 3, dtype=np.uint8)
+    want = base.copy()
+    oracle.rectangle(want, rows, cols, cols * 3, 5, 6, 30, 20, 9, 8, 7, 1)
+    m = Mat(rows, cols, 3, data=base.copy())
+    imgproc.rectangle(m, Rect(5, 6, 30, 20), Scalar(9, 8, 7), 1)
+    assert np.array_equal(m.data, want)
+    img = rand_img(rng, 40, 52, 3)
+    k = rng.integers(-8, 9, size=(3, 3)).astype(np.int8)
+    got = Mat.new(40, 52, 3)
+    imgproc.filter2d(Mat.from_array(img), got, k, shift=4)
+    assert np.array_equal(got.to_array(), oracle.filter2d_i8(img, k, 4))
+
+
 def test_rectangle_short_vec_guard(ctx, oracle, rng):
     # data.len() shorter than rows*step: only the `idx+2 < len` guard protects memory (drawing.rs:82)
     rows, cols, step = 20, 30, 90

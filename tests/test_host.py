@@ -27,6 +27,16 @@ def test_mat_mirrors_reference_constructors():
     assert (r.rows, r.cols, r.channels, r.step, r.cap, r.device) == (2, 4, 3, 16, 32, 0)
 
 
+def test_default_context_is_lazy_and_defined():
+    # the process-wide context of calls made without ctx= : the module-level slot must exist (a NameError here broke every
+    # imgproc.* / videoio.* call without an explicit context); creating it needs a GPU, so only the slot is checked on CPU
+    from rustcv_amd import core
+    assert core._default_ctx is None or isinstance(core._default_ctx, core.Context)
+    if core._default_ctx is None and rustcv_amd.device_count() == 0:
+        with pytest.raises(rustcv_amd.RcvError):     # no GPU: a loud device error, not a NameError and not a CPU fallback
+            core.default_context()
+
+
 @pytest.mark.parametrize("n,world", [(64, 1), (64, 8), (256, 8), (512, 8), (10, 4), (3, 8), (0, 2), (7, 7)])
 def test_frame_ranges_partition_the_batch(n, world):
     r = shard.all_ranges(n, world)
