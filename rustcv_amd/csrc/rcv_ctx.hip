@@ -31,7 +31,6 @@ static void load_knobs()
     g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
     g_knobs.warp_lds = env_int("RCV_WARP_LDS", -1);
     g_knobs.warp_gray4 = env_int("RCV_WARP_GRAY4", -1);
-    g_knobs.warp_resize_loop = env_int("RCV_WARP_RESIZE_LOOP", -1);
     g_knobs.warp_fpg = env_int("RCV_WARP_FPG", 0);
 }
 const RcvKnobs& rcv_knobs()

@@ -75,7 +75,7 @@ struct rcv_ctx {
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
-// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), thirteen in all; nothing
+// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), twelve in all; nothing
 // needs them in production and no tuning parameter is among them (those are arguments of the measurement entries in
 // librustcv_hip_bench.so).  Read ONCE per process -- a launch-bound call (a single 1080p frame: 6 us) must not pay for getenv -- and
 // again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 lists each with the test that uses it.
@@ -91,7 +91,6 @@ struct RcvKnobs {
     int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too
     int warp_lds;         // RCV_WARP_LDS      0: never the LDS-staged warpAffine kernel (the gather kernel on the same maps)
     int warp_gray4;       // RCV_WARP_GRAY4    0: one-channel warpAffine never on the four-frames-per-pass kernel
-    int warp_resize_loop; // RCV_WARP_RESIZE_LOOP  1: the fused warp -> down-scale on the frame-loop kernel (default: one workgroup per frame tile)
     int warp_fpg;         // RCV_WARP_FPG      frames per workgroup of the warp kernels (an incomplete last group); + 256 * (s + 1): tile strips of s columns
 };
 const RcvKnobs& rcv_knobs();

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     warp_resize_box_px<S>(s, d, A, bz, x, y);
 }
 
+#ifdef RCV_WRL_BENCH   // measurement build only (librustcv_hip_bench.so): measured, bit-exact, slower -- DESIGN.md 9, profiles/r05_warp_resize_*
 // ---- the same launch as a FRAME LOOP (round 5) -----------------------------------------------------------------------------------
 // One affine map serves every frame of a batch, so everything k_warp_resize_box computes before its first load -- the four sample
 // coordinates, the interior test, floor / fraction, the tap offsets and alignment shifts: ~150 of its 278 VALU instructions per
@@ -304,17 +305,17 @@ int wrl_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
     const int tpx = p.xcd == 1 ? (int)((tiles + 7) / 8) : (p.xcd == 2 ? -pg : 0);
     const dim3 grid = p.xcd == 1 ? dim3((unsigned)(8 * tpx)) : (p.xcd == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
     uint32_t* dump = (uint32_t*)(ctx->kconst + RCV_KC_SOBEL_DUMP);
-#ifdef RCV_WRL_BENCH
     if (p.dbg == 1) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 1>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
     if (p.dbg == 3) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 3>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
     if (p.dbg == 2) { RCV_LAUNCH((k_warp_resize_loop<4, 32, 2>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump); return rcv_launch_check(ctx); }
-#endif
 #define WRL_GO(S_, W_) RCV_LAUNCH((k_warp_resize_loop<S_, W_>), grid, dim3(kBlock), p.lds, ctx->stream, s, d, A, fpg, gx, gy, groups, tpx, p.strip, dump)
     if (S == 2) { if (ww == 16) WRL_GO(2, 16); else if (ww == 64) WRL_GO(2, 64); else WRL_GO(2, 32); }
     else { if (ww == 16) WRL_GO(4, 16); else if (ww == 64) WRL_GO(4, 64); else WRL_GO(4, 32); }
 #undef WRL_GO
     return rcv_launch_check(ctx);
 }
+
+#endif   // RCV_WRL_BENCH
 
 } // namespace
 
@@ -334,8 +335,6 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            if (rcv_knobs().warp_resize_loop > 0 && d.n > 1 && wrl_ok(s, d))   // (measured slower than the per-frame launch on 32 x 8K: DESIGN.md 9; tests only)
-                return wrl_launch(ctx, s, d, A, S, WrlPlan{});
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
             // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)

@@ -314,4 +314,4 @@ def test_product_library_is_slim():
     assert {s for s in exported if s.startswith("rcv__")} == {"rcv__debug_kernels", "rcv__debug_kernels_reset", "rcv__debug_occupancy", "rcv__debug_reload_knobs"}
     assert not [s for s in exported if "graph" in s or "bench" in s or "stripwalk" in s]
     bench = subprocess.run(["nm", "-D", "--defined-only", _ffi.BENCH_LIB_PATH], capture_output=True, text=True).stdout
-    assert {"rcv__filter_rows_bench", "rcv__membench", "rcv__stripwalk", "rcv__storebench", "rcv__clock_probe"} <= set(re.findall(r" T (rcv_\w+)", bench))
+    assert {"rcv__filter_rows_bench", "rcv__warp_resize_bench", "rcv__membench", "rcv__stripwalk", "rcv__storebench", "rcv__clock_probe"} <= set(re.findall(r" T (rcv_\w+)", bench))

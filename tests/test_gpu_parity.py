@@ -1415,6 +1415,38 @@ def test_warp_affine_resize_fused_lds_tiles(ctx, oracle, rng, knob, kernel, fpg,
     dst.free()
 
 
+@pytest.mark.parametrize("plan", [(1, 1, 32, 0, 0), (1, 2, 32, 0, 0), (1, 3, 16, 1, 0), (1, 5, 64, 2, 0), (1, 8, 32, 2, 2), (1, 4, 32, 1, 3), (0, 0, 0, 1, 2), (0, 0, 0, 2, 3)])
+@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "ident", "flip", "far"])
+def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, M):
+    """round 5: the kernels tools/ablate_warp_resize.py times through rcv__warp_resize_bench (librustcv_hip_bench.so) -- the frame-loop
+    kernel (frames per wave 1 .. 8 on a 5-frame batch: every tail of the two-deep pipeline; wave tiles 16 / 32 / 64 wide) and the
+    XCD-contiguous / synchronous-stripes tile orders of both kernels -- produce the oracle's resize(warp_affine(.)) bit for bit:
+    interior waves, waves at the source border and outside, ragged last tile row / column, canaries around the destination"""
+    variant, fpg, ww, order, strip = plan
+    dr, dc = 52, 100
+    mr, mc = scale * dr, scale * dc
+    sr, sc = mr + 37, mc + 22
+    Ms = {"rot7": _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), "rot-20": _rot(-20.0, mc / 2, mr / 2, 20.0, 30.0),
+          "shear": np.array([1, 0.25, 3.5, -0.125, 1, 60.25], np.float32), "ident": np.array([1, 0, 4, 0, 1, 2], np.float32),
+          "flip": np.array([-1, 0, mc + 5.5, 0, -1, mr + 3.25], np.float32), "far": np.array([1, 0, 1e6, 0, 1, 0], np.float32)}[M]
+    n = 5
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + (-(sc * 3)) % 4 + 4)
+    dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    a, b = src.as_rcv(), dst.as_rcv()
+    m = np.ascontiguousarray(Ms, dtype=np.float32)
+    _ffi.check(_ffi.bench_lib().rcv__warp_resize_bench(ctx.handle, C.byref(a), C.byref(b), m.ctypes.data_as(C.POINTER(C.c_float)), scale, variant, fpg, ww,
+                                                       order, strip, -1), "rcv__warp_resize_bench")
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (plan, M, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("M", [[np.nan, 0, 0, 0, 1, 0], [1, 0, np.nan, 0, 1, 0], [np.inf, 0, 0, 0, 1, 0], [1, np.inf, 3, 0, 1, 0],
                                [1, 0, 0, -np.inf, 1, 0], [0, 0, 5.5, 0, 0, 7.25], [1e-30, 0, 1, 0, 1e-30, 2], [-1, 0, 63, 0, -1, 31],
                                [1, 0, -0.999, 0, 1, -0.999], [1, 0, 0.999, 0, 1, 0.999], [1.0000001, 0, -1, 0, 1, -1]])
