@@ -97,14 +97,16 @@ struct FRArgs {
     long long tstart[4], tlen[4];
     unsigned long long* trace;   // (DBG & 1024, profiling builds) per-wave {start, end} of the 100 MHz counter
     size_t gstep, gfs;
-    // chained bands (k_filter_rows_chain, round 4): every XCD owns fpx whole frames cut into bpf bands each; wave (xcd, strip, g) of
-    // the ng band groups per XCD takes bands g, g + ng, g + 2 ng, ... of its XCD's list, one after the other, in ONE pipeline
-    int ng, bpf, fpx;
+    // chained bands (k_filter_rows_chain, round 4): every frame is cut into bpf bands; the batch's n * bpf bands (frame-major) are dealt
+    // to the XCDs in eight contiguous runs -- XCD x owns bands [gb0[x], gb0[x] + nbx[x]) (round 5: any frame count; a frame may be shared
+    // by two XCDs) -- and its waves draw (band, strip) items from that run
+    int bpf;
+    unsigned cbands;             // n * bpf: XCD x owns bands [cbands * x / 8, cbands * (x + 1) / 8)
     unsigned bmul;               // ceil(rows * 2^20 / bpf): band j of a frame = rows [(j * bmul) >> 20, ((j + 1) * bmul) >> 20)
     int n_edge, edge_waves;          // strips whose windows stick out of the row (the first + the last one or two); waves per XCD that start on them
     unsigned long long inv_edge, inv_int, inv_bpf;   // ceil(2^32 / n_edge), ceil(2^32 / (nstrips - n_edge)), ceil(2^32 / bpf): exact quotients for a launch's item counts
-    unsigned long long* tickets;     // 16 counters (XCD x {interior, edge}), 16 x 8 bytes apart (one 128-byte line each)
-    unsigned long long tbase[16];    // their values when this launch starts
+    unsigned long long* tickets;     // this launch's SET of 16 counters (XCD x {interior, edge}), 16 x 8 bytes apart (one 128-byte line each), all zero at its start
+    unsigned long long* tickets_next;   // the set of the launch after the next one: every wave zeroes its own XCD's two counters of it
 };
 
 // packed i16 arithmetic on two pixels (the Sobel stage of the SOB instantiation; same forms as rcv_harris_fused.hip)
@@ -581,9 +583,13 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 // sequence: requests (RP - 1 pairs ahead), operand preparation (NP - 1 ahead), output.  The NP - 1 steps whose window straddles
 // two items compute garbage that is never stored.  The strip changes from item to item, so the border repair of the first / last
 // strip sits under a wave-uniform branch in `prepare` (VALU only) and every store is exec-masked by `byte offset < row bytes`.
-// Tickets: one 64-bit counter per XCD (ctx->kconst + RCV_KC_FR_TICKETS, 128 bytes apart), never reset: a launch hands its base
-// values over (tbase) and consumes exactly items + waves tickets per XCD (a wave draws one ticket ahead and ends on its first
-// ticket past the list), which the host adds up.
+// Tickets (round 5: every launch self-contained).  One 64-bit counter per XCD and queue, 128 bytes apart, in FOUR sets (ctx->kconst +
+// RCV_KC_FR_TICKETS): launch i of a context draws from set i % 4, which is all zero when it starts, and every wave of launch i zeroes
+// the two counters of ITS XCD in set (i + 2) % 4 -- the set launch i - 2 used, idle since then, next used by launch i + 2 (launches of
+// a context run in stream order).  No host-side count of what a launch draws exists any more, so nothing can drift.  A counter is only
+// ever touched by waves of one XCD: the XCD is read from the hardware (HW_REG_XCC_ID), not inferred from the block index, so the
+// L2-scope atomic is coherent whatever the dispatcher does; that every XCD receives waves (block b -> XCD b % 8) is still needed for
+// the launch to finish its lists and holds on an unpartitioned MI355X (the host gates on 256 CUs).
 struct FRItem {                // (all scalar)
     int X;                     // byte offset of the strip in a destination row
     int ys, nrows, P;          // rows [ys, ys + nrows) of the frame, P = ceil(nrows / 2) + NP - 1 pairs
@@ -596,8 +602,9 @@ struct FRItem {                // (all scalar)
 // stick out of the row) or of the interior strips, band-major.  EDGE is a compile-time property of the loop -- the border repair
 // and the masked stores exist in the edge loop only -- so a wave runs the loop of its own kind until that queue is empty and then
 // helps with the other one (kernel below).  Returns when the queue is empty.
-template <int KS, int PP, bool EDGE, int DBG>
-__device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, const int xcd, const v4i (&A)[2][(KS + 1) / 2], const v4i& initv)
+template <int KS, int PP, bool EDGE, int DBG, int DMASK>
+__device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, const int xcd, const v4i (&A)[2][(KS + 1) / 2], const v4i (&A2)[2][(KS + 1) / 2],
+                                             const v4i& initv)
 {
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;
@@ -607,10 +614,11 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     const int rv = ((a.cols & 15) + 4) & 15;
     const unsigned sstep = (unsigned)a.sstep, dstep = (unsigned)a.dstep;   // (in-frame offsets are 32-bit: host check)
     const int kstrips = EDGE ? a.n_edge : a.nstrips - a.n_edge;            // strips of this kind
-    const unsigned nitems = (unsigned)(a.fpx * a.bpf * kstrips);           // of this XCD and kind
+    // (computed, not looked up: a dynamic index into the by-value argument struct would move the whole struct to scratch memory)
+    const unsigned gb0 = (unsigned)(((unsigned long long)a.cbands * (unsigned)xcd) >> 3), gb1 = (unsigned)(((unsigned long long)a.cbands * (unsigned)(xcd + 1)) >> 3);
+    const unsigned nitems = (gb1 - gb0) * (unsigned)kstrips;               // of this XCD and kind
     if (nitems == 0) return;
     unsigned long long* const tick = a.tickets + 16 * (2 * xcd + (EDGE ? 1 : 0));
-    const unsigned long long tbase = a.tbase[2 * xcd + (EDGE ? 1 : 0)];
     const unsigned long long inv_k = EDGE ? a.inv_edge : a.inv_int;
 
     // A ticket is drawn with a SCALAR atomic (s_atomic_add_x2, returns the old value): its latency is counted by lgkmcnt, which
@@ -621,18 +629,19 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     auto draw = [&]() -> unsigned {
         unsigned long long t = 1ull;
         asm volatile("s_atomic_add_x2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tick) : "memory");
-        return (unsigned)(t - tbase);   // items per launch < 2^31 (host check)
+        return (unsigned)t;   // items per launch < 2^31 (host check)
     };
     auto make_item = [&](unsigned li, FRItem& it) {   // item li of this queue: band-major, the strips of a band neighbours
         if (li >= nitems) {
             it.done = true;
             return;
         }
-        const unsigned band = (unsigned)(((unsigned long long)li * inv_k) >> 32);
-        const unsigned ks = li - band * (unsigned)kstrips;
+        const unsigned bl = (unsigned)(((unsigned long long)li * inv_k) >> 32);
+        const unsigned ks = li - bl * (unsigned)kstrips;
+        const unsigned band = gb0 + bl;                                  // of the batch, frame-major
         const unsigned f = (unsigned)(((unsigned long long)band * a.inv_bpf) >> 32);
         const unsigned j = band - f * (unsigned)a.bpf;
-        const int frame = xcd * a.fpx + (int)f;
+        const int frame = (int)f;
         // edge strips: 0, then the trailing ones; interior strips: 1 .. nstrips - n_edge
         const int strip = EDGE ? (ks == 0 ? 0 : a.nstrips - a.n_edge + (int)ks) : 1 + (int)ks;
         it.X = strip * 768;
@@ -666,6 +675,9 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     unsigned r_cb;                       // lane: clamped chunk offset
     auto enter_rc = [&]() {
         r_sf = pend.sf; ri = 0; r_P = pend.P; r_y = pend.ys - RAD; r_last = pend.ys + pend.nrows - 1 + RAD; r_int = pend.interior;
+        if constexpr ((DBG & 128) != 0) {   // (experiment: no halo rows -- the band's own rows only, the last one re-read)
+            r_y = pend.ys; r_last = pend.ys + pend.nrows - 1; r_int = false;
+        }
         r_off = (unsigned)r_y * sstep;
         // (EDGE: chunks that stick out of the row are read shifted into it)
         r_cb = EDGE ? (unsigned)min(max(pend.X + lane_cb, 0), rb - 48) : (unsigned)(pend.X + lane_cb);
@@ -769,7 +781,11 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
         w[1] = v4i{(int)(pg[0] ^ 0x80808080u), (int)(pg[1] ^ 0x80808080u), (int)(pg[2] ^ 0x80808080u), (int)(pg[3] ^ 0x80808080u)};
         w[2] = v4i{(int)(prr[0] ^ 0x80808080u), (int)(prr[1] ^ 0x80808080u), (int)(prr[2] ^ 0x80808080u), (int)(prr[3] ^ 0x80808080u)};
     };
-    auto store_row = [&](const v4i(&acc)[3], unsigned roff, bool ok) {
+    auto store_row = [&](v4i(&acc)[3], const v4i(&acc2)[3], unsigned roff, bool ok) {
+        if constexpr (DMASK != 0) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
+        }
         U3w o;
         o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
         o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
@@ -800,16 +816,25 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
                 if (valid && two && o_in) __builtin_nontemporal_store(v3i{w1[0], w1[1], w1[2]}, (v3i*)(o_df + (size_t)(o_off + dstep + o_so)));
             } else if (valid) {   // (wave-uniform)
                 prepare((s + NP - 1) % RP);
-                v4i acc[2][3];
+                v4i acc[2][3], acc2[2][3];
+                const v4i zerov = v4i{0, 0, 0, 0};
 #pragma unroll
                 for (int par = 0; par < 2; ++par)
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
+                        for (int pl = 0; pl < 3; ++pl) {
                             acc[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[par][p], W[(s + p) % RP][pl], p == 0 ? initv : acc[par][pl], 0, 0, 0);
-                store_row(acc[0], o_off, true);
-                store_row(acc[1], o_off + dstep, two);
+                            if constexpr (DMASK != 0) {   // second weight table (fr_segment has the scheme)
+                                const int bits = (DMASK >> (par * NP)) & ((1 << NP) - 1);
+                                if ((bits >> p) & 1) {
+                                    const bool first = (bits & ((1 << p) - 1)) == 0;
+                                    acc2[par][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2[par][p], W[(s + p) % RP][pl], first ? zerov : acc2[par][pl], 0, 0, 0);
+                                }
+                            }
+                        }
+                store_row(acc[0], acc2[0], o_off, true);
+                store_row(acc[1], acc2[1], o_off + dstep, two);
             } else {              // the NP - 1 windows that straddle two items: operands only
                 prepare((s + NP - 1) % RP);
             }
@@ -823,20 +848,37 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     }
 }
 
-template <int KS, int PP, int DBG>
+template <int KS, int PP, int DBG, int DMASK = 0>
 __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
 {
     constexpr int NP = (KS + 1) / 2;
     const int lane = threadIdx.x;
-    const int xcd = blockIdx.x & 7;
-    const int slot = (int)(blockIdx.x >> 3);   // of this XCD
-    v4i A[2][NP];
+    // the XCD this wave RUNS on (bits 3:0 of the XCC_ID register), not the one its block index suggests: the ticket counters are
+    // L2-scope and one XCD's L2 is only coherent with itself
+    const int xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));   // hwreg(HW_REG_XCC_ID, 0, 4); wave-uniform
+    const int slot = (int)(blockIdx.x >> 3);   // of this XCD (with the usual placement)
+    {   // (see "Tickets" above; uniform addresses: a lane-dependent index here made the compiler keep the counter addresses in VGPRs)
+        int xz = xcd;
+        asm volatile("" : "+s"(xz));   // (its own copy: shared with the draw addresses, the vector store pulled the whole address chain into VGPRs)
+        unsigned long long* const nx = a.tickets_next + 32 * xz;
+        if (lane == 0) {
+            nx[0] = 0ull;
+            nx[16] = 0ull;
+        }
+    }
+    v4i A[2][NP], A2[2][NP];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const uint4 w = a.wtab[(par * NP + p) * 64 + lane];
             A[par][p] = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+            if constexpr (DMASK != 0) {
+                if ((DMASK >> (par * NP + p)) & 1) {
+                    const uint4 w2 = a.wtab[(2 * NP + par * NP + p) * 64 + lane];
+                    A2[par][p] = v4i{(int)w2.x, (int)w2.y, (int)w2.z, (int)w2.w};
+                }
+            }
         }
     v4i initv = v4i{a.acc_init, a.acc_init, a.acc_init, a.acc_init};
     asm volatile("" : "+v"(initv));
@@ -845,8 +887,8 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
     bool edge = slot < a.edge_waves;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {   // (one copy of each loop in the binary)
-        if (edge) fr_chain_run<KS, PP, true, DBG>(a, lane, xcd, A, initv);
-        else fr_chain_run<KS, PP, false, DBG>(a, lane, xcd, A, initv);
+        if (edge) fr_chain_run<KS, PP, true, DBG, DMASK>(a, lane, xcd, A, A2, initv);
+        else fr_chain_run<KS, PP, false, DBG, DMASK>(a, lane, xcd, A, A2, initv);
         edge = !edge;
     }
 }
@@ -1276,20 +1318,28 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     a.acc_init = (int)(128 * ksum + (shift > 0 ? (1 << (shift - 1)) : 0));
     // Chained bands (k_filter_rows_chain): launches that fill the GPU, whole frames per XCD, the plain BGR instantiation.  Bands of
     // ~chain_rows rows (at least 8: an item must hold more pairs than the ring), items = (band, strip) drawn from per-XCD ticket counters.
-    if (src_yuyv == 0 && !sob && dmask == 0 && (small_plan == 0 || kn.chain == 1) && kn.band_rows == 0 && kn.chain != 0 && s.n >= 8 && s.n % 8 == 0 &&
-        s.rows >= 64) {
-        const int fpx = s.n / 8;
+    // (round 5: any frame count -- the batch's bands are dealt to the XCDs in eight contiguous runs.  Kernels with two weight tables stay on
+    //  the one-band-per-wave kernel: chained, the 7x7 integer Gaussian measured 0.623 against 0.615 ms on 64 4K frames -- 13/8 of the matrix
+    //  work per row, the launch is not memory-bound enough for the shorter bands to pay; profiles/r05_batch_cliffs.txt.  The measurement
+    //  build keeps the chained two-table instantiations behind chain = 2.)
+#ifdef RCV_ROWS_BENCH
+    const bool chain_dual_ok = kn.chain == 2;
+#else
+    const bool chain_dual_ok = false;
+#endif
+    if (src_yuyv == 0 && !sob && (dmask == 0 || chain_dual_ok) && (small_plan == 0 || kn.chain >= 1) && kn.band_rows == 0 && kn.chain != 0 && s.rows >= 64 &&
+        ctx->cu_count == 256) {
         const int want_rows = kn.chain_rows > 0 ? (kn.chain_rows > 2048 ? 2048 : kn.chain_rows) : 32;   // (bmul < 2^32)
         int bpf = (s.rows + want_rows / 2) / want_rows;
         bpf = bpf < 1 ? 1 : (bpf > s.rows / 8 ? s.rows / 8 : bpf);
-        const unsigned long long nitems = (unsigned long long)fpx * bpf * a.nstrips;
+        const unsigned long long nbands = (unsigned long long)s.n * bpf, nitems = ((nbands + 7) / 8) * a.nstrips;   // (items of the longest run)
         const int cwpc = kn.wpc == 12 || kn.wpc == 4 || kn.wpc == 6 || kn.wpc == 10 ? kn.wpc : 8;   // (knob: waves per CU, sweeps)
         const unsigned waves = (unsigned)(ctx->cu_count / 8 * cwpc);   // per XCD: cu_count / 8 CUs x 8 waves
-        if (nitems * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31) &&
+        // (the kernel's quotients by multiply-and-shift are exact for these ranges)
+        if (nbands >= 8 && nbands * (unsigned long long)(a.nstrips > bpf ? a.nstrips : bpf) < (1ull << 32) && nitems + waves < (1ull << 31) &&
             (unsigned long long)s.rows * d.step < (1ull << 32)) {
-            a.ng = 0;
             a.bpf = bpf;
-            a.fpx = fpx;
+            a.cbands = (unsigned)nbands;
             a.bmul = (unsigned)((((unsigned long long)s.rows << 20) + bpf - 1) / bpf);
             // edge strips: strip 0 and every strip whose last window reaches past the row (the last one; the last two when the row ends
             // within 36 bytes of a strip seam)
@@ -1310,34 +1360,39 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             }
             if (!ctx->fr_tickets_ready) {
                 RCV_HIP(hipMemsetAsync(ctx->kconst + RCV_KC_FR_TICKETS, 0, RCV_KC_FR_TICKETS_BYTES, ctx->stream));
-                for (int x = 0; x < 16; ++x) ctx->fr_ticket_base[x] = 0;
+                ctx->fr_seq = 0;
                 ctx->fr_tickets_ready = true;
             }
-            a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS);
-            for (int x = 0; x < 16; ++x) {
-                const unsigned long long items = (unsigned long long)fpx * bpf * ((x & 1) ? n_edge : n_int);
-                a.tbase[x] = ctx->fr_ticket_base[x];
-                // what this launch draws from the counter: one ticket per item and one past the list per wave (a queue without items is never drawn from)
-                if (items) ctx->fr_ticket_base[x] += items + waves;
-            }
+            static_assert(RCV_KC_FR_TICKETS_BYTES == 4 * 2048, "four sets of 16 counters, 128 bytes apart");
+            a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * (ctx->fr_seq & 3u));
+            a.tickets_next = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq + 2u) & 3u));
             const dim3 grid(8u * waves);
             // EXACTLY 8 waves per CU, all resident from the start: the 7x7 instantiation's registers would let the dispatcher stack 12
             // waves on some CUs and leave others short.  An untouched dynamic-LDS request of an eighth of the CU's 160 KB caps it.
             const unsigned cap = (163840u / (unsigned)cwpc) & ~511u;
+            constexpr int kAll7 = 255;
+            (void)kAll7;
+            const bool centre7 = ksize == 7 && dmask != 0 && (dmask & ~kCentre7) == 0;
             if (ksize == 7) {
 #ifdef RCV_ROWS_BENCH
                 if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
+                else if ((kn.dbg & 255) == 132) RCV_LAUNCH((k_filter_rows_chain<7, 3, 384>), grid, dim3(64), cap, ctx->stream, a);
+                else if ((kn.dbg & 255) == 128) RCV_LAUNCH((k_filter_rows_chain<7, 3, 128>), grid, dim3(64), cap, ctx->stream, a);
                 else if (kn.pp == 4) RCV_LAUNCH((k_filter_rows_chain<7, 4, 0>), grid, dim3(64), cap, ctx->stream, a);
                 else if (kn.pp == 2) RCV_LAUNCH((k_filter_rows_chain<7, 2, 0>), grid, dim3(64), cap, ctx->stream, a);
                 else
 #endif
+#ifdef RCV_ROWS_BENCH
+                if (dmask != 0 && centre7) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kCentre7>), grid, dim3(64), cap, ctx->stream, a);
+                else if (dmask != 0) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kAll7>), grid, dim3(64), cap, ctx->stream, a);
+                else
+#endif
                     RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
-            } else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+            } else if (dmask != 0) return RCV_ERR_UNSUPPORTED;   // (measurement build: two tables chained for 7x7 only)
+            else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
             const int rc = rcv_launch_check(ctx);
-            // a launch that did not start drew nothing: the host's count of the counters would be ahead of them from here on (items of
-            // later launches skipped) -- start over from zeroed counters next time
-            if (rc != RCV_OK) ctx->fr_tickets_ready = false;
+            if (rc == RCV_OK) ++ctx->fr_seq;   // (a launch that did not start touched no counter: the same set serves the next one)
             return rc;
         }
     }

@@ -12,7 +12,7 @@
 constexpr size_t RCV_KC_F7_TAB = 0, RCV_KC_F7_TAB_BYTES = 8192;          // strip kernel: 2 x 4 tables x 64 lanes x 16 B
 constexpr size_t RCV_KC_SOBEL_DUMP = 8192, RCV_KC_SOBEL_DUMP_BYTES = 4096;   // 256 lanes x 16 B
 constexpr size_t RCV_KC_F7_DUMP = 16384, RCV_KC_F7_DUMP_BYTES = 4096;    // strip kernel: 3 KiB
-constexpr size_t RCV_KC_FR_TICKETS = 20480, RCV_KC_FR_TICKETS_BYTES = 2048;   // chained row kernel: 16 ticket counters, one 128-byte line each
+constexpr size_t RCV_KC_FR_TICKETS = 20480, RCV_KC_FR_TICKETS_BYTES = 8192;   // chained row kernel: four sets of 16 ticket counters, one 128-byte line each
 constexpr size_t RCV_KC_FR_TAB = 32768, RCV_KC_FR_TAB_BYTES = 16384;     // row kernel: up to 2 x 2 x 4 tables x 1 KiB (two weight tables)
 constexpr size_t RCV_KC_BENCH = 49152, RCV_KC_BENCH_BYTES = 4096;        // rcv__membench read-only dump (256 threads x 16 B)
 constexpr size_t RCV_KC_PROBE = 57344, RCV_KC_PROBE_BYTES = 128;         // rcv__clock_probe: 8 x 2 counters
@@ -58,7 +58,7 @@ struct rcv_ctx {
         int8_t host[16384];
     } fr_tab[4];
     bool fr_tickets_ready;        // the chained row kernel's ticket counters (kconst + RCV_KC_FR_TICKETS) have been zeroed
-    unsigned long long fr_ticket_base[16];   // ... and what they will read when the next launch starts (every launch draws a known number)
+    unsigned fr_seq;              // chained launches of this context so far: launch i draws from counter set i % 4 and zeroes set (i + 2) % 4
     uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
     unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix

@@ -28,6 +28,17 @@ class DeviceBatch:
         _ffi.check(_ffi.lib().rcv_malloc(ctx.handle, self.nbytes, C.byref(p)), "rcv_malloc")
         self.ptr = p
 
+    def view(self, first, n):
+        """frames [first, first + n) of this batch as a batch of their own (same memory; free() only the parent)"""
+        assert 0 <= first and n >= 0 and first + n <= self.n
+        v = object.__new__(DeviceBatch)
+        v.__dict__.update(self.__dict__)
+        v.n = int(n)
+        v.ptr = C.c_void_p((self.ptr.value or 0) + int(first) * self.frame_stride)
+        v.nbytes = max(v.n, 1) * self.frame_stride
+        v._parent = self      # keeps the allocation alive; a view never frees it
+        return v
+
     def as_rcv(self):
         b = _ffi.rcv_batch()
         m = b.frame0
@@ -77,7 +88,7 @@ class DeviceBatch:
         _ffi.check(_ffi.lib().rcv_memset(self.ctx.handle, self.ptr, value, self.nbytes), "rcv_memset")
 
     def free(self):
-        if self.ptr is not None and self.ctx._h is not None:
+        if getattr(self, "_parent", None) is None and self.ptr is not None and self.ctx._h is not None:
             _ffi.lib().rcv_free(self.ctx.handle, self.ptr)
         self.ptr = None
 

@@ -471,7 +471,9 @@ def test_row_kernel_tapered_bands_every_frame(ctx, oracle, knob, variant, chain)
         b.free()
 
 
-CHAIN_SHAPES = [(8, 64, 256), (8, 70, 272), (8, 97, 1084), (16, 131, 1040), (8, 200, 3840), (24, 66, 16), (8, 65, 772)]
+CHAIN_SHAPES = [(8, 64, 256), (8, 70, 272), (8, 97, 1084), (16, 131, 1040), (8, 200, 3840), (24, 66, 16), (8, 65, 772),
+                # round 5: any frame count -- the batch's bands are dealt to the XCDs in eight runs that may cut through a frame
+                (1, 300, 772), (3, 131, 1040), (7, 64, 256), (9, 70, 272), (13, 97, 1084), (63, 64, 528)]
 
 
 @pytest.mark.parametrize("n,rows,cols", CHAIN_SHAPES)
@@ -479,7 +481,8 @@ CHAIN_SHAPES = [(8, 64, 256), (8, 70, 272), (8, 97, 1084), (16, 131, 1040), (8, 
 def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
     """round 4: k_filter_rows_chain -- persistent waves that walk SHORT bands of their strip back to back through one register ring (the
     next band's rows, halo included, are in flight while the last rows of the current one are computed; the steps whose window straddles
-    two bands store nothing).  Whole frames per XCD (n % 8 == 0); band heights 8 / 13 / 32 rows incl. odd heights and a last band that is
+    two bands store nothing).  Frame counts that are and are not multiples of 8 (round 5: an XCD's run of bands may start and end inside
+    a frame; one frame alone); band heights 8 / 13 / 32 rows incl. odd heights and a last band that is
     shorter; one strip, a partial last strip, widths with every residue of 4 mod 16; padded steps / frame strides with canaries; every
     frame of the batch against the oracle for ksize 3 / 5 / 7 and the integer Gaussian 5x5 (the same launch path)."""
     knob("RCV_FR_CHAIN", 1)
@@ -489,8 +492,8 @@ def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
         knob("RCV_FR_CHAIN_ROWS", band_rows)
     r = np.random.default_rng(9000 + 31 * rows + cols + band_rows + _SOAK_SEED)
     frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
-    frames[1, : rows // 2] = 255
-    frames[2, :, : min(cols, 40)] = 0
+    frames[n // 2, : rows // 2] = 255
+    frames[n - 1, :, : min(cols, 40)] = 0
     src = device.DeviceBatch(ctx, n, rows, cols, 3, step=cols * 3 + 16, frame_stride=rows * (cols * 3 + 16) + 64)
     src.upload(frames)
     L = _ffi.lib()
@@ -506,21 +509,23 @@ def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
             assert np.array_equal(got[i], want), (ks, i, np.argwhere(got[i] != want)[:4])
         _assert_canaries(dst)
         dst.free()
-    dst = _canary_batch(ctx, n, rows, cols, 3, pad=32)
-    L.rcv__debug_kernels_reset()
-    device.gaussian_blur(src, dst, 5, 0.0)
-    assert "k_filter_rows_chain<5" in L.rcv__debug_kernels().decode()
-    got = dst.download()
-    for i in range(n):
-        assert np.array_equal(got[i], oracle.gaussian_blur(frames[i], 5, 0.0)), ("gauss", i)
-    _assert_canaries(dst)
-    dst.free()
+    # the integer Gaussian 5x5 (one table: chained); 7x7 (two weight tables) stays on the one-band-per-wave kernel -- measured slower chained
+    for gk, kern in ((5, "k_filter_rows_chain<5"), (7, "k_filter_rows_mfma<")):
+        dst = _canary_batch(ctx, n, rows, cols, 3, pad=32)
+        L.rcv__debug_kernels_reset()
+        device.gaussian_blur(src, dst, gk, 0.0)
+        assert kern in L.rcv__debug_kernels().decode(), L.rcv__debug_kernels().decode()
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i], oracle.gaussian_blur(frames[i], gk, 0.0)), ("gauss", gk, i)
+        _assert_canaries(dst)
+        dst.free()
     src.free()
 
 
 def test_filter_rows_chain_ticket_accounting(oracle, knob):
-    """the chained-band kernel's ticket counters are never reset: every launch gets their base values from the host, which adds up what
-    each launch draws (items + waves per queue).  Sixty launches of four different geometries (different item counts, one / three edge
+    """the chained-band kernel's ticket counters (round 5: four sets; launch i draws from set i % 4, found zero, and zeroes set (i + 2) % 4;
+    no host-side count of what a launch draws).  Sixty launches of four different geometries (different item counts, one / three edge
     strips, a single-strip image whose interior queue is empty) and three kernel sizes queued back to back WITHOUT a sync on a fresh
     context, every result against the oracle: a counter / base mismatch would make later launches skip or repeat items"""
     import rustcv_amd as rcv
