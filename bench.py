@@ -30,8 +30,12 @@ Prints ONE JSON line on rank 0 with the contract keys plus
                   between; shader_mhz_under_load = the shader clock sampled while launches run (a separate window)
   "verified_frames": frames of the LAST timed launches' outputs (every context) compared bit for bit with the CPU oracle
                   (mismatch: exit 1)
-  "other_configs": (default run at N = 1 only) compact records of BASELINE configs 4 and 5 measured in the same process:
-                  {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic}, verified}
+  "other_configs": (default run at N = 1 only) compact records measured in the same process, one stream each:
+                  "3s" / "3f" the Sobel half of BASELINE configs[2] (rcv_sobel_batch on a BGR batch; the whole config as ONE launch,
+                  rcv_filter2d_i8_sobel_batch), "4" and "5" the two 8-GPU configs at their per-GPU batch:
+                  {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic}, verified, cpu_baseline}
+  "value_single_stream", roofline.single_stream_{launch_ms, achieved, frac}: one 64-frame launch at a time (BASELINE's literal
+                  "batch=64", the round-1..3 measurement) as top-level / flat scalars
   "cpu_baseline": the C oracle (a port: C restatement, the Rust reference cannot be built here) timed on this box's host
                   cores on a bounded sample of the same workload.
 """
@@ -67,9 +71,18 @@ CONFIGS = {
         "workload": "4K (3840x2160) u8 BGR cornerHarris pipeline (cvtColor -> Sobel -> response, blockSize 2, k 0.04 -> 3x3 NMS -> u8 mask), batches of 64 frames "
                     "(BASELINE configs[4]: 512 frames over 8 GPUs)"},
 }
-SEEDS = {3: 0x5EED0003, 4: 0x5EED0004, 5: 0x5EED0005}
+# the Sobel half of BASELINE configs[2] ("7x7 filter2D + Sobel gradient"), records of the default run only (other_configs["3s"] / ["3f"]):
+#  "3s": rcv_sobel_batch on a 4K BGR batch (gray conversion fused: 3 B read + 2 x 2 B of i16 gradients written per pixel) -- the second launch of the two-call form;
+#  "3f": rcv_filter2d_i8_sobel_batch, the whole config in ONE launch (7x7 filter -> gray -> Sobel; the filtered image never exists in HBM)
+CONFIGS["3s"] = {"metric": "Mpixels/sec on 4K Sobel gradient (BGR source)", "batch": 64, "px": ROWS * COLS, "alg_bytes": ROWS * COLS * 7, "dtype": "i16 on u8", "bound": "hbm",
+                 "workload": "4K (3840x2160) u8 BGR -> gray -> Sobel 3x3 dx, dy (i16), batches of 64 frames (the Sobel half of BASELINE configs[2])"}
+CONFIGS["3f"] = {"metric": "Mpixels/sec on 4K 7x7 filter2D + Sobel gradient, one launch", "batch": 64, "px": ROWS * COLS, "alg_bytes": ROWS * COLS * 7, "dtype": "u8 / i16",
+                 "bound": "hbm", "workload": "4K (3840x2160) u8 BGR 7x7 filter2D (integer weights >>6) -> gray -> Sobel dx, dy (i16) fused in one launch, batches of 64 "
+                                             "frames (BASELINE configs[2] whole)"}
+SEEDS = {3: 0x5EED0003, 4: 0x5EED0004, 5: 0x5EED0005, "3s": 0x5EED0003, "3f": 0x5EED0003}
 HARRIS_THR = 1e-4
-TRAFFIC_KEYS = {3: "filter2d_i8_7x7_hbm_bytes_per_launch", 4: "warp_resize_fused_hbm_bytes_per_launch", 5: "harris_pipeline_hbm_bytes_per_launch"}
+TRAFFIC_KEYS = {3: "filter2d_i8_7x7_hbm_bytes_per_launch", 4: "warp_resize_fused_hbm_bytes_per_launch", 5: "harris_pipeline_hbm_bytes_per_launch",
+                "3s": "sobel_bgr_hbm_bytes_per_launch", "3f": "filter2d_sobel_fused_hbm_bytes_per_launch"}
 
 
 def warp_matrix():
@@ -85,7 +98,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json config (default 3: the north star)")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json config (default 3: the north star)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight per GPU = contexts (streams) per GPU, each with its own buffers (default: 2 for config 3, else 1)")
     ap.add_argument("--unfused", action="store_true", help="config 4: warpAffine and resize as two launches through an 8K intermediate")
@@ -96,6 +109,7 @@ def parse(argv=None):
     ap.add_argument("--no-probe", action="store_true", help="skip the shader-clock probe")
     ap.add_argument("--no-others", action="store_true", help="skip the compact config-4 / config-5 records of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-time budget of the cpu_baseline sample")
+    ap.add_argument("--other-cpu-seconds", type=float, default=2.5, help="CPU-time budget of the cpu_baseline sample of each other_configs record")
     ap.add_argument("--family", type=int, default=0, help="synthetic family: 0 noise (default), 1 scene")
     ap.add_argument("--sustained", type=int, default=400, help="steps of the sustained roofline window (at least --steps)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
@@ -135,11 +149,17 @@ def oracle_step(orc, cfg, frame):
         return orc.filter2d_i8(frame, orc.bench_kernel7(), 6)
     if cfg == 4:
         return orc.resize(orc.warp_affine(frame, warp_matrix(), 4320, 7680), 1080, 1920)
+    if cfg == "3s":
+        return orc.sobel(orc.bgr2gray(frame))                                              # (dx, dy)
+    if cfg == "3f":
+        return orc.sobel(orc.bgr2gray(orc.filter2d_i8(frame, orc.bench_kernel7(), 6)))
     return orc.harris_pipeline(frame, 2, 0.04, HARRIS_THR)
 
 
 def synth_args(cfg, family):
     """(rows, cols, family, seed) of the config's source frames: noise for the filters, the scene family (real corners) for Harris"""
+    if cfg in ("3s", "3f"):
+        return ROWS, COLS, 0, SEEDS[cfg]
     if cfg == 4:
         return 4320, 7680, family, SEEDS[4]
     return ROWS, COLS, (1 if cfg == 5 else family), SEEDS[cfg]
@@ -163,7 +183,8 @@ def cpu_baseline(budget_s, cfg=3, family=0):
             break
     mpix = frames * CONFIGS[cfg]["px"] / 1e6 / dt
     what = {3: "4K BGR frame(s), 7x7 i8 filter2D", 4: "8K BGR frame(s), warpAffine + resize -> 1080p (two oracle passes)",
-            5: "4K BGR frame(s), Harris pipeline"}[cfg]
+            5: "4K BGR frame(s), Harris pipeline", "3s": "4K BGR frame(s), BGR2GRAY + Sobel (two oracle passes)",
+            "3f": "4K BGR frame(s), 7x7 i8 filter2D + BGR2GRAY + Sobel (three oracle passes)"}[cfg]
     out = {"value": round(mpix, 2), "unit": "Mpix/s", "cores": used, "kind": "port",
            "sample": f"{frames} whole {what}, gcc -O3 -march=native OpenMP over rows, {dt:.1f} s"}
     if cfg == 3:
@@ -243,6 +264,18 @@ class Lane:
             else:
                 def step():
                     dev.warp_affine_resize(src, dst, M, 4320, 7680)
+        elif cfg in ("3s", "3f"):
+            from rustcv_amd._ffi import RCV_16S
+            self.dst = dx = dev.DeviceBatch(ctx, n, ROWS, COLS, 1, RCV_16S)
+            self.mid = dy = dev.DeviceBatch(ctx, n, ROWS, COLS, 1, RCV_16S)   # (second output: freed with the lane)
+            dy.memset(0)
+            src, k = self.src, bench_kernel7()
+            if cfg == "3s":
+                def step():
+                    dev.sobel(src, dx, dy)
+            else:
+                def step():
+                    dev.filter2d_sobel(src, dx, dy, k, 6)
         else:
             self.dst = dst = dev.DeviceBatch(ctx, n, ROWS, COLS, 1)
             src = self.src
@@ -263,7 +296,11 @@ class Lane:
         for i in frames:
             got = self.dst.download_frame(i)
             want = oracle_step(orc, self.cfg, orc.synth_frame(rows, cols, CH, fam, seed, self.base + i))
-            if not np.array_equal(got, want):
+            if self.cfg in ("3s", "3f"):     # two outputs: (dx, dy)
+                ok = np.array_equal(got, want[0]) and np.array_equal(self.mid.download_frame(i), want[1])
+            else:
+                ok = np.array_equal(got, want)
+            if not ok:
                 bad.append(self.base + i)
         return [self.base + i for i in frames], bad
 
@@ -392,7 +429,7 @@ def run_rank(a, rank, world, device, fence, torch):
 
     # ---- compact records of the other two BASELINE configs (default run, one GPU): same process, one stream each ----
     if cfg == 3 and world == 1 and not a.no_others:
-        res["other_configs"] = {str(c): other_config(a, c, ctx0, lanes) for c in (4, 5)}
+        res["other_configs"] = {str(c): other_config(a, c, ctx0, lanes) for c in ("3s", "3f", 4, 5)}
     lanes.close()
     return res
 
@@ -442,6 +479,8 @@ def other_config(a, cfg, ctx, lanes, launches=100):
         rec["verified"] = "bit-exact vs the CPU oracle" if not bad else f"MISMATCH in frames {bad}"
         rec["mismatched_frames"] = bad
     ln.free()
+    if not a.no_cpu:   # the CPU path timed beside every reported throughput (north_star): a short bounded sample of the same workload
+        rec["cpu_baseline"] = cpu_baseline(a.other_cpu_seconds, cfg, a.family)
     return rec
 
 
@@ -476,6 +515,9 @@ def report(a, world, results):
         s_ms = max(r["single_launch_ms"] for r in results)
         s_ach = alg_bytes / (s_ms * 1e-3) / 1e9
         roof["single_stream"] = {"launch_ms": round(s_ms, 4), "achieved": round(s_ach, 1), "frac": round(s_ach / HBM_PEAK_GBS, 4)}
+        # the same three as scalars (a parser that drops nested objects keeps them): BASELINE's literal "batch=64", one stream
+        roof["single_stream_launch_ms"], roof["single_stream_achieved"], roof["single_stream_frac"] = round(s_ms, 4), round(s_ach, 1), round(s_ach / HBM_PEAK_GBS, 4)
+        roof["single_stream_note"] = "copy_ceiling_gbs and memory_only_gbs are one-stream measurements: compare them with single_stream_achieved"
     if "shader_mhz_under_load" in results[0]:
         roof["shader_mhz_under_load"] = min(r["shader_mhz_under_load"] for r in results)
     if "copy_ceiling_gbs" in results[0]:
@@ -509,6 +551,8 @@ def report(a, world, results):
         "config": config,
         "roofline": roof,
     }
+    if "single_launch_ms" in results[0]:   # like-for-like with rounds 1-3 and BASELINE's batch=64: one 64-frame launch at a time per GPU
+        out["value_single_stream"] = round(world * n * c["px"] / (max(r["single_launch_ms"] for r in results) * 1e-3) / 1e6, 1)
     bad = []
     if "verified_frames" in results[0]:
         out["verified_frames"] = sorted(f for r in results for f in r["verified_frames"])

@@ -47,6 +47,10 @@ def test_report_two_batches_in_flight():
     assert rf["in_flight"] == 2 and rf["alg_bytes_per_launch"] == 3185049600 and rf["launches"] == 800
     assert abs(rf["achieved"] - 3185049600 / 0.548e-3 / 1e9) < 0.1 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-4
     assert rf["single_stream"]["launch_ms"] == 0.61 and abs(rf["single_stream"]["frac"] - 3185049600 / 0.61e-3 / 1e9 / 8000.0) < 1e-4
+    # round 5: the one-stream figure also as SCALARS of the roofline object and as a top-level value (a parser that drops nested objects keeps them)
+    assert rf["single_stream_launch_ms"] == 0.61 and rf["single_stream_frac"] == rf["single_stream"]["frac"] and rf["single_stream_achieved"] == rf["single_stream"]["achieved"]
+    assert all(not isinstance(rf[k], (dict, list)) for k in ("single_stream_launch_ms", "single_stream_frac", "single_stream_achieved"))
+    assert abs(out["value_single_stream"] - px / 0.61e-3 / 1e6) < 1 and out["value_single_stream"] < out["value"]
     assert abs(rf["launch_ms_timed_steps"] - 0.55) < 1e-9 and "overlap" in rf["launch_ms_note"]
     assert out["verified_frames"] == [0, 31, 63, 64, 95, 127]
 
@@ -66,6 +70,31 @@ def test_report_carries_the_other_configs():
     r = dict(_rank(0.011, 0.55, 6000.0, [0, 31, 63]), other_configs={"4": dict(rec), "5": dict(rec, mismatched_frames=[7])})
     out, bad = bench.report(a, 1, [r])
     assert set(out["other_configs"]) == {"4", "5"} and bad == [7] and "mismatched_frames" not in out["other_configs"]["5"]
+
+
+def test_other_configs_cover_the_sobel_half_of_config_3():
+    """round 5: BASELINE configs[2] reads "7x7 filter2D + Sobel gradient" -- the default run carries the Sobel launch
+    ("3s") and the one-launch form ("3f") beside configs 4 and 5, each with its algorithmic bytes (3 B read + 2 x i16
+    written = 7 B per pixel) and an oracle step that is the composition of the oracle's own passes"""
+    import numpy as np
+    for key in ("3s", "3f"):
+        c = bench.CONFIGS[key]
+        assert c["batch"] == 64 and c["alg_bytes"] == 2160 * 3840 * 7 and c["px"] == 2160 * 3840 and key in bench.TRAFFIC_KEYS and key in bench.SEEDS
+        assert bench.synth_args(key, 0) == (2160, 3840, 0, bench.SEEDS[3])
+    assert "Sobel" in bench.CONFIGS["3s"]["metric"] and "one launch" in bench.CONFIGS["3f"]["metric"]
+    a = bench.parse([])
+    assert a.config == 3 and a.other_cpu_seconds > 0
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.parse(["--config", "3s"])        # records of the default run, not headline configs
+
+    class Orc:   # stand-in that records the composition
+        def bench_kernel7(self): return "k7"
+        def filter2d_i8(self, f, k, s): return ("filt", f, k, s)
+        def bgr2gray(self, f): return ("gray", f)
+        def sobel(self, g): return ("sobel", g)
+    assert bench.oracle_step(Orc(), "3s", "F") == ("sobel", ("gray", "F"))
+    assert bench.oracle_step(Orc(), "3f", "F") == ("sobel", ("gray", ("filt", "F", "k7", 6)))
 
 
 def test_parse_defaults():

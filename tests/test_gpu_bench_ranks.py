@@ -66,3 +66,32 @@ def test_torchrun_two_ranks_on_one_device():
 def test_torchrun_failing_rank_exits_nonzero():
     p, out = _run(_torchrun(["--dist-backend", "gloo", "--fail-rank", "1"], 29533), timeout=300)
     assert p.returncode != 0 and out is None
+
+
+def test_one_process_eight_ranks_on_one_device():
+    """the EIGHT-rank one-process form (the shape of the driver's first SCALE run: 8 host threads, 8 x 2 contexts, the
+    thread barrier with 8 parties, per-rank verification and the report over 8 results) executed before the driver does -- all ranks on GPU 0"""
+    p, out = _run([sys.executable, "bench.py", "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--no-ceiling"] + SMALL)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["config"]["contexts"] == 8 and "not a scaling" in out["config"]["note"]
+    assert out["verified"].startswith("bit-exact")
+    # 8 ranks x 2 contexts x 4 frames = 16 lanes: first / middle / last frame of every lane's batch
+    assert out["verified_frames"] == sorted(4 * lane + i for lane in range(16) for i in (0, 1, 3)) and out["config"]["global_batch"] == 64
+    assert len(out["roofline"]["launch_ms_per_gpu"]) == 8 and all(t > 0 for t in out["roofline"]["launch_ms_per_gpu"])
+    assert out["roofline"]["in_flight"] == 2 and "cpu_baseline" not in out and "other_configs" not in out
+
+
+def test_default_run_carries_the_other_configs_small():
+    """the default (N = 1) line at a reduced batch: other_configs has the Sobel half of config 3 ("3s", "3f") and configs 4 / 5, every
+    record with its own roofline, verification and cpu_baseline; the one-stream figure is flattened into scalars"""
+    p, out = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--sustained", "12", "--settle-ms", "20", "--no-probe", "--no-ceiling",
+                   "--cpu-seconds", "1", "--other-cpu-seconds", "0.5"], timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert set(out["other_configs"]) == {"3s", "3f", "4", "5"}
+    for key, rec in out["other_configs"].items():
+        assert rec["verified"].startswith("bit-exact"), (key, rec["verified"])
+        assert 0.05 < rec["roofline"]["frac"] < 1.0 and rec["roofline"]["launch_ms"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
+    assert out["other_configs"]["3s"]["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 7
+    r = out["roofline"]
+    assert r["single_stream_frac"] == r["single_stream"]["frac"] and 0 < out["value_single_stream"] <= out["value"] * 1.02
+    assert out["cpu_baseline"]["value"] > 0
