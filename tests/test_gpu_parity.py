@@ -1420,7 +1420,8 @@ def test_warp_affine_resize_fused_lds_tiles(ctx, oracle, rng, knob, kernel, fpg,
     dst.free()
 
 
-@pytest.mark.parametrize("plan", [(1, 1, 32, 0, 0), (1, 2, 32, 0, 0), (1, 3, 16, 1, 0), (1, 5, 64, 2, 0), (1, 8, 32, 2, 2), (1, 4, 32, 1, 3), (0, 0, 0, 1, 2), (0, 0, 0, 2, 3)])
+@pytest.mark.parametrize("plan", [(1, 1, 32, 0, 0), (1, 2, 32, 0, 0), (1, 3, 16, 1, 0), (1, 5, 64, 2, 0), (1, 8, 32, 2, 2), (1, 4, 32, 1, 3), (0, 0, 0, 1, 2), (0, 0, 0, 2, 3),
+                                  (2, 1, 0, 0, 0), (2, 2, 0, 1, 0), (2, 3, 0, 2, 2), (2, 5, 0, 0, 0), (2, 8, 0, 1, 3)])
 @pytest.mark.parametrize("scale", [2, 4])
 @pytest.mark.parametrize("M", ["rot7", "rot-20", "shear", "ident", "flip", "far"])
 def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, M):
@@ -1447,6 +1448,38 @@ def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, 
     got = dst.download()
     for i in range(n):
         assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (plan, M, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
+@pytest.mark.parametrize("fpg,order", [(1, 0), (2, 1), (3, 0), (7, 2), (4, 0)])
+@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("M", ["rot7", "rot-3", "rot12", "shear", "ident", "flip", "shrink", "grow"])
+def test_warp_affine_resize_staged_row_pieces(ctx, oracle, rng, fpg, order, scale, M):
+    """round 5: k_warp_resize_stage (exact row pieces of the tile's footprint fetched global -> LDS, unaligned 8-byte tap reads, two buffers,
+    frames walked per tile) on frames large enough that most tiles are interior: odd frame counts against every group size (the tails
+    of the two-buffer loop), rows that are 4- but not 16-byte aligned (chunks straddle lines), maps whose footprint fits (staged) and
+    does not fit (steeper rotation, magnification: the workgroup falls back), ragged last tile row / column, canaries"""
+    dr, dc = 70, 328
+    mr, mc = scale * dr, scale * dc
+    sr, sc = mr + 45, mc + 31
+    Ms = {"rot7": _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), "rot-3": _rot(-3.0, mc / 2, mr / 2, 16.5, 21.25), "rot12": _rot(12.0, mc / 2, mr / 2, 14.0, 20.0),
+          "shear": np.array([1, 0.0625, 3.5, -0.03125, 1, 30.25], np.float32), "ident": np.array([1, 0, 4, 0, 1, 2], np.float32),
+          "flip": np.array([-1, 0, mc + 5.5, 0, -1, mr + 3.25], np.float32), "shrink": np.array([0.5, 0, 40.3, 0, 0.5, 20.7], np.float32),
+          "grow": np.array([1.25, 0, 2.5, 0, 1.0625, 1.75], np.float32)}[M]
+    n = 5
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + (-(sc * 3)) % 4 + 4)
+    dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    a, b = src.as_rcv(), dst.as_rcv()
+    m = np.ascontiguousarray(Ms, dtype=np.float32)
+    _ffi.check(_ffi.bench_lib().rcv__warp_resize_bench(ctx.handle, C.byref(a), C.byref(b), m.ctypes.data_as(C.POINTER(C.c_float)), scale, 2, fpg, 0,
+                                                       order, 0, -1), "rcv__warp_resize_bench")
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (fpg, order, M, i)
     _assert_canaries(dst)
     src.free()
     dst.free()
