@@ -29,6 +29,21 @@ constexpr int kBoxTileW = RCV_BOX_TW, kBoxTileH = 256 / RCV_BOX_TW;   // output 
 //                x1.3 of the source at 7 degrees) are L2 hits a few workgroups later, and DRAM sees one band of one frame group.
 __device__ __forceinline__ bool wr_tile(int per_xcd, int strip, int gx, int gy, int ngroups, int& bx, int& by, int& bz)
 {
+    if (per_xcd >= (1 << 30)) {
+        // BLOCKS (round 5): the tile grid cut into blocks of bw x bh tiles, block j of a frame group on XCD j % 8 (its bw * bh tiles
+        // consecutive in that XCD's dispatch order): neighbouring tiles of a block share an L2 -- the lines at the ends of a rotated
+        // tile's row pieces continue in the tile above / below / beside it -- while the eight XCDs stay in one neighbourhood of the image
+        const int bw = per_xcd & 255, bh = (per_xcd >> 8) & 255, nbx = (gx + bw - 1) / bw, nby = (gy + bh - 1) / bh, per = bw * bh;
+        const int q = (int)(blockIdx.x >> 3), blk8 = q / per, idx = q - blk8 * per;
+        int blk = 8 * blk8 + (int)(blockIdx.x & 7);
+        const int nb = nbx * nby;
+        bz = blk / nb;
+        blk -= bz * nb;
+        const int byb = blk / nbx, bxb = blk - byb * nbx, iy = idx / bw;
+        bx = bxb * bw + (idx - iy * bw);
+        by = byb * bh + iy;
+        return bz < ngroups && bx < gx && by < gy;
+    }
     if (per_xcd >= 0) return wl_tile(per_xcd, strip, gx, gy, gx * gy * ngroups, bx, by, bz);
     const int pg = -per_xcd, q = (int)(blockIdx.x >> 3);
     bz = q / pg;
@@ -127,6 +142,243 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
     const int x = bx * kBoxTileW + (wave % (kBoxTileW / WW)) * WW + (lane % WW);   // d.cols % 4 == 0: quads never straddle the row end
     const int y = by * kBoxTileH + (wave / (kBoxTileW / WW)) * WH + (lane / WW);
     warp_resize_box_px<S>(s, d, A, bz, x, y);
+}
+
+// ---- the same launch on EXACT ROW PIECES staged through LDS (round 5, second design) ------------------------------------------------
+// What the counters of the two gather kernels say (profiles/r05_warp_resize_pmc_*): 367 M L1 cache accesses per launch = 0.89 per
+// CU and cycle (eight gathers of ~41 distinct lines each per wave: the tag pipeline is full), 33 M L1 -> L2 line requests of which
+// 93 % miss, 287 M VALU instructions of which ~150 per pixel repeat for every frame.  Halving the gathers alone does not help (four
+// 16-byte row windows per lane instead of eight 12-byte taps, measured: 0.78 against 0.68 ms, gathers only -- every window is an L1
+// miss).  This kernel changes all three at once:
+//  * a workgroup keeps ONE 64 x 4 output tile and walks the frames of its frame group; per tile, once: the sample coordinates, the
+//    interior test, fractions, and a PLAN of the source bytes the tile reads -- for every source row the exact byte range
+//    [3 x0_min, 3 x0_max + 5] over the tile's samples that tap it (LDS atomics), cut to 16-byte chunks: ~750 chunks = 47 B per output
+//    pixel at 7 degrees (the bounding box of the rotated tile is 1.9x that);
+//  * per frame the chunk list is fetched by three `buffer_load_dwordx4 ... lds` per lane (global -> LDS directly: chunk c lands at
+//    byte 16 c of the buffer; the lane's source offset is the only register it needs, the frame base sits in the buffer resource) --
+//    ~10 L1 accesses per wave instruction instead of 41, every line requested once per tile and frame;
+//  * the taps come out of LDS: a row piece is contiguous there, so the tap pair (x0, y0) is the three dwords from tab[y0] + 3 x0 (hoisted;
+//    lanes 12 bytes apart: no systematic bank conflict), read as ds_read2_b32 + ds_read_b32 and shifted into place as before;
+//  * two buffers: frame f + 1 is in flight while frame f is computed; one barrier per frame.
+// Per frame and pixel that leaves the tap shifts, the exact bilinear arithmetic (4 x 31), the box average and the store: ~160 VALU instructions.
+// Tiles with a tap outside the source, with more than 64 source rows or more than kStageChunks chunks take k_warp_resize_box's path.
+#ifndef RCV_STAGE_CHUNKS
+#define RCV_STAGE_CHUNKS 768
+#endif
+constexpr int kStageChunks = RCV_STAGE_CHUNKS, kStageLoads = kStageChunks / 256, kStageBuf = kStageChunks * 16;   // chunks (16 B) per buffer: three per thread
+
+template <int S, int DBG = 0, int OCC = 5>   // OCC: waves per SIMD the register allocation aims at
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_warp_resize_stage(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int per_xcd, int strip, int pad)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wrs_lds[];   // 2 x kStageBuf (+ whatever the host adds to cap the occupancy)
+    int bx, by, bz;
+    if (!wr_tile(per_xcd, strip, gx, gy, ngroups, bx, by, bz)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = bx * 64 + lane, y = by * 4 + wave;
+    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
+    const int xq = min(x & ~3, d.cols - 4) + (x & 3), yq = min(y, d.rows - 1);   // whole quads clamped into the image (d.cols % 4 == 0)
+    constexpr int o = S / 2 - 1;
+    float sx[4], sy[4];
+    bool inter = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
+        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
+        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
+    }
+    // plan tables: alias the SECOND buffer (its first load is issued behind the barrier every table read has passed)
+    int* const rowmin = (int*)(wrs_lds + kStageBuf);   // [64] first byte a row's taps need, then 16 * (first chunk in LDS - first chunk in the row)
+    int* const rowmax = rowmin + 64;                   // [64] last byte; then the row's first chunk in the list
+    int* const goff = rowmax + 64;                     // [64] byte offset of the row's first chunk inside a frame
+    int* const scal = goff + 64;                       // [0] lowest row, [1] highest row, [2] chunks in the list
+    uint8_t* const map = (uint8_t*)(scal + 4);         // [kStageChunks] chunk -> row of the tile
+    if (tid < 64) { rowmin[tid] = 0x7fffffff; rowmax[tid] = -1; }
+    if (tid == 0) { scal[0] = 0x7fffffff; scal[1] = -0x7fffffff; scal[2] = 0; }
+    bool staged = __syncthreads_and(inter) != 0;       // (the barrier also publishes the table initialisation)
+    int x0[4], y0[4];
+    f2 fxy[4];
+    if (staged) {
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
+            fxy[i] = f2{sx[i] - x0f, sy[i] - y0f};
+            x0[i] = (int)x0f;
+            y0[i] = (int)y0f;
+            lo = min(lo, y0[i]);
+            hi = max(hi, y0[i] + 1);
+        }
+        atomicMin(&scal[0], lo);
+        atomicMax(&scal[1], hi);
+    }
+    __syncthreads();
+    const int r0 = scal[0];
+    staged = staged && scal[1] - r0 < 64;
+    if (staged) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = y0[i] - r0, b = 3 * x0[i];
+            atomicMin(&rowmin[r], b);
+            atomicMax(&rowmax[r], b + 5);
+            atomicMin(&rowmin[r + 1], b);
+            atomicMax(&rowmax[r + 1], b + 5);
+        }
+    }
+    __syncthreads();
+    if (staged && wave == 0) {   // one wave: chunk counts of the rows, their prefix sums, the chunk -> row map
+        const int mn = rowmin[lane], mx = rowmax[lane];
+        const int qs = mn >> 4, len = mx >= 0 ? (mx >> 4) - qs + 1 : 0;
+        // pad = 1 (measurement): an ODD number of chunk slots per row (the last one possibly unused).  Along a wave the rows change every
+        // other lane at the same offset inside the piece, so with 64- or 68-dword pieces lanes l, l + 2, l + 4, ... meet in one bank
+        // (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles); odd counts put them 4 (mod 8) dwords apart.  Measured: -0.5 % (the LDS is not
+        // the bound), and the slots cost buffer space: off
+        const int slots = len | (len > 0 ? pad : 0);
+        int inc = slots;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            const int t = __shfl_up(inc, k);
+            if (lane >= k) inc += t;
+        }
+        const int cb = inc - slots;
+        if (lane == 63) scal[2] = inc;
+        if (inc <= kStageChunks)
+            for (int i = 0; i < slots; ++i) map[cb + i] = (uint8_t)(i < len ? lane : 255);   // (255: a slot nothing is loaded into)
+        rowmin[lane] = 16 * (cb - qs);
+        rowmax[lane] = cb;
+        goff[lane] = (int)((unsigned)(r0 + lane) * (unsigned)s.step + 16u * (unsigned)qs);
+    }
+    __syncthreads();
+    const int total = scal[2];
+    staged = staged && total <= kStageChunks;
+    if (!staged) {   // workgroup-uniform: a tap outside the source, or a footprint the buffers do not hold (steep or magnifying maps)
+        if (x >= d.cols || y >= d.rows) return;
+        for (int f = f0; f < f1; ++f) warp_resize_box_px<S>(s, d, A, f, x, y);
+        return;
+    }
+    unsigned voff[kStageLoads];   // the lane's chunk of each load instruction: byte offset inside a frame (past the frame: no fetch)
+#pragma unroll
+    for (int j = 0; j < kStageLoads; ++j) {
+        const int c = j * 256 + tid;
+        voff[j] = 0xffffff00u;
+        if (c < total) {
+            const int r = map[c];
+            if (r != 255) voff[j] = (unsigned)goff[r] + 16u * (unsigned)(c - rowmax[r]);
+        }
+    }
+    const int nload = (total + 255) >> 8;   // load instructions that carry chunks (workgroup-uniform)
+    unsigned la[4], lb[4], sh[4];   // LDS byte offset (buffer 0) of the dword below the upper / lower tap pair of each sample; the taps' byte in it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = y0[i] - r0;
+        sh[i] = (unsigned)(3 * x0[i]) & 3u;               // (row pieces start on 16-byte chunks: the same shift in both rows)
+        la[i] = (unsigned)(rowmin[r] + 3 * x0[i]) & ~3u;
+        lb[i] = (unsigned)(rowmin[r + 1] + 3 * x0[i]) & ~3u;
+    }
+    const int kq = min(lane & 3, 2);   // (the store scheme of k_warp_resize_loop: every lane one dword of its quad's 12 bytes)
+    const unsigned doff = (unsigned)yq * (unsigned)d.step + (unsigned)(xq & ~3) * 3u + 4u * (unsigned)kq;
+    const uint32_t psel = kq == 0 ? 0x04020100u : (kq == 1 ? 0x05040201u : 0x06050402u);
+    constexpr int kRsrc = 0x00020000;
+    const unsigned sbytes = (unsigned)min((unsigned long long)s.cap, (unsigned long long)s.rows * s.step);
+    const uint8_t* sf = s.p + (size_t)f0 * s.fstride;
+    uint8_t* df = d.p + (size_t)f0 * d.fstride;
+    auto issue = [&](const uint8_t* base, const int buf) {   // frame -> buffer `buf`: three direct-to-LDS loads per lane
+        if constexpr (DBG == 2) return;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, sbytes, kRsrc);
+#pragma unroll
+        for (int j = 0; j < kStageLoads; ++j)
+            if (j < 2 || nload > j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(wrs_lds + buf * kStageBuf + (j * 256 + wave * 64) * 16), 16,
+                                                     voff[j], 0, 0, 0);
+    };
+    auto finish = [&](uint8_t* dbase, const int buf) {
+        const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0xffffffff, kRsrc);
+        if constexpr (DBG == 1) {   // staging and stores only
+            __builtin_amdgcn_raw_buffer_store_b32(voff[0] + buf, w, doff, 0, 0);
+            return;
+        }
+        // three dwords from the dword below the tap: ds_read2_b32 + ds_read_b32.  (A DS read wider than a dword that is not naturally
+        // aligned -- b64 off 8, b96 / b128 off 16 -- is served one lane per cycle on gfx950: 62 cycles per wave instruction against 7-13
+        // for this pair, tools/ubench_lds_taps.hip.)
+        uint32_t p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t* qa = (const uint32_t*)(wrs_lds + (la[i] + buf * kStageBuf));
+            const uint32_t* qb = (const uint32_t*)(wrs_lds + (lb[i] + buf * kStageBuf));
+            const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+            p[i] = bilerp_bgr<true>(__builtin_amdgcn_alignbyte(a1, a0, sh[i]), __builtin_amdgcn_alignbyte(a2, a1, sh[i]),
+                                    __builtin_amdgcn_alignbyte(b1, b0, sh[i]), __builtin_amdgcn_alignbyte(b2, b1, sh[i]), fxy[i]);
+        }
+        const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
+        const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
+        const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
+        const uint32_t pa = __builtin_amdgcn_update_dpp(0u, px, 0xA4, 0xf, 0xf, true);   // quad_perm [0,1,2,2]
+        const uint32_t pb = __builtin_amdgcn_update_dpp(0u, px, 0xF9, 0xf, 0xf, true);   // quad_perm [1,2,3,3]
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(pb, pa, psel), w, doff, 0, 0);
+    };
+    const size_t sfs = s.fstride, dfs = d.fstride;
+    issue(sf, 0);
+    int f = f0;
+#pragma unroll 1
+    for (;;) {
+        // frame f is in buffer 0 once every wave's loads have landed; all waves have left frame f - 1 (buffer 1 is free)
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
+        __syncthreads();
+        if (f + 1 < f1) issue(sf + sfs, 1);
+        finish(df, 0);
+        if (++f >= f1) break;
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (f + 1 < f1) issue(sf + 2 * sfs, 0);
+        finish(df + dfs, 1);
+        if (++f >= f1) break;
+        sf += 2 * sfs;
+        df += 2 * dfs;
+    }
+}
+
+// (Round 3 built the fused warp -> 4x down-scale on an LDS-staged source patch as well -- k_warp_resize_lds: 16 x 16 output tiles, the warp
+//  kernel's staging plan and double buffer; bit-exact, 0.91 ms against this gather kernel's 0.715 ms on 32 x 8K -> 1080p because the samples
+//  sit 4 pixels apart: <= 9 of 16 staged pixels are ever read and the tap reads are a 4-way bank conflict for every pitch.  Removed from the
+//  product in round 4; the measurement is profiles/r03_warp_resize_lds.txt, the source is in the history at commit e87cdfd.)
+
+bool wrl_ok(const View& s, const View& d)
+{
+    return ((uintptr_t)s.p & 3) == 0 && (s.step & 3) == 0 && (s.fstride & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
+           (unsigned long long)s.rows * s.step < (1ull << 32) && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
+}
+
+// host side of the staged kernel.  order: 0 raster grid, 1 XCD-contiguous runs of the whole list, 2 synchronous stripes
+int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S, int fpg_, int order, int strip, unsigned extra_lds, int dbg, int occ = 5)
+{
+    const int gx = (d.cols + 63) / 64, gy = (d.rows + 3) / 4;
+    const int fpg = fpg_ > 0 ? min(fpg_, d.n) : min(d.n, 16);
+    const int groups = (d.n + fpg - 1) / fpg;
+    const unsigned long long tiles = (unsigned long long)gx * gy * groups;
+    if (tiles >= (1ull << 28)) return RCV_ERR_UNSUPPORTED;
+    const int pg = (gx * gy + 7) / 8;
+    int per = order == 1 ? (int)((tiles + 7) / 8) : (order == 2 ? -pg : 0);
+    dim3 grid = order == 1 ? dim3((unsigned)(8 * per)) : (order == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
+    const int pad = (strip >> 16) & 1;   // (measurement: + 65536 = an odd number of chunk slots per row)
+    strip &= 0xffff;
+    if (order == 3) {   // blocks of bw x bh tiles (strip = bw + 256 * bh), dealt to the XCDs in turn
+        const int bw = max(strip & 255, 1), bh = max((strip >> 8) & 255, 1);
+        const long long nb = (long long)((gx + bw - 1) / bw) * ((gy + bh - 1) / bh) * groups;
+        per = (1 << 30) | bw | (bh << 8);
+        grid = dim3((unsigned)(((nb + 7) / 8) * 8 * bw * bh));
+    }
+    const unsigned lds = 2 * kStageBuf + extra_lds;
+#define WRS_GO(S_, D_) RCV_LAUNCH((k_warp_resize_stage<S_, D_>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad)
+    if (S == 2) WRS_GO(2, 0);
+#ifdef RCV_WRL_BENCH
+    else if (dbg == 1) WRS_GO(4, 1);
+    else if (dbg == 2) WRS_GO(4, 2);
+    else if (occ == 4) RCV_LAUNCH((k_warp_resize_stage<4, 0, 4>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad);
+    else if (occ == 6) RCV_LAUNCH((k_warp_resize_stage<4, 0, 6>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad);
+#endif
+    else WRS_GO(4, 0);
+#undef WRS_GO
+    return rcv_launch_check(ctx);
 }
 
 #ifdef RCV_WRL_BENCH   // measurement build only (librustcv_hip_bench.so): measured, bit-exact, slower -- DESIGN.md 9, profiles/r05_warp_resize_*
@@ -276,204 +528,10 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_loop(View s, View d, Aff
     }
 }
 
-// ---- the same launch on EXACT ROW PIECES staged through LDS (round 5, second design) ------------------------------------------------
-// What the counters of the two gather kernels say (profiles/r05_warp_resize_pmc_*): 367 M L1 cache accesses per launch = 0.89 per
-// CU and cycle (eight gathers of ~41 distinct lines each per wave: the tag pipeline is full), 33 M L1 -> L2 line requests of which
-// 93 % miss, 287 M VALU instructions of which ~150 per pixel repeat for every frame.  Halving the gathers alone does not help (four
-// 16-byte row windows per lane instead of eight 12-byte taps, measured: 0.78 against 0.68 ms, gathers only -- every window is an L1
-// miss).  This kernel changes all three at once:
-//  * a workgroup keeps ONE 64 x 4 output tile and walks the frames of its frame group; per tile, once: the sample coordinates, the
-//    interior test, fractions, and a PLAN of the source bytes the tile reads -- for every source row the exact byte range
-//    [3 x0_min, 3 x0_max + 5] over the tile's samples that tap it (LDS atomics), cut to 16-byte chunks: ~750 chunks = 47 B per output
-//    pixel at 7 degrees (the bounding box of the rotated tile is 1.9x that);
-//  * per frame the chunk list is fetched by three `buffer_load_dwordx4 ... lds` per lane (global -> LDS directly: chunk c lands at
-//    byte 16 c of the buffer; the lane's source offset is the only register it needs, the frame base sits in the buffer resource) --
-//    ~10 L1 accesses per wave instruction instead of 41, every line requested once per tile and frame;
-//  * the taps come out of LDS: a row piece is contiguous there, so the tap pair (x0, y0) is the three dwords from tab[y0] + 3 x0 (hoisted;
-//    lanes 12 bytes apart: no systematic bank conflict), read as ds_read2_b32 + ds_read_b32 and shifted into place as before;
-//  * two buffers: frame f + 1 is in flight while frame f is computed; one barrier per frame.
-// Per frame and pixel that leaves the tap shifts, the exact bilinear arithmetic (4 x 31), the box average and the store: ~160 VALU instructions.
-// Tiles with a tap outside the source, with more than 64 source rows or more than kStageChunks chunks take k_warp_resize_box's path.
-constexpr int kStageChunks = 768, kStageBuf = kStageChunks * 16;   // chunks (16 B) per buffer: three per thread
-
-template <int S, int DBG = 0>
-__global__ __launch_bounds__(kBlock) void k_warp_resize_stage(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int per_xcd, int strip)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t wrs_lds[];   // 2 x kStageBuf (+ whatever the host adds to cap the occupancy)
-    int bx, by, bz;
-    if (!wr_tile(per_xcd, strip, gx, gy, ngroups, bx, by, bz)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x = bx * 64 + lane, y = by * 4 + wave;
-    const int f0 = bz * fpg, f1 = min(f0 + fpg, d.n);
-    const int xq = min(x & ~3, d.cols - 4) + (x & 3), yq = min(y, d.rows - 1);   // whole quads clamped into the image (d.cols % 4 == 0)
-    constexpr int o = S / 2 - 1;
-    float sx[4], sy[4];
-    bool inter = true;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
-        sx[i] = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2]));
-        sy[i] = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
-        inter = inter && sx[i] >= 0.0f && sx[i] < (float)(s.cols - 3) && sy[i] >= 0.0f && sy[i] < (float)(s.rows - 1);
-    }
-    // plan tables: alias the SECOND buffer (its first load is issued behind the barrier every table read has passed)
-    int* const rowmin = (int*)(wrs_lds + kStageBuf);   // [64] first byte a row's taps need, then 16 * (first chunk in LDS - first chunk in the row)
-    int* const rowmax = rowmin + 64;                   // [64] last byte; then the row's first chunk in the list
-    int* const goff = rowmax + 64;                     // [64] byte offset of the row's first chunk inside a frame
-    int* const scal = goff + 64;                       // [0] lowest row, [1] highest row, [2] chunks in the list
-    uint8_t* const map = (uint8_t*)(scal + 4);         // [kStageChunks] chunk -> row of the tile
-    if (tid < 64) { rowmin[tid] = 0x7fffffff; rowmax[tid] = -1; }
-    if (tid == 0) { scal[0] = 0x7fffffff; scal[1] = -0x7fffffff; scal[2] = 0; }
-    bool staged = __syncthreads_and(inter) != 0;       // (the barrier also publishes the table initialisation)
-    int x0[4], y0[4];
-    f2 fxy[4];
-    if (staged) {
-        int lo = 0x7fffffff, hi = -0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0f = floorf(sx[i]), y0f = floorf(sy[i]);
-            fxy[i] = f2{sx[i] - x0f, sy[i] - y0f};
-            x0[i] = (int)x0f;
-            y0[i] = (int)y0f;
-            lo = min(lo, y0[i]);
-            hi = max(hi, y0[i] + 1);
-        }
-        atomicMin(&scal[0], lo);
-        atomicMax(&scal[1], hi);
-    }
-    __syncthreads();
-    const int r0 = scal[0];
-    staged = staged && scal[1] - r0 < 64;
-    if (staged) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = y0[i] - r0, b = 3 * x0[i];
-            atomicMin(&rowmin[r], b);
-            atomicMax(&rowmax[r], b + 5);
-            atomicMin(&rowmin[r + 1], b);
-            atomicMax(&rowmax[r + 1], b + 5);
-        }
-    }
-    __syncthreads();
-    if (staged && wave == 0) {   // one wave: chunk counts of the rows, their prefix sums, the chunk -> row map
-        const int mn = rowmin[lane], mx = rowmax[lane];
-        const int qs = mn >> 4, len = mx >= 0 ? (mx >> 4) - qs + 1 : 0;
-        int inc = len;
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            const int t = __shfl_up(inc, k);
-            if (lane >= k) inc += t;
-        }
-        const int cb = inc - len;
-        if (lane == 63) scal[2] = inc;
-        if (inc <= kStageChunks)
-            for (int i = 0; i < len; ++i) map[cb + i] = (uint8_t)lane;
-        rowmin[lane] = 16 * (cb - qs);
-        rowmax[lane] = cb;
-        goff[lane] = (int)((unsigned)(r0 + lane) * (unsigned)s.step + 16u * (unsigned)qs);
-    }
-    __syncthreads();
-    const int total = scal[2];
-    staged = staged && total <= kStageChunks;
-    if (!staged) {   // workgroup-uniform: a tap outside the source, or a footprint the buffers do not hold (steep or magnifying maps)
-        if (x >= d.cols || y >= d.rows) return;
-        for (int f = f0; f < f1; ++f) warp_resize_box_px<S>(s, d, A, f, x, y);
-        return;
-    }
-    unsigned voff[3];   // the lane's chunk of each of the three load instructions: byte offset inside a frame (past the frame: no fetch)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int c = j * 256 + tid;
-        voff[j] = 0xffffff00u;
-        if (c < total) {
-            const int r = map[c];
-            voff[j] = (unsigned)goff[r] + 16u * (unsigned)(c - rowmax[r]);
-        }
-    }
-    unsigned la[4], lb[4], sh[4];   // LDS byte offset (buffer 0) of the dword below the upper / lower tap pair of each sample; the taps' byte in it
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = y0[i] - r0;
-        sh[i] = (unsigned)(3 * x0[i]) & 3u;               // (row pieces start on 16-byte chunks: the same shift in both rows)
-        la[i] = (unsigned)(rowmin[r] + 3 * x0[i]) & ~3u;
-        lb[i] = (unsigned)(rowmin[r + 1] + 3 * x0[i]) & ~3u;
-    }
-    const int kq = min(lane & 3, 2);   // (the store scheme of k_warp_resize_loop: every lane one dword of its quad's 12 bytes)
-    const unsigned doff = (unsigned)yq * (unsigned)d.step + (unsigned)(xq & ~3) * 3u + 4u * (unsigned)kq;
-    const uint32_t psel = kq == 0 ? 0x04020100u : (kq == 1 ? 0x05040201u : 0x06050402u);
-    constexpr int kRsrc = 0x00020000;
-    const unsigned sbytes = (unsigned)min((unsigned long long)s.cap, (unsigned long long)s.rows * s.step);
-    const uint8_t* sf = s.p + (size_t)f0 * s.fstride;
-    uint8_t* df = d.p + (size_t)f0 * d.fstride;
-    auto issue = [&](const uint8_t* base, const int buf) {   // frame -> buffer `buf`: three direct-to-LDS loads per lane
-        if constexpr (DBG == 2) return;
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, sbytes, kRsrc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(wrs_lds + buf * kStageBuf + (j * 256 + wave * 64) * 16), 16,
-                                                     voff[j], 0, 0, 0);
-    };
-    auto finish = [&](uint8_t* dbase, const int buf) {
-        const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0xffffffff, kRsrc);
-        if constexpr (DBG == 1) {   // staging and stores only
-            __builtin_amdgcn_raw_buffer_store_b32(voff[0] + buf, w, doff, 0, 0);
-            return;
-        }
-        // three dwords from the dword below the tap: ds_read2_b32 + ds_read_b32.  (A DS read wider than a dword that is not naturally
-        // aligned -- b64 off 8, b96 / b128 off 16 -- is served one lane per cycle on gfx950: 62 cycles per wave instruction against 7-13
-        // for this pair, tools/ubench_lds_taps.hip.)
-        uint32_t p[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t* qa = (const uint32_t*)(wrs_lds + (la[i] + buf * kStageBuf));
-            const uint32_t* qb = (const uint32_t*)(wrs_lds + (lb[i] + buf * kStageBuf));
-            const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
-            p[i] = bilerp_bgr<true>(__builtin_amdgcn_alignbyte(a1, a0, sh[i]), __builtin_amdgcn_alignbyte(a2, a1, sh[i]),
-                                    __builtin_amdgcn_alignbyte(b1, b0, sh[i]), __builtin_amdgcn_alignbyte(b2, b1, sh[i]), fxy[i]);
-        }
-        const uint32_t br = (p[0] & 0x00ff00ffu) + (p[1] & 0x00ff00ffu) + (p[2] & 0x00ff00ffu) + (p[3] & 0x00ff00ffu) + 0x00020002u;
-        const uint32_t gg = ((p[0] >> 8) & 0xffu) + ((p[1] >> 8) & 0xffu) + ((p[2] >> 8) & 0xffu) + ((p[3] >> 8) & 0xffu) + 2u;
-        const uint32_t px = ((br >> 2) & 0x00ff00ffu) | ((gg >> 2) << 8);
-        const uint32_t pa = __builtin_amdgcn_update_dpp(0u, px, 0xA4, 0xf, 0xf, true);   // quad_perm [0,1,2,2]
-        const uint32_t pb = __builtin_amdgcn_update_dpp(0u, px, 0xF9, 0xf, 0xf, true);   // quad_perm [1,2,3,3]
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(pb, pa, psel), w, doff, 0, 0);
-    };
-    const size_t sfs = s.fstride, dfs = d.fstride;
-    issue(sf, 0);
-    int f = f0;
-#pragma unroll 1
-    for (;;) {
-        // frame f is in buffer 0 once every wave's loads have landed; all waves have left frame f - 1 (buffer 1 is free)
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
-        __syncthreads();
-        if (f + 1 < f1) issue(sf + sfs, 1);
-        finish(df, 0);
-        if (++f >= f1) break;
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (f + 1 < f1) issue(sf + 2 * sfs, 0);
-        finish(df + dfs, 1);
-        if (++f >= f1) break;
-        sf += 2 * sfs;
-        df += 2 * dfs;
-    }
-}
-
-// (Round 3 built the fused warp -> 4x down-scale on an LDS-staged source patch as well -- k_warp_resize_lds: 16 x 16 output tiles, the warp
-//  kernel's staging plan and double buffer; bit-exact, 0.91 ms against this gather kernel's 0.715 ms on 32 x 8K -> 1080p because the samples
-//  sit 4 pixels apart: <= 9 of 16 staged pixels are ever read and the tap reads are a 4-way bank conflict for every pitch.  Removed from the
-//  product in round 4; the measurement is profiles/r03_warp_resize_lds.txt, the source is in the history at commit e87cdfd.)
-
 // ---- host side of the frame-loop kernel ---------------------------------------------------------------------------------------
 // fpg: frames per wave (0: by batch size); ww: wave sub-tile width; xcd: contiguous run of the tile list per XCD; strip: tile columns per
 // vertical strip of that list (0: raster); lds: dynamic-LDS request that caps the workgroups per CU (0: none)
 struct WrlPlan { int fpg = 0, ww = 32, xcd = 1, strip = 0; unsigned lds = 0; int dbg = 0; };
-
-bool wrl_ok(const View& s, const View& d)
-{
-    return ((uintptr_t)s.p & 3) == 0 && (s.step & 3) == 0 && (s.fstride & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-           (unsigned long long)s.rows * s.step < (1ull << 32) && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
-}
 
 int wrl_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S, WrlPlan p)
 {
@@ -498,27 +556,6 @@ int wrl_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
     return rcv_launch_check(ctx);
 }
 
-// host side of the staged kernel.  order: 0 raster grid, 1 XCD-contiguous runs of the whole list, 2 synchronous stripes
-int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S, int fpg_, int order, int strip, unsigned extra_lds, int dbg)
-{
-    const int gx = (d.cols + 63) / 64, gy = (d.rows + 3) / 4;
-    const int fpg = fpg_ > 0 ? min(fpg_, d.n) : min(d.n, 16);
-    const int groups = (d.n + fpg - 1) / fpg;
-    const unsigned long long tiles = (unsigned long long)gx * gy * groups;
-    if (tiles >= (1ull << 28)) return RCV_ERR_UNSUPPORTED;
-    const int pg = (gx * gy + 7) / 8;
-    const int per = order == 1 ? (int)((tiles + 7) / 8) : (order == 2 ? -pg : 0);
-    const dim3 grid = order == 1 ? dim3((unsigned)(8 * per)) : (order == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
-    const unsigned lds = 2 * kStageBuf + extra_lds;
-#define WRS_GO(S_, D_) RCV_LAUNCH((k_warp_resize_stage<S_, D_>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip)
-    if (S == 2) WRS_GO(2, 0);
-    else if (dbg == 1) WRS_GO(4, 1);
-    else if (dbg == 2) WRS_GO(4, 2);
-    else WRS_GO(4, 0);
-#undef WRS_GO
-    return rcv_launch_check(ctx);
-}
-
 #endif   // RCV_WRL_BENCH
 
 } // namespace
@@ -539,6 +576,13 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
+            // batches of 8+ frames, 4x: the staged kernel (a tile's plan is paid once per frame group of <= 11 frames: 32 frames = 3 groups;
+            // 32 x 8K -> 1080p at 7 degrees 0.69 against 0.72 ms, profiles/r05_warp_resize_staged.txt).  Fewer frames per tile do not
+            // repay the plan, and the 2x footprints were not measured: both stay on the gather kernel
+            if (S == 4 && d.n >= 8 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d)) {
+                const int groups = (d.n + 10) / 11;
+                return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, 0, 0, 0u, 0);
+            }
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
             // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)
@@ -603,7 +647,7 @@ extern "C" int rcv__warp_resize_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
         return rcv_launch_check(ctx);
     }
     if (!wrl_ok(s, d)) return RCV_ERR_UNSUPPORTED;
-    if (variant == 2) return wrs_launch(ctx, s, d, A, S, fpg, xcd & 3, strip, lds < 0 ? 0u : (unsigned)lds, (xcd >> 4) & 15);   // (ww unused)
+    if (variant == 2) return wrs_launch(ctx, s, d, A, S, fpg, xcd & 3, strip, lds < 0 ? 0u : (unsigned)lds, (xcd >> 4) & 15, ww);   // (ww: waves per SIMD the build aims at, 4 / 6; else 5)
     WrlPlan p;
     p.fpg = fpg; p.ww = ww; p.xcd = xcd & 3; p.dbg = (xcd >> 4) & 15; p.strip = strip; p.lds = lds < 0 ? 0u : (unsigned)lds;   // (xcd + 16 * dbg)
     return wrl_launch(ctx, s, d, A, S, p);

@@ -1453,14 +1453,49 @@ def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, 
     dst.free()
 
 
-@pytest.mark.parametrize("fpg,order", [(1, 0), (2, 1), (3, 0), (7, 2), (4, 0)])
+@pytest.mark.parametrize("n", [8, 9, 12, 23])
+@pytest.mark.parametrize("M", ["rot7", "rot-3", "shear", "rot-20"])
+def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M):
+    """round 5: rcv_warp_affine_resize_batch sends 4x launches of 8+ frames to k_warp_resize_stage (frame groups of <= 11: one group, an
+    uneven pair, three groups), everything else and RCV_WARP_LDS=0 to k_warp_resize_box; both produce the oracle's bytes"""
+    dr, dc = 38, 200
+    mr, mc = 4 * dr, 4 * dc
+    sr, sc = mr + 33, mc + 27
+    Ms = {"rot7": _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), "rot-3": _rot(-3.0, mc / 2, mr / 2, 16.5, 21.25),
+          "shear": np.array([1, 0.0625, 3.5, -0.03125, 1, 30.25], np.float32), "rot-20": _rot(-20.0, mc / 2, mr / 2, 20.0, 30.0)}[M]
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + (-(sc * 3)) % 4)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    want = [oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc) for i in range(n)]
+    for lds_knob, kern in ((None, "k_warp_resize_stage<4"), (0, "k_warp_resize_box<4")):
+        if lds_knob is not None:
+            knob("RCV_WARP_LDS", lds_knob)
+        dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+        names = _kernels_launched(ctx, lambda: device.warp_affine_resize(src, dst, Ms, mr, mc))
+        assert kern in names, names
+        got = dst.download()
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (kern, n, M, i)
+        _assert_canaries(dst)
+        dst.free()
+    # seven frames: the gather kernel whatever the knob says
+    v = src.view(0, 7)
+    dst = _canary_batch(ctx, 7, dr, dc, 3, pad=8)
+    assert "k_warp_resize_box<4" in _kernels_launched(ctx, lambda: device.warp_affine_resize(v, dst, Ms, mr, mc))
+    dst.free()
+    src.free()
+
+
+@pytest.mark.parametrize("fpg,order,strip", [(1, 0, 0), (2, 1, 0), (3, 0, 65536), (7, 2, 0), (4, 0, 0), (2, 3, 2 + 256 * 2), (5, 3, 4 + 256 * 3), (3, 3, 1 + 256 * 7)])
 @pytest.mark.parametrize("scale", [2, 4])
 @pytest.mark.parametrize("M", ["rot7", "rot-3", "rot12", "shear", "ident", "flip", "shrink", "grow"])
-def test_warp_affine_resize_staged_row_pieces(ctx, oracle, rng, fpg, order, scale, M):
+def test_warp_affine_resize_staged_row_pieces(ctx, oracle, rng, fpg, order, strip, scale, M):
     """round 5: k_warp_resize_stage (exact row pieces of the tile's footprint fetched global -> LDS, unaligned 8-byte tap reads, two buffers,
     frames walked per tile) on frames large enough that most tiles are interior: odd frame counts against every group size (the tails
     of the two-buffer loop), rows that are 4- but not 16-byte aligned (chunks straddle lines), maps whose footprint fits (staged) and
-    does not fit (steeper rotation, magnification: the workgroup falls back), ragged last tile row / column, canaries"""
+    does not fit (steeper rotation, magnification: the workgroup falls back), ragged last tile row / column, canaries; tile orders: raster,
+    XCD-contiguous, synchronous stripes and blocks of bw x bh tiles (strip = bw + 256 bh; blocks that overhang the tile grid); strip + 65536:
+    row pieces packed without the odd-slot rule"""
     dr, dc = 70, 328
     mr, mc = scale * dr, scale * dc
     sr, sc = mr + 45, mc + 31
@@ -1476,10 +1511,10 @@ def test_warp_affine_resize_staged_row_pieces(ctx, oracle, rng, fpg, order, scal
     a, b = src.as_rcv(), dst.as_rcv()
     m = np.ascontiguousarray(Ms, dtype=np.float32)
     _ffi.check(_ffi.bench_lib().rcv__warp_resize_bench(ctx.handle, C.byref(a), C.byref(b), m.ctypes.data_as(C.POINTER(C.c_float)), scale, 2, fpg, 0,
-                                                       order, 0, -1), "rcv__warp_resize_bench")
+                                                       order, strip, -1), "rcv__warp_resize_bench")
     got = dst.download()
     for i in range(n):
-        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (fpg, order, M, i)
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (fpg, order, strip, M, i)
     _assert_canaries(dst)
     src.free()
     dst.free()

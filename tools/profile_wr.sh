@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes of the fused warp -> down-scale launch through tools/ablate_warp_resize.py:  bash tools/profile_wr.sh <tag> "<plan>"
 set -u
-TAG=$1; PLAN=$2
+TAG=$1; PLAN=$2; KSUB=${3:-k_warp_resize}
 OUT=$PWD/gpurun_out/prof_$TAG; mkdir -p $OUT; REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/tools/ablate_warp_resize.py --rot 1 --launches 10 --plans $PLAN"
@@ -11,5 +11,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
 done
 cd $REPO
-python tools/summarize_op_prof.py $OUT "k_warp_resize" 1990656000 "fused warp -> 4x resize, plan $PLAN" > $OUT/summary.txt 2>&1
+python tools/summarize_op_prof.py $OUT "$KSUB" 1990656000 "fused warp -> 4x resize, plan $PLAN" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
