@@ -26,6 +26,10 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = 256;
 
+// the row-pair kernel of the separable pass can be switched off for A/B tests (RCV_GAUSS_ROWS=0, the knob that also keeps small integer
+// Gaussians off the register-window kernel)
+static inline bool rcv_f32_pairs_off() { return rcv_knobs().gauss_rows == 0; }
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -255,6 +259,138 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     }
 }
 
+// ---- the separable pass on ROW PAIRS (round 5) ---------------------------------------------------------------------------------
+// k_filter_f32_stream pairs ADJACENT SAMPLES of one row in a packed-f32 register: tap kx of the pair starting at sample m reads
+// {p[m + kx CH], p[m + 1 + kx CH]}, which for three channels is an even-aligned register pair only for every other kx -- the rest are
+// rebuilt with moves, and the converted window is per row.  Here the two halves of a pair are the SAME sample of two consecutive
+// rows: P2[b] = {row r byte b, row r + 1 byte b} (each half one v_cvt_f32_ubyteN), every tap index is an aligned pair, the
+// horizontal pass gives he = {h(r), h(r + 1)} per column, and the vertical pass accumulates OUTPUT row pairs (y, y + 1):
+//     acc(y, y + 1) += t[ky] * {h(y + ky - RAD), h(y + 1 + ky - RAD)}
+// -- the pair that starts on the row pair's first row is he itself, the one that starts a row earlier is ho = {previous he.y, he.x}
+// (one v_pk_mov per column and row pair).  Every output sees its taps in ky order (within a row pair: ho, one ky lower, before he),
+// each chain starts with a multiply (= fma(w, x, 0) for everything a u8 store can tell apart), so the result is the oracle's, bit for
+// bit.  RAD + 1 output pairs are in flight (static slots: the loop is unrolled by RAD + 1 row pairs).  Per sample: 3.25 conversions +
+// 2 x KS / 2 packed fma + 0.5 move + the store conversion -- 12.3 instructions for 7 taps of BGR against ~15.4.
+template <int KS, int CH>
+__global__ __launch_bounds__(kBlock) void k_gauss_f32_pairs(View s, View d, FWeights<KS, true> W, int seg_rows, int gx, int gy, int nblocks, int blocks_per_xcd)
+{
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (blocks_per_xcd > 0) {
+        const int tb = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);
+        if (tb >= nblocks) return;
+        bz = tb / (gx * gy);
+        const int rem = tb - bz * gx * gy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    constexpr int BPT = 8, RAD = KS / 2, LEAD = RAD * CH, LEADW = (LEAD + 3) / 4 * 4, OFF = LEADW - LEAD, NW = (LEADW + BPT + LEAD + 3) / 4, NB = 2 * LEAD + BPT;
+    constexpr int NS = RAD + 1;   // output row pairs in flight
+    const int rowbytes = s.cols * CH;
+    const int xb0 = BPT * (bx * (int)blockDim.x + (int)threadIdx.x);
+    if (xb0 >= rowbytes) return;
+    const int ys = by * seg_rows, ye = min(s.rows, ys + seg_rows);
+    const uint8_t* sf = s.p + (size_t)bz * s.fstride;
+    uint8_t* df = d.p + (size_t)bz * d.fstride + xb0;
+    const int wstart = min(max(xb0 - LEADW, 0), rowbytes - 4 * NW);   // (threads whose window leaves the row: redone by the EDGE launch)
+    auto load_row = [&](int ry, uint32_t (&w)[NW]) __attribute__((always_inline)) {
+        ry = min(ry, ye - 1 + RAD);
+        const uint8_t* row = sf + (size_t)rcv_reflect101(ry, s.rows) * s.step + wstart;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+    };
+    auto byte_f = [](const uint32_t (&w)[NW], int b) __attribute__((always_inline)) { return (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff); };
+    f2 acc[NS][BPT];
+    float hp[BPT];   // h of the row before the current pair
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+        hp[j] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) acc[q][j] = f2{0.0f, 0.0f};
+    }
+    const int r0 = ys - RAD;   // the stream's first row; output pairs are (r0 + 2q, r0 + 2q + 1)
+    auto feed = [&](const uint32_t (&wa)[NW], const uint32_t (&wb)[NW], int R, auto pi_tag) __attribute__((always_inline)) {
+        constexpr int PI = decltype(pi_tag)::value;   // (row pair index) mod NS
+        f2 P2[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) P2[b] = f2{byte_f(wa, b), byte_f(wb, b)};
+        f2 he[BPT], ho[BPT];
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            f2 a = P2[j] * f2{W.w2[0][0], W.w2[0][0]};
+#pragma unroll
+            for (int kx = 1; kx < KS; ++kx) a = pk_fma_w(kx & 1, W.w2[kx >> 1], P2[j + kx * CH], a);
+            he[j] = a;
+            ho[j] = f2{hp[j], a.x};
+            hp[j] = a.y;
+        }
+        // vertical taps: output pair (row pair index + dq) gets ky = RAD - 1 - 2 dq from ho and ky = RAD - 2 dq from he
+#pragma unroll
+        for (int dq = RAD; dq >= -RAD - 1; --dq) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int kyo = RAD - 1 - 2 * dq, kye = RAD - 2 * dq;
+            const int slot = ((PI + dq) % NS + NS) % NS;
+            if (kyo >= 0 && kyo < KS) {
+#pragma unroll
+                for (int j = 0; j < BPT; ++j)
+                    acc[slot][j] = kyo == 0 ? ho[j] * f2{W.w2[0][0], W.w2[0][0]} : pk_fma_w(kyo & 1, W.w2[kyo >> 1], ho[j], acc[slot][j]);
+            }
+            if (kye >= 0 && kye < KS) {
+#pragma unroll
+                for (int j = 0; j < BPT; ++j)
+                    acc[slot][j] = kye == 0 ? he[j] * f2{W.w2[0][0], W.w2[0][0]} : pk_fma_w(kye & 1, W.w2[kye >> 1], he[j], acc[slot][j]);
+            }
+            if (kyo == KS - 1 || kye == KS - 1) {   // this output pair is complete: rows y, y + 1
+                const int y = (kyo == KS - 1 ? R - 1 : R) - RAD;
+                if (W.iscale != 0.0f) {   // (uniform) integer mode: floor((sum + half) / 2^shift), exact
+#pragma unroll
+                    for (int j = 0; j < BPT; ++j)
+                        acc[slot][j] = __builtin_elementwise_floor(__builtin_elementwise_fma(acc[slot][j], f2{W.iscale, W.iscale}, f2{0.5f, 0.5f}));
+                }
+                uint32_t o0[2], o1[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q].x, 0, 0u);
+                    v = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 1].x, 1, v);
+                    v = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 2].x, 2, v);
+                    o0[q] = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 3].x, 3, v);
+                    uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q].y, 0, 0u);
+                    u = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 1].y, 1, u);
+                    u = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 2].y, 2, u);
+                    o1[q] = __builtin_amdgcn_cvt_pk_u8_f32(acc[slot][4 * q + 3].y, 3, u);
+                }
+                if (y >= ys && y < ye) *(uint2*)(df + (size_t)y * d.step) = make_uint2(o0[0], o0[1]);
+                if (y + 1 >= ys && y + 1 < ye) *(uint2*)(df + (size_t)(y + 1) * d.step) = make_uint2(o1[0], o1[1]);
+            }
+        }
+    };
+    uint32_t A0[NW], A1[NW], B0[NW], B1[NW];
+    load_row(r0, A0);
+    load_row(r0 + 1, A1);
+    // the last output row ye - 1 completes with the row pair that holds row ye - 1 + RAD (he) or ye + RAD (ho)
+    for (int R = r0; R <= ye + RAD; R += 2 * NS) {
+        static_for<0, NS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i % 2 == 0) {
+                load_row(R + 2 * i + 2, B0);
+                load_row(R + 2 * i + 3, B1);
+                feed(A0, A1, R + 2 * i, I);
+            } else {
+                load_row(R + 2 * i + 2, A0);
+                load_row(R + 2 * i + 3, A1);
+                feed(B0, B1, R + 2 * i, I);
+            }
+        });
+        if constexpr (NS % 2 == 1) {   // an odd number of row pairs per block: the pair in flight sits in B
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                A0[q] = B0[q];
+                A1[q] = B1[q];
+            }
+        }
+    }
+}
+
 template <int KS, int CH, bool SEP, int BPT, bool RAG = false>
 int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float delta, float iscale)
 {
@@ -284,6 +420,14 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
         const bool xcd = nb < (1LL << 30);
         const int bpx = xcd ? (int)((nb + 7) / 8) : 0;
         const dim3 grid = xcd ? dim3((unsigned)bpx * 8u) : dim3(gx, gy, s.n);
+        if constexpr (SEP && BPT == 8 && !RAG) {
+            // where it measured faster (tools/ab_gauss_sigma.py, 64 x 4K / 64 x 1080p: BGR 3 / 5 / 7 / 11 taps -1.6 .. -3 %; 9 taps and the
+            // one-channel shapes +0 .. +11 %: 11 % fewer instructions per sample buy little -- neither kernel is bound by its instruction
+            // count); RCV_GAUSS_ROWS=1 (tests) sends every shape here
+            const bool pairs = rcv_knobs().gauss_rows == 1 || (CH == 3 && KS != 9);
+            if (pairs && !rcv_f32_pairs_off()) RCV_LAUNCH((k_gauss_f32_pairs<KS, CH>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, (int)gx, (int)gy, (int)nb, bpx);
+            else RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
+        } else
         RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
     }
     RCV_TRY(rcv_launch_check(ctx));
@@ -315,7 +459,8 @@ int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksi
     const bool wide = (s.cols * s.ch) % 8 == 0 && (uintptr_t)s.p % 8 == 0 && s.step % 8 == 0 && (s.n <= 1 || s.fstride % 8 == 0) &&
                       (uintptr_t)d.p % 8 == 0 && d.step % 8 == 0 && (d.n <= 1 || d.fstride % 8 == 0) &&
                       // (small launches -- at most ~2 rows of 8-byte threads per SIMD lane -- are latency-bound: twice the threads, half the work per row)
-                      (long long)s.rows * s.n * ((s.cols * s.ch + 7) / 8) > 128LL * 64 * 4 * ctx->cu_count;   // (one or two 4K frames, four 1080p: -15 % with 4-byte threads)
+                      ((long long)s.rows * s.n * ((s.cols * s.ch + 7) / 8) > 128LL * 64 * 4 * ctx->cu_count ||   // (one or two 4K frames, four 1080p: -15 % with 4-byte threads)
+                       (SEP && rcv_knobs().gauss_rows == 1));   // (tests: the row-pair kernel on small images)
 #define RCV_CASE(KS, CH)                                                                 \
     if (ksize == KS && s.ch == CH) {                                                     \
         if (wide) {                                                                      \

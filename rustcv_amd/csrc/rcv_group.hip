@@ -71,9 +71,10 @@ extern "C" int rcv_group_sync(rcv_group* g)
 
 // Stream timing across the group (bench.py: two batches in flight on two contexts of ONE device overlap, so no single stream's
 // events bracket the work).  start: one event on every context's stream, in rank order; stop: one event on every stream, then
-// wait for all of them.  Elapsed = the latest stop against the EARLIEST-recorded start of its device (rank order: the first
-// context of that device) -- events of one device share a clock, events of different devices do not, so a multi-device group
-// reports the maximum over its devices of each device's own span.
+// wait for all of them.  Elapsed = the latest stop against the earliest-completed start event of its device (the maximum over all
+// start / stop pairs of the device) -- events of one device share a clock, events of different devices do not, so a multi-device
+// group reports the maximum over its devices of each device's own span.  The timer uses each context's ev0 / ev1: a per-context
+// rcv_timer_start / rcv_timer_stop between the group's start and stop would overwrite them (do not mix the two).
 extern "C" int rcv_group_timer_start(rcv_group* g)
 {
     if (!g) return RCV_ERR_ARG;
@@ -92,12 +93,14 @@ extern "C" int rcv_group_timer_stop(rcv_group* g, float* elapsed_ms)
     for (rcv_ctx* c : g->ctxs) {
         RCV_TRY(rcv_bind(c));
         RCV_HIP(hipEventSynchronize(c->ev1));
-        rcv_ctx* first = c;
-        for (rcv_ctx* o : g->ctxs)
-            if (o->device == c->device) { first = o; break; }
-        float ms = 0.0f;
-        RCV_HIP(hipEventElapsedTime(&ms, first->ev0, c->ev1));
-        if (ms > best) best = ms;
+        // against EVERY start event of the device: the earliest-COMPLETED one gives the longest span (a stream that was still busy at
+        // timer_start completes its start event late; the rank-order first context need not be the earliest)
+        for (rcv_ctx* o : g->ctxs) {
+            if (o->device != c->device) continue;
+            float ms = 0.0f;
+            RCV_HIP(hipEventElapsedTime(&ms, o->ev0, c->ev1));
+            if (ms > best) best = ms;
+        }
     }
     *elapsed_ms = best;
     return RCV_OK;

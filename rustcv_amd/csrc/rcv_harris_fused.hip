@@ -107,8 +107,13 @@ typedef float F2m __attribute__((ext_vector_type(2), aligned(4)));
 // result equals harris_pipeline(yuyv_to_bgr(.)) bit for bit with 3 instead of 4 algorithmic bytes per pixel.
 // SRCK: 0 = BGR, 1 = packed YUYV, 2 = one-channel gray (cornerHarris' own input: the window starts at the Sobel stage).
 // WANT_MASK = false: response only (rcv_corner_harris): no NMS stage, no mask store.
+#ifdef RCV_HF_OCC   // (measurement: cap the registers for RCV_HF_OCC waves per SIMD)
+#define RCV_HF_OCC_ATTR __attribute__((amdgpu_waves_per_eu(RCV_HF_OCC, RCV_HF_OCC)))
+#else
+#define RCV_HF_OCC_ATTR
+#endif
 template <bool WANT_RESP, int SRCK, bool WANT_MASK = true, bool RAG = false>
-__global__ __launch_bounds__(256) void k_harris_fused(HArgs a)
+__global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
     // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are

@@ -1624,6 +1624,32 @@ def test_stream_filters_on_byte_aligned_rows(ctx, oracle, rows, cols, ch):
     src.free()
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 64, 3), (2, 61, 136, 1), (1, 9, 40, 3), (2, 5, 96, 3), (1, 2, 64, 1), (2, 130, 200, 3), (1, 1, 48, 3)])
+@pytest.mark.parametrize("ks", [3, 5, 7, 9, 11])
+def test_gaussian_sigma_row_pair_kernel(ctx, oracle, rng, knob, shape, ks):
+    """round 5: k_gauss_f32_pairs (the separable pass on row pairs: {row r, row r + 1} halves, output row pairs, RAD + 1 pairs in flight)
+    against the oracle on images of a few rows (fewer than the taps), odd heights (a half-used last output pair), row segments of
+    every parity, 1 / 3 channels, every tap count; the integer Gaussian (sigma = 0) through the same kernel where its taps allow;
+    RCV_GAUSS_ROWS=0 sends the same call to the one-row kernel"""
+    n, rows, cols, ch = shape
+    frames = rng.integers(0, 256, size=(n, rows, cols, ch) if ch > 1 else (n, rows, cols), dtype=np.uint8)
+    src = device.DeviceBatch(ctx, n, rows, cols, ch)
+    src.upload(frames)
+    for sigma in (1.3, 0.8 if ks <= 7 else 2.6):
+        want = [oracle.gaussian_blur(frames[i], ks, sigma) for i in range(n)]
+        for val, kern in ((1, "k_gauss_f32_pairs<"), (0, "k_filter_f32_stream<")):
+            knob("RCV_GAUSS_ROWS", val)
+            dst = _canary_batch(ctx, n, rows, cols, ch, pad=8)
+            names = _kernels_launched(ctx, lambda: device.gaussian_blur(src, dst, ks, sigma))
+            assert kern in names, (names, shape, ks)
+            got = dst.download()
+            for i in range(n):
+                assert np.array_equal(got[i], want[i]), (kern, shape, ks, sigma, i)
+            _assert_canaries(dst)
+            dst.free()
+    src.free()
+
+
 def _kernels_launched(ctx, fn):
     L = _ffi.lib()
     L.rcv__debug_kernels_reset()
