@@ -61,7 +61,7 @@ CONFIGS = {
     3: {"metric": "Mpixels/sec on 4K 7x7 filter2D", "batch": 64, "px": ROWS * COLS, "alg_bytes": ROWS * COLS * 6, "dtype": "u8", "bound": "hbm",
         "workload": "4K (3840x2160) u8 BGR 7x7 filter2D, integer weights >>6, batches of 64 frames (BASELINE configs[2])"},
     # fused warp -> exact 4x down-scale: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written
-    # per OUTPUT pixel.  `value` counts the 1080p OUTPUT pixels the launch produces ("quote Mpix/s on
+    # per OUTPUT pixel (DESIGN_HISTORY.md 4).  `value` counts the 1080p OUTPUT pixels the launch produces ("quote Mpix/s on
     # output pixels and, separately, input pixels"); config.input_mpix_s is the 8K source-pixel rate
     4: {"metric": "Mpixels/sec (1080p output pixels) on 8K warpAffine + resize->1080p", "batch": 32, "px": 1080 * 1920, "alg_bytes": 1080 * 1920 * 30,
         "dtype": "f32 bilinear on u8", "bound": "hbm",

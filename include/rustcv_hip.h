@@ -123,7 +123,7 @@ int         rcv_group_sync(rcv_group* g);                /* every context's stre
  * flight on one GPU (the reference's caller is one: rustcv/src/videoio/mod.rs:168-265 feeds examples/camera_demo.rs:50-76):
  * batch k on context k % 2, each context with its own src/dst buffers; the launches of consecutive batches overlap and fill
  * each other's ramp-up and tail (measured on 64 x 4K 7x7 filter2D: one batch finishes every 0.55 ms instead of every 0.61 ms,
- * DESIGN.md 4.1 round 4).  Ordering holds per context only.
+ * DESIGN_HISTORY.md 4.1 round 4).  Ordering holds per context only.
  * Group timer: events on every context's stream; elapsed = latest stop against the first start (per device).                */
 int         rcv_group_timer_start(rcv_group* g);
 int         rcv_group_timer_stop(rcv_group* g, float* elapsed_ms);   /* records, waits for every stream, returns ms */

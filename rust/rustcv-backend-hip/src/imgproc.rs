@@ -10,8 +10,9 @@
 //!     gradients and the f32 Harris response.
 //!   * errors: a negative `rcv` status becomes `Err(HipError)`, the way `rustcv-camera/src/backend/macos/mod.rs:145-164,230-241`
 //!     maps the bridge's codes to `CameraError`; the reference's silent length-guard returns (RCV_NOOP) stay `Ok(false)`.
-//!   * handles own their C object and free it in `Drop` (macos/mod.rs:264-272); `Send`, not `Sync`: one thread per context
-//!     (bridge.h:4-7).
+//!   * handles own their C object and free it in `Drop` (macos/mod.rs:264-272).  `HipContext` is `Send`, not `Sync`: one thread per
+//!     context (bridge.h:4-7).  `DeviceBatch` and `StagingRing` are neither (since round 4: they hold a raw pointer into their
+//!     context's device and must be used and dropped on the thread that owns the context).
 //!
 //! SOURCE ONLY -- never compiled in the build image (no rustc / cargo); see INTEGRATION.md.
 use crate::ffi::*;

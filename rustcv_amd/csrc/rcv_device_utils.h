@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 // v_ashr_pk_u8_i32 D, S0, S1, S2 (gfx950):  D[7:0] = sat_u8(S0 >> S2), D[15:8] = sat_u8(S1 >> S2), D[31:16] are PRESERVED
-// (measured on MI355X: D preset to 0xDEADBEEF comes back 0xDEADxxxx).  The ROCm 7.2 compiler pattern-
+// (measured on MI355X: D preset to 0xDEADBEEF comes back 0xDEADxxxx; DESIGN_HISTORY.md 6).  The ROCm 7.2 compiler pattern-
 // matches pairs of clamp(x >> s, 0, 255) into this instruction and then treats D[31:16] as zero, which silently
 // corrupts the neighbouring bytes.  The BUILTIN, in contrast, is typed as a 16-bit result and is handled correctly, and
 // being a real instruction to the compiler it also gets the MFMA -> VALU wait states that an inline-asm copy would miss

@@ -1,7 +1,7 @@
 // rcv_filter7_mfma.hip -- filter2D with integer (i8) weights, ksize 3/5/7, u8 BGR -> u8 BGR, as a
 // sliding-window stencil whose 49 MACs per sample run on the i8 matrix cores of gfx950.
 //
-// Why MFMA here: the op moves 6 algorithmic bytes per pixel but needs
+// Why MFMA here (DESIGN_HISTORY.md §4): the op moves 6 algorithmic bytes per pixel but needs
 // 147 MACs per pixel.  At the 70 %-of-HBM target (5.6 TB/s) that is 137 T MAC/s -- beyond the f32 VALU
 // peak (78.6 T FMA/s) and right at the v_dot4 issue limit -- so the VALU cannot keep this kernel
 // HBM-bound.  One v_mfma_i32_16x16x64_i8 per 16x16 output tile and per kernel-row PAIR does
@@ -32,7 +32,7 @@
 //     pixels of the first/last strip by byte permutes in registers;
 //   * epilogue: v_ashr_pk_u8_i32 does shift + saturate + pack, the 12 bytes a lane owns per tile go through a per-wave
 //     LDS transpose so that every global store is a 16-byte vector in 192-byte contiguous runs.
-// Measured on MI355X (4K, 64 frames, sustained clocks): 0.59-0.66 ms per launch = 60-67 % of 8 TB/s; the
+// Measured on MI355X (4K, 64 frames, sustained clocks, DESIGN_HISTORY.md 4.1 / 5): 0.59-0.66 ms per launch = 60-67 % of 8 TB/s; the
 // same launch with the MFMAs and LDS reads removed takes ~0.58 ms, loads alone ~0.27-0.31 ms, stores alone 0.29 ms.
 #include "rcv_internal.h"
 #include "rcv_kernels.h"

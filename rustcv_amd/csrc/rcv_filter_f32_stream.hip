@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
 {
     // Block order (speed only): hardware places block b on XCD b % 8; with blocks_per_xcd > 0 (one-dimensional grid) every XCD works
     // through its own contiguous eighth of the (frame, row segment, column block) list, so that what ONE XCD has in flight is a
-    // compact address range
+    // compact address range (DESIGN_HISTORY.md 6)
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (blocks_per_xcd > 0) {
         const int tb = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);

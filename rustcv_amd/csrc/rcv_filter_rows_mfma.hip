@@ -2,7 +2,7 @@
 // on the i8 matrix cores whose data operands never leave the register file: no LDS, no barrier, nothing shared between waves.
 // (Round 2's north-star kernel; the round-1 strip kernel, rcv_filter7_mfma.hip, keeps the shapes this one does not take.)
 //
-// Why MFMA at all: 147 MACs per pixel against 6 bytes -- the vector ALU cannot keep the op HBM-bound.
+// Why MFMA at all: 147 MACs per pixel against 6 bytes (DESIGN_HISTORY.md 4.1) -- the vector ALU cannot keep the op HBM-bound.
 //
 // The matrix product.  Per colour plane a 16-pixel output tile needs a 22-pixel source window, so the 64-deep data operand of
 // v_mfma_i32_16x16x64_i8 holds the 32-pixel windows of TWO source rows:
@@ -38,7 +38,7 @@
 // 0.563 / 0.573 ms; 3 pairs (8 waves) 0.557-0.566; 6 / 4 waves 0.583 / 0.62 -- more streams in flight do not help on this
 // memory system, deeper streams do (the memory-only variant of the kernel moves the same way).  Default: 3 pairs.
 //
-// What was tried on the way (DESIGN.md 4.1 has the numbers): byte-space operands straight from global memory with one kernel
+// What was tried on the way (DESIGN_HISTORY.md 4.1 has the numbers): byte-space operands straight from global memory with one kernel
 // row per MFMA (taps every 3rd byte; 7 MFMAs per tile, no VALU de-interleave) -- correct, but 1.75x the matrix work pulls the
 // clock from 2.25 to 1.95 GHz and the per-CU memory path with it; the same with v_smfmac_i32_16x16x128_i8 (the byte-space band
 // IS 2:4 sparse; layout probed with tools/probe_smfmac.hip) -- half the instructions, each twice as long.
@@ -570,7 +570,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
 }
 
 // ---- chained bands (round 4) ---------------------------------------------------------------------------------------------------
-// What the memory system wants (tools/ablate_walk*.py, ablate_bands.py): the strip-walker copy -- this
+// What the memory system wants (tools/ablate_walk*.py, ablate_bands.py; DESIGN_HISTORY.md 4.1 round 4): the strip-walker copy -- this
 // kernel's access pattern without the kernel -- runs 6-10 % faster when the bands are 16-32 rows instead of 103: what one XCD's 256
 // waves touch at a time is then a window of ~500 rows (6 MB) instead of a whole frame (25 MB).  The one-band-per-wave kernel cannot
 // use short bands: every band costs a wave launch, the weight tables, 2 * RAD halo rows and a pipeline fill (32-row bands: 0.587
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
 {
     // A workgroup is `wpb` independent waves (nothing is shared, no barrier): wave w of workgroup b takes item slot
     // (b >> 3) * wpb + w of XCD b & 7, so that the waves of one workgroup -- one CU -- are neighbouring strips of one band: their
-    // seam lines meet in that CU's L1 and the CU streams wpb * 768 contiguous bytes per row (RCV_FR_WPB).
+    // seam lines meet in that CU's L1 and the CU streams wpb * 768 contiguous bytes per row (RCV_FR_WPB; DESIGN_HISTORY.md 4.1).
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long t_start = 0;
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     // order 0.551 ms; bands dealt round-robin to the XCDs (order 1: each XCD's waves spread over eight frames) 0.600 ms; one
     // XCD's concurrent bands spread over its whole eighth 0.639 against 0.579 ms -- the wider the address range an XCD touches
     // at one time, the slower its memory path (translation reach per XCD is the likely cause).  RCV_FR_ORDER keeps it measurable.
-    // (Round 3, DESIGN.md 4.1 "sweep orders": order 1 with bands down to 8 rows -- the whole GPU inside one moving window of a
+    // (Round 3, DESIGN_HISTORY.md 4.1 "sweep orders": order 1 with bands down to 8 rows -- the whole GPU inside one moving window of a
     // few MB -- and a plain raster over (band, strip) were measured too: never better than this order, short bands much worse.)
     const int strip = slot % a.nstrips;
     const int bi = slot / a.nstrips;   // dispatch order of this band on its XCD

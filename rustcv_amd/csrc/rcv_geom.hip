@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_affine_bgr(View s, View d, Affi
 // ---- warpAffine BGR through an LDS-staged source patch ------------------------------------------------------------------
 // k_warp_affine_bgr is bound by its tap gathers: every pixel costs two 12-byte vector loads whose 64 lanes spread over many
 // cache lines, and the texture-address path spends ~32 cycles on each such wave instruction whatever its width (4 / 8 / 12 /
-// 16-byte tap loads time the same) -- 512 of them per wave and frame against ~330 cycles of arithmetic.  Here a
+// 16-byte tap loads time the same; DESIGN_HISTORY.md 4) -- 512 of them per wave and frame against ~330 cycles of arithmetic.  Here a
 // workgroup (4 waves, an output tile of 64 columns x 32 rows: near-square, so the rotated source patch is only ~1.4x the
 // tile) copies the patch into LDS with coalesced 12-byte loads of 4 pixels each -- three per thread and frame at 7 degrees instead
 // of sixteen gathers -- unpacked to one dword per pixel {b g r x}: a pixel's two taps of a row are then two consecutive dwords

@@ -78,7 +78,7 @@ struct rcv_ctx {
 // Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), twelve in all; nothing
 // needs them in production and no tuning parameter is among them (those are arguments of the measurement entries in
 // librustcv_hip_bench.so).  Read ONCE per process -- a launch-bound call (a single 1080p frame: 6 us) must not pay for getenv -- and
-// again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 lists each with the test that uses it.
+// again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 names them; DESIGN_HISTORY.md 5 lists each with the test that uses it.
 struct RcvKnobs {
     int f7_rows;          // RCV_F7_ROWS       row-streaming MFMA kernel: 1 every eligible shape, 0 never, -1 (unset) by size
     int f7_no_lat;        // RCV_F7_NO_LAT     small launches take the pipelined strip kernel instead of its latency variant

@@ -3,7 +3,7 @@
 //
 // One WAVE owns a strip of 512 px (64 lanes x 8 px: 512 B of gray, 1024 B of each i16 output per row -- whole 128-B
 // lines, so no two waves ever write parts of the same line; strips with seams inside a line measured ~35 % lower
-// store rates) and walks down a row segment.  Per source row a lane loads its 8 pixels as one
+// store rates, see DESIGN_HISTORY.md 4.1) and walks down a row segment.  Per source row a lane loads its 8 pixels as one
 // 8-byte vector, gets the pixel left/right of its run from the neighbouring lanes with one DPP wave shift each (the
 // wave's outermost two pixels come from one extra byte load per lane 0 / lane 63), and forms the horizontal parts
 // with packed 16-bit math:
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_sobel_rows(SobelArgs a)
     const int lane = threadIdx.x & 63;
     // Block order (speed only): hardware places block b on XCD b % 8.  Each XCD works through its own contiguous eighth of the
     // (frame, segment, strip) list, so that what ONE XCD has in flight is a compact address range (measured on the filter
-    // kernel: -9 % against dealing neighbouring work round-robin to the XCDs)
+    // kernel: -9 % against dealing neighbouring work round-robin to the XCDs, DESIGN_HISTORY.md 6)
     const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));   // scalar: row indices and row bases on the SALU
     if (wid >= a.total_waves) return;

@@ -381,7 +381,7 @@ int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
     return rcv_launch_check(ctx);
 }
 
-#ifdef RCV_WRL_BENCH   // measurement build only (librustcv_hip_bench.so): measured, bit-exact, slower -- DESIGN.md 9, profiles/r05_warp_resize_*
+#ifdef RCV_WRL_BENCH   // measurement build only (librustcv_hip_bench.so): measured, bit-exact, slower -- DESIGN.md 6.2, profiles/r05_warp_resize_*
 // ---- the same launch as a FRAME LOOP (round 5) -----------------------------------------------------------------------------------
 // One affine map serves every frame of a batch, so everything k_warp_resize_box computes before its first load -- the four sample
 // coordinates, the interior test, floor / fraction, the tap offsets and alignment shifts: ~150 of its 278 VALU instructions per
@@ -391,7 +391,7 @@ int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
 // software-pipelined by hand, two frames deep with two register sets (A, B): the gathers of frame f + 2 are issued before the
 // arithmetic of frame f + 1, so a wave always has 8-16 gathers in flight and does not depend on occupancy to hide their latency
 // (round 4's frame groups without the pipeline lost: 0.81-1.18 against 0.70 ms).
-// Counting rules of gfx9's one in-order vmcnt the loop is shaped by (tests/test_isa_waits.py pins the numbers):
+// Counting rules of gfx9's one in-order vmcnt the loop is shaped by (DESIGN_HISTORY.md 6; tests/test_isa_waits.py pins the numbers):
 //  * no load or store of the loop sits behind a lane-dependent branch: every lane stores one dword of its quad's 12 bytes (lane 3
 //    repeats lane 2's dword), coordinates are clamped into the image by whole quads (a clamped quad recomputes and rewrites its
 //    neighbour's bytes with the same values), so ragged tiles need no bounds test;
@@ -585,7 +585,7 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
             }
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
-            // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN.md 6)
+            // rotated source footprint less -- measured 0.834 -> 0.706 ms on 32 x 8K -> 1080p (sweep: DESIGN_HISTORY.md 6)
             constexpr unsigned kLds = 27136;
             if (S == 2) RCV_LAUNCH(k_warp_resize_box<2>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A, 0, 0, (int)grid.x, (int)grid.y);
             else RCV_LAUNCH(k_warp_resize_box<4>, grid, dim3(kBlock), kLds, ctx->stream, s, d, A, 0, 0, (int)grid.x, (int)grid.y);

@@ -116,7 +116,7 @@ class NativeGroup:
     def in_flight(cls, device, depth=2):
         """`depth` contexts (= HIP streams) on ONE GPU: a frame stream keeps `depth` batches in flight, batch k on
         ctxs[k % depth], every context with its own src / dst buffers, so that consecutive launches overlap (64 x 4K 7x7
-        filter2D at depth 2: one batch per 0.55 ms instead of 0.61 ms -- DESIGN.md 4.1 round 4).  Ordering holds per context."""
+        filter2D at depth 2: one batch per 0.55 ms instead of 0.61 ms -- DESIGN_HISTORY.md 4.1 round 4).  Ordering holds per context."""
         return cls([int(device)] * max(1, int(depth)))
 
     def timer_start(self):

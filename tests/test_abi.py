@@ -315,3 +315,14 @@ def test_product_library_is_slim():
     assert not [s for s in exported if "graph" in s or "bench" in s or "stripwalk" in s]
     bench = subprocess.run(["nm", "-D", "--defined-only", _ffi.BENCH_LIB_PATH], capture_output=True, text=True).stdout
     assert {"rcv__filter_rows_bench", "rcv__warp_resize_bench", "rcv__membench", "rcv__stripwalk", "rcv__storebench", "rcv__clock_probe"} <= set(re.findall(r" T (rcv_\w+)", bench))
+
+
+def test_design_md_is_the_short_current_state_document():
+    """DESIGN.md = current state in <= 200 lines of <= 160 characters; the per-round studies live in DESIGN_HISTORY.md"""
+    lines = open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")
+    assert len(lines) <= 200, len(lines)
+    assert max(len(l) for l in lines) <= 160, [i + 1 for i, l in enumerate(lines) if len(l) > 160]
+    assert os.path.exists(os.path.join(ROOT, "DESIGN_HISTORY.md"))
+    text = "\n".join(lines)
+    for must in ("k_filter_rows_chain", "k_warp_resize_stage", "k_harris_fused", "parity unpinned", "no collective", "Out of scope"):
+        assert must in text, must

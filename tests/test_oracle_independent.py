@@ -1,6 +1,6 @@
 """The C oracle against independent second implementations (tests/npref.py, written from SURVEY.md §8-A and the reference's
 Rust, not from the C code) on images of at least 200 x 300: the pin of the oracle rows that the reference itself cannot pin
-(DESIGN.md §3 lists, per op, which check pins it)."""
+(DESIGN_HISTORY.md §3 lists, per op, which check pins it)."""
 import numpy as np
 import pytest
 

@@ -265,7 +265,7 @@ def main():
     sg.free(); dg.free()
     d = B(32, 1080, 1920, 3)
     record("warpAffine + resize 8K -> 1080p FUSED (next row f1)", "8K batch=32/GPU", s.n, 1920 * 1080, 30,
-           lambda: device.warp_affine_resize(s, d, M, 4320, 7680), valu=278,
+           lambda: device.warp_affine_resize(s, d, M, 4320, 7680), valu=202,   # (k_warp_resize_stage, SQ_INSTS_VALU 2.09e8 per launch: ~160 in the frame loop + plans + border tiles; the gather kernel: 278)
            note="30 B per OUTPUT px: the centre 2x2 warped pixels of each 4x4 block tap a 3x3 source block (27 B) + 3 B written; "
                 "the unfused pair moves 6 B/px of 8K intermediate on top")
     d2 = B(32, 2880, 5120, 3)
