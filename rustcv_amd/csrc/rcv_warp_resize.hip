@@ -2,6 +2,7 @@
 // (8K warpAffine + resize -> 1080p).  Not in the reference; semantics = resize(warp_affine(.)) of SURVEY.md 8-A ==
 // oracle/rcv_oracle.c orc_resize(orc_warp_affine(.)), bit for bit.
 #include "rcv_geom_dev.h"
+#include <limits.h>
 
 namespace {
 
@@ -209,20 +210,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
             lo = min(lo, y0[i]);
             hi = max(hi, y0[i] + 1);
         }
-        atomicMin(&scal[0], lo);
-        atomicMax(&scal[1], hi);
+        // (an affine map is monotone along a wave's 64 x 1 pixels: the extremes of a wave sit in its first and last lane -- two lanes
+        //  instead of 64 on one LDS address)
+        if (lane == 0 || lane == 63) {
+            atomicMin(&scal[0], lo);
+            atomicMax(&scal[1], hi);
+        }
     }
     __syncthreads();
     const int r0 = scal[0];
     staged = staged && scal[1] - r0 < 64;
     if (staged) {
+        // Byte range per source row.  Along a wave both x0 and y0 of a sample are monotone (affine map, one output row per wave), so
+        // the lanes of a wave that tap one source row are a contiguous run and the run's extreme columns sit at its two ends: only
+        // lanes whose row differs from a neighbour's (or that have no neighbour inside their 16-lane DPP row) touch the LDS -- at 0
+        // degrees two lanes per wave and sample instead of 64 on one address (the plan of the first version cost 0.73 against 0.62 ms
+        // for the gather kernel at 0 degrees; 8-way conflicts at 7 degrees)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = y0[i] - r0, b = 3 * x0[i];
-            atomicMin(&rowmin[r], b);
-            atomicMax(&rowmax[r], b + 5);
-            atomicMin(&rowmin[r + 1], b);
-            atomicMax(&rowmax[r + 1], b + 5);
+            const int rl = (int)__builtin_amdgcn_update_dpp((unsigned)-1, (unsigned)r, 0x111, 0xf, 0xf, false);   // row_shr:1 (lane - 1; none: -1)
+            const int rr = (int)__builtin_amdgcn_update_dpp((unsigned)-1, (unsigned)r, 0x101, 0xf, 0xf, false);   // row_shl:1 (lane + 1; none: -1)
+            if (rl != r || rr != r) {
+                atomicMin(&rowmin[r], b);
+                atomicMax(&rowmax[r], b + 5);
+                atomicMin(&rowmin[r + 1], b);
+                atomicMax(&rowmax[r + 1], b + 5);
+            }
         }
     }
     __syncthreads();
@@ -346,6 +360,56 @@ bool wrl_ok(const View& s, const View& d)
 {
     return ((uintptr_t)s.p & 3) == 0 && (s.step & 3) == 0 && (s.fstride & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
            (unsigned long long)s.rows * s.step < (1ull << 32) && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
+}
+
+// Does the staged kernel's plan hold for this map?  The plans of nine tiles spread over the output (a 3 x 3 grid at 1/4, 1/2, 3/4 of
+// the tile grid), evaluated on the host with the kernel's own arithmetic: source rows a tile spans and 16-byte chunks of its row
+// pieces.  Interior tiles of one map differ only by the fractional position of their corner (751 +- 11 chunks at 7 degrees), so the
+// sample decides for the launch; tiles with a tap outside the source say nothing.  Maps that fail (steeper rotations, magnification)
+// would send every workgroup down the staged kernel's fallback, which is much slower than the gather kernel itself (15 degrees:
+// 1.83 against 1.06 ms), so they stay on the gather kernel.
+bool wrs_fits(const View& s, const View& d, const Affine& A, int S)
+{
+    const int gx = (d.cols + 63) / 64, gy = (d.rows + 3) / 4, o = S / 2 - 1;
+    int judged = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int bx = gx * (1 + t % 3) / 4, by = gy * (1 + t / 3) / 4;
+        int lo = INT_MAX, hi = INT_MIN, rmin[64], rmax[64];
+        bool interior = true;
+        for (int pass = 0; pass < 2 && interior; ++pass) {
+            if (pass == 1) {
+                if (hi - lo >= 64) return false;
+                for (int r = 0; r <= hi - lo; ++r) { rmin[r] = INT_MAX; rmax[r] = -1; }
+            }
+            for (int ty = 0; ty < 4 && interior; ++ty)
+                for (int tx = 0; tx < 64 && interior; ++tx) {
+                    const int x = bx * 64 + tx, y = by * 4 + ty;
+                    const int xq = min(x & ~3, d.cols - 4) + (x & 3), yq = min(y, d.rows - 1);
+                    for (int i = 0; i < 4; ++i) {
+                        const float fxx = (float)(S * xq + o + (i & 1)), fyy = (float)(S * yq + o + (i >> 1));
+                        const float sx = fmaf(A.m[0], fxx, fmaf(A.m[1], fyy, A.m[2])), sy = fmaf(A.m[3], fxx, fmaf(A.m[4], fyy, A.m[5]));
+                        if (!(sx >= 0.0f && sx < (float)(s.cols - 3) && sy >= 0.0f && sy < (float)(s.rows - 1))) { interior = false; break; }
+                        const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+                        if (pass == 0) {
+                            lo = min(lo, y0);
+                            hi = max(hi, y0 + 1);
+                        } else {
+                            for (int k = 0; k < 2; ++k) {
+                                rmin[y0 + k - lo] = min(rmin[y0 + k - lo], 3 * x0);
+                                rmax[y0 + k - lo] = max(rmax[y0 + k - lo], 3 * x0 + 5);
+                            }
+                        }
+                    }
+                }
+        }
+        if (!interior) continue;
+        int total = 0;
+        for (int r = 0; r <= hi - lo; ++r)
+            if (rmax[r] >= 0) total += (rmax[r] >> 4) - (rmin[r] >> 4) + 1;
+        if (total > kStageChunks) return false;
+        ++judged;
+    }
+    return judged > 0;
 }
 
 // host side of the staged kernel.  order: 0 raster grid, 1 XCD-contiguous runs of the whole list, 2 synchronous stripes
@@ -576,12 +640,15 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            // batches of 8+ frames, 4x: the staged kernel (a tile's plan is paid once per frame group of <= 11 frames: 32 frames = 3 groups;
-            // 32 x 8K -> 1080p at 7 degrees 0.69 against 0.72 ms, profiles/r05_warp_resize_staged.txt).  Fewer frames per tile do not
-            // repay the plan, and the 2x footprints were not measured: both stay on the gather kernel
-            if (S == 4 && d.n >= 8 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d)) {
+            // batches of 16+ frames, 4x, maps whose tile footprints fit: the staged kernel (a tile's plan is paid once per frame group of
+            // <= 11 frames: 32 frames = 3 groups).  32 x 8K -> 1080p: 0.57 against 0.62 ms at 0 degrees, 0.67 / 0.68 at 3, 0.67-0.69 /
+            // 0.71-0.72 at 7; 16 frames: -4 % / +-1 % / -4 %; 8 frames +2 .. +9 % (the plan is not repaid): tools/sweep_warp_resize_angles.sh,
+            // profiles/r05_warp_resize_angles.txt.  The 2x footprints were not measured: they stay on the gather kernel
+            if (S == 4 && d.n >= 16 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits(s, d, A, S)) {
                 const int groups = (d.n + 10) / 11;
-                return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, 0, 0, 0u, 0);
+                // tiles in blocks of 2 x 4, dealt to the XCDs in turn: the lines at the ends of a tile's row pieces are hits in the L2 of the
+                // XCD that runs its neighbours (FETCH 4.16 -> 3.4 GB; -1.5 .. -4 % at 0 / 3 / 7 / 10 degrees once the plan was cheap)
+                return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, 3, 2 + 256 * 4, 0u, 0);
             }
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the
