@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
 constexpr int kStageChunks = RCV_STAGE_CHUNKS, kStageLoads = kStageChunks / 256, kStageBuf = kStageChunks * 16;   // chunks (16 B) per buffer: three per thread
 
 template <int S, int DBG = 0, int OCC = 5>   // OCC: waves per SIMD the register allocation aims at
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_warp_resize_stage(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int per_xcd, int strip, int pad)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_warp_resize_stage(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int per_xcd, int strip, int pad, int zfill)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t wrs_lds[];   // 2 x kStageBuf (+ whatever the host adds to cap the occupancy)
     int bx, by, bz;
@@ -191,12 +191,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     // plan tables: alias the SECOND buffer (its first load is issued behind the barrier every table read has passed)
     int* const rowmin = (int*)(wrs_lds + kStageBuf);   // [64] first byte a row's taps need, then 16 * (first chunk in LDS - first chunk in the row)
     int* const rowmax = rowmin + 64;                   // [64] last byte; then the row's first chunk in the list
-    int* const goff = rowmax + 64;                     // [64] byte offset of the row's first chunk inside a frame
+    int* const goff = rowmax + 64;                     // [64] the row's first chunk, counted from the row start (< 0: left of the image)
     int* const scal = goff + 64;                       // [0] lowest row, [1] highest row, [2] chunks in the list
     uint8_t* const map = (uint8_t*)(scal + 4);         // [kStageChunks] chunk -> row of the tile
-    if (tid < 64) { rowmin[tid] = 0x7fffffff; rowmax[tid] = -1; }
+    if (tid < 64) { rowmin[tid] = 0x7fffffff; rowmax[tid] = (int)0x80000000; }
     if (tid == 0) { scal[0] = 0x7fffffff; scal[1] = -0x7fffffff; scal[2] = 0; }
-    bool staged = __syncthreads_and(inter) != 0;       // (the barrier also publishes the table initialisation)
+    // zfill (rows whose length is a multiple of 16 bytes: no chunk straddles a row end): tiles at the source border are staged too, on
+    // a VIRTUAL source that is zero outside the image -- chunks outside the rows / outside a row are not fetched (buffer range: zeros
+    // arrive in LDS), which is the constant border tap by tap; a sample the specification sets to 0 without reading taps (not
+    // sx > -1 && sx < cols && sy > -1 && sy < rows; NaN coordinates included) gets zero weights on a pixel outside the image.
+    bool staged = zfill != 0 || __syncthreads_and(inter) != 0;
+    if (zfill != 0) __syncthreads();                   // (the barrier also publishes the table initialisation)
     int x0[4], y0[4];
     f2 fxy[4];
     if (staged) {
@@ -207,12 +212,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
             fxy[i] = f2{sx[i] - x0f, sy[i] - y0f};
             x0[i] = (int)x0f;
             y0[i] = (int)y0f;
+            const bool inx = sx[i] > -1.0f && sx[i] < (float)s.cols, iny = sy[i] > -1.0f && sy[i] < (float)s.rows;
+            if (!(inx && iny)) {   // value 0: zero weights on a tap pair whose first pixel lies outside the image, next to the tile's own rows / columns
+                if (!inx) x0[i] = sx[i] >= (float)s.cols ? s.cols : -2;   // (NaN: -2)
+                if (!iny) y0[i] = sy[i] >= (float)s.rows ? s.rows : -2;
+                fxy[i] = f2{0.0f, 0.0f};
+            }
             lo = min(lo, y0[i]);
             hi = max(hi, y0[i] + 1);
         }
         // (an affine map is monotone along a wave's 64 x 1 pixels: the extremes of a wave sit in its first and last lane -- two lanes
         //  instead of 64 on one LDS address)
-        if (lane == 0 || lane == 63) {
+        //  (border tiles: samples pointed at row -2 break the order, so there a lane also reports when its value differs from its
+        //  neighbour's)
+        const int lol = (int)__builtin_amdgcn_update_dpp(0x7fffffffu, (unsigned)lo, 0x111, 0xf, 0xf, false);
+        const int hil = (int)__builtin_amdgcn_update_dpp(0x80000001u, (unsigned)hi, 0x111, 0xf, 0xf, false);
+        if (lane == 0 || lane == 63 || (zfill != 0 && (lol != lo || hil != hi))) {
             atomicMin(&scal[0], lo);
             atomicMax(&scal[1], hi);
         }
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     __syncthreads();
     if (staged && wave == 0) {   // one wave: chunk counts of the rows, their prefix sums, the chunk -> row map
         const int mn = rowmin[lane], mx = rowmax[lane];
-        const int qs = mn >> 4, len = mx >= 0 ? (mx >> 4) - qs + 1 : 0;
+        const int qs = mn >> 4, len = mn != 0x7fffffff ? (mx >> 4) - qs + 1 : 0;
         // pad = 1 (measurement): an ODD number of chunk slots per row (the last one possibly unused).  Along a wave the rows change every
         // other lane at the same offset inside the piece, so with 64- or 68-dword pieces lanes l, l + 2, l + 4, ... meet in one bank
         // (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles); odd counts put them 4 (mod 8) dwords apart.  Measured: -0.5 % (the LDS is not
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
             for (int i = 0; i < slots; ++i) map[cb + i] = (uint8_t)(i < len ? lane : 255);   // (255: a slot nothing is loaded into)
         rowmin[lane] = 16 * (cb - qs);
         rowmax[lane] = cb;
-        goff[lane] = (int)((unsigned)(r0 + lane) * (unsigned)s.step + 16u * (unsigned)qs);
+        goff[lane] = qs;   // (the row's first chunk, in chunks from the row start: may be negative)
     }
     __syncthreads();
     const int total = scal[2];
@@ -277,7 +292,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
         voff[j] = 0xffffff00u;
         if (c < total) {
             const int r = map[c];
-            if (r != 255) voff[j] = (unsigned)goff[r] + 16u * (unsigned)(c - rowmax[r]);
+            if (r != 255) {
+                const int row = r0 + r, q = goff[r] + (c - rowmax[r]);   // chunk q of source row `row`: fetched only if it lies inside the image
+                if (row >= 0 && row < s.rows && q >= 0 && 16 * q < s.cols * 3) voff[j] = (unsigned)row * (unsigned)s.step + 16u * (unsigned)q;
+            }
         }
     }
     const int nload = (total + 255) >> 8;   // load instructions that carry chunks (workgroup-uniform)
@@ -424,6 +442,7 @@ int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
     int per = order == 1 ? (int)((tiles + 7) / 8) : (order == 2 ? -pg : 0);
     dim3 grid = order == 1 ? dim3((unsigned)(8 * per)) : (order == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
     const int pad = (strip >> 16) & 1;   // (measurement: + 65536 = an odd number of chunk slots per row)
+    const int no_zfill = (strip >> 17) & 1;   // (measurement: + 131072 = border tiles on the gather path)
     strip &= 0xffff;
     if (order == 3) {   // blocks of bw x bh tiles (strip = bw + 256 * bh), dealt to the XCDs in turn
         const int bw = max(strip & 255, 1), bh = max((strip >> 8) & 255, 1);
@@ -432,13 +451,14 @@ int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
         grid = dim3((unsigned)(((nb + 7) / 8) * 8 * bw * bh));
     }
     const unsigned lds = 2 * kStageBuf + extra_lds;
-#define WRS_GO(S_, D_) RCV_LAUNCH((k_warp_resize_stage<S_, D_>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad)
+    const int zfill = (s.cols * 3) % 16 == 0 && !no_zfill ? 1 : 0;
+#define WRS_GO(S_, D_) RCV_LAUNCH((k_warp_resize_stage<S_, D_>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad, zfill)
     if (S == 2) WRS_GO(2, 0);
 #ifdef RCV_WRL_BENCH
     else if (dbg == 1) WRS_GO(4, 1);
     else if (dbg == 2) WRS_GO(4, 2);
-    else if (occ == 4) RCV_LAUNCH((k_warp_resize_stage<4, 0, 4>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad);
-    else if (occ == 6) RCV_LAUNCH((k_warp_resize_stage<4, 0, 6>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad);
+    else if (occ == 4) RCV_LAUNCH((k_warp_resize_stage<4, 0, 4>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad, zfill);
+    else if (occ == 6) RCV_LAUNCH((k_warp_resize_stage<4, 0, 6>), grid, dim3(kBlock), lds, ctx->stream, s, d, A, fpg, gx, gy, groups, per, strip, pad, zfill);
 #endif
     else WRS_GO(4, 0);
 #undef WRS_GO

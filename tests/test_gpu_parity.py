@@ -1453,6 +1453,39 @@ def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, 
     dst.free()
 
 
+@pytest.mark.parametrize("fpg,order,strip", [(1, 0, 0), (3, 3, 2 + 256 * 4), (5, 1, 0), (2, 0, 131072)])
+@pytest.mark.parametrize("M", ["left", "right", "top", "bottom", "corner", "rot7out", "far", "farneg", "nan", "inf", "flip", "zero", "graze-1", "grazecols", "big"])
+def test_warp_affine_resize_staged_border_tiles(ctx, oracle, rng, fpg, order, strip, M):
+    """round 5: tiles at the source border on the staged path (rows of a multiple of 16 bytes: `zfill`): chunks outside the image are not
+    fetched and arrive as zeros (the constant border tap by tap), samples the specification zeroes without reading taps get zero weights
+    on a pixel outside the image.  Maps that leave the source on every side and at a corner, tiles wholly outside, maps thousands of
+    pixels away, NaN / inf / all-zero matrices, a mirrored map, coordinates grazing -1 and cols exactly, a magnifying map (footprint
+    too large: fallback); strip + 131072: the same launch with border tiles on the gather path.  Oracle bytes, canaries."""
+    dr, dc = 44, 264
+    mr, mc = 4 * dr, 4 * dc
+    sr, sc = 150, 1040                      # 1040 * 3 = 3120 = 16 * 195
+    c7, s7 = np.cos(np.deg2rad(7.0)), np.sin(np.deg2rad(7.0))
+    Ms = {"left": [1, 0, -300.25, 0, 1, 3.5], "right": [1, 0, 400.75, 0, 1, 2.25], "top": [1, 0, 5.5, 0, 1, -70.5], "bottom": [1, 0, 7.25, 0, 1, 60.75],
+          "corner": [1, 0, -200.5, 0, 1, -90.25], "rot7out": [c7, -s7, -40.5, s7, c7, -30.25], "far": [1, 0, 1e6, 0, 1, 0], "farneg": [1, 0, -3e5, 0, 1, -2e5],
+          "nan": [np.nan, 0, 0, 0, 1, 0], "inf": [1, np.inf, 3, 0, 1, 0], "flip": [-1, 0, mc + 5.5 - 30, 0, -1, mr + 3.25 - 20], "zero": [0, 0, 5.5, 0, 0, 7.25],
+          "graze-1": [1, 0, -2.0, 0, 1, -2.0], "grazecols": [1, 0, float(sc - mc + 1), 0, 1, float(sr - mr + 1)], "big": [2.5, 0, 0, 0, 2.5, 0]}[M]
+    Ms = np.array(Ms, np.float32)
+    n = 5
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + 16)
+    dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+    frames = rng.integers(1, 256, size=(n, sr, sc, 3), dtype=np.uint8)     # (no zero pixels: a wrongly fetched tap shows)
+    src.upload(frames)
+    a, b = src.as_rcv(), dst.as_rcv()
+    _ffi.check(_ffi.bench_lib().rcv__warp_resize_bench(ctx.handle, C.byref(a), C.byref(b), Ms.ctypes.data_as(C.POINTER(C.c_float)), 4, 2, fpg, 0,
+                                                       order, strip, -1), "rcv__warp_resize_bench")
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc)), (fpg, order, strip, M, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("n", [16, 17, 23, 34])
 @pytest.mark.parametrize("M", ["rot7", "rot-3", "shear", "rot-20"])
 def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M):

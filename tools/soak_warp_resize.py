@@ -23,7 +23,8 @@ for case in range(FIRST, FIRST + N):
     rng = np.random.default_rng(0x5A6E00 + case)
     dr, dc = int(rng.integers(5, 90)), 4 * int(rng.integers(2, 120))
     mr, mc = 4 * dr, 4 * dc
-    sr, sc = mr + int(rng.integers(0, 60)), mc + int(rng.integers(0, 60))
+    sr, sc = mr + int(rng.integers(0, 60)) - (40 if case % 5 == 3 else 0), mc + int(rng.integers(0, 60))
+    if case % 2: sc = (sc + 15) & ~15   # (every second case: rows of a multiple of 16 bytes -- border tiles staged too)
     n = int(rng.integers(16, 30))
     kind = case % 6
     if kind == 0: M = rot(float(rng.uniform(-14, 14)), mc / 2, mr / 2, float(rng.uniform(0, 30)), float(rng.uniform(0, 30)))
