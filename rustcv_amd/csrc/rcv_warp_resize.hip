@@ -166,6 +166,9 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
 #ifndef RCV_STAGE_CHUNKS
 #define RCV_STAGE_CHUNKS 768
 #endif
+#ifndef RCV_STAGE_WAIT
+#define RCV_STAGE_WAIT 0x0f71   // vmcnt(1); 0x0f70: vmcnt(0)
+#endif
 constexpr int kStageChunks = RCV_STAGE_CHUNKS, kStageLoads = kStageChunks / 256, kStageBuf = kStageChunks * 16;   // chunks (16 B) per buffer: three per thread
 
 template <int S, int DBG = 0, int OCC = 5>   // OCC: waves per SIMD the register allocation aims at
@@ -350,16 +353,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     };
     const size_t sfs = s.fstride, dfs = d.fstride;
     issue(sf, 0);
+    // gfx9 counts loads and stores in one in-order counter: with the frame's store as the YOUNGEST operation at the loop head, vmcnt(1)
+    // waits for the staged loads and leaves the store in flight.  A first store (the lane's own output dword of frame f0, rewritten by
+    // the frame itself) gives the entry edge the same shape as the back edge.
+    __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc((void*)df, 0, 0xffffffff, kRsrc), doff, 0, 0);
     int f = f0;
 #pragma unroll 1
     for (;;) {
         // frame f is in buffer 0 once every wave's loads have landed; all waves have left frame f - 1 (buffer 1 is free)
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
+        __builtin_amdgcn_s_waitcnt(RCV_STAGE_WAIT);   // vmcnt(1) (expcnt / lgkmcnt untouched)
         __syncthreads();
         if (f + 1 < f1) issue(sf + sfs, 1);
         finish(df, 0);
         if (++f >= f1) break;
-        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_waitcnt(RCV_STAGE_WAIT);
         __syncthreads();
         if (f + 1 < f1) issue(sf + 2 * sfs, 0);
         finish(df + dfs, 1);
