@@ -580,6 +580,9 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
         const int small = rcv_plan_seg_rows(s.rows, (long long)a.nstrips * s.n, ctx->cu_count, 13, 16);
         if (small > 0) seg = small;
     }
+#ifdef RCV_HF_SEG   // (measurement builds: rows per segment fixed)
+    seg = RCV_HF_SEG;
+#endif
     a.seg_rows = seg;
     a.nsegs = (s.rows + seg - 1) / seg;
     long long waves = (long long)a.nstrips * a.nsegs * s.n;
