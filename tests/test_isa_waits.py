@@ -64,3 +64,41 @@ def test_staging_wait_leaves_the_stores_outstanding(geom_asm, kernel, store, nst
             hits += 1
         i = max(j, i + 1)
     assert hits >= 2, (kernel, hits)   # both halves of the loop unrolled by two
+
+
+@pytest.fixture(scope="module")
+def warp_resize_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "rcv_warp_resize.s"
+    flags = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math".split()
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), os.path.join(ROOT, "rustcv_amd", "csrc", "rcv_warp_resize.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def test_staged_warp_resize_loop_head_leaves_the_store_in_flight(warp_resize_asm):
+    """round 5, k_warp_resize_stage<4>: in the frame loop the three (two + a conditional one) direct-to-LDS loads of the next frame are
+    followed by the frame's arithmetic and ONE store; the wait in front of the loop's barrier must be vmcnt(1) -- the store, the youngest
+    operation, stays in flight (vmcnt(0) there cost 4-7 % of the launch) -- and nothing between a frame's loads and that barrier may
+    wait for vmcnt(0); the taps are read as ds_read2_b32 + ds_read_b32 (a wider read that is not naturally aligned is served one lane
+    per cycle: profiles/r05_ubench_lds_taps.txt)"""
+    body = _body(warp_resize_asm, "19k_warp_resize_stageILi4ELi0ELi5E")
+    keep = [l for l in body if l.startswith(("buffer_load_dwordx4", "buffer_store_dword", "s_waitcnt vmcnt", "s_barrier", "ds_read"))]
+    lds_loads = [i for i, l in enumerate(keep) if l.startswith("buffer_load_dwordx4") and l.endswith("lds")]
+    assert len(lds_loads) == 9, keep          # prologue + two unrolled frames, three loads each
+    first_loop_load = lds_loads[3]
+    loop = keep[first_loop_load:]
+    # per unrolled frame: loads, tap reads, one store, then `s_waitcnt vmcnt(1)` directly in front of the barrier
+    barriers = [i for i, l in enumerate(loop) if l == "s_barrier"]
+    assert len(barriers) >= 1
+    for b in barriers:
+        assert loop[b - 1] == "s_waitcnt vmcnt(1)", loop[max(0, b - 4):b + 1]
+    assert "s_waitcnt vmcnt(0)" not in loop, [l for l in loop if "vmcnt" in l]
+    assert sum(l.startswith("buffer_store_dword") for l in loop) == 2
+    reads = [l for l in loop if l.startswith("ds_read")]
+    assert reads and all(l.startswith(("ds_read2_b32", "ds_read_b32")) for l in reads), sorted(set(l.split()[0] for l in reads))
+    # ... and the wait in front of the FIRST loop barrier (entry edge: loads of the first frame + the shaping store) is vmcnt(1) as well
+    pre = keep[:first_loop_load]
+    pb = max(i for i, l in enumerate(pre) if l == "s_barrier")
+    assert pre[pb - 1] == "s_waitcnt vmcnt(1)" and pre[pb - 2].startswith("buffer_store_dword"), pre[pb - 4:pb + 1]
