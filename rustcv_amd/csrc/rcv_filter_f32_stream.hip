@@ -59,6 +59,28 @@ __device__ __forceinline__ f2 pk_fma_w(int half, f2 wp, f2 x, f2 acc)
     return d;
 }
 
+// The NW window dwords of a thread as 16-byte loads (+ an 8- / 4-byte rest): the rows are 4-byte aligned, which is all a global load
+// needs.  As NW separate dword loads (round 1-4) the window cost 8 address-path slots of ~13 cycles per wave and row -- as much
+// as the row's arithmetic (tools/ubench_gather.hip: a wave-level load costs the same 13-16 cycles whether it moves 4 or 16 bytes
+// per lane).
+template <int NW>
+__device__ __forceinline__ void load_window(const uint8_t* row, uint32_t* w)
+{
+    typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(4)));
+    constexpr int N4 = NW / 4;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const u4a v = *(const u4a*)(row + 16 * i);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    if constexpr (NW % 4 >= 2) {
+        const u2a v = *(const u2a*)(row + 16 * N4);
+        w[4 * N4] = v.x; w[4 * N4 + 1] = v.y;
+    }
+    if constexpr (NW % 2 == 1) w[NW - 1] = *(const uint32_t*)(row + 4 * (NW - 1));
+}
+
 // EDGE = true is the same computation for the few threads per row whose byte window leaves the row: they gather their
 // 2*LEAD+4 window bytes one by one at BORDER_REFLECT_101 positions (offsets fixed per thread, computed once) and then
 // run the identical accumulation code -- so the border columns are bit-identical by construction and cost microseconds
@@ -132,8 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
             w[NW] = base[mis ? NW : NW - 1];   // (an aligned row needs no further dword: never read past the window then)
             w[NW + 1] = mis;
         } else {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+            load_window<NW>(row, w);
         }
     };
 
@@ -295,8 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_f32_pairs(View s, View d, FWei
     auto load_row = [&](int ry, uint32_t (&w)[NW]) __attribute__((always_inline)) {
         ry = min(ry, ye - 1 + RAD);
         const uint8_t* row = sf + (size_t)rcv_reflect101(ry, s.rows) * s.step + wstart;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) w[i] = *(const uint32_t*)(row + 4 * i);
+        load_window<NW>(row, w);
     };
     auto byte_f = [](const uint32_t (&w)[NW], int b) __attribute__((always_inline)) { return (float)((w[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff); };
     f2 acc[NS][BPT];
