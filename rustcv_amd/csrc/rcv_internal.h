@@ -65,6 +65,11 @@ struct rcv_ctx {
     bool wl_valid = false, wl_ok = false;
     float wl_M[6] = {0, 0, 0, 0, 0, 0};
     int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
+    // last verdict of the staged fused warp -> down-scale kernel's host-side plan check (rcv_warp_resize.hip: wrs_fits), keyed by the
+    // matrix and the geometry: the check evaluates ~9 000 sample coordinates, a stream of launches with one map pays it once
+    bool wrs_valid = false, wrs_ok = false;
+    float wrs_M[6] = {0, 0, 0, 0, 0, 0};
+    int wrs_geom[5] = {0, 0, 0, 0, 0};   // source rows / cols, destination rows / cols, S
     hipStream_t side;            // second stream of the context (the measurement library's clock probe runs beside the main one)
     // grow-only pinned staging for small per-call host tables that outlive the call (rcv_text_blend.hip)
     uint8_t* pin;

@@ -437,6 +437,18 @@ bool wrs_fits(const View& s, const View& d, const Affine& A, int S)
     return judged > 0;
 }
 
+bool wrs_fits_cached(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S)
+{
+    const int geom[5] = {s.rows, s.cols, d.rows, d.cols, S};
+    if (!(ctx->wrs_valid && memcmp(ctx->wrs_M, A.m, sizeof(ctx->wrs_M)) == 0 && memcmp(ctx->wrs_geom, geom, sizeof(geom)) == 0)) {
+        ctx->wrs_ok = wrs_fits(s, d, A, S);
+        memcpy(ctx->wrs_M, A.m, sizeof(ctx->wrs_M));
+        memcpy(ctx->wrs_geom, geom, sizeof(geom));
+        ctx->wrs_valid = true;
+    }
+    return ctx->wrs_ok;
+}
+
 // host side of the staged kernel.  order: 0 raster grid, 1 XCD-contiguous runs of the whole list, 2 synchronous stripes
 int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S, int fpg_, int order, int strip, unsigned extra_lds, int dbg, int occ = 5)
 {
@@ -671,7 +683,7 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
             // <= 11 frames: 32 frames = 3 groups).  32 x 8K -> 1080p: 0.57 against 0.62 ms at 0 degrees, 0.67 / 0.68 at 3, 0.67-0.69 /
             // 0.71-0.72 at 7; 16 frames: -4 % / +-1 % / -4 %; 8 frames +2 .. +9 % (the plan is not repaid): tools/sweep_warp_resize_angles.sh,
             // profiles/r05_warp_resize_angles.txt.  The 2x footprints were not measured: they stay on the gather kernel
-            if (S == 4 && d.n >= 16 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits(s, d, A, S)) {
+            if (S == 4 && d.n >= 16 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits_cached(ctx, s, d, A, S)) {
                 const int groups = (d.n + 10) / 11;
                 // tiles in blocks of 2 x 4, dealt to the XCDs in turn: the lines at the ends of a tile's row pieces are hits in the L2 of the
                 // XCD that runs its neighbours (FETCH 4.16 -> 3.4 GB; -1.5 .. -4 % at 0 / 3 / 7 / 10 degrees once the plan was cheap)

@@ -1453,6 +1453,29 @@ def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, 
     dst.free()
 
 
+def test_warp_affine_resize_plan_check_is_cached_per_map(ctx, oracle, rng):
+    """the host-side plan check of the staged kernel is cached in the context, keyed by matrix and geometry: alternating maps and a
+    changed destination size on one context must each get their own verdict (kernel names) and the oracle's bytes"""
+    dr, dc = 38, 200
+    mr, mc = 4 * dr, 4 * dc
+    sr, sc, n = mr + 33, mc + 27, 16
+    fits, steep = _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), _rot(-20.0, mc / 2, mr / 2, 20.0, 30.0)
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=sc * 3 + (-(sc * 3)) % 4)
+    frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    for M, kern, (r_, c_) in ((fits, "k_warp_resize_stage<4", (dr, dc)), (steep, "k_warp_resize_box<4", (dr, dc)), (fits, "k_warp_resize_stage<4", (dr, dc)),
+                              (fits, "k_warp_resize_stage<4", (dr - 4, dc - 8)), (steep, "k_warp_resize_box<4", (dr - 4, dc - 8))):
+        dst = _canary_batch(ctx, n, r_, c_, 3, pad=8)
+        names = _kernels_launched(ctx, lambda: device.warp_affine_resize(src, dst, M, 4 * r_, 4 * c_))
+        assert kern in names, (names, kern)
+        got = dst.download()
+        for i in (0, n - 1):
+            assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], M, 4 * r_, 4 * c_), r_, c_)), (kern, i)
+        _assert_canaries(dst)
+        dst.free()
+    src.free()
+
+
 @pytest.mark.parametrize("fpg,order,strip", [(1, 0, 0), (3, 3, 2 + 256 * 4), (5, 1, 0), (2, 0, 131072)])
 @pytest.mark.parametrize("M", ["left", "right", "top", "bottom", "corner", "rot7out", "far", "farneg", "nan", "inf", "flip", "zero", "graze-1", "grazecols", "big"])
 def test_warp_affine_resize_staged_border_tiles(ctx, oracle, rng, fpg, order, strip, M):
