@@ -679,12 +679,13 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
-            // batches of 16+ frames, 4x, maps whose tile footprints fit: the staged kernel (a tile's plan is paid once per frame group of
-            // <= 11 frames: 32 frames = 3 groups).  32 x 8K -> 1080p: 0.57 against 0.62 ms at 0 degrees, 0.67 / 0.68 at 3, 0.67-0.69 /
-            // 0.71-0.72 at 7; 16 frames: -4 % / +-1 % / -4 %; 8 frames +2 .. +9 % (the plan is not repaid): tools/sweep_warp_resize_angles.sh,
-            // profiles/r05_warp_resize_angles.txt.  The 2x footprints were not measured: they stay on the gather kernel
-            if (S == 4 && d.n >= 16 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits_cached(ctx, s, d, A, S)) {
-                const int groups = (d.n + 10) / 11;
+            // batches of 8+ frames, 4x, maps whose tile footprints fit: the staged kernel (a tile's plan is paid once per frame group of
+            // <= 12 frames: 32 frames = 3 groups of 11).  8K -> 1080p against the gather kernel, final version (tools/sweep_warp_resize_angles.sh,
+            // profiles/r05_warp_resize_angles.txt, r05_warp_resize_small_batches.txt): 32 frames -12 % / -5.5 % / -17 % / -20 % at 0 / 3 / 7 / 10
+            // degrees, 16 frames -13 %, 12 frames -16 %, 8 frames -10 .. -18 %, 4 frames -3 .. +4 % (the plan is not repaid: gather kernel).
+            // The 2x footprints were not measured: they stay on the gather kernel
+            if (S == 4 && d.n >= 8 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits_cached(ctx, s, d, A, S)) {
+                const int groups = (d.n + 11) / 12;
                 // tiles in blocks of 2 x 4, dealt to the XCDs in turn: the lines at the ends of a tile's row pieces are hits in the L2 of the
                 // XCD that runs its neighbours (FETCH 4.16 -> 3.4 GB; -1.5 .. -4 % at 0 / 3 / 7 / 10 degrees once the plan was cheap)
                 return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, 3, 2 + 256 * 4, 0u, 0);

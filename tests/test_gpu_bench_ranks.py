@@ -93,5 +93,5 @@ def test_default_run_carries_the_other_configs_small():
         assert 0.05 < rec["roofline"]["frac"] < 1.0 and rec["roofline"]["launch_ms"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
     assert out["other_configs"]["3s"]["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 7
     r = out["roofline"]
-    assert r["single_stream_frac"] == r["single_stream"]["frac"] and 0 < out["value_single_stream"] <= out["value"] * 1.02
+    assert r["single_stream_frac"] == r["single_stream"]["frac"] and out["value_single_stream"] > 0    # (four timed steps: no ordering of the two values is asserted)
     assert out["cpu_baseline"]["value"] > 0

@@ -79,7 +79,7 @@ def test_fast_kernels_are_dispatched(ctx):
         ("warpAffine BGR", lambda: device.warp_affine(bgr, bgr2, M), "k_warp_affine_lds<3, false>"),
         ("warpAffine gray", lambda: device.warp_affine(gray, gray2, M), "k_warp_gray_lds4<4>"),
         ("resize BGR 4K -> 960x540 (box)", lambda: device.resize(bgr, small), "k_resize_box<4>"),
-        ("fused warp -> 4x down-scale, 8 frames (gather kernel; 16+ frames: row pieces staged through LDS)", lambda: device.warp_affine_resize(bgr, small, M, rows, cols), "k_warp_resize_box<4"),
+        ("fused warp -> 4x down-scale, 8 frames (row pieces staged through LDS)", lambda: device.warp_affine_resize(bgr, small, M, rows, cols), "k_warp_resize_stage<4"),
         ("cvtColor BGR2GRAY", lambda: device.cvt_color(bgr, gray2, _ffi.RCV_BGR2GRAY), "k_bgr2gray16"),
         ("cvtColor YUYV2BGR", lambda: device.cvt_color(yuyv, bgr2, _ffi.RCV_YUYV2BGR), "k_yuyv2bgr_vec"),
     ]

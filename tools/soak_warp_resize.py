@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/soak_warp_resize.py [N] -- N seeded random (shape, map, batch, row padding) cases of the fused warpAffine -> 4x down-scale against the
-oracle's resize(warp_affine(.)), through the product entry (16+ frames and a map whose tile footprints fit: k_warp_resize_stage; the same call with RCV_WARP_LDS=0: k_warp_resize_box) and
+oracle's resize(warp_affine(.)), through the product entry (8+ frames and a map whose tile footprints fit: k_warp_resize_stage; the same call with RCV_WARP_LDS=0: k_warp_resize_box) and
 through the measurement entry with random frames per tile / tile orders; prints the launches per kernel and the number of mismatches."""
 import ctypes as C, os, sys
 import numpy as np
@@ -25,7 +25,7 @@ for case in range(FIRST, FIRST + N):
     mr, mc = 4 * dr, 4 * dc
     sr, sc = mr + int(rng.integers(0, 60)) - (40 if case % 5 == 3 else 0), mc + int(rng.integers(0, 60))
     if case % 2: sc = (sc + 15) & ~15   # (every second case: rows of a multiple of 16 bytes -- border tiles staged too)
-    n = int(rng.integers(16, 30))
+    n = int(rng.integers(8, 30))
     kind = case % 6
     if kind == 0: M = rot(float(rng.uniform(-14, 14)), mc / 2, mr / 2, float(rng.uniform(0, 30)), float(rng.uniform(0, 30)))
     elif kind == 1: M = rot(7.0, mc / 2, mr / 2, 13.25, -8.5 + 20)
