@@ -81,6 +81,20 @@ def test_one_process_eight_ranks_on_one_device():
     assert out["roofline"]["in_flight"] == 2 and "cpu_baseline" not in out and "other_configs" not in out
 
 
+def test_torchrun_eight_ranks_on_one_device():
+    """the form the driver's SCALE run uses (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) with EIGHT ranks, all on
+    GPU 0: eight processes, barrier + all_gather_object over the process group (RCCL refuses eight ranks on one device: gloo carries the
+    same branch), every rank's frames verified, the report over eight results"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           "bench.py", "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--no-ceiling", "--dist-backend", "gloo"] + SMALL
+    p, out = _run(cmd, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 1 and out["config"]["contexts"] == 8 and out["verified"].startswith("bit-exact")
+    assert out["verified_frames"] == sorted(4 * lane + i for lane in range(16) for i in (0, 1, 3)) and out["config"]["global_batch"] == 64
+    assert len(out["roofline"]["launch_ms_per_gpu"]) == 8 and all(t > 0 for t in out["roofline"]["launch_ms_per_gpu"])
+    assert "cpu_baseline" not in out and "other_configs" not in out
+
+
 def test_default_run_carries_the_other_configs_small():
     """the default (N = 1) line at a reduced batch: other_configs has the Sobel half of config 3 ("3s", "3f") and configs 4 / 5, every
     record with its own roofline, verification and cpu_baseline; the one-stream figure is flattened into scalars"""
