@@ -683,12 +683,12 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
             // <= 12 frames: 32 frames = 3 groups of 11).  8K -> 1080p against the gather kernel, final version (tools/sweep_warp_resize_angles.sh,
             // profiles/r05_warp_resize_angles.txt, r05_warp_resize_small_batches.txt): 32 frames -12 % / -5.5 % / -17 % / -20 % at 0 / 3 / 7 / 10
             // degrees, 16 frames -13 %, 12 frames -16 %, 8 frames -10 .. -18 %, 4 frames -3 .. +4 % (the plan is not repaid: gather kernel).
-            // The 2x footprints were not measured: they stay on the gather kernel
-            if (S == 4 && d.n >= 8 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits_cached(ctx, s, d, A, S)) {
+            // 2x (8K -> 4K, 7 degrees): 8 frames 0.40 against 0.56 ms, 16 frames 0.80 / 1.11 (-27 %), raster order (blocks +2 %).
+            if (d.n >= 8 && rcv_knobs().warp_lds != 0 && wrl_ok(s, d) && wrs_fits_cached(ctx, s, d, A, S)) {
                 const int groups = (d.n + 11) / 12;
                 // tiles in blocks of 2 x 4, dealt to the XCDs in turn: the lines at the ends of a tile's row pieces are hits in the L2 of the
                 // XCD that runs its neighbours (FETCH 4.16 -> 3.4 GB; -1.5 .. -4 % at 0 / 3 / 7 / 10 degrees once the plan was cheap)
-                return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, 3, 2 + 256 * 4, 0u, 0);
+                return wrs_launch(ctx, s, d, A, S, (d.n + groups - 1) / groups, S == 4 ? 3 : 0, S == 4 ? 2 + 256 * 4 : 0, 0u, 0);
             }
             dim3 grid((unsigned)((d.cols + kBoxTileW - 1) / kBoxTileW), (unsigned)((d.rows + kBoxTileH - 1) / kBoxTileH), d.n);
             // occupancy cap (6 workgroups per CU through an untouched dynamic-LDS request): fewer concurrent tiles thrash the

@@ -1509,14 +1509,15 @@ def test_warp_affine_resize_staged_border_tiles(ctx, oracle, rng, fpg, order, st
     dst.free()
 
 
+@pytest.mark.parametrize("scale", [4, 2])
 @pytest.mark.parametrize("n", [8, 13, 23, 37])
 @pytest.mark.parametrize("M", ["rot7", "rot-3", "shear", "rot-20"])
-def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M):
-    """round 5: rcv_warp_affine_resize_batch sends 4x launches of 8+ frames to k_warp_resize_stage when the map's tile footprints fit
+def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M, scale):
+    """round 5: rcv_warp_affine_resize_batch sends 4x and 2x launches of 8+ frames to k_warp_resize_stage when the map's tile footprints fit
     (frame groups of <= 12: one group, an uneven pair, two, four groups), everything else and RCV_WARP_LDS=0 to k_warp_resize_box;
     both produce the oracle's bytes"""
     dr, dc = 38, 200
-    mr, mc = 4 * dr, 4 * dc
+    mr, mc = scale * dr, scale * dc
     sr, sc = mr + 33, mc + 27
     Ms = {"rot7": _rot(7.0, mc / 2, mr / 2, 13.25, 9.5), "rot-3": _rot(-3.0, mc / 2, mr / 2, 16.5, 21.25),
           "shear": np.array([1, 0.0625, 3.5, -0.03125, 1, 30.25], np.float32), "rot-20": _rot(-20.0, mc / 2, mr / 2, 20.0, 30.0)}[M]
@@ -1524,8 +1525,9 @@ def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M):
     frames = rng.integers(0, 256, size=(n, sr, sc, 3), dtype=np.uint8)
     src.upload(frames)
     want = [oracle.resize(oracle.warp_affine(frames[i], Ms, mr, mc), dr, dc) for i in range(n)]
-    # (a 20-degree rotation spans more source rows per tile than the staged kernel holds: the host's plan check keeps it on the gather kernel)
-    for lds_knob, kern in ((None, "k_warp_resize_stage<4" if M != "rot-20" else "k_warp_resize_box<4"), (0, "k_warp_resize_box<4")):
+    # (at 4x a 20-degree rotation spans more source rows per tile than the staged kernel holds: the host's plan check keeps it on the gather
+    #  kernel; the 2x footprint of the same map fits)
+    for lds_knob, kern in ((None, f"k_warp_resize_stage<{scale}" if (M != "rot-20" or scale == 2) else f"k_warp_resize_box<{scale}"), (0, f"k_warp_resize_box<{scale}")):
         if lds_knob is not None:
             knob("RCV_WARP_LDS", lds_knob)
         dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
@@ -1539,7 +1541,7 @@ def test_warp_affine_resize_product_dispatch(ctx, oracle, rng, knob, n, M):
     # seven frames: the gather kernel whatever the knob says
     v = src.view(0, 7)
     dst = _canary_batch(ctx, 7, dr, dc, 3, pad=8)
-    assert "k_warp_resize_box<4" in _kernels_launched(ctx, lambda: device.warp_affine_resize(v, dst, Ms, mr, mc))
+    assert f"k_warp_resize_box<{scale}" in _kernels_launched(ctx, lambda: device.warp_affine_resize(v, dst, Ms, mr, mc))
     dst.free()
     src.free()
 

@@ -16,13 +16,15 @@ ap.add_argument("--rot", type=int, default=5)
 ap.add_argument("--launches", type=int, default=30)
 ap.add_argument("--deg", type=float, default=7.0)
 ap.add_argument("--n", type=int, default=32)
+ap.add_argument("--scale", type=int, default=4, help="down-scale factor of the fused launch (4: 8K -> 1080p; 2: 8K -> 4K)")
 ap.add_argument("--same-frame", action="store_true", help="every frame reads frame 0 of the source (frame stride 0): the launch without its HBM reads")
 ap.add_argument("--plans", default="0:0:0:0:0:-1,1:8:32:1:0:-1,1:16:32:1:0:-1,1:32:32:1:0:-1,1:8:32:0:0:-1,1:16:32:0:0:-1,1:16:16:1:0:-1,1:16:64:1:0:-1,"
                                    "1:16:32:1:4:-1,1:16:32:1:8:-1,1:16:32:1:0:27136,1:16:32:1:0:40000")
 a = ap.parse_args()
 L = _ffi.lib(); B = _ffi.bench_lib(); ctx = rcv.Context(0)
 n, rows, cols = a.n, 4320, 7680
-s = device.DeviceBatch(ctx, n, rows, cols, 3); d = device.DeviceBatch(ctx, n, rows // 4, cols // 4, 3); ref = device.DeviceBatch(ctx, n, rows // 4, cols // 4, 3)
+SC = a.scale
+s = device.DeviceBatch(ctx, n, rows, cols, 3); d = device.DeviceBatch(ctx, n, rows // SC, cols // SC, 3); ref = device.DeviceBatch(ctx, n, rows // SC, cols // SC, 3)
 device.synth(s, 0, 0x5EED0004, 0)
 t = np.deg2rad(a.deg); c, sn = np.cos(t), np.sin(t); cx, cy = cols / 2, rows / 2
 M = np.array([c, -sn, cx - c * cx + sn * cy + 13.25, sn, c, cy - sn * cx - c * cy - 8.5], np.float32)
@@ -34,7 +36,7 @@ def go(plan, dst):
     if plan[0] == 9:   # the product entry point (whatever kernel its dispatch picks)
         _ffi.check(L.rcv_warp_affine_resize_batch(ctx.handle, C.byref(bs), C.byref(bd), Mp, rows, cols), "rcv_warp_affine_resize_batch"); return
     if a.same_frame: plan = plan[:3] + (plan[3] | 256,) + plan[4:]
-    _ffi.check(B.rcv__warp_resize_bench(ctx.handle, C.byref(bs), C.byref(bd), Mp, 4, *plan), "rcv__warp_resize_bench")
+    _ffi.check(B.rcv__warp_resize_bench(ctx.handle, C.byref(bs), C.byref(bd), Mp, SC, *plan), "rcv__warp_resize_bench")
 
 def timed(plan):
     t0 = time.perf_counter()
@@ -55,8 +57,8 @@ res = {p: [] for p in plans}
 for r in range(a.rot):
     for p in plans:
         res[p].append(timed(p))
-alg = n * (rows // 4) * (cols // 4) * 30
-print(f"{n} x {cols}x{rows} -> {cols // 4}x{rows // 4} fused warp -> 4x down-scale, rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = 30 B per output px / ms / 8 TB/s")
+alg = n * (rows // SC) * (cols // SC) * (30 if SC == 4 else 15)   # (2x: every source pixel of the 2x2 block is sampled: 4 x 3 B read + 3 B written)
+print(f"{n} x {cols}x{rows} -> {cols // SC}x{rows // SC} fused warp -> {SC}x down-scale, rot {a.deg} deg, {a.launches} launches per sample, {a.rot} rotations; frac = 30 B per output px / ms / 8 TB/s")
 print("  plan = variant (0 box, 1 frame loop, 2 staged row pieces, 9 product entry) : frames per wave : wave width : XCD-contiguous : strip : dynamic LDS (-1 default)")
 for p in plans:
     m = statistics.median(res[p])
