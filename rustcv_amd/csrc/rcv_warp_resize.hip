@@ -314,6 +314,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     const unsigned doff = (unsigned)yq * (unsigned)d.step + (unsigned)(xq & ~3) * 3u + 4u * (unsigned)kq;
     const uint32_t psel = kq == 0 ? 0x04020100u : (kq == 1 ? 0x05040201u : 0x06050402u);
     constexpr int kRsrc = 0x00020000;
+    // (the buffer range check is per dword -- tools/probe_buffer_range.hip: a chunk that runs past the end of the frame still delivers the
+    //  dwords below it, and every tap byte lies in one)
     const unsigned sbytes = (unsigned)min((unsigned long long)s.cap, (unsigned long long)s.rows * s.step);
     const uint8_t* sf = s.p + (size_t)f0 * s.fstride;
     uint8_t* df = d.p + (size_t)f0 * d.fstride;
