@@ -1453,6 +1453,32 @@ def test_warp_affine_resize_measurement_variants(ctx, oracle, rng, plan, scale, 
     dst.free()
 
 
+@pytest.mark.parametrize("sc", [1340, 1344])
+def test_warp_affine_resize_staged_tight_capacity(ctx, oracle, rng, sc):
+    """a source whose stated capacity ends with the last pixel of the last row (cap = (rows - 1) * step + cols * 3, the reference's
+    Vec::len() of a packed Mat): the staged kernel's last chunk of that row runs past the capacity; the buffer range check is per
+    dword, so every tap byte below it still arrives (rows of 4020 bytes: not a multiple of 16; 4032: the zero-filled path)"""
+    dr, dc = 40, 328
+    mr, mc = 4 * dr, 4 * dc
+    sr = mr + 3
+    n = 3
+    M = np.array([1, 0, float(sc - mc) - 0.5, 0, 1, float(sr - mr) - 0.5], np.float32)     # the map ends on the source's last row / last columns
+    step = sc * 3
+    src = device.DeviceBatch(ctx, n, sr, sc, 3, step=step, frame_cap=(sr - 1) * step + sc * 3)
+    frames = rng.integers(1, 256, size=(n, sr, sc, 3), dtype=np.uint8)
+    src.upload(frames)
+    dst = _canary_batch(ctx, n, dr, dc, 3, pad=8)
+    a, b = src.as_rcv(), dst.as_rcv()
+    _ffi.check(_ffi.bench_lib().rcv__warp_resize_bench(ctx.handle, C.byref(a), C.byref(b), M.ctypes.data_as(C.POINTER(C.c_float)), 4, 2, 3, 0, 0, 0, -1),
+               "rcv__warp_resize_bench")
+    got = dst.download()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.resize(oracle.warp_affine(frames[i], M, mr, mc), dr, dc)), (sc, i)
+    _assert_canaries(dst)
+    src.free()
+    dst.free()
+
+
 def test_warp_affine_resize_plan_check_is_cached_per_map(ctx, oracle, rng):
     """the host-side plan check of the staged kernel is cached in the context, keyed by matrix and geometry: alternating maps and a
     changed destination size on one context must each get their own verdict (kernel names) and the oracle's bytes"""
