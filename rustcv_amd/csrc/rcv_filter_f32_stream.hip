@@ -21,6 +21,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef RCV_FS_SCHED
+#define RCV_FS_SCHED 1   // scheduling barriers that keep the tap-major order of the fma chains
+#endif
+
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -183,27 +187,36 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
 #pragma unroll
         for (int b = 0; b < NB; ++b) p[b] = EDGE ? (float)w[b] : (float)((wa[(OFF + b) >> 2] >> (((OFF + b) & 3) * 8)) & 0xff);
         f2 h[NP];
-        if (SEP) {
+        if (SEP) {   // (tap-major: NP independent chains side by side)
 #pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                f2 a = {0.0f, 0.0f};
+            for (int jj = 0; jj < NP; ++jj) h[jj] = f2{0.0f, 0.0f};
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) a = pk_fma_w(kx & 1, W.w2[kx >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, a);
-                h[jj] = a;
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) h[jj] = pk_fma_w(kx & 1, W.w2[kx >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, h[jj]);
+                if (RCV_FS_SCHED) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (SEP) {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
+            for (int ky = 0; ky < KS; ++ky) {
+                const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
 #pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                if (SEP) {
-                    acc[slot][jj] = pk_fma_w(ky & 1, W.w2[ky >> 1], h[jj], acc[slot][jj]);
-                } else {
+                for (int jj = 0; jj < NP; ++jj) acc[slot][jj] = pk_fma_w(ky & 1, W.w2[ky >> 1], h[jj], acc[slot][jj]);
+            }
+        } else {
+            // dense: tap-major as well -- for one kx the KS output slots x NP pairs are independent accumulators (each still sees its own
+            // taps in (ky, kx) order: a slot takes one ky per source row), instead of KS dependent fmas in a row per accumulator
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx)
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int slot = ((RHO - ky + RAD) % KS + KS) % KS;
+#pragma unroll
+                    for (int jj = 0; jj < NP; ++jj)
                         acc[slot][jj] = pk_fma_w((ky * KS + kx) & 1, W.w2[(ky * KS + kx) >> 1], f2{p[2 * jj + kx * CH], p[2 * jj + 1 + kx * CH]}, acc[slot][jj]);
                 }
+                if (RCV_FS_SCHED) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the output whose last kernel row (ky = KS-1) was just applied: y = r - RAD, slot (RHO + RAD + 1) % KS
@@ -334,14 +347,19 @@ __global__ __launch_bounds__(kBlock) void k_gauss_f32_pairs(View s, View d, FWei
 #pragma unroll
         for (int b = 0; b < NB; ++b) P2[b] = f2{byte_f(wa, b), byte_f(wb, b)};
         f2 he[BPT], ho[BPT];
+        // (tap-major: consecutive instructions belong to different columns -- eight independent chains instead of one seven deep)
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) he[j] = P2[j] * f2{W.w2[0][0], W.w2[0][0]};
+#pragma unroll
+        for (int kx = 1; kx < KS; ++kx) {
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) he[j] = pk_fma_w(kx & 1, W.w2[kx >> 1], P2[j + kx * CH], he[j]);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the tap-major order: without it the compiler re-serialises the chains, +3 % at 7 taps)
+        }
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
-            f2 a = P2[j] * f2{W.w2[0][0], W.w2[0][0]};
-#pragma unroll
-            for (int kx = 1; kx < KS; ++kx) a = pk_fma_w(kx & 1, W.w2[kx >> 1], P2[j + kx * CH], a);
-            he[j] = a;
-            ho[j] = f2{hp[j], a.x};
-            hp[j] = a.y;
+            ho[j] = f2{hp[j], he[j].x};
+            hp[j] = he[j].y;
         }
         // vertical taps: output pair (row pair index + dq) gets ky = RAD - 1 - 2 dq from ho and ky = RAD - 2 dq from he
 #pragma unroll
@@ -441,10 +459,10 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
         const int bpx = xcd ? (int)((nb + 7) / 8) : 0;
         const dim3 grid = xcd ? dim3((unsigned)bpx * 8u) : dim3(gx, gy, s.n);
         if constexpr (SEP && BPT == 8 && !RAG) {
-            // where it measured faster (tools/ab_gauss_sigma.py, 64 x 4K / 64 x 1080p: BGR 3 / 5 / 7 / 11 taps -1.6 .. -3 %; 9 taps and the
-            // one-channel shapes +0 .. +11 %: 11 % fewer instructions per sample buy little -- neither kernel is bound by its instruction
-            // count); RCV_GAUSS_ROWS=1 (tests) sends every shape here
-            const bool pairs = rcv_knobs().gauss_rows == 1 || (CH == 3 && KS != 9);
+            // where it measures faster than the one-row kernel in its tap-major form (tools/ab_fs_variants.sh, same call, 64 x 4K BGR:
+            // 3 taps 0.640 against 0.665 ms; 5 / 7 taps equal; 11 taps 3.5 % slower; one channel never); RCV_GAUSS_ROWS=1 (tests)
+            // sends every shape here
+            const bool pairs = rcv_knobs().gauss_rows == 1 || (CH == 3 && KS == 3);
             if (pairs && !rcv_f32_pairs_off()) RCV_LAUNCH((k_gauss_f32_pairs<KS, CH>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, (int)gx, (int)gy, (int)nb, bpx);
             else RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
         } else
