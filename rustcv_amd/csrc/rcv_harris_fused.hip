@@ -34,6 +34,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef RCV_HF_FSOB
 #define RCV_HF_FSOB 1
 #endif
+#ifndef RCV_HF_LIMROW
+#define RCV_HF_LIMROW 1
+#endif
 constexpr int kAhead = RCV_HF_AHEAD;   // source rows in flight per lane (x 6 VGPRs)
 constexpr int kStripPx = 62 * 8;
 
@@ -326,6 +329,9 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         if constexpr (WANT_MASK && !RAG) flush_mask();
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
+        constexpr bool kLimRow = !WANT_RESP && !RAG && RCV_HF_LIMROW;
+        const float limv = mirrored ? -INFINITY : 0.0f;   // (scalar select)
+        f2 lim2 = f2{limv, limv};
         // f32 stages on PACKED pairs {pixel j, pixel j+4} (v_pk_mul/add_f32): with this pairing the horizontal neighbour
         // P(x-1) of a pair is simply the previous pair register (j >= 1) -- pairing adjacent pixels {2j, 2j+1} instead leaves
         // every neighbour pair {2j-1, 2j} straddling two registers, and the compiler rebuilds it with ~3 v_mov per pixel
@@ -394,7 +400,14 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
             const f2 t1 = fa * fc, t2 = fb * fb, t3 = fa + fc;
             const f2 t4 = a.k * t3;
             const f2 t5 = t4 * t3;
-            const f2 rr2 = (t1 - t2) - t5;
+            f2 rr2 = (t1 - t2) - t5;
+            if constexpr (kLimRow) {
+                // (round 5) a row outside the image: every response -inf -- as a packed ADD of a row-uniform term (+0 on the rows of the
+                // image: exact, only -0 becomes +0, which no comparison below can tell apart; -inf outside: finite + -inf = -inf) on the pairs
+                // themselves (gfx950 has no packed f32 minimum).  The branch that overwrote r[] on those two rows per frame made every r[j] a
+                // merge of two definitions: six to seven register copies on EVERY row to bring the packed results into the merged registers.
+                rr2 = rr2 + lim2;
+            }
             r[j] = rr2.x;
             r[j + 4] = rr2.y;
         }
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         // A row outside the image (scalar condition, two rows per frame edge): every response is -inf.  Columns outside the
         // image belong to whole lanes (cols % 8 == 0: the lane left of x = 0, lanes right of the last column) that never
         // store; only the values they hand to their neighbours matter, and those are replaced right here.
-        if (u < 0 || u >= a.rows) {
+        if (!kLimRow && (u < 0 || u >= a.rows)) {
             // (a branch, not eight selects on every row: the compiler had if-converted this into a v_cndmask per pixel AND, no longer
             //  knowing the selected value canonical, a v_max_f32 x, x per pixel in front of the maxima below -- 2 of 29 instructions per
             //  pixel; round 4, from the ISA)
