@@ -33,7 +33,8 @@ Prints ONE JSON line on rank 0 with the contract keys plus
   "other_configs": (default run at N = 1 only) compact records measured in the same process, one stream each:
                   "3s" / "3f" the Sobel half of BASELINE configs[2] (rcv_sobel_batch on a BGR batch; the whole config as ONE launch,
                   rcv_filter2d_i8_sobel_batch), "4" and "5" the two 8-GPU configs at their per-GPU batch:
-                  {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic}, verified, cpu_baseline}
+                  {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic, in_flight2_launch_ms, in_flight2_frac},
+                  verified, cpu_baseline}  (in_flight2_*: for information, the same launch with a second batch in flight on a second context)
   "value_single_stream", roofline.single_stream_{launch_ms, achieved, frac}: one 64-frame launch at a time (BASELINE's literal
                   "batch=64", the round-1..3 measurement) as top-level / flat scalars
   "cpu_baseline": the C oracle (a port: C restatement, the Rust reference cannot be built here) timed on this box's host
@@ -472,6 +473,22 @@ def other_config(a, cfg, ctx, lanes, launches=100):
     if cfg == 4:
         rec["input_mpix_s"] = round(c["batch"] * 4320 * 7680 * launches / wall / 1e6, 1)
         rec["path"] = "one fused launch (rcv_warp_affine_resize_batch)"
+    if len(lanes.ctxs) > 1:
+        # for information: the same launch with a second batch in flight on a second context of the device (what the headline does for
+        # config 3); `frac` / `launch_ms` above stay the one-stream figures of the config's literal per-GPU batch
+        ln2 = Lane(a, cfg, lanes.ctxs[1], c["batch"], n=c["batch"])
+
+        def both():
+            ln.step()
+            ln2.step()
+        settle(60.0, both, lanes.sync)
+        lanes.timer_start()
+        for _ in range(launches // 2):
+            both()
+        ms2 = lanes.timer_stop() / (2 * (launches // 2))
+        rec["roofline"]["in_flight2_launch_ms"] = round(ms2, 4)
+        rec["roofline"]["in_flight2_frac"] = round(alg / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        ln2.free()
     if not a.no_verify:
         from oracle import pyoracle as orc
         ok, bad = ln.verify(orc)

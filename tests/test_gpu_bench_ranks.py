@@ -106,6 +106,7 @@ def test_default_run_carries_the_other_configs_small():
         assert rec["verified"].startswith("bit-exact"), (key, rec["verified"])
         assert 0.05 < rec["roofline"]["frac"] < 1.0 and rec["roofline"]["launch_ms"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
     assert out["other_configs"]["3s"]["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 7
+    assert all(rec["roofline"]["in_flight2_launch_ms"] > 0 and 0.05 < rec["roofline"]["in_flight2_frac"] < 1.0 for rec in out["other_configs"].values())
     r = out["roofline"]
     assert r["single_stream_frac"] == r["single_stream"]["frac"] and out["value_single_stream"] > 0    # (four timed steps: no ordering of the two values is asserted)
     assert out["cpu_baseline"]["value"] > 0
