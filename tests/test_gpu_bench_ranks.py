@@ -81,6 +81,16 @@ def test_one_process_eight_ranks_on_one_device():
     assert out["roofline"]["in_flight"] == 2 and "cpu_baseline" not in out and "other_configs" not in out
 
 
+def test_torchrun_one_rank_rccl():
+    """the RCCL transport itself (what carries the barrier and the gather of the per-rank timings on a multi-GPU node): one rank under
+    torch.distributed.run with the default backend -- init_process_group("nccl"), barrier, all_gather_object, destroy"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29551",
+           "bench.py", "--gpus", "1", "--no-ceiling", "--no-others"] + SMALL
+    p, out = _run(cmd, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 1 and out["verified"].startswith("bit-exact") and out["roofline"]["in_flight"] == 2 and out["config"]["global_batch"] == 8
+
+
 def test_torchrun_eight_ranks_on_one_device():
     """the form the driver's SCALE run uses (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) with EIGHT ranks, all on
     GPU 0: eight processes, barrier + all_gather_object over the process group (RCCL refuses eight ranks on one device: gloo carries the
