@@ -164,12 +164,13 @@ __global__ __launch_bounds__(kBlock) void k_warp_resize_box(View s, View d, Affi
 // Per frame and pixel that leaves the tap shifts, the exact bilinear arithmetic (4 x 31), the box average and the store: ~160 VALU instructions.
 // Tiles with a tap outside the source, with more than 64 source rows or more than kStageChunks chunks take k_warp_resize_box's path.
 #ifndef RCV_STAGE_CHUNKS
-#define RCV_STAGE_CHUNKS 768
+#define RCV_STAGE_CHUNKS 832
 #endif
 #ifndef RCV_STAGE_WAIT
 #define RCV_STAGE_WAIT 0x0f71   // vmcnt(1); 0x0f70: vmcnt(0)
 #endif
-constexpr int kStageChunks = RCV_STAGE_CHUNKS, kStageLoads = kStageChunks / 256, kStageBuf = kStageChunks * 16;   // chunks (16 B) per buffer: three per thread
+// chunk slots (16 B) per buffer: three load instructions of 256 chunks + one of 64 (wave 0); 2 x 13 KB of LDS per workgroup
+constexpr int kStageChunks = RCV_STAGE_CHUNKS, kStageLoads = (kStageChunks + 255) / 256, kStageBuf = kStageChunks * 16;
 
 template <int S, int DBG = 0, int OCC = 5>   // OCC: waves per SIMD the register allocation aims at
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_warp_resize_stage(View s, View d, Affine A, int fpg, int gx, int gy, int ngroups, int per_xcd, int strip, int pad, int zfill)
@@ -261,20 +262,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     if (staged && wave == 0) {   // one wave: chunk counts of the rows, their prefix sums, the chunk -> row map
         const int mn = rowmin[lane], mx = rowmax[lane];
         const int qs = mn >> 4, len = mn != 0x7fffffff ? (mx >> 4) - qs + 1 : 0;
-        // pad = 1 (measurement): an ODD number of chunk slots per row (the last one possibly unused).  Along a wave the rows change every
-        // other lane at the same offset inside the piece, so with 64- or 68-dword pieces lanes l, l + 2, l + 4, ... meet in one bank
-        // (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles); odd counts put them 4 (mod 8) dwords apart.  Measured: -0.5 % (the LDS is not
-        // the bound), and the slots cost buffer space: off
-        const int slots = len | (len > 0 ? pad : 0);
-        int inc = slots;
+        int inc = len;
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) {
             const int t = __shfl_up(inc, k);
             if (lane >= k) inc += t;
         }
-        const int cb = inc - slots;
-        if (lane == 63) scal[2] = inc;
-        if (inc <= kStageChunks)
+        // One spare chunk slot behind every row piece when the buffer has room for it.  Along a wave the rows change every other lane at
+        // nearly the same offset inside the piece, so with pieces of 16 chunks = 64 dwords the lanes l, l + 2, l + 4, ... meet in the same
+        // few banks (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles, the LDS 61 % busy); with the spare slot consecutive rows sit
+        // 4 (+- 2) dwords further round the 64 banks.  pad = 0 (measurement): packed.
+        const unsigned long long nonempty = __builtin_amdgcn_ballot_w64(len > 0);
+        const int rows_used = __builtin_popcountll(nonempty), tot = __shfl(inc, 63);
+        const int spare = (pad != 0 && tot + rows_used <= kStageChunks) ? 1 : 0;
+        const int before = __builtin_popcountll(nonempty & ((1ull << lane) - 1ull));
+        const int slots = len + (len > 0 ? spare : 0);
+        const int cb = inc - len + spare * before;
+        if (lane == 63) scal[2] = tot + spare * rows_used;
+        if (tot + spare * rows_used <= kStageChunks)
             for (int i = 0; i < slots; ++i) map[cb + i] = (uint8_t)(i < len ? lane : 255);   // (255: a slot nothing is loaded into)
         rowmin[lane] = 16 * (cb - qs);
         rowmax[lane] = cb;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, sbytes, kRsrc);
 #pragma unroll
         for (int j = 0; j < kStageLoads; ++j)
-            if (j < 2 || nload > j)
+            if ((j < 2 || nload > j) && j * 256 + wave * 64 < kStageChunks)   // (the last instruction: only the waves whose 64 slots exist)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(wrs_lds + buf * kStageBuf + (j * 256 + wave * 64) * 16), 16,
                                                      voff[j], 0, 0, 0);
     };
@@ -462,7 +467,7 @@ int wrs_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
     const int pg = (gx * gy + 7) / 8;
     int per = order == 1 ? (int)((tiles + 7) / 8) : (order == 2 ? -pg : 0);
     dim3 grid = order == 1 ? dim3((unsigned)(8 * per)) : (order == 2 ? dim3((unsigned)(8 * pg * groups)) : dim3((unsigned)gx, (unsigned)gy, (unsigned)groups));
-    const int pad = (strip >> 16) & 1;   // (measurement: + 65536 = an odd number of chunk slots per row)
+    const int pad = (strip >> 16) & 1 ? 0 : 1;   // (measurement: + 65536 = row pieces packed without the spare slots)
     const int no_zfill = (strip >> 17) & 1;   // (measurement: + 131072 = border tiles on the gather path)
     strip &= 0xffff;
     if (order == 3) {   // blocks of bw x bh tiles (strip = bw + 256 * bh), dealt to the XCDs in turn

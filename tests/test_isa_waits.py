@@ -78,7 +78,7 @@ def warp_resize_asm(tmp_path_factory):
 
 
 def test_staged_warp_resize_loop_head_leaves_the_store_in_flight(warp_resize_asm):
-    """round 5, k_warp_resize_stage<4>: in the frame loop the three (two + a conditional one) direct-to-LDS loads of the next frame are
+    """round 5, k_warp_resize_stage<4>: in the frame loop the four (two + two conditional ones) direct-to-LDS loads of the next frame are
     followed by the frame's arithmetic and ONE store; the wait in front of the loop's barrier must be vmcnt(1) -- the store, the youngest
     operation, stays in flight (vmcnt(0) there cost 4-7 % of the launch) -- and nothing between a frame's loads and that barrier may
     wait for vmcnt(0); the taps are read as ds_read2_b32 + ds_read_b32 (a wider read that is not naturally aligned is served one lane
@@ -86,8 +86,8 @@ def test_staged_warp_resize_loop_head_leaves_the_store_in_flight(warp_resize_asm
     body = _body(warp_resize_asm, "19k_warp_resize_stageILi4ELi0ELi5E")
     keep = [l for l in body if l.startswith(("buffer_load_dwordx4", "buffer_store_dword", "s_waitcnt vmcnt", "s_barrier", "ds_read"))]
     lds_loads = [i for i, l in enumerate(keep) if l.startswith("buffer_load_dwordx4") and l.endswith("lds")]
-    assert len(lds_loads) == 9, keep          # prologue + two unrolled frames, three loads each
-    first_loop_load = lds_loads[3]
+    assert len(lds_loads) == 12, keep         # prologue + two unrolled frames, four loads each (the fourth: the 64 slots past 768, wave 0)
+    first_loop_load = lds_loads[4]
     loop = keep[first_loop_load:]
     # per unrolled frame: loads, tap reads, one store, then `s_waitcnt vmcnt(1)` directly in front of the barrier
     barriers = [i for i, l in enumerate(loop) if l == "s_barrier"]
