@@ -28,6 +28,8 @@ for d in ("inflight1", "inflight2"):
     except Exception as e:  # noqa: BLE001
         print("   (no bench line)", e)
     st = rows_of(d, "kernel_stats.csv")
+    if d == "inflight2":
+        print("   (two contexts: the other_configs records also run their in_flight2 leg here, so every kernel's average mixes overlapped and single launches; the one-stream durations are in the inflight1 section)")
     for row in st[:8]:
         print("   stats:", row.get("Name", "")[:86], "calls", row.get("Calls"), "avg ns", row.get("AverageNs"), "min", row.get("MinNs"), "max", row.get("MaxNs"))
     try:
@@ -36,7 +38,7 @@ for d in ("inflight1", "inflight2"):
             print(f"   other_configs[{k}]: {rr['kernel']}  launch_ms {rr['launch_ms']}  frac {rr['frac']}")
     except Exception:  # noqa: BLE001
         pass
-    tr = [r for r in rows_of(d, "kernel_trace.csv") if "k_filter_rows" in r.get("Kernel_Name", "")]
+    tr = [r for r in rows_of(d, "kernel_trace.csv") if "k_filter_rows_chain" in r.get("Kernel_Name", "")]   # (the headline kernel only: k_filter_rows_mfma is the "3f" record)
     if not tr:
         continue
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
