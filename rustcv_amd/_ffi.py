@@ -149,20 +149,20 @@ BENCH_SIGNATURES = {
     "rcv__storebench": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i, _i]),
     "rcv__clock_probe": (_i, [_ctx, _i, C.POINTER(C.c_float)]),
     "rcv__stripwalk": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _i, _sz, _i, _i, _i, _i, _i, _i]),
-    # the row-streaming filter with every plan parameter explicit + its measurement instantiations (tune: 14 ints, see ROWS_TUNE)
+    # the row-streaming filter with every plan parameter explicit + its measurement instantiations (tune: 15 ints, see ROWS_TUNE)
     "rcv__filter_rows_bench": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i, _P(C.c_int), C.c_void_p]),
     # the fused warp -> down-scale launch: (src, dst, M, S, variant 0 box / 1 frame loop, fpg, ww, xcd, strip, lds (-1: the product's))
     "rcv__warp_resize_bench": (_i, [_ctx, _bat, _bat, _P(_f), _i, _i, _i, _i, _i, _i, _i]),
 }
 
 # order of the ints rcv__filter_rows_bench takes (defaults = the product's plan; dbg 4 = the kernel's memory-only variant)
-ROWS_TUNE = ("f7_rows", "dual_full", "chain", "chain_rows", "dbg", "wpc", "rounds", "pp", "order", "bpf", "band_rows", "taper", "wpb", "edge_pct")
+ROWS_TUNE = ("f7_rows", "dual_full", "chain", "chain_rows", "dbg", "wpc", "rounds", "pp", "order", "bpf", "band_rows", "taper", "wpb", "edge_pct", "var")
 ROWS_TUNE_DEFAULTS = {"f7_rows": 1, "dual_full": 0, "chain": -1, "chain_rows": 0, "dbg": 0, "wpc": 0, "rounds": 0, "pp": 0, "order": 0, "bpf": 0,
-                      "band_rows": 0, "taper": -1, "wpb": 0, "edge_pct": 0}
+                      "band_rows": 0, "taper": -1, "wpb": 0, "edge_pct": 0, "var": 0}
 
 
 def rows_tune(**kw):
-    """ctypes int[14] for rcv__filter_rows_bench: rows_tune(dbg=4), rows_tune(chain=0, bpf=68), ..."""
+    """ctypes int[15] for rcv__filter_rows_bench: rows_tune(dbg=4), rows_tune(chain=0, bpf=68), ..."""
     bad = set(kw) - set(ROWS_TUNE)
     if bad:
         raise TypeError(f"unknown tune field(s) {sorted(bad)}")

@@ -26,6 +26,7 @@ static void load_knobs()
     g_knobs.f7_dual_full = getenv("RCV_F7_DUAL_FULL") != nullptr;
     g_knobs.fr_chain = env_int("RCV_FR_CHAIN", -1);
     g_knobs.fr_chain_rows = env_int("RCV_FR_CHAIN_ROWS", 0);
+    g_knobs.fr_chain_drop_xcd = env_int("RCV_FR_CHAIN_DROP_XCD", -1);
     g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);
     g_knobs.gr_seg = env_int("RCV_GR_SEG", 0);
     g_knobs.harris_general = env_int("RCV_HARRIS_GENERAL", 0);
@@ -161,6 +162,7 @@ static void ctx_finalize(rcv_ctx* c)
     for (int e = 0; e < 4; ++e)
         if (c->fr_tab[e].uploaded) (void)hipEventDestroy(c->fr_tab[e].uploaded);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->fr_fault) (void)hipHostFree(c->fr_fault);
     if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -182,11 +184,26 @@ int rcv_launch_check(rcv_ctx*)
     return e == hipSuccess ? RCV_OK : RCV_ERR_DEVICE;
 }
 
+// Every host-side wait for the context's stream goes through here: the chained row filter's last launch gets its completion check
+// enqueued first, and a fault that any check has raised comes back as RCV_ERR_DEVICE (rcv_filter_rows_mfma.hip: rcv_chain_flush / _poll).
+int rcv_wait(rcv_ctx* ctx)
+{
+    const int frc = rcv_chain_flush(ctx);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->fr_tickets_ready = false;   // whatever ran last may have left a counter set half-drawn: the next chained launch zeroes them all
+        ctx->fr_unchecked = false;
+        return RCV_ERR_DEVICE;
+    }
+    RCV_TRY(frc);
+    return rcv_chain_poll(ctx);
+}
+
 extern "C" int rcv_sync(rcv_ctx* ctx)
 {
     RCV_TRY(rcv_bind(ctx));
-    RCV_HIP(hipStreamSynchronize(ctx->stream));
-    return RCV_OK;
+    return rcv_wait(ctx);
 }
 
 extern "C" int rcv_ctx_device(const rcv_ctx* ctx) { return ctx ? ctx->device : RCV_ERR_ARG; }
@@ -217,8 +234,7 @@ extern "C" int rcv_upload(rcv_ctx* ctx, void* dst, const void* src, size_t bytes
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
     RCV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    RCV_HIP(hipStreamSynchronize(ctx->stream));
-    return RCV_OK;
+    return rcv_wait(ctx);
 }
 
 extern "C" int rcv_download(rcv_ctx* ctx, void* dst, const void* src, size_t bytes)
@@ -226,9 +242,9 @@ extern "C" int rcv_download(rcv_ctx* ctx, void* dst, const void* src, size_t byt
     RCV_TRY(rcv_bind(ctx));
     if (bytes == 0) return RCV_OK;
     if (!dst || !src) return RCV_ERR_ARG;
+    RCV_TRY(rcv_chain_flush(ctx));
     RCV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RCV_HIP(hipStreamSynchronize(ctx->stream));
-    return RCV_OK;
+    return rcv_wait(ctx);
 }
 
 extern "C" int rcv_memset(rcv_ctx* ctx, void* dst, int value, size_t bytes)
@@ -254,7 +270,7 @@ extern "C" int rcv_timer_stop(rcv_ctx* ctx, float* ms)
     RCV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     RCV_HIP(hipEventSynchronize(ctx->ev1));
     RCV_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-    return RCV_OK;
+    return rcv_chain_poll(ctx);   // (the timed window is not lengthened by a check launch; earlier launches have checked each other)
 }
 
 // ---- host-only helpers --------------------------------------------------------------------
@@ -452,6 +468,6 @@ int stage_finish(Stage* s, int rc)
             RCV_HIP(hipMemcpyAsync(sm->host->data, sm->dev.data, sm->host->cap, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    RCV_HIP(hipStreamSynchronize(ctx->stream));
-    return rc;
+    const int wrc = rcv_wait(ctx);
+    return rc < 0 ? rc : (wrc < 0 ? wrc : rc);
 }

@@ -30,6 +30,33 @@ __device__ __forceinline__ uint32_t rcv_ashr_sat_pk4(int a, int b, int c, int d,
     return rcv_ashr_sat_pk2(a, b, sh) | (rcv_ashr_sat_pk2(c, d, sh) << 16);
 }
 
+// Twelve i32 (three MFMA accumulator quads read crosswise) -> three dwords of saturated bytes with SIX VALU ops: op_sel[3] makes
+// v_ashr_pk_u8_i32 write D[31:16] and keep D[15:0] (tools/probe_ashr_pk_opsel.hip, measured on MI355X), so a dword is two
+// instructions instead of 2 + shift + or.  The compiler has no pattern for that form, hence inline asm -- and the hazard recognizer
+// does not look into inline asm: a VALU read of an XDL result needs passes + 2 (+ 1 on gfx950 for 4 passes) = 7 wait states after the
+// LAST matrix instruction that wrote an input (the 16x16x64 i8 MFMA has 4 passes; LLVM GCNHazardRecognizer::checkMAIVALUHazards).
+// The block therefore opens with its own `s_nop 6` (7 wait states; costs this wave 7 issue cycles, the SIMD's other wave runs on), which makes
+// it correct wherever the scheduler puts it.  Outputs are early-clobber: they are written while later inputs are still to be read.
+// Order of the inputs: the bytes of the three output dwords, low to high.
+__device__ __forceinline__ void rcv_ashr_sat_pk12_mfma(const int (&v)[12], int sh, uint32_t& o0, uint32_t& o1, uint32_t& o2)
+{
+#ifdef RCV_NO_PK_BUILTIN
+    o0 = rcv_ashr_sat_pk4(v[0], v[1], v[2], v[3], sh);
+    o1 = rcv_ashr_sat_pk4(v[4], v[5], v[6], v[7], sh);
+    o2 = rcv_ashr_sat_pk4(v[8], v[9], v[10], v[11], sh);
+#else
+    asm("s_nop 6\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, %15\n\t"
+        "v_ashr_pk_u8_i32 %1, %7, %8, %15\n\t"
+        "v_ashr_pk_u8_i32 %2, %11, %12, %15\n\t"
+        "v_ashr_pk_u8_i32 %0, %5, %6, %15 op_sel:[0,0,0,1]\n\t"
+        "v_ashr_pk_u8_i32 %1, %9, %10, %15 op_sel:[0,0,0,1]\n\t"
+        "v_ashr_pk_u8_i32 %2, %13, %14, %15 op_sel:[0,0,0,1]"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "s"(sh));
+#endif
+}
+
 // (x >> sh) saturated to [0,255]; opaque to the compiler's (broken) v_ashr_pk_u8_i32 matcher
 __device__ __forceinline__ int rcv_ashr_sat1(int x, int sh)
 {

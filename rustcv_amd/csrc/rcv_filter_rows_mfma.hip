@@ -68,6 +68,7 @@ struct RowsTune {
     int taper = -1;       // 0 equal bands, -1 / 1 tapered tail, n > 1: n % of a round
     int wpb = 0;          // waves per workgroup (2 / 4 / 8)
     int edge_pct = 0;     // (chain) weight of an edge strip against an interior one, % (0 = 115)
+    int var = 0;          // (chain, 7x7) code variant under test, a bit mask: see CV_* below
     void* trace = nullptr;   // device buffer of the per-wave timeline
 };
 
@@ -107,7 +108,43 @@ struct FRArgs {
     unsigned long long inv_edge, inv_int, inv_bpf;   // ceil(2^32 / n_edge), ceil(2^32 / (nstrips - n_edge)), ceil(2^32 / bpf): exact quotients for a launch's item counts
     unsigned long long* tickets;     // this launch's SET of 16 counters (XCD x {interior, edge}), 16 x 8 bytes apart (one 128-byte line each), all zero at its start
     unsigned long long* tickets_next;   // the set of the launch after the next one: every wave zeroes its own XCD's two counters of it
+    // tapered tail: the last tp2 bands of every XCD's run are drawn as quarter-height items, the tp1 bands before them as half-height
+    // ones, so that the waves of a launch's last round finish close together (fr_queue_items has the item count)
+    unsigned tp1, tp2;
+    // completion check (see k_chain_check): the counter set of the context's PREVIOUS chained launch and that launch's plan; the fault word
+    // lives in pinned host memory and is only ever written when a queue was left short
+    const unsigned long long* prev_tickets;
+    unsigned prev_cbands, prev_kint, prev_kedge, prev_tp1, prev_tp2;
+    unsigned* fault;
+    int drop_xcd;                    // (fault injection, RCV_FR_CHAIN_DROP_XCD; -1 = none) waves that run on this XCD leave at once
 };
+
+// items of one queue (interior or edge strips: `kstrips` of them) of XCD x: its run of bands, the tapered ones counted 2 / 4 times
+__host__ __device__ __forceinline__ unsigned fr_queue_items(unsigned cbands, unsigned x, unsigned kstrips, unsigned tp1, unsigned tp2)
+{
+    const unsigned gb0 = (unsigned)(((unsigned long long)cbands * x) >> 3), gb1 = (unsigned)(((unsigned long long)cbands * (x + 1)) >> 3);
+    const unsigned nb = gb1 - gb0, t2 = tp2 < nb ? tp2 : nb, t1 = tp1 < nb - t2 ? tp1 : nb - t2;
+    return (nb + t1 + 3 * t2) * kstrips;
+}
+
+// Did the chained launch that drew from `set` finish its lists?  Every queue's counter ends at items + (waves that found it empty); a
+// counter below its item count means that nobody drew the rest -- an XCD that received no waves (a CU mask, a partitioned device that
+// still reports 256 CUs, a dispatcher that does not place block b on XCD b % 8).  16 lanes, one counter each.
+__device__ __forceinline__ void fr_check_set(const unsigned long long* set, unsigned cbands, unsigned kint, unsigned kedge, unsigned tp1, unsigned tp2, unsigned* fault,
+                                             int lane)
+{
+    if (lane < 16) {
+        const unsigned need = fr_queue_items(cbands, (unsigned)lane >> 1, (lane & 1) ? kedge : kint, tp1, tp2);
+        const unsigned long long got = __builtin_nontemporal_load(set + 16 * lane);
+        if (got < need) __hip_atomic_store(fault, 1u + (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#ifndef RCV_ROWS_BENCH
+__global__ void k_chain_check(const unsigned long long* set, unsigned cbands, unsigned kint, unsigned kedge, unsigned tp1, unsigned tp2, unsigned* fault)
+{
+    fr_check_set(set, cbands, kint, kedge, tp1, tp2, fault, (int)threadIdx.x);
+}
+#endif
 
 // packed i16 arithmetic on two pixels (the Sobel stage of the SOB instantiation; same forms as rcv_harris_fused.hip)
 typedef short fr_s2v __attribute__((ext_vector_type(2)));
@@ -437,9 +474,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         }
         if constexpr (SOB != 0) {
             // the lane's four filtered pixels as (B,G,R,x) dwords out of the 12 interleaved bytes, gray into byte 2
-            const uint32_t oa = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
-            const uint32_t ob = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
-            const uint32_t oc = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+            uint32_t oa, ob, oc;
+            {
+                const int v[12] = {acc[0][0], acc[1][0], acc[2][0], acc[0][1], acc[1][1], acc[2][1], acc[0][2], acc[1][2], acc[2][2], acc[0][3], acc[1][3], acc[2][3]};
+                rcv_ashr_sat_pk12_mfma(v, a.shift, oa, ob, oc);
+            }
             const uint32_t px[4] = {oa, __builtin_amdgcn_alignbyte(ob, oa, 3), __builtin_amdgcn_alignbyte(oc, ob, 2), oc >> 8};
             uint32_t g[4];
 #pragma unroll
@@ -474,7 +513,11 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
             // lane (q, n): four consecutive pixels of window n in each of the three blocks -> transpose -> window n of block q
             uint32_t D[4];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) D[pl] = rcv_ashr_sat_pk4(acc[pl][0], acc[pl][1], acc[pl][2], acc[pl][3], a.shift);
+            for (int pl = 0; pl < 3; ++pl) D[pl] = 0u;
+            {
+                const int v[12] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3], acc[2][0], acc[2][1], acc[2][2], acc[2][3]};
+                rcv_ashr_sat_pk12_mfma(v, a.shift, D[0], D[1], D[2]);
+            }
             D[3] = D[2];
             sw16(D[0], D[1]);
             sw16(D[2], D[3]);
@@ -492,9 +535,10 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         }
         // lane (q, n) holds pixels 16n + 4q .. +3 of the three planes: 12 interleaved output bytes
         U3w o;
-        o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
-        o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
-        o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        {
+            const int v[12] = {acc[0][0], acc[1][0], acc[2][0], acc[0][1], acc[1][1], acc[2][1], acc[0][2], acc[1][2], acc[2][2], acc[0][3], acc[1][3], acc[2][3]};
+            rcv_ashr_sat_pk12_mfma(v, a.shift, o.a, o.b, o.c);
+        }
         if (DBG & 16) {
             o.a = (uint32_t)__builtin_amdgcn_ds_bpermute(ordl, (int)o.a);
             o.b = (uint32_t)__builtin_amdgcn_ds_bpermute(ordl, (int)o.b);
@@ -602,7 +646,18 @@ struct FRItem {                // (all scalar)
 // stick out of the row) or of the interior strips, band-major.  EDGE is a compile-time property of the loop -- the border repair
 // and the masked stores exist in the edge loop only -- so a wave runs the loop of its own kind until that queue is empty and then
 // helps with the other one (kernel below).  Returns when the queue is empty.
-template <int KS, int PP, bool EDGE, int DBG, int DMASK>
+// Code variants of the chained loop (a bit mask; the product instantiates kChainVar, the measurement build also 0 and the traced form):
+//   CV_PACK2   the four accumulators of an output dword packed by TWO v_ashr_pk_u8_i32 (the second with op_sel[3]: writes D[31:16]) instead of
+//              2 + shift + or: 6 instead of 12 VALU per row (rcv_ashr_sat_pk12_mfma)
+//   CV_TRACE   (measurement) every wave records the chip-wide 100 MHz counter at its start and after its last store (FRArgs::trace)
+// Round 6, same-process A/B on four boxes (profiles/r06_chain_variants.txt): CV_PACK2 -0.9 ... -1.2 % on three, +0.2 % on one -- with it the
+// filter runs level with its own memory-only form.  Built, measured and removed again: twelve more VALU instructions per step +0.2 % (an
+// instruction costs next to nothing here); a second, discarded ticket draw per item from a line of the same XCD and queue +0.1 % (a draw costs
+// nothing measurable); the next item's ticket requested three steps ahead and waited for at the item's end 0 ... +0.4 % (and the pending
+// scalar register pair is invisible to the compiler: not worth the hazard).
+constexpr int CV_PACK2 = 1, CV_TRACE = 32;
+constexpr int kChainVar = CV_PACK2;   // the product's form
+template <int KS, int PP, bool EDGE, int DBG, int DMASK, int VAR>
 __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, const int xcd, const v4i (&A)[2][(KS + 1) / 2], const v4i (&A2)[2][(KS + 1) / 2],
                                              const v4i& initv)
 {
@@ -616,7 +671,9 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     const int kstrips = EDGE ? a.n_edge : a.nstrips - a.n_edge;            // strips of this kind
     // (computed, not looked up: a dynamic index into the by-value argument struct would move the whole struct to scratch memory)
     const unsigned gb0 = (unsigned)(((unsigned long long)a.cbands * (unsigned)xcd) >> 3), gb1 = (unsigned)(((unsigned long long)a.cbands * (unsigned)(xcd + 1)) >> 3);
-    const unsigned nitems = (gb1 - gb0) * (unsigned)kstrips;               // of this XCD and kind
+    const unsigned nb = gb1 - gb0, t2 = min(a.tp2, nb), t1 = min(a.tp1, nb - t2), nbn = nb - t1 - t2;   // bands of the run: ordinary, halved, quartered
+    const unsigned n0 = nbn * (unsigned)kstrips, n1 = n0 + 2u * t1 * (unsigned)kstrips;
+    const unsigned nitems = n1 + 4u * t2 * (unsigned)kstrips;             // of this XCD and kind (= fr_queue_items)
     if (nitems == 0) return;
     unsigned long long* const tick = a.tickets + 16 * (2 * xcd + (EDGE ? 1 : 0));
     const unsigned long long inv_k = EDGE ? a.inv_edge : a.inv_int;
@@ -636,8 +693,13 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
             it.done = true;
             return;
         }
-        const unsigned bl = (unsigned)(((unsigned long long)li * inv_k) >> 32);
-        const unsigned ks = li - bl * (unsigned)kstrips;
+        // ordinary items: band li / kstrips of the run; in the tapered tail 2 / 4 consecutive rows of strips share a band
+        const unsigned l2 = li < n0 ? li : (li < n1 ? li - n0 : li - n1);
+        const unsigned sb = (unsigned)(((unsigned long long)l2 * inv_k) >> 32);
+        const unsigned ks = l2 - sb * (unsigned)kstrips;
+        const unsigned lg = li < n0 ? 0u : (li < n1 ? 1u : 2u);          // pieces per band = 1 << lg
+        const unsigned bl = li < n0 ? sb : (li < n1 ? nbn + (sb >> 1) : nbn + t1 + (sb >> 2));
+        const unsigned piece = sb & ((1u << lg) - 1u);
         const unsigned band = gb0 + bl;                                  // of the batch, frame-major
         const unsigned f = (unsigned)(((unsigned long long)band * a.inv_bpf) >> 32);
         const unsigned j = band - f * (unsigned)a.bpf;
@@ -645,8 +707,9 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
         // edge strips: 0, then the trailing ones; interior strips: 1 .. nstrips - n_edge
         const int strip = EDGE ? (ks == 0 ? 0 : a.nstrips - a.n_edge + (int)ks) : 1 + (int)ks;
         it.X = strip * 768;
-        it.ys = (int)(((unsigned long long)j * a.bmul) >> 20);
-        it.nrows = (int)(((unsigned long long)(j + 1) * a.bmul) >> 20) - it.ys;
+        const int bys = (int)(((unsigned long long)j * a.bmul) >> 20), bnr = (int)(((unsigned long long)(j + 1) * a.bmul) >> 20) - bys;
+        it.ys = bys + (int)(((unsigned)bnr * piece) >> lg);
+        it.nrows = bys + (int)(((unsigned)bnr * (piece + 1u)) >> lg) - it.ys;
         it.P = (it.nrows + 1) / 2 + NP - 1;
         it.interior = it.ys >= RAD && it.ys + it.nrows + RAD + 1 <= a.rows;   // (+ 1: an odd band's last pair holds one row more)
         it.sf = a.src + (size_t)frame * a.sfs;
@@ -787,9 +850,14 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
             for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
         }
         U3w o;
-        o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
-        o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
-        o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        if constexpr ((VAR & CV_PACK2) != 0) {
+            const int v[12] = {acc[0][0], acc[1][0], acc[2][0], acc[0][1], acc[1][1], acc[2][1], acc[0][2], acc[1][2], acc[2][2], acc[0][3], acc[1][3], acc[2][3]};
+            rcv_ashr_sat_pk12_mfma(v, a.shift, o.a, o.b, o.c);
+        } else {
+            o.a = rcv_ashr_sat_pk4(acc[0][0], acc[1][0], acc[2][0], acc[0][1], a.shift);
+            o.b = rcv_ashr_sat_pk4(acc[1][1], acc[2][1], acc[0][2], acc[1][2], a.shift);
+            o.c = rcv_ashr_sat_pk4(acc[2][2], acc[0][3], acc[1][3], acc[2][3], a.shift);
+        }
         // non-temporal: the launch never reads its output back; (EDGE) windows past the row end (a partial last strip) are masked off
         if (ok && o_in) __builtin_nontemporal_store(v3i{(int)o.a, (int)o.b, (int)o.c}, (v3i*)(o_df + (size_t)(roff + o_so)));
     };
@@ -848,7 +916,7 @@ __device__ __forceinline__ void fr_chain_run(const FRArgs& a, const int lane, co
     }
 }
 
-template <int KS, int PP, int DBG, int DMASK = 0>
+template <int KS, int PP, int DBG, int DMASK = 0, int VAR = 0>
 __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
 {
     constexpr int NP = (KS + 1) / 2;
@@ -857,6 +925,12 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
     // L2-scope and one XCD's L2 is only coherent with itself
     const int xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));   // hwreg(HW_REG_XCC_ID, 0, 4); wave-uniform
     const int slot = (int)(blockIdx.x >> 3);   // of this XCD (with the usual placement)
+    unsigned long long t_start = 0;
+    if constexpr ((VAR & CV_TRACE) != 0) t_start = __builtin_amdgcn_s_memrealtime();
+    // the first wave of the launch checks that the context's previous chained launch drew all of its items (the launch boundary has made
+    // every XCD's counters visible); the last launch before a host-side wait is checked by k_chain_check (rcv_chain_flush)
+    if (blockIdx.x == 0 && a.prev_tickets) fr_check_set(a.prev_tickets, a.prev_cbands, a.prev_kint, a.prev_kedge, a.prev_tp1, a.prev_tp2, a.fault, lane);
+    if (xcd == a.drop_xcd) return;             // (fault injection for the completion check's test)
     {   // (see "Tickets" above; uniform addresses: a lane-dependent index here made the compiler keep the counter addresses in VGPRs)
         int xz = xcd;
         asm volatile("" : "+s"(xz));   // (its own copy: shared with the draw addresses, the vector store pulled the whole address chain into VGPRs)
@@ -887,9 +961,16 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
     bool edge = slot < a.edge_waves;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {   // (one copy of each loop in the binary)
-        if (edge) fr_chain_run<KS, PP, true, DBG, DMASK>(a, lane, xcd, A, A2, initv);
-        else fr_chain_run<KS, PP, false, DBG, DMASK>(a, lane, xcd, A, A2, initv);
+        if (edge) fr_chain_run<KS, PP, true, DBG, DMASK, VAR>(a, lane, xcd, A, A2, initv);
+        else fr_chain_run<KS, PP, false, DBG, DMASK, VAR>(a, lane, xcd, A, A2, initv);
         edge = !edge;
+    }
+    if constexpr ((VAR & CV_TRACE) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's last stores have left
+        if (lane == 0 && a.trace) {
+            a.trace[2 * (size_t)blockIdx.x] = t_start;
+            a.trace[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 
@@ -983,7 +1064,8 @@ template <int KS, int PP>
 void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t st, int dbg)
 {
 #ifdef RCV_ROWS_BENCH
-    switch (dbg & 255) {
+    // (the ablation instantiations exist for the default prefetch depth only: 21 variants x 6 depths made this file a four-minute build)
+    if constexpr (PP == 3) switch (dbg & 255) {
     case 32: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 32>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 96: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 96>), grid, dim3(64 * a.wpb), lds, st, a); return;
     case 128: RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 128>), grid, dim3(64 * a.wpb), lds, st, a); return;
@@ -1091,6 +1173,30 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                        const View* gy, const RowsTune& kn);
 
 #ifndef RCV_ROWS_BENCH
+// Completion check of the chained kernel, host side (rcv_internal.h has the scheme).
+int rcv_chain_flush(rcv_ctx* ctx)
+{
+    if (!ctx->fr_unchecked) return RCV_OK;
+    ctx->fr_unchecked = false;
+    const unsigned long long* set = (const unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq - 1u) & 3u));
+    hipLaunchKernelGGL(k_chain_check, dim3(1), dim3(64), 0, ctx->stream, set, ctx->fr_prev[0], ctx->fr_prev[1], ctx->fr_prev[2], ctx->fr_prev[3], ctx->fr_prev[4],
+                       ctx->fr_fault);
+    return rcv_launch_check(ctx);
+}
+int rcv_chain_poll(rcv_ctx* ctx)
+{
+    // (after a fault no chained launch is enqueued any more; the ones that were already queued behind the faulty one raise the word again --
+    //  old news: the fault has been reported and those launches belong to the same failed stretch of the stream)
+    if (!ctx->fr_fault || ctx->fr_chain_off || __atomic_load_n(ctx->fr_fault, __ATOMIC_ACQUIRE) == 0u) return RCV_OK;
+    // some queue of a chained launch was left short: what that launch (and the chained ones after it) wrote is incomplete.  Reported once;
+    // the counters are zeroed again before they are used and this context stays on the one-band-per-wave kernel from here on.
+    __atomic_store_n(ctx->fr_fault, 0u, __ATOMIC_RELEASE);
+    ctx->fr_tickets_ready = false;
+    ctx->fr_unchecked = false;
+    ctx->fr_chain_off = true;
+    return RCV_ERR_DEVICE;
+}
+
 int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size,
                         const View* gx, const View* gy)
 {
@@ -1107,7 +1213,7 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
 }
 #else
 // Measurement entry (librustcv_hip_bench.so): the BGR -> BGR filter of a device-resident batch with every plan parameter explicit.
-// tune: 14 ints {f7_rows, dual_full, chain, chain_rows, dbg, wpc, rounds, pp, order, bpf, band_rows, taper, wpb, edge_pct}; trace: the
+// tune: 15 ints {f7_rows, dual_full, chain, chain_rows, dbg, wpc, rounds, pp, order, bpf, band_rows, taper, wpb, edge_pct, var}; trace: the
 // per-wave timeline buffer (dbg 24) or NULL.  With dbg != 0 the output is NOT a filtered image.
 extern "C" int rcv__filter_rows_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift, const int* tune, void* trace)
 {
@@ -1122,6 +1228,7 @@ extern "C" int rcv__filter_rows_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
     RowsTune t;
     t.f7_rows = tune[0]; t.dual_full = tune[1]; t.chain = tune[2]; t.chain_rows = tune[3]; t.dbg = tune[4]; t.wpc = tune[5]; t.rounds = tune[6];
     t.pp = tune[7]; t.order = tune[8]; t.bpf = tune[9]; t.band_rows = tune[10]; t.taper = tune[11]; t.wpb = tune[12]; t.edge_pct = tune[13];
+    t.var = tune[14];
     t.trace = trace;
     return rows_launch(ctx, s, d, k16, ksize, shift, 0, true, nullptr, nullptr, t);
 }
@@ -1230,7 +1337,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     ctx->fr_tab[slot].stamp = ++ctx->fr_clock;
     const int dmask = ctx->fr_tab[slot].dmask;
 
-    FRArgs a;
+    FRArgs a = {};
     a.src = s.p;
     a.dst = d.p;
     a.wtab = (const uint4*)(ctx->fr_tabs + (size_t)slot * 16384);
@@ -1327,12 +1434,13 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
 #else
     const bool chain_dual_ok = false;
 #endif
+    RCV_TRY(rcv_chain_poll(ctx));   // (a fault raised by an earlier chained launch of this context: reported before anything else is enqueued)
     if (src_yuyv == 0 && !sob && (dmask == 0 || chain_dual_ok) && (small_plan == 0 || kn.chain >= 1) && kn.band_rows == 0 && kn.chain != 0 && s.rows >= 64 &&
-        ctx->cu_count == 256) {
+        ctx->cu_count == 256 && !ctx->fr_chain_off) {
         const int want_rows = kn.chain_rows > 0 ? (kn.chain_rows > 2048 ? 2048 : kn.chain_rows) : 32;   // (bmul < 2^32)
         int bpf = (s.rows + want_rows / 2) / want_rows;
         bpf = bpf < 1 ? 1 : (bpf > s.rows / 8 ? s.rows / 8 : bpf);
-        const unsigned long long nbands = (unsigned long long)s.n * bpf, nitems = ((nbands + 7) / 8) * a.nstrips;   // (items of the longest run)
+        const unsigned long long nbands = (unsigned long long)s.n * bpf, nitems = 4 * ((nbands + 7) / 8) * a.nstrips;   // (bound on the items of the longest run, all of it quartered)
         const int cwpc = kn.wpc == 12 || kn.wpc == 4 || kn.wpc == 6 || kn.wpc == 10 ? kn.wpc : 8;   // (knob: waves per CU, sweeps)
         const unsigned waves = (unsigned)(ctx->cu_count / 8 * cwpc);   // per XCD: cu_count / 8 CUs x 8 waves
         // (the kernel's quotients by multiply-and-shift are exact for these ranges)
@@ -1358,11 +1466,36 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                 int ew = (int)(share * waves + 0.5);
                 a.edge_waves = n_int == 0 ? (int)waves : (ew < 1 ? 1 : ew);
             }
+            if (!ctx->fr_fault) {
+                RCV_HIP(hipHostMalloc((void**)&ctx->fr_fault, 64, hipHostMallocDefault));
+                *ctx->fr_fault = 0u;
+            }
             if (!ctx->fr_tickets_ready) {
+                RCV_TRY(rcv_chain_flush(ctx));   // (the check of the last launch reads the counters this is about to zero)
                 RCV_HIP(hipMemsetAsync(ctx->kconst + RCV_KC_FR_TICKETS, 0, RCV_KC_FR_TICKETS_BYTES, ctx->stream));
                 ctx->fr_seq = 0;
                 ctx->fr_tickets_ready = true;
             }
+            // tapered tail (kn.taper: -1 the product's plan, 0 none, else halved + 256 * quartered bands per XCD)
+            {
+                // Product plan: 8 bands halved + 4 quartered per XCD and queue (tools/chain_timeline.py, four boxes, 64 x 4K: the waves of an XCD
+                // leave over ~21 us = one 32-row item without the taper, ~12-16 us with it; idle wave slots 2.9-3.5 % -> 2.1-2.8 %; back to
+                // back -0.4 %, 16 frames -2.5 %; 16 + 8, 24 + 12, 0 + 8 within 0.2 % of it: profiles/r06_chain_timeline.txt), less on short runs
+                const unsigned per_xcd = (unsigned)(nbands / 8);
+                unsigned t1 = per_xcd / 8 < 8 ? per_xcd / 8 : 8, t2 = per_xcd / 16 < 4 ? per_xcd / 16 : 4;
+                if (kn.taper >= 0) t1 = (unsigned)kn.taper & 255u, t2 = (unsigned)kn.taper >> 8;
+                if (t1 + t2 > per_xcd / 2) t1 = t2 = 0;   // short runs: no taper
+                // an item needs >= 7 rows (more row pairs than the ring's prefetch depth): halves of bands of 14+, quarters of bands of 28+ rows
+                const int br_min = s.rows / bpf;
+                if (br_min < 28) t2 = 0;
+                if (br_min < 14) t1 = 0;
+                a.tp1 = t1;
+                a.tp2 = t2;
+            }
+            a.prev_tickets = ctx->fr_unchecked ? (const unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq - 1u) & 3u)) : nullptr;
+            a.prev_cbands = ctx->fr_prev[0]; a.prev_kint = ctx->fr_prev[1]; a.prev_kedge = ctx->fr_prev[2]; a.prev_tp1 = ctx->fr_prev[3]; a.prev_tp2 = ctx->fr_prev[4];
+            a.fault = ctx->fr_fault;
+            a.drop_xcd = rcv_knobs().fr_chain_drop_xcd;
             static_assert(RCV_KC_FR_TICKETS_BYTES == 4 * 2048, "four sets of 16 counters, 128 bytes apart");
             a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * (ctx->fr_seq & 3u));
             a.tickets_next = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq + 2u) & 3u));
@@ -1372,12 +1505,16 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             const unsigned cap = (163840u / (unsigned)cwpc) & ~511u;
             constexpr int kAll7 = 255;
             (void)kAll7;
+#ifdef RCV_ROWS_BENCH
             const bool centre7 = ksize == 7 && dmask != 0 && (dmask & ~kCentre7) == 0;
+#endif
             if (ksize == 7) {
 #ifdef RCV_ROWS_BENCH
                 if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
                 else if ((kn.dbg & 255) == 132) RCV_LAUNCH((k_filter_rows_chain<7, 3, 384>), grid, dim3(64), cap, ctx->stream, a);
                 else if ((kn.dbg & 255) == 128) RCV_LAUNCH((k_filter_rows_chain<7, 3, 128>), grid, dim3(64), cap, ctx->stream, a);
+                else if (kn.var == 1000) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 0>), grid, dim3(64), cap, ctx->stream, a);   // (the round-5 form)
+                else if (kn.var == 33) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 33>), grid, dim3(64), cap, ctx->stream, a);   // wave timeline
                 else if (kn.pp == 4) RCV_LAUNCH((k_filter_rows_chain<7, 4, 0>), grid, dim3(64), cap, ctx->stream, a);
                 else if (kn.pp == 2) RCV_LAUNCH((k_filter_rows_chain<7, 2, 0>), grid, dim3(64), cap, ctx->stream, a);
                 else
@@ -1387,12 +1524,18 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                 else if (dmask != 0) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kAll7>), grid, dim3(64), cap, ctx->stream, a);
                 else
 #endif
-                    RCV_LAUNCH((k_filter_rows_chain<7, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+                    RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
             } else if (dmask != 0) return RCV_ERR_UNSUPPORTED;   // (measurement build: two tables chained for 7x7 only)
-            else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
-            else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0>), grid, dim3(64), cap, ctx->stream, a);
+            else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
+            else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
             const int rc = rcv_launch_check(ctx);
-            if (rc == RCV_OK) ++ctx->fr_seq;   // (a launch that did not start touched no counter: the same set serves the next one)
+            if (rc == RCV_OK) {   // (a launch that did not start touched no counter: the same set serves the next one)
+                ++ctx->fr_seq;
+                ctx->fr_prev[0] = a.cbands; ctx->fr_prev[1] = (unsigned)n_int; ctx->fr_prev[2] = (unsigned)n_edge; ctx->fr_prev[3] = a.tp1; ctx->fr_prev[4] = a.tp2;
+                ctx->fr_unchecked = true;
+            } else {
+                ctx->fr_tickets_ready = false;
+            }
             return rc;
         }
     }

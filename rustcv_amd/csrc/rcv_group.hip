@@ -89,12 +89,17 @@ extern "C" int rcv_group_timer_stop(rcv_group* g, float* elapsed_ms)
         RCV_TRY(rcv_bind(c));
         RCV_HIP(hipEventRecord(c->ev1, c->stream));
     }
-    float best = 0.0f;
+    // first wait for EVERY stop event (a stream's stop event implies its start event): hipEventElapsedTime on an event that has not
+    // completed returns hipErrorNotReady -- a stream that was still busy at timer_start completes its start event late
     for (rcv_ctx* c : g->ctxs) {
         RCV_TRY(rcv_bind(c));
         RCV_HIP(hipEventSynchronize(c->ev1));
-        // against EVERY start event of the device: the earliest-COMPLETED one gives the longest span (a stream that was still busy at
-        // timer_start completes its start event late; the rank-order first context need not be the earliest)
+    }
+    float best = 0.0f;
+    for (rcv_ctx* c : g->ctxs) {
+        RCV_TRY(rcv_bind(c));
+        // against EVERY start event of the device: the earliest-COMPLETED one gives the longest span (the rank-order first context
+        // need not be the earliest)
         for (rcv_ctx* o : g->ctxs) {
             if (o->device != c->device) continue;
             float ms = 0.0f;

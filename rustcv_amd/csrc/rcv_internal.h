@@ -59,6 +59,13 @@ struct rcv_ctx {
     } fr_tab[4];
     bool fr_tickets_ready;        // the chained row kernel's ticket counters (kconst + RCV_KC_FR_TICKETS) have been zeroed
     unsigned fr_seq;              // chained launches of this context so far: launch i draws from counter set i % 4 and zeroes set (i + 2) % 4
+    // completion check of the chained kernel (rcv_filter_rows_mfma.hip: fr_check_set): launch i + 1 checks launch i, rcv_chain_flush() the last
+    // one before a host-side wait; a launch that left items undone raises *fr_fault (pinned host memory), rcv_chain_poll() turns that into
+    // RCV_ERR_DEVICE once, re-zeroes the counters and sends the context's later launches to the one-band-per-wave kernel
+    unsigned* fr_fault;           // hipHostMalloc'ed word, 0 = fine; written by the device on a fault only
+    bool fr_unchecked;            // the last chained launch has not been checked yet
+    bool fr_chain_off;            // a fault was seen: no chained launches on this context any more
+    unsigned fr_prev[5];          // plan of the last chained launch: cbands, interior strips, edge strips, tapered bands (half, quarter)
     uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
     unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
@@ -80,7 +87,7 @@ struct rcv_ctx {
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
-// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), twelve in all; nothing
+// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), thirteen in all (one of them a fault injection); nothing
 // needs them in production and no tuning parameter is among them (those are arguments of the measurement entries in
 // librustcv_hip_bench.so).  Read ONCE per process -- a launch-bound call (a single 1080p frame: 6 us) must not pay for getenv -- and
 // again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 names them; DESIGN_HISTORY.md 5 lists each with the test that uses it.
@@ -91,6 +98,7 @@ struct RcvKnobs {
     int f7_dual_full;     // RCV_F7_DUAL_FULL  large-weight kernels use K = 4Q + R even where the centre split applies
     int fr_chain;         // RCV_FR_CHAIN      chained-band kernel: 0 never, 1 every eligible launch, -1 (unset) launches that fill the GPU
     int fr_chain_rows;    // RCV_FR_CHAIN_ROWS rows per chained band (0 = 32): band seams at other rows
+    int fr_chain_drop_xcd;  // RCV_FR_CHAIN_DROP_XCD  FAULT INJECTION (test of the completion check): the chained kernel's waves on this XCD leave at once
     int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian: 1 every eligible shape, 0 never, -1 (unset) small launches
     int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan): segment seams at every height
     int harris_general;   // RCV_HARRIS_GENERAL   1: blockSize 2 on the general-block kernel too
@@ -143,6 +151,9 @@ static inline int rcv_elem_size(int depth) { return depth == RCV_8U ? 1 : (depth
 void rcv_ctx_child_released(rcv_ctx* ctx);                   // a graph / ring of this context was destroyed
 int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ctx->device)
 int rcv_launch_check(rcv_ctx* ctx);                           // hipGetLastError -> code
+int rcv_wait(rcv_ctx* ctx);                                   // every host-side wait on the context's stream: flush + synchronize + poll (below)
+int rcv_chain_flush(rcv_ctx* ctx);                            // enqueue the completion check of the last chained launch, if it is still unchecked
+int rcv_chain_poll(rcv_ctx* ctx);                             // RCV_ERR_DEVICE (once) if a chained launch left items undone
 int rcv_ws_reserve(rcv_ctx* ctx, size_t total);               // (re)size the workspace, reset the carve pointer
 int rcv_ws_alloc(rcv_ctx* ctx, size_t bytes, uint8_t** out);  // 256-B aligned carve
 int rcv_side_reserve(rcv_ctx* ctx, size_t bytes, uint8_t** out);   // the side buffer, grown if needed

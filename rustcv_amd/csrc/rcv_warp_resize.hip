@@ -368,15 +368,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
 #pragma unroll 1
     for (;;) {
         // frame f is in buffer 0 once every wave's loads have landed; all waves have left frame f - 1 (buffer 1 is free)
+        // (scheduling barriers: the wait's count assumes that a half's loads are all OLDER than its store -- nothing may move a load
+        //  below the store or the store above a load; tests/test_isa_waits.py checks the order in the ISA as well)
         __builtin_amdgcn_s_waitcnt(RCV_STAGE_WAIT);   // vmcnt(1) (expcnt / lgkmcnt untouched)
         __syncthreads();
         if (f + 1 < f1) issue(sf + sfs, 1);
+        __builtin_amdgcn_sched_barrier(0);
         finish(df, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (++f >= f1) break;
         __builtin_amdgcn_s_waitcnt(RCV_STAGE_WAIT);
         __syncthreads();
         if (f + 1 < f1) issue(sf + 2 * sfs, 0);
+        __builtin_amdgcn_sched_barrier(0);
         finish(df + dfs, 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (++f >= f1) break;
         sf += 2 * sfs;
         df += 2 * dfs;
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC, OCC
 bool wrl_ok(const View& s, const View& d)
 {
     return ((uintptr_t)s.p & 3) == 0 && (s.step & 3) == 0 && (s.fstride & 3) == 0 && s.step < (1u << 24) && s.rows < (1 << 24) &&
-           (unsigned long long)s.rows * s.step < (1ull << 32) && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
+           (unsigned long long)s.rows * s.step <= 0xffffff00ull && (unsigned long long)d.rows * d.step < (1ull << 32) && d.cols >= 4;
+    // (<= 0xffffff00: the staged kernel's do-not-fetch offset must lie beyond the buffer descriptor's range, which is the frame's size)
 }
 
 // Does the staged kernel's plan hold for this map?  The plans of nine tiles spread over the output (a 3 x 3 grid at 1/4, 1/2, 3/4 of

@@ -97,6 +97,24 @@ def test_other_configs_cover_the_sobel_half_of_config_3():
     assert bench.oracle_step(Orc(), "3f", "F") == ("sobel", ("gray", ("filt", "F", "k7", 6)))
 
 
+def test_default_run_names_every_baseline_config():
+    """round 6: the driver's line carries a record for EVERY BASELINE config -- "1" (640x480 YUYV -> BGR + rectangle: the
+    reference's own path, rustcv/src/videoio/mod.rs:201-258 + imgproc/drawing.rs:67-106; CPU restatement on one thread and all cores, GPU
+    latency beside it) and "2" (1080p 5x5, us per launch with the empty-kernel and frame-copy floors of the same run) beside 3s / 3f / 4 / 5,
+    and config 5 reports its worst-case launch (the time depends on corner density since the threshold-first NMS).  The GPU side of this is
+    tests/test_gpu_bench_ranks.py::test_default_run_carries_the_other_configs_small; here: the wiring."""
+    import inspect
+    src = inspect.getsource(bench.run_rank)
+    assert '"1": config1_record(a, ctx0)' in src and '"2": config2_record(a, ctx0)' in src and '("3s", "3f", 4, 5)' in src
+    c1, c2, oc = inspect.getsource(bench.config1_record), inspect.getsource(bench.config2_record), inspect.getsource(bench.other_config)
+    for must in ("value_1thread", "gpu_device_resident", "gpu_host_mat", "Rect(200, 150, 240, 240)", "alg_bytes_per_px"):
+        assert must in c1, must
+    for must in ("empty_kernel_us", "copy_of_the_frame_us", '"higher_is_better": False', "gaussian_blur(src, dst, 5, 0.0)"):
+        assert must in c2, must
+    for must in ("worst_case_launch_ms", "worst_case_frac", 'float("-inf")'):
+        assert must in oc, must
+
+
 def test_parse_defaults():
     a = bench.parse([])
     assert a.in_flight == 2 and a.batch == 64 and a.gpus == 1 and a.device_list is None

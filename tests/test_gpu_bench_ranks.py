@@ -106,17 +106,28 @@ def test_torchrun_eight_ranks_on_one_device():
 
 
 def test_default_run_carries_the_other_configs_small():
-    """the default (N = 1) line at a reduced batch: other_configs has the Sobel half of config 3 ("3s", "3f") and configs 4 / 5, every
-    record with its own roofline, verification and cpu_baseline; the one-stream figure is flattened into scalars"""
+    """the default (N = 1) line at a reduced batch: other_configs has EVERY BASELINE config beside the headline (round 6: "1" the reference's own
+    640x480 YUYV -> BGR + rectangle path with its CPU timing on one thread and all cores and the GPU latency; "2" one 1080p frame 5x5 in us per
+    launch with the floors of the same run), the Sobel half of config 3 ("3s", "3f") and configs 4 / 5 (round 6: "5" also with the worst-case
+    launch -- noise, thr = -inf), every record with its verification and cpu_baseline; the one-stream figure is flattened into scalars"""
     p, out = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--sustained", "12", "--settle-ms", "20", "--no-probe", "--no-ceiling",
                    "--cpu-seconds", "1", "--other-cpu-seconds", "0.5"], timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert set(out["other_configs"]) == {"3s", "3f", "4", "5"}
+    assert set(out["other_configs"]) == {"1", "2", "3s", "3f", "4", "5"}
     for key, rec in out["other_configs"].items():
         assert rec["verified"].startswith("bit-exact"), (key, rec["verified"])
-        assert 0.05 < rec["roofline"]["frac"] < 1.0 and rec["roofline"]["launch_ms"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
+        assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
+        if key in ("1", "2"):
+            continue
+        assert 0.05 < rec["roofline"]["frac"] < 1.0 and rec["roofline"]["launch_ms"] > 0
+        assert rec["roofline"]["in_flight2_launch_ms"] > 0 and 0.05 < rec["roofline"]["in_flight2_frac"] < 1.0
+    c1, c2, c5 = out["other_configs"]["1"], out["other_configs"]["2"], out["other_configs"]["5"]
+    assert c1["cpu_baseline"]["value_1thread"] > 0 and c1["alg_bytes_per_px"] == 5 and "roofline" not in c1       # SURVEY.md 8(d): the CPU path is this config's headline
+    assert 1.0 < c1["gpu_device_resident"]["us_per_frame"] < 200.0 and c1["gpu_host_mat"]["us_per_frame"] > c1["gpu_device_resident"]["us_per_frame"]
+    assert c2["unit"] == "us" and c2["higher_is_better"] is False and "roofline" not in c2                            # latency config: no HBM fraction claimed
+    assert 1.0 < c2["floors"]["empty_kernel_us"] <= c2["value"] * 1.05 and c2["floors"]["copy_of_the_frame_us"] > 1.0 and c2["value"] < 50.0
+    assert c5["roofline"]["worst_case_launch_ms"] >= 0.9 * c5["roofline"]["launch_ms"] and c5["roofline"]["worst_case_verified"].startswith("bit-exact")
     assert out["other_configs"]["3s"]["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 7
-    assert all(rec["roofline"]["in_flight2_launch_ms"] > 0 and 0.05 < rec["roofline"]["in_flight2_frac"] < 1.0 for rec in out["other_configs"].values())
     r = out["roofline"]
     assert r["single_stream_frac"] == r["single_stream"]["frac"] and out["value_single_stream"] > 0    # (four timed steps: no ordering of the two values is asserted)
     assert out["cpu_baseline"]["value"] > 0

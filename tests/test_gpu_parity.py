@@ -523,6 +523,94 @@ def test_filter_rows_chained_bands(ctx, oracle, knob, n, rows, cols, band_rows):
     src.free()
 
 
+@pytest.mark.parametrize("drop", [0, 5])
+def test_filter_rows_chain_reports_an_xcd_without_waves(oracle, knob, drop):
+    """round 6: the chained kernel's lists are per XCD and only drawn by waves that RUN on that XCD; an XCD that
+    receives no waves (a CU mask, a partition that still reports 256 CUs) used to leave an eighth of the batch unfiltered without a word.
+    Now every launch checks that its predecessor drew all of its items (first wave of the launch) and every host-side wait enqueues the
+    check of the last launch; a short queue comes back as RCV_ERR_DEVICE, once, and the context stays on the one-band-per-wave kernel.
+    Fault injection RCV_FR_CHAIN_DROP_XCD: the waves on that XCD leave at once.  Never stale output without an error."""
+    import rustcv_amd as rcv
+    from rustcv_amd._ffi import RcvError
+    knob("RCV_FR_CHAIN", 1)
+    knob("RCV_F7_ROWS", 1)
+    c = rcv.Context(0)
+    r = np.random.default_rng(77 + drop + _SOAK_SEED)
+    n, rows, cols = 16, 80, 1040
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    k = r.integers(-9, 10, size=(7, 7)).astype(np.int8)
+    src = device.DeviceBatch(c, n, rows, cols, 3)
+    src.upload(frames)
+    dst = device.DeviceBatch(c, n, rows, cols, 3)
+    L = _ffi.lib()
+    want = [oracle.filter2d_i8(frames[i], k, 5) for i in range(n)]
+    # (a) healthy launches: no false alarm, whichever path does the check (successor launch or the wait)
+    for reps in (1, 3):
+        for _ in range(reps):
+            device.filter2d(src, dst, k, shift=5)
+        c.sync()
+    got = dst.download()
+    assert all(np.array_equal(got[i], want[i]) for i in range(n))
+    # (b) one faulty launch, then a wait: the wait reports it
+    knob("RCV_FR_CHAIN_DROP_XCD", drop)
+    dst.memset(0)
+    L.rcv__debug_kernels_reset()
+    device.filter2d(src, dst, k, shift=5)
+    assert "k_filter_rows_chain<7" in L.rcv__debug_kernels().decode()
+    with pytest.raises(RcvError) as e:
+        c.sync()
+    assert e.value.code == -4   # RCV_ERR_DEVICE
+    got = dst.download()        # (reported once: the download itself succeeds)
+    assert any(not np.array_equal(got[i], want[i]) for i in range(n)), "the injected fault left no trace: the hook did not work"
+    # (c) the context has left the chained kernel for good: correct bytes from the one-band-per-wave kernel, hook still set
+    dst.memset(0)
+    L.rcv__debug_kernels_reset()
+    device.filter2d(src, dst, k, shift=5)
+    c.sync()
+    assert "k_filter_rows_mfma<" in L.rcv__debug_kernels().decode() and "chain" not in L.rcv__debug_kernels().decode()
+    got = dst.download()
+    assert all(np.array_equal(got[i], want[i]) for i in range(n))
+    c.close()
+    # (d) a fresh context, faulty launches queued back to back without a wait: a LATER call reports the fault (successor's check)
+    c2 = rcv.Context(0)
+    src2 = device.DeviceBatch(c2, n, rows, cols, 3)
+    src2.upload(frames)
+    dst2 = device.DeviceBatch(c2, n, rows, cols, 3)
+    with pytest.raises(RcvError):
+        for _ in range(200):
+            device.filter2d(src2, dst2, k, shift=5)
+        c2.sync()
+    c2.sync()
+    src2.free(); dst2.free()
+    c2.close()
+
+
+@pytest.mark.parametrize("taper", [0, 3 + 256 * 2, 1 + 256 * 1, 6])
+@pytest.mark.parametrize("n,rows,cols", [(16, 100, 1040), (9, 64, 256), (24, 131, 772)])
+def test_filter_rows_chain_tapered_tail(ctx, oracle, n, rows, cols, taper):
+    """round 6: the last bands of every XCD's run drawn as half- and quarter-height items (FRArgs::tp1 / tp2); through the measurement entry,
+    where the plan is an argument (the product's own plan is covered by every other chained test); every frame against the oracle"""
+    import ctypes as C
+    BL = _ffi.bench_lib()
+    r = np.random.default_rng(515 + rows + taper + _SOAK_SEED)
+    frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+    k = r.integers(-9, 10, size=(7, 7)).astype(np.int8)
+    src = device.DeviceBatch(ctx, n, rows, cols, 3)
+    src.upload(frames)
+    dst = _canary_batch(ctx, n, rows, cols, 3, pad=32)
+    bs, bd = src.as_rcv(), dst.as_rcv()
+    for chain_rows in (0, 16):
+        rc = BL.rcv__filter_rows_bench(ctx.handle, C.byref(bs), C.byref(bd), k.ctypes.data_as(C.POINTER(C.c_int8)), 7, 5,
+                                       _ffi.rows_tune(chain=1, taper=taper, chain_rows=chain_rows), None)
+        assert rc == 0
+        got = dst.download()
+        for i in range(n):
+            want = oracle.filter2d_i8(frames[i], k, 5)
+            assert np.array_equal(got[i], want), (chain_rows, i, np.argwhere(got[i] != want)[:4])
+        _assert_canaries(dst)
+    src.free(); dst.free()
+
+
 def test_filter_rows_chain_ticket_accounting(oracle, knob):
     """the chained-band kernel's ticket counters (round 5: four sets; launch i draws from set i % 4, found zero, and zeroes set (i + 2) % 4;
     no host-side count of what a launch draws).  Sixty launches of four different geometries (different item counts, one / three edge

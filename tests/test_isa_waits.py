@@ -96,6 +96,19 @@ def test_staged_warp_resize_loop_head_leaves_the_store_in_flight(warp_resize_asm
         assert loop[b - 1] == "s_waitcnt vmcnt(1)", loop[max(0, b - 4):b + 1]
     assert "s_waitcnt vmcnt(0)" not in loop, [l for l in loop if "vmcnt" in l]
     assert sum(l.startswith("buffer_store_dword") for l in loop) == 2
+    # ... and inside a loop half every staged load is OLDER than the half's store (a load scheduled below the store would still
+    # be in flight across the next barrier; the kernel pins the order with scheduling barriers): between two barriers, no load after the store
+    segs, cur = [], []
+    for l in loop:
+        if l == "s_barrier":
+            segs.append(cur)
+            cur = []
+        else:
+            cur.append(l)
+    for seg in segs:
+        st = [i for i, l in enumerate(seg) if l.startswith("buffer_store_dword")]
+        if st:
+            assert not [l for l in seg[st[0]:] if l.startswith("buffer_load_dwordx4") and l.endswith("lds")], seg
     reads = [l for l in loop if l.startswith("ds_read")]
     assert reads and all(l.startswith(("ds_read2_b32", "ds_read_b32")) for l in reads), sorted(set(l.split()[0] for l in reads))
     # ... and the wait in front of the FIRST loop barrier (entry edge: loads of the first frame + the shaping store) is vmcnt(1) as well
