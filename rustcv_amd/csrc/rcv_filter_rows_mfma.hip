@@ -206,14 +206,22 @@ __device__ __forceinline__ void deint4w(uint32_t d0, uint32_t d1, uint32_t d2, u
 // `finish` would store goes through the gray formula (weights times 4: the value lands in byte 2 of its dword, as in
 // rcv_harris_fused.hip) and a Sobel stage in packed i16 that keeps the horizontal parts of the two previous filtered rows in
 // registers: filtered row y completes gradient row y - 1.  The horizontal neighbours of a lane's four pixels live in lanes
-// l -+ 16 (or l +- 47 across windows): two ds_bpermute per row.  A wave's 256-pixel tile has no neighbours outside itself, so
-// the strips are laid 240 pixels apart and a strip stores tile pixels 8 .. 247 (strip 0: 0 .. 247, pixel -1 := pixel 1) -- whole
-// lane pairs, see the stores; the lane whose last pixel is the row's last takes pixel cols := cols - 2 from itself.  A band of gradient rows [oys, oye) runs
-// the filter over rows oys - 1 .. oye (clamped to the image); at the image's top / bottom the missing row is the mirror image
-// (gradient row 0 is formed from rows 1, 0, 1; row rows - 1 after the loop from rows - 2, rows - 1, rows - 2).
+// l -+ 16 (or l +- 47 across windows): two ds_bpermute per row.
+// Layout (round 6; rounds 3-5 laid single waves 240 pixels apart and stored 240 pixels each -- 480-byte row pieces whose seams fall inside
+// the 128-byte lines of the i16 planes: the two halves of such a line are written by two waves at unrelated times, and those stores, not
+// the arithmetic, were 40 % of the launch: profiles/r06_sob_store_pattern.txt).  A WORKGROUP of four waves owns a group of 960 output pixels
+// = 15 whole lines of each gradient plane and walks a band of rows in step (one s_barrier per row pair).  Its 64 windows are the 60 regular
+// ones of the group (waves 0-2: 16 each, wave 3: 12) plus two SEAM windows in wave 3's spare slots -- the 16 pixels left of the group and
+// the 16 right of it, of which only the nearest pixel is used: the horizontal neighbour of the group's first / last pixel.  (A lane loads
+// its window's bytes itself, so a wave's windows need not be neighbours.)  The gray values that cross a wave seam -- 2 per wave and row --
+// go through LDS.  Matrix work 64 / 60 of the output as before, but every store is a whole line, written once, non-temporally.
+// A band of gradient rows [oys, oye) runs the filter over rows oys - 1 .. oye (clamped to the image); at the image's top / bottom the missing
+// row is the mirror image (gradient row 0 is formed from rows 1, 0, 1; row rows - 1 after the loop from rows - 2, rows - 1, rows - 2); the
+// row's first pixel takes pixel -1 := pixel 1, the lane whose last pixel is the row's last pixel cols := cols - 2, from itself.
 template <int KS, int PP, bool EDGE, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
 __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, const int X, const int ys, const int ye, const uint8_t* sframe,
-                                           uint8_t* dframe, const int oys = 0, const int oye = 0, uint8_t* dxf = nullptr, uint8_t* dyf = nullptr)
+                                           uint8_t* dframe, const int oys = 0, const int oye = 0, uint8_t* dxf = nullptr, uint8_t* dyf = nullptr,
+                                           const int tw = 0, uint32_t* const seam = nullptr)
 {
     constexpr int RAD = KS / 2, NP = (KS + 1) / 2;
     constexpr int RP = NP + PP;   // ring of row pairs: the NP-pair window + PP pairs requested ahead
@@ -247,7 +255,10 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     // the lane's 48 source bytes per pair: pixels [16n - 4 + 16c, +16) of row 2i + h.  Chunks that stick out of the row are read
     // shifted into it and repaired after the de-interleave (EDGE); without EDGE the clamp is a no-op.
     // (gray: X counts pixels = bytes, and the chunk of block pl starts 256 * pl further)
-    const int cb = (GRAY ? X : (X / 3) * SB) + CB * n - 4 * SB + CB * c;
+    // SOB: X = 3 * (first pixel of wave tw's 256 pixels of its group); the lane's window begins wpx pixels from there: 16 n, except the two
+    // seam windows of wave 3 (n = 12: the 16 pixels left of the group; n = 13 .. 15: the 16 right of it)
+    const int wpx = (SOB && tw == 3 && n >= 12) ? (n == 12 ? -784 : 192) : 16 * n;
+    const int cb = SOB ? X + 3 * wpx - 12 + 48 * c : (GRAY ? X : (X / 3) * SB) + CB * n - 4 * SB + CB * c;
     const unsigned cbo = (unsigned)min(max(cb, 0), rbs - CB);
     // The chunk that holds pixel `cols` (the first one past the row) has `rv` valid pixels in front of it: 4 when the width is a
     // multiple of 16; BGR also takes widths that are a multiple of 4 (a 1080-pixel portrait frame): rv = 0, 8, 12 then (the same in
@@ -443,15 +454,27 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
     const int nrows = ye - ys;
     // SOB: Sobel state (horizontal parts of filtered rows y-2, y-1 as packed i16 pairs) and the lane's place in the tile
     uint32_t sh1a[2] = {0u, 0u}, sh1b[2] = {0u, 0u}, sh2a[2] = {0u, 0u}, sh2b[2] = {0u, 0u};
-    const int tpx = 16 * n + 4 * q, gpx = X / 3 + tpx;                      // the lane's first output pixel: in the tile / in the row
-    const bool g_first = X == 0 && lane == 0, g_last = gpx + 4 == a.cols;   // the lane holds the row's first / last pixel
+    const int tpx = (SOB ? wpx : 16 * n) + 4 * q, gpx = X / 3 + tpx;         // the lane's first output pixel: in the wave's 256 / in the row
+    const bool g_first = gpx == 0 && lane == 0, g_last = gpx + 4 == a.cols;  // the lane holds the row's first / last pixel
     const int addrL = 4 * (q > 0 ? lane - 16 : (n > 0 ? lane + 47 : lane)), addrR = 4 * (q < 3 ? lane + 16 : (n < 15 ? lane - 47 : lane));
+    // gray values that cross a wave seam (dword slots per row: 0-3 the first pixel of wave 0-3, 4-6 the last pixel of wave 0-2, 7 the pixel
+    // left of the group, 8 the pixel right of it): what this lane writes (its first pixel: sel 0, its last: sel 1) and what it reads instead
+    // of the bpermute's value
+    int wr_slot = -1, wr_sel = 0, rdL = -1, rdR = -1;
+    if (SOB) {
+        if (lane == 0) wr_slot = tw, rdL = tw > 0 ? 3 + tw : 7;
+        if (lane == 63 && tw < 3) wr_slot = 4 + tw, wr_sel = 1, rdR = tw + 1;
+        if (tw == 3 && lane == 60) wr_slot = 7, wr_sel = 1;   // (n = 12, q = 3): the last pixel of the left seam window
+        if (tw == 3 && lane == 13) wr_slot = 8;               // (n = 13, q = 0): the first pixel of the right seam window
+        if (tw == 3 && lane == 59) rdR = 8;                   // (n = 11, q = 3): the group's last pixel
+    }
     // stores: lanes (n, q) and (n, q + 1), q even, hold eight consecutive pixels; after one v_permlane16_swap per dword the even
-    // lane has both lanes' dx and the odd lane both lanes' dy: ONE 16-byte store per lane and row.  Pair-local validity: tile
-    // pixels 8 .. 247 (strip 0: from 0), inside the row; a width that is not a multiple of 8 ends on a half pair.
-    const int tp2 = 16 * n + 8 * (q >> 1), gp2 = X / 3 + tp2;
-    const bool pair_ok = SOB && tp2 >= (X == 0 ? 0 : 8) && tp2 < 248;
-    const bool g_full = pair_ok && gp2 + 8 <= a.cols, g_half = pair_ok && gp2 + 8 > a.cols && gp2 + 4 <= a.cols;
+    // lane has both lanes' dx and the odd lane both lanes' dy: ONE 16-byte store per lane and row.  Valid: the regular windows' pixels
+    // inside the group's 960 and inside the row; a width that is not a multiple of 8 ends on a half pair.
+    const int tp2 = (SOB ? wpx : 16 * n) + 8 * (q >> 1), gp2 = X / 3 + tp2;
+    const int glim = min(X / 3 - 256 * tw + 960, a.cols);                  // end of the group's output pixels
+    const bool pair_ok = SOB && !(tw == 3 && n >= 12);
+    const bool g_full = pair_ok && gp2 + 8 <= glim, g_half = pair_ok && gp2 + 8 > glim && gp2 + 4 <= glim;
     uint8_t* const gplane = (q & 1) ? dyf : dxf;
     typedef uint32_t fr_u2 __attribute__((ext_vector_type(2)));
     typedef uint32_t fr_u4 __attribute__((ext_vector_type(4)));
@@ -462,52 +485,61 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         sw16(x0, y0);   // even q: (x0, x1) own dx, (y0, y1) the dx of lane + 16; odd q: (x0, x1) the dy of lane - 16, (y0, y1) own dy
         sw16(x1, y1);
         uint8_t* const o = gplane + (size_t)gy * a.gstep + 2 * (size_t)gp2;
-        // plain stores: the 480-byte row pieces of neighbouring strips share lines, which the L2 merges (non-temporal: 1.05
-        // instead of 0.78 ms on 64 4K frames)
-        if (g_full) *(fr_u4*)o = fr_u4{x0, x1, y0, y1};
+        // whole 128-byte lines of each plane, written once: non-temporal (the launch never reads its output back)
+        if constexpr ((DBG & 1) != 0) {   // (measurement: no gradient stores)
+            if (x0 == 0x12345678u && y1 == 0x9abcdef0u) *(fr_u4*)o = fr_u4{x0, x1, y0, y1};
+        } else if (g_full) __builtin_nontemporal_store(fr_u4{x0, x1, y0, y1}, (fr_u4*)o);
         else if (g_half) *(fr_u2*)o = fr_u2{x0, x1};
+    };
+    // SOB, per filtered row: the lane's four gray values (byte 2 of each dword) ...
+    auto gray_row = [&](v4i(&acc)[3], uint32_t(&g)[4]) {
+        uint32_t oa, ob, oc;
+        {
+            const int v[12] = {acc[0][0], acc[1][0], acc[2][0], acc[0][1], acc[1][1], acc[2][1], acc[0][2], acc[1][2], acc[2][2], acc[0][3], acc[1][3], acc[2][3]};
+            rcv_ashr_sat_pk12_mfma(v, a.shift, oa, ob, oc);
+        }
+        if constexpr ((DBG & 2048) != 0) {   // (measurement: no gray arithmetic)
+            g[0] = oa; g[1] = ob; g[2] = oc; g[3] = oa;
+            return;
+        }
+        const uint32_t px[4] = {oa, __builtin_amdgcn_alignbyte(ob, oa, 3), __builtin_amdgcn_alignbyte(oc, ob, 2), oc >> 8};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t hi8 = __builtin_amdgcn_udot4(px[i], 0x004c961du, 0u, false);      // 4 * (1868, 9617, 4899) = 256 * {29,150,76} + {48,68,140}
+            const uint32_t lo8 = __builtin_amdgcn_udot4(px[i], 0x008c4430u, 32768u, false);  // (+ 4 * 8192): gray = bits 16..23
+            g[i] = (hi8 << 8) + lo8;
+        }
+    };
+    // ... and, once the gray values of the wave seams are in LDS (row slot rs of this step's buffer), the row's horizontal parts and the gradient
+    // row above it
+    auto sobel_row = [&](const uint32_t(&g)[4], const uint32_t* sx, int y) {
+        uint32_t gl = (uint32_t)__builtin_amdgcn_ds_bpermute(addrL, (int)g[3]), gr = (uint32_t)__builtin_amdgcn_ds_bpermute(addrR, (int)g[0]);
+        if (rdL >= 0) gl = sx[rdL];
+        if (rdR >= 0) gr = sx[rdR];
+        if (g_first) gl = g[1];   // pixel -1 := pixel 1
+        if (g_last) gr = g[2];    // pixel cols := pixel cols - 2
+        constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
+        const uint32_t Pa = __builtin_amdgcn_perm(g[0], gl, kPair), Pb = __builtin_amdgcn_perm(g[2], g[1], kPair), Pc = __builtin_amdgcn_perm(gr, g[3], kPair);
+        const uint32_t C0 = __builtin_amdgcn_perm(g[1], g[0], kPair), C1 = __builtin_amdgcn_perm(g[3], g[2], kPair);
+        const uint32_t h1[2] = {fr_pk_sub(Pb, Pa), fr_pk_sub(Pc, Pb)};
+        const uint32_t h2[2] = {fr_pk_add2x(fr_pk_add(Pa, Pb), C0), fr_pk_add2x(fr_pk_add(Pb, Pc), C1)};
+        const int gy = y - 1;
+        if (gy >= oys && gy < oye) {   // (scalar conditions)
+            if (gy == 0) emit(h1, sh1b, h1, h2, h2, gy);   // row -1 := row 1
+            else emit(sh1a, sh1b, h1, sh2a, h2, gy);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sh1a[j] = sh1b[j];
+            sh1b[j] = h1[j];
+            sh2a[j] = sh2b[j];
+            sh2b[j] = h2[j];
+        }
     };
     auto finish = [&](v4i(&acc)[3], const v4i(&acc2)[3], int y) {
         if constexpr (DMASK != 0) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) acc[pl] += acc2[pl] << a.dual_shift;
-        }
-        if constexpr (SOB != 0) {
-            // the lane's four filtered pixels as (B,G,R,x) dwords out of the 12 interleaved bytes, gray into byte 2
-            uint32_t oa, ob, oc;
-            {
-                const int v[12] = {acc[0][0], acc[1][0], acc[2][0], acc[0][1], acc[1][1], acc[2][1], acc[0][2], acc[1][2], acc[2][2], acc[0][3], acc[1][3], acc[2][3]};
-                rcv_ashr_sat_pk12_mfma(v, a.shift, oa, ob, oc);
-            }
-            const uint32_t px[4] = {oa, __builtin_amdgcn_alignbyte(ob, oa, 3), __builtin_amdgcn_alignbyte(oc, ob, 2), oc >> 8};
-            uint32_t g[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t hi8 = __builtin_amdgcn_udot4(px[i], 0x004c961du, 0u, false);      // 4 * (1868, 9617, 4899) = 256 * {29,150,76} + {48,68,140}
-                const uint32_t lo8 = __builtin_amdgcn_udot4(px[i], 0x008c4430u, 32768u, false);  // (+ 4 * 8192): gray = bits 16..23
-                g[i] = (hi8 << 8) + lo8;
-            }
-            uint32_t gl = (uint32_t)__builtin_amdgcn_ds_bpermute(addrL, (int)g[3]), gr = (uint32_t)__builtin_amdgcn_ds_bpermute(addrR, (int)g[0]);
-            if (g_first) gl = g[1];   // pixel -1 := pixel 1
-            if (g_last) gr = g[2];    // pixel cols := pixel cols - 2
-            constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
-            const uint32_t Pa = __builtin_amdgcn_perm(g[0], gl, kPair), Pb = __builtin_amdgcn_perm(g[2], g[1], kPair), Pc = __builtin_amdgcn_perm(gr, g[3], kPair);
-            const uint32_t C0 = __builtin_amdgcn_perm(g[1], g[0], kPair), C1 = __builtin_amdgcn_perm(g[3], g[2], kPair);
-            const uint32_t h1[2] = {fr_pk_sub(Pb, Pa), fr_pk_sub(Pc, Pb)};
-            const uint32_t h2[2] = {fr_pk_add2x(fr_pk_add(Pa, Pb), C0), fr_pk_add2x(fr_pk_add(Pb, Pc), C1)};
-            const int gy = y - 1;
-            if (gy >= oys && gy < oye) {   // (scalar conditions)
-                if (gy == 0) emit(h1, sh1b, h1, h2, h2, gy);   // row -1 := row 1
-                else emit(sh1a, sh1b, h1, sh2a, h2, gy);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                sh1a[j] = sh1b[j];
-                sh1b[j] = h1[j];
-                sh2a[j] = sh2b[j];
-                sh2b[j] = h2[j];
-            }
-            return;
         }
         if constexpr (GRAY) {
             // lane (q, n): four consecutive pixels of window n in each of the three blocks -> transpose -> window n of block q
@@ -568,6 +600,7 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
         }
     };
     const int nsteps = (nrows + 1) >> 1;
+    if constexpr (SOB != 0) __builtin_amdgcn_s_barrier();   // (the previous segment's last step may have used the seam buffer this one begins with)
     for (int u0 = 0; u0 < nsteps; u0 += RP) {
 #pragma unroll
         for (int s = 0; s < RP; ++s) {
@@ -604,8 +637,26 @@ __device__ __forceinline__ void fr_segment(const FRArgs& a, const int lane, cons
                             }
                         }
                     }
-            finish(acc[0], acc2[0], ys + 2 * u);
-            if (2 * u + 1 < nrows) finish(acc[1], acc2[1], ys + 2 * u + 1);
+            if constexpr (SOB != 0) {
+                // both rows' gray values, the wave seams' through LDS (two buffers by step parity: a wave that is a step ahead writes the
+                // other one), ONE barrier per step, then the Sobel stage of both rows
+                uint32_t gA[4], gB[4];
+                gray_row(acc[0], gA);
+                gray_row(acc[1], gB);
+                uint32_t* const sx = seam + 32 * (u & 1);
+                if (wr_slot >= 0) {
+                    sx[wr_slot] = wr_sel ? gA[3] : gA[0];
+                    sx[16 + wr_slot] = wr_sel ? gB[3] : gB[0];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if constexpr ((DBG & 4096) == 0) __builtin_amdgcn_s_barrier();   // (DBG & 4096, measurement: what keeping the four waves in step costs)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                sobel_row(gA, sx, ys + 2 * u);
+                if (2 * u + 1 < nrows) sobel_row(gB, sx + 16, ys + 2 * u + 1);
+            } else {
+                finish(acc[0], acc2[0], ys + 2 * u);
+                if (2 * u + 1 < nrows) finish(acc[1], acc2[1], ys + 2 * u + 1);
+            }
         }
     }
     if constexpr (SOB != 0) {
@@ -1004,8 +1055,10 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
     if (bi >= a.bands_per_xcd) return;
     const int band = a.order == 0 ? xcd * a.bands_per_xcd + bi : bi * 8 + xcd;
     if (a.tn == 0 && band >= a.nbands) return;
-    // byte offset of the strip's TILE in a destination row (gray: also the pixel offset; SOB = 1: tiles 240 pixels apart)
-    const int X = strip * (SOB ? 720 : 768);
+    // byte offset of the strip's TILE in a destination row (gray: also the pixel offset); SOB: the workgroup's four waves are `strips`
+    // 4 g .. 4 g + 3 = the four waves of group g, 960 output pixels apart, wave t beginning 256 t pixels into the group (fr_segment)
+    const int X = SOB ? 3 * (960 * (strip >> 2) + 256 * (strip & 3)) : strip * 768;
+    __shared__ uint32_t seam_lds[SOB ? 64 : 1];   // (SOB: two buffers x two rows x 16 dword slots, nine of them used)
     // the last chunk a strip touches ends at destination byte X + 804 (gray: at pixel X + 780)
     const bool edge = X == 0 || (SRC == 2 ? X + 780 > a.cols : X + 804 > a.cols * 3);
     const long long G = (long long)a.nframes * a.rows;
@@ -1028,8 +1081,8 @@ __global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
             const int fys = max(ys - 1, 0), fye = min(ye + 1, a.rows);
             uint8_t* dxf = a.gdx + (size_t)frame * a.gfs;
             uint8_t* dyf = a.gdy + (size_t)frame * a.gfs;
-            if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
-            else fr_segment<KS, PP, false, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf);
+            if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf, strip & 3, seam_lds);
+            else fr_segment<KS, PP, false, DBG, DMASK, SRC, SOB>(a, lane, X, fys, fye, sframe, dframe, ys, ye, dxf, dyf, strip & 3, seam_lds);
         } else if (edge) fr_segment<KS, PP, true, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe, phi);
         else fr_segment<KS, PP, false, DBG, DMASK, SRC>(a, lane, X, ys, ye, sframe, dframe, phi);
         g0 += ye - ys;
@@ -1128,6 +1181,19 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 {
     const dim3 grid((unsigned)(((long long)a.bands_per_xcd * a.nstrips + a.wpb - 1) / a.wpb * 8));
     if (a.gdx) {   // filter2D -> gray -> Sobel (BGR source, one weight table: the caller checked)
+#ifdef RCV_ROWS_BENCH
+        if constexpr (KS == 7) {   // (measurement forms of the fused launch: rcv__filter_rows_sobel_bench)
+            switch (dbg) {
+            case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 1, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 4: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 4, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 5, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 2048: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 2048, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 2052: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 2052, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 4096: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 4096, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            default: break;
+            }
+        }
+#endif
         RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
@@ -1232,6 +1298,23 @@ extern "C" int rcv__filter_rows_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
     t.trace = trace;
     return rows_launch(ctx, s, d, k16, ksize, shift, 0, true, nullptr, nullptr, t);
 }
+// ... and the fused filter2D -> gray -> Sobel launch of a device-resident batch (dx, dy: i16 planes), same tune array
+extern "C" int rcv__filter_rows_sobel_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy, const int8_t* k, int ksize, int shift, const int* tune)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dx || !dy || !k || !tune || (ksize != 3 && ksize != 5 && ksize != 7) || shift < 0 || shift > 24) return RCV_ERR_ARG;
+    View s, vx, vy;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dx, RCV_16S, &vx));
+    RCV_TRY(rcv_view_batch(dy, RCV_16S, &vy));
+    int16_t k16[49];
+    for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+    RowsTune t;
+    t.f7_rows = tune[0]; t.dual_full = tune[1]; t.chain = tune[2]; t.chain_rows = tune[3]; t.dbg = tune[4]; t.wpc = tune[5]; t.rounds = tune[6];
+    t.pp = tune[7]; t.order = tune[8]; t.bpf = tune[9]; t.band_rows = tune[10]; t.taper = tune[11]; t.wpb = tune[12]; t.edge_pct = tune[13];
+    t.var = tune[14];
+    return rows_launch(ctx, s, s, k16, ksize, shift, 0, true, &vx, &vy, t);
+}
 #endif
 
 static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t* k, int ksize, int shift, int src_yuyv, bool any_size, const View* gx,
@@ -1267,10 +1350,9 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     const long long rb = (long long)s.cols * (gray ? 1 : 3);
     // in-frame source offsets are 32-bit
     if (rb >= (1 << 30) || (unsigned long long)s.rows * s.step >= (1ull << 32)) return RCV_ERR_UNSUPPORTED;
-    // (sob: strips 240 pixels apart, each storing 240 pixels -- strip 0: 248 -- with plain stores.  Line-aligned 192-pixel strips with
-    //  non-temporal stores were built in round 3 and measured 7 % slower -- 33 % instead of 7 % redundant matrix work --; removed in round 4,
-    //  profiles/ops_table.md keeps the A/B)
-    const int nstrips = sob ? (s.cols > 248 ? (s.cols - 8 + 239) / 240 : 1) : (int)((rb + 767) / 768);
+    // (sob, rounds 3-5: single waves 240 pixels apart with plain stores; line-aligned 192-pixel strips with non-temporal stores measured 7 %
+    //  slower in round 3 -- 33 % instead of 7 % redundant matrix work.  Round 6: groups of four waves, see fr_segment)
+    const int nstrips = sob ? 4 * ((s.cols + 959) / 960) : (int)((rb + 767) / 768);   // (sob: four waves per group of 960 output pixels)
     const long long G = (long long)s.n * s.rows;
     // (any_size: shapes the strip kernel does not take -- widths that are not a multiple of 16 -- where the alternative is the
     //  streaming VALU kernel: 4-7x slower even on one frame)
@@ -1540,7 +1622,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         }
     }
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
-    a.wpb = kn.wpb == 2 || kn.wpb == 4 || kn.wpb == 8 ? kn.wpb : 1;
+    a.wpb = sob ? 4 : (kn.wpb == 2 || kn.wpb == 4 || kn.wpb == 8 ? kn.wpb : 1);   // (sob: a group's four waves are one workgroup)
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)
     const int pp = kn.pp > 0 ? kn.pp : 3;
     if (ksize == 7) launch_rows<7>(a, pp, ldsw, dmask, src_yuyv, ctx->stream, kn.dbg);

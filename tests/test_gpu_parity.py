@@ -1248,14 +1248,18 @@ def test_sobel_of_bgr_source(ctx, oracle, rng, rows, cols):
 
 
 @pytest.mark.parametrize("rows,cols", [(4, 16), (9, 20), (33, 248), (40, 252), (31, 256), (37, 260), (21, 496), (18, 500), (26, 504), (70, 520),
-                                       (64, 748), (19, 1032), (130, 1920), (300, 64), (5, 1000), (7, 3), (12, 18), (3, 64)])
+                                       (64, 748), (19, 1032), (130, 1920), (300, 64), (5, 1000), (7, 3), (12, 18), (3, 64),
+                                       (23, 764), (11, 768), (14, 772), (29, 944), (10, 956), (35, 960), (13, 964), (9, 972), (12, 976), (16, 1016),
+                                       (27, 1024), (8, 1028), (15, 1916), (22, 1924), (9, 2884), (6, 3844)])
 @pytest.mark.parametrize("ksize", [3, 5, 7])
 def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
     """f1: filter2D -> BGR2GRAY -> Sobel in one launch == sobel(bgr2gray(filter2d_i8(.))) of the oracle, bit
     for bit.  The SOB instantiation of the row-streaming MFMA kernel takes BGR images with a width that is a multiple of 4 (>= 16,
-    >= 4 rows) on 4-byte aligned rows -- strips 240 pixels apart, so widths around the multiples of 240 put the row's end into every
-    place of a tile; every other shape runs the two ordinary launches through the side buffer.  Batch of 3 (bands cross frames),
-    padded steps, canaries around the i16 outputs; black/white frames drive the gradients to +-1020."""
+    >= 4 rows) on 4-byte aligned rows.  Round 6 layout: workgroups of four waves own 960 output pixels (60 regular windows + the two seam
+    windows left and right of the group in wave 3's spare slots, wave-seam gray values through LDS) -- widths around the wave seams (256,
+    512, 768), around the groups' ends (960, 1920, 2880, 3840) and around 944 / 976 (the seam windows' own ends) put the row's end into
+    every place of a group; every other shape runs the two ordinary launches through the side buffer.  Batch of 3 (bands cross
+    frames), padded steps, canaries around the i16 outputs; black/white frames drive the gradients to +-1020."""
     n = 3
     r = np.random.default_rng(rows * 1009 + cols * 7 + ksize + _SOAK_SEED)
     frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
