@@ -29,6 +29,16 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = 256;
+// This file is compiled a second time, with -DRCV_FS_BENCH, into librustcv_hip_bench.so: rcv__gauss_f32_bench runs the separable f32 launch with
+// an untouched dynamic-LDS request per workgroup (an occupancy cap: what the pass gains from the waves it holds, tools/occupancy_f32.py) and with
+// the row-pair kernel forced on or off.  The product passes 0 / its own rule.
+#ifdef RCV_FS_BENCH
+static unsigned g_fs_lds = 0;
+static int g_fs_pairs = -1;
+#else
+constexpr unsigned g_fs_lds = 0;
+constexpr int g_fs_pairs = -1;
+#endif
 
 // the row-pair kernel of the separable pass can be switched off for A/B tests (RCV_GAUSS_ROWS=0, the knob that also keeps small integer
 // Gaussians off the register-window kernel)
@@ -462,9 +472,13 @@ int launch(rcv_ctx* ctx, const View& s, const View& d, const float* w, float del
             // where it measures faster than the one-row kernel in its tap-major form (tools/ab_fs_variants.sh, same call, 64 x 4K BGR:
             // 3 taps 0.640 against 0.665 ms; 5 / 7 taps equal; 11 taps 3.5 % slower; one channel never); RCV_GAUSS_ROWS=1 (tests)
             // sends every shape here
-            const bool pairs = rcv_knobs().gauss_rows == 1 || (CH == 3 && KS == 3);
-            if (pairs && !rcv_f32_pairs_off()) RCV_LAUNCH((k_gauss_f32_pairs<KS, CH>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, (int)gx, (int)gy, (int)nb, bpx);
-            else RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
+            const bool pairs = g_fs_pairs >= 0 ? g_fs_pairs != 0 : (rcv_knobs().gauss_rows == 1 || (CH == 3 && KS == 3));
+            if (g_fs_lds > 65536u) {   // (measurement build: more than the default 64 KB of dynamic LDS needs the attribute)
+                (void)hipFuncSetAttribute((const void*)k_gauss_f32_pairs<KS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_fs_lds);
+                (void)hipFuncSetAttribute((const void*)k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_fs_lds);
+            }
+            if (pairs && (g_fs_pairs >= 0 || !rcv_f32_pairs_off())) RCV_LAUNCH((k_gauss_f32_pairs<KS, CH>), grid, dim3(kBlock), g_fs_lds, ctx->stream, s, d, W, seg, (int)gx, (int)gy, (int)nb, bpx);
+            else RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), g_fs_lds, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
         } else
         RCV_LAUNCH((k_filter_f32_stream<KS, CH, SEP, false, BPT, RAG>), grid, dim3(kBlock), 0, ctx->stream, s, d, W, seg, 0, 0, (int)gx, (int)gy, (int)nb, bpx);
     }
@@ -515,6 +529,27 @@ int dispatch(rcv_ctx* ctx, const View& s, const View& d, const float* w, int ksi
 
 } // namespace
 
+#ifdef RCV_FS_BENCH
+// Measurement entry: GaussianBlur sigma > 0 of a device-resident batch; lds_bytes = untouched dynamic LDS per workgroup of four waves (0 = none),
+// pairs = -1 the product's kernel choice, 0 the one-row kernel, 1 the row-pair kernel
+extern "C" int rcv__gauss_f32_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, int ksize, double sigma, unsigned lds_bytes, int pairs)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !dst || !(sigma > 0.0) || !(ksize & 1) || ksize < 3 || ksize > 11) return RCV_ERR_ARG;
+    View s, d;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(dst, RCV_8U, &d));
+    if (s.rows != d.rows || s.cols != d.cols || s.n != d.n || s.ch != d.ch) return RCV_ERR_ARG;
+    float taps[32];
+    RCV_TRY(rcv_gaussian_taps_f32(ksize, sigma, taps));
+    g_fs_lds = lds_bytes;
+    g_fs_pairs = pairs;
+    const int rc = dispatch<true>(ctx, s, d, taps, ksize, 0.0f);
+    g_fs_lds = 0;
+    g_fs_pairs = -1;
+    return rc;
+}
+#else
 int rcv_filter_f32_fast(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta)
 {
     return dispatch<false>(ctx, s, d, k, ksize, delta);
@@ -555,3 +590,4 @@ int rcv_gauss_int_stream(rcv_ctx* ctx, const View& s, const View& d, const int* 
     if (sum * sum * 255 >= (1 << 23)) return RCV_ERR_UNSUPPORTED;
     return dispatch<true>(ctx, s, d, w, ksize, 0.0f, ldexpf(1.0f, -shift));
 }
+#endif   // RCV_FS_BENCH
