@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64, 2) void k_filter_rows_chain(FRArgs a)
 }
 
 template <int KS, int PP, int DBG, int DMASK = 0, int SRC = 0, int SOB = 0>
-__global__ __launch_bounds__(512, 2) void k_filter_rows_mfma(FRArgs a)
+__global__ __launch_bounds__(SOB ? 256 : 512, (SOB && PP <= 2) ? 3 : 2) void k_filter_rows_mfma(FRArgs a)   // (SOB: see kSobPP)
 {
     // A workgroup is `wpb` independent waves (nothing is shared, no barrier): wave w of workgroup b takes item slot
     // (b >> 3) * wpb + w of XCD b & 7, so that the waves of one workgroup -- one CU -- are neighbouring strips of one band: their
@@ -1161,6 +1161,12 @@ void launch_rows_dbg(const FRArgs& a, const dim3 grid, unsigned lds, hipStream_t
     RCV_LAUNCH((k_filter_rows_mfma<KS, PP, 0>), grid, dim3(64 * a.wpb), lds, st, a);
 }
 
+// The fused filter2D -> gray -> Sobel launch is bound by instruction issue, not by its streams (tools/ablate_sob.py: adds instead of the matrix
+// instructions -10 ... -18 %, no stores -11 ... -16 %): TWO row pairs in flight instead of three fit three waves per SIMD (168 VGPRs, four
+// of them spilled outside the row loop) -- 64 x 4K: 0.80 -> 0.72 ms on the same box, -9 ... -10 % on three boxes; one pair in flight: -3 %
+// (profiles/r06_3f_ab.txt).  The plain filter goes the other way (three waves per SIMD: +6 %, round 3): its streams bind it.
+constexpr int kSobPP = 2;
+
 // which row pairs of which parity carry kernel rows [lo, hi]: the DMASK of a second table confined to those rows
 constexpr int rows_dmask(int ksize, int lo, int hi)
 {
@@ -1184,17 +1190,18 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
 #ifdef RCV_ROWS_BENCH
         if constexpr (KS == 7) {   // (measurement forms of the fused launch: rcv__filter_rows_sobel_bench)
             switch (dbg) {
-            case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 1, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
-            case 4: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 4, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
-            case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 5, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
-            case 2048: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 2048, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
-            case 2052: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 2052, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
-            case 4096: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 4096, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 1: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 1, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 4: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 4, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 5: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 5, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 2048: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 2048, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 2052: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 2052, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 4096: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 4096, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 8192: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;   // three row pairs in flight, two waves per SIMD (round 6's first form)
             default: break;
             }
         }
 #endif
-        RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
+        RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a);
         return;
     }
     if (src_yuyv == 1) {   // (one weight table only: the caller checked)
@@ -1441,7 +1448,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
     // occupancy: 174 VGPRs (3 row pairs in flight) = 2 waves per SIMD = 8 waves per CU.  `wpc` is the number of wave slots per CU
     // the BANDS are sized for (10 measured best: slightly more, slightly shorter bands than the resident waves need); the knob
     // RCV_FR_WPC also caps the real occupancy below 8 through a dynamic-LDS request that the kernel never touches (sweeps).
-    const int wpc = kn.wpc > 0 ? (kn.wpc > 12 ? 12 : kn.wpc) : 10;
+    const int wpc = kn.wpc > 0 ? (kn.wpc > 12 ? 12 : kn.wpc) : (sob ? 12 : 10);   // (sob: three waves per SIMD)
     const unsigned lds = kn.wpc > 0 && wpc < 12 ? (unsigned)((163840 / wpc) & ~511) : 0u;
     int small_plan = 0;
     // bands: the batch's frame-rows in equal parts, `rounds` x as many (band, strip) waves as the GPU holds (measured on 64 4K

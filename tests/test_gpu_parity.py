@@ -1274,7 +1274,7 @@ def test_filter2d_sobel_fused(ctx, oracle, rows, cols, ksize):
     dy = _canary_batch(ctx, n, rows, cols, 1, depth=_ffi.RCV_16S, pad=16)
     launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, shift))
     fused = aligned and cols >= 16 and rows >= 4
-    assert ("k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>" in launched) == fused, launched
+    assert ("k_filter_rows_mfma<KS, kSobPP, 0, 0, 0, 1>" in launched) == fused, launched
     assert ("k_sobel_rows" in launched or "k_sobel" in launched) == (not fused), launched
     gx, gy = dx.download(), dy.download()
     for i in range(n):
@@ -1299,7 +1299,7 @@ def test_filter2d_sobel_fused_unequal_plane_layouts(ctx, oracle):
         dx = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=stepx)
         dy = device.DeviceBatch(ctx, n, rows, cols, 1, _ffi.RCV_16S, step=stepy)
         launched = _kernels_launched(ctx, lambda: device.filter2d_sobel(src, dx, dy, k, 5))
-        assert "k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>" not in launched and "k_sobel" in launched, launched
+        assert "k_filter_rows_mfma<KS, kSobPP, 0, 0, 0, 1>" not in launched and "k_sobel" in launched, launched
         gx, gy = dx.download(), dy.download()
         for i in range(n):
             wx, wy = oracle.sobel(oracle.bgr2gray(oracle.filter2d_i8(frames[i], k, 5)))

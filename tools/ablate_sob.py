@@ -39,6 +39,7 @@ VARIANTS = [("3f product launch", sob()),
             ("3f, stores fed with the filter output (no gray / Sobel arithmetic)", sob(dbg=2048)),
             ("3f, neither MFMA nor gray / Sobel arithmetic (loads + stores)", sob(dbg=2052)),
             ("3f, no barrier (the seam values race: a measurement)", sob(dbg=4096)),
+            ("3f, three row pairs in flight, two waves per SIMD (184 VGPRs), bands for 10 waves per CU", sob(dbg=8192, wpc=10)),
             ("3f, 10 bands per frame", sob(bpf=10)), ("3f, 28 bands per frame", sob(bpf=28)),
             ("3f, 42 bands per frame (51 rows)", sob(bpf=42)), ("3f, 68 bands per frame (32 rows)", sob(bpf=68)), ("3f, 14 bands per frame", sob(bpf=14)),
             ("3f, bands for 8 waves per CU", sob(wpc=8)), ("3f, bands for 12 waves per CU", sob(wpc=12)),
