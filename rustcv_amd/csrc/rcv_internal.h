@@ -74,9 +74,14 @@ struct rcv_ctx {
     int wl_pitch = 0, wl_prow = 0, wl_cpr = 0;
     // last verdict of the staged fused warp -> down-scale kernel's host-side plan check (rcv_warp_resize.hip: wrs_fits), keyed by the
     // matrix and the geometry: the check evaluates ~9 000 sample coordinates, a stream of launches with one map pays it once
-    bool wrs_valid = false, wrs_ok = false;
-    float wrs_M[6] = {0, 0, 0, 0, 0, 0};
-    int wrs_geom[5] = {0, 0, 0, 0, 0};   // source rows / cols, destination rows / cols, S
+    // (round 6: four entries, replaced in turn -- a caller that alternates between a few maps, or whose matrix changes slowly and returns,
+    //  does not pay the check on every launch)
+    struct WrsEntry {
+        bool valid, ok;
+        float M[6];
+        int geom[5];   // source rows / cols, destination rows / cols, S
+    } wrs[4];
+    int wrs_next;
     hipStream_t side;            // second stream of the context (the measurement library's clock probe runs beside the main one)
     // grow-only pinned staging for small per-call host tables that outlive the call (rcv_text_blend.hip)
     uint8_t* pin;

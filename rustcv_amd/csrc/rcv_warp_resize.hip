@@ -454,13 +454,15 @@ bool wrs_fits(const View& s, const View& d, const Affine& A, int S)
 bool wrs_fits_cached(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int S)
 {
     const int geom[5] = {s.rows, s.cols, d.rows, d.cols, S};
-    if (!(ctx->wrs_valid && memcmp(ctx->wrs_M, A.m, sizeof(ctx->wrs_M)) == 0 && memcmp(ctx->wrs_geom, geom, sizeof(geom)) == 0)) {
-        ctx->wrs_ok = wrs_fits(s, d, A, S);
-        memcpy(ctx->wrs_M, A.m, sizeof(ctx->wrs_M));
-        memcpy(ctx->wrs_geom, geom, sizeof(geom));
-        ctx->wrs_valid = true;
-    }
-    return ctx->wrs_ok;
+    for (const rcv_ctx::WrsEntry& e : ctx->wrs)
+        if (e.valid && memcmp(e.M, A.m, sizeof(e.M)) == 0 && memcmp(e.geom, geom, sizeof(geom)) == 0) return e.ok;
+    rcv_ctx::WrsEntry& e = ctx->wrs[ctx->wrs_next];
+    ctx->wrs_next = (ctx->wrs_next + 1) & 3;
+    e.ok = wrs_fits(s, d, A, S);
+    memcpy(e.M, A.m, sizeof(e.M));
+    memcpy(e.geom, geom, sizeof(geom));
+    e.valid = true;
+    return e.ok;
 }
 
 // host side of the staged kernel.  order: 0 raster grid, 1 XCD-contiguous runs of the whole list, 2 synchronous stripes
