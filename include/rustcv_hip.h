@@ -105,6 +105,10 @@ int         rcv_device_count(int* n);
 int         rcv_ctx_create(int device, rcv_ctx** out);
 void        rcv_ctx_destroy(rcv_ctx* ctx);
 int         rcv_sync(rcv_ctx* ctx);                       /* block until the ctx stream is idle */
+/* Every call that waits for the stream (rcv_sync, rcv_download, rcv_upload, the host-Mat entry points, rcv_timer_stop) also reports work the
+ * device left undone: RCV_ERR_DEVICE if a chained filter launch did not finish its work lists (an XCD that received no waves under a CU mask /
+ * partition mode).  Everything enqueued since the context's last successful wait must then be treated as failed; the error is reported once and
+ * the context keeps working (on the kernel that does not depend on wave placement). */
 int         rcv_ctx_device(const rcv_ctx* ctx);
 void*       rcv_ctx_stream(const rcv_ctx* ctx);           /* the hipStream_t, for event timing by the harness */
 
