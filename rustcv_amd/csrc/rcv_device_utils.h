@@ -33,10 +33,14 @@ __device__ __forceinline__ uint32_t rcv_ashr_sat_pk4(int a, int b, int c, int d,
 // Twelve i32 (three MFMA accumulator quads read crosswise) -> three dwords of saturated bytes with SIX VALU ops: op_sel[3] makes
 // v_ashr_pk_u8_i32 write D[31:16] and keep D[15:0] (tools/probe_ashr_pk_opsel.hip, measured on MI355X), so a dword is two
 // instructions instead of 2 + shift + or.  The compiler has no pattern for that form, hence inline asm -- and the hazard recognizer
-// does not look into inline asm: a VALU read of an XDL result needs passes + 2 (+ 1 on gfx950 for 4 passes) = 7 wait states after the
-// LAST matrix instruction that wrote an input (the 16x16x64 i8 MFMA has 4 passes; LLVM GCNHazardRecognizer::checkMAIVALUHazards).
-// The block therefore opens with its own `s_nop 6` (7 wait states; costs this wave 7 issue cycles, the SIMD's other wave runs on), which makes
-// it correct wherever the scheduler puts it.  Outputs are early-clobber: they are written while later inputs are still to be read.
+// does not look into inline asm: a VALU read of an XDL result needs EIGHT wait states after the LAST matrix instruction that wrote an
+// input (what the compiler itself puts between v_mfma_i32_16x16x64_i8 and a dependent VALU instruction on gfx950: `s_nop 7`; LLVM
+// GCNHazardRecognizer::checkMAIVALUHazards).  The block therefore opens with its own `s_nop 7` (costs this wave 8 issue cycles, the SIMD's
+// other waves run on), which makes it correct wherever the scheduler puts it -- directly behind the last MFMA included (235 of the 620 blocks of
+// rcv_filter_rows_mfma.hip are; tests/test_isa_waits.py checks that every block opens with `s_nop 7`).  (The first builds of round 6 carried
+// `s_nop 6`, one wait state less than the compiler's own figure; every parity test and soak passed with it, but the guarantee must be the
+// compiler's, not the luck of a placement.)
+// Outputs are early-clobber: they are written while later inputs are still to be read.
 // Order of the inputs: the bytes of the three output dwords, low to high.
 __device__ __forceinline__ void rcv_ashr_sat_pk12_mfma(const int (&v)[12], int sh, uint32_t& o0, uint32_t& o1, uint32_t& o2)
 {
@@ -45,7 +49,7 @@ __device__ __forceinline__ void rcv_ashr_sat_pk12_mfma(const int (&v)[12], int s
     o1 = rcv_ashr_sat_pk4(v[4], v[5], v[6], v[7], sh);
     o2 = rcv_ashr_sat_pk4(v[8], v[9], v[10], v[11], sh);
 #else
-    asm("s_nop 6\n\t"
+    asm("s_nop 7\n\t"
         "v_ashr_pk_u8_i32 %0, %3, %4, %15\n\t"
         "v_ashr_pk_u8_i32 %1, %7, %8, %15\n\t"
         "v_ashr_pk_u8_i32 %2, %11, %12, %15\n\t"

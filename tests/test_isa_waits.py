@@ -115,3 +115,40 @@ def test_staged_warp_resize_loop_head_leaves_the_store_in_flight(warp_resize_asm
     pre = keep[:first_loop_load]
     pb = max(i for i, l in enumerate(pre) if l == "s_barrier")
     assert pre[pb - 1] == "s_waitcnt vmcnt(1)" and pre[pb - 2].startswith("buffer_store_dword"), pre[pb - 4:pb + 1]
+
+
+def test_opsel_pack_blocks_carry_their_own_mfma_wait(tmp_path):
+    """round 6: rcv_ashr_sat_pk12_mfma packs twelve MFMA accumulators with six v_ashr_pk_u8_i32 in inline asm (the second of a pair with op_sel[3]).  The
+    hazard recognizer does not look into inline asm, so the block must open with the wait the compiler itself puts between v_mfma_i32_16x16x64_i8 and
+    a dependent VALU instruction on gfx950 -- `s_nop 7`, eight wait states -- wherever the scheduler places it (many blocks sit directly behind an MFMA).
+    Checked in the ISA of the row filter: every op_sel block is s_nop 7 + three plain + three op_sel instructions, and the compiler's own figure is read
+    from a two-instruction probe compiled next to it."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    flags = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math".split()
+    probe = tmp_path / "probe.hip"
+    probe.write_text("""#include <hip/hip_runtime.h>
+typedef int v4i __attribute__((ext_vector_type(4)));
+__global__ void k(const v4i* in, unsigned* out, int sh) {
+    v4i a = in[threadIdx.x], b = in[threadIdx.x + 64], c = in[threadIdx.x + 128];
+    v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+    out[threadIdx.x] = (unsigned)(unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(acc[0], acc[1], sh);
+}
+""")
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(tmp_path / "probe.s"), str(probe)], stderr=subprocess.DEVNULL)
+    pl = [l.strip() for l in open(tmp_path / "probe.s") if l.strip() and not l.strip().startswith(";")]
+    i = next(i for i, l in enumerate(pl) if l.startswith("v_mfma_i32_16x16x64_i8"))
+    assert pl[i + 1] == "s_nop 7" and pl[i + 2].startswith("v_ashr_pk_u8_i32"), pl[i:i + 3]      # the compiler's own wait: the helper must carry no less
+    out = tmp_path / "rows.s"
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), os.path.join(ROOT, "rustcv_amd", "csrc", "rcv_filter_rows_mfma.hip")],
+                          stderr=subprocess.DEVNULL)
+    lines = [l.strip() for l in open(out) if l.strip() and not l.strip().startswith(";")]
+    blocks = 0
+    for i, l in enumerate(lines):
+        if l.startswith("v_ashr_pk_u8_i32") and "op_sel" in l and not (lines[i - 1].startswith("v_ashr_pk_u8_i32") and "op_sel" in lines[i - 1]):
+            # first op_sel instruction of a block: three plain ones and the wait in front of it
+            assert all(lines[i - j].startswith("v_ashr_pk_u8_i32") and "op_sel" not in lines[i - j] for j in (1, 2, 3)), lines[i - 4:i + 3]
+            assert lines[i - 4] == "s_nop 7", lines[i - 5:i + 1]
+            assert all(lines[i + j].startswith("v_ashr_pk_u8_i32") and "op_sel" in lines[i + j] for j in (1, 2)), lines[i:i + 3]
+            blocks += 1
+    assert blocks >= 100, blocks
