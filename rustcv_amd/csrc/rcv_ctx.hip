@@ -5,8 +5,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <new>
+#include <vector>
 
 extern "C" int rcv_abi_version(void) { return RCV_ABI_VERSION; }
 
@@ -26,6 +28,7 @@ static void load_knobs()
     g_knobs.f7_dual_full = getenv("RCV_F7_DUAL_FULL") != nullptr;
     g_knobs.fr_chain = env_int("RCV_FR_CHAIN", -1);
     g_knobs.fr_chain_rows = env_int("RCV_FR_CHAIN_ROWS", 0);
+    g_knobs.fr_split = env_int("RCV_FR_SPLIT", -1);
     g_knobs.fr_chain_drop_xcd = env_int("RCV_FR_CHAIN_DROP_XCD", -1);
     g_knobs.gauss_rows = env_int("RCV_GAUSS_ROWS", -1);
     g_knobs.gr_seg = env_int("RCV_GR_SEG", 0);
@@ -94,6 +97,25 @@ extern "C" int rcv_device_count(int* n)
     return RCV_OK;
 }
 
+// Every live context, for one question of the split launch: does ANOTHER context of this device have work in flight right now (a caller that keeps
+// two batches in flight covers the launches' tails already)?  Asked with hipStreamQuery on the other contexts' streams -- their handles never change
+// after creation, and the query is thread-safe; a hint: no correctness depends on the answer.
+static std::mutex g_reg_mu;
+static std::vector<rcv_ctx*> g_reg;
+bool rcv_other_context_busy(const rcv_ctx* me)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (const rcv_ctx* o : g_reg) {
+        if (o == me || o->device != me->device) continue;
+        if ((o->stream && hipStreamQuery(o->stream) == hipErrorNotReady) || (o->half && hipStreamQuery(o->half) == hipErrorNotReady)) {
+            (void)hipGetLastError();
+            return true;
+        }
+    }
+    (void)hipGetLastError();
+    return false;
+}
+
 extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
 {
     if (!out) return RCV_ERR_ARG;
@@ -113,6 +135,9 @@ extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
     c->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->half, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&c->kconst, RCV_KC_BYTES);
@@ -120,6 +145,10 @@ extern "C" int rcv_ctx_create(int device, rcv_ctx** out)
         (void)hipGetLastError();
         rcv_ctx_destroy(c);
         return e == hipErrorOutOfMemory ? RCV_ERR_OOM : RCV_ERR_DEVICE;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_reg.push_back(c);
     }
     *out = c;
     return RCV_OK;
@@ -135,6 +164,7 @@ extern "C" void rcv_ctx_destroy(rcv_ctx* c)
     if (!c) return;
     if (c->children > 0) {
         (void)hipSetDevice(c->device);
+        if (c->half) (void)hipStreamSynchronize(c->half);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         c->zombie = true;
         return;
@@ -152,7 +182,16 @@ void rcv_ctx_child_released(rcv_ctx* c)
 static void ctx_finalize(rcv_ctx* c)
 {
     (void)hipSetDevice(c->device);
+    if (c->half) (void)hipStreamSynchronize(c->half);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (size_t i = 0; i < g_reg.size(); ++i)
+            if (g_reg[i] == c) {
+                g_reg.erase(g_reg.begin() + (long)i);
+                break;
+            }
+    }
     if (c->ws) (void)hipFree(c->ws);
     if (c->tmp2) (void)hipFree(c->tmp2);
     for (int i = 0; i < RCV_MAX_STAGE; ++i)
@@ -167,14 +206,38 @@ static void ctx_finalize(rcv_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->half) (void)hipStreamDestroy(c->half);
+    if (c->ev_half) (void)hipEventDestroy(c->ev_half);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-int rcv_bind(rcv_ctx* ctx)
+int rcv_bind_raw(rcv_ctx* ctx)
 {
     if (!ctx || ctx->zombie) return RCV_ERR_ARG;
     RCV_HIP(hipSetDevice(ctx->device));
+    return RCV_OK;
+}
+
+// `stream` waits for everything `half` holds: after this the context's stream alone orders all of its work again
+int rcv_join_half(rcv_ctx* ctx)
+{
+    if (!ctx->half_busy) return RCV_OK;
+    RCV_HIP(hipEventRecord(ctx->ev_half, ctx->half));
+    RCV_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_half, 0));
+    ctx->half_busy = false;
+    ctx->half_r = ctx->half_w = rcv_ctx::Hull{0, 0};
+    return RCV_OK;
+}
+
+// Every entry point but the split launch itself comes through here: whatever it enqueues on `stream` is ordered behind both halves of every
+// earlier split call, and the half stream will wait for `stream` before it runs anything again (main_unknown).
+int rcv_bind(rcv_ctx* ctx)
+{
+    RCV_TRY(rcv_bind_raw(ctx));
+    RCV_TRY(rcv_join_half(ctx));
+    ctx->main_unknown = true;
     return RCV_OK;
 }
 
@@ -188,14 +251,19 @@ int rcv_launch_check(rcv_ctx*)
 // enqueued first, and a fault that any check has raised comes back as RCV_ERR_DEVICE (rcv_filter_rows_mfma.hip: rcv_chain_flush / _poll).
 int rcv_wait(rcv_ctx* ctx)
 {
+    const int jrc = rcv_join_half(ctx);   // (callers have come through rcv_bind: normally nothing left to join)
     const int frc = rcv_chain_flush(ctx);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
+    if (e != hipSuccess || jrc < 0) {
         (void)hipGetLastError();
-        ctx->fr_tickets_ready = false;   // whatever ran last may have left a counter set half-drawn: the next chained launch zeroes them all
-        ctx->fr_unchecked = false;
+        if (ctx->half) (void)hipStreamSynchronize(ctx->half);
+        for (rcv_ctx::ChainLane& l : ctx->fr_lane) {
+            l.tickets_ready = false;   // whatever ran last may have left a counter set half-drawn: the next chained launch zeroes them all
+            l.unchecked = false;
+        }
         return RCV_ERR_DEVICE;
     }
+    ctx->main_r = ctx->main_w = rcv_ctx::Hull{0, 0};
     RCV_TRY(frc);
     return rcv_chain_poll(ctx);
 }
@@ -207,7 +275,15 @@ extern "C" int rcv_sync(rcv_ctx* ctx)
 }
 
 extern "C" int rcv_ctx_device(const rcv_ctx* ctx) { return ctx ? ctx->device : RCV_ERR_ARG; }
-extern "C" void* rcv_ctx_stream(const rcv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+// (the caller may enqueue its own work on the stream from now on: the context stops running calls as two halves on two streams)
+extern "C" void* rcv_ctx_stream(const rcv_ctx* ctx)
+{
+    if (!ctx) return nullptr;
+    rcv_ctx* c = const_cast<rcv_ctx*>(ctx);
+    c->stream_exported = true;
+    if (c->half_busy && hipSetDevice(c->device) == hipSuccess) (void)rcv_join_half(c);
+    return (void*)ctx->stream;
+}
 
 extern "C" int rcv_malloc(rcv_ctx* ctx, size_t bytes, void** out)
 {

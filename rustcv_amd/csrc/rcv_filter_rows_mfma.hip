@@ -69,6 +69,8 @@ struct RowsTune {
     int wpb = 0;          // waves per workgroup (2 / 4 / 8)
     int edge_pct = 0;     // (chain) weight of an edge strip against an interior one, % (0 = 115)
     int var = 0;          // (chain, 7x7) code variant under test, a bit mask: see CV_* below
+    int lane = 0;         // launch lane: 0 the context's stream, 1 its half stream (the second half of a split call)
+    bool must_chain = false;   // RCV_ERR_UNSUPPORTED (nothing enqueued) unless the launch takes the chained kernel
     void* trace = nullptr;   // device buffer of the per-wave timeline
 };
 
@@ -1249,12 +1251,16 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
 // Completion check of the chained kernel, host side (rcv_internal.h has the scheme).
 int rcv_chain_flush(rcv_ctx* ctx)
 {
-    if (!ctx->fr_unchecked) return RCV_OK;
-    ctx->fr_unchecked = false;
-    const unsigned long long* set = (const unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq - 1u) & 3u));
-    hipLaunchKernelGGL(k_chain_check, dim3(1), dim3(64), 0, ctx->stream, set, ctx->fr_prev[0], ctx->fr_prev[1], ctx->fr_prev[2], ctx->fr_prev[3], ctx->fr_prev[4],
-                       ctx->fr_fault);
-    return rcv_launch_check(ctx);
+    // (both lanes' checks run on the context's stream: callers come through rcv_bind, which has made it wait for the half stream)
+    for (int l = 0; l < 2; ++l) {
+        rcv_ctx::ChainLane& ln = ctx->fr_lane[l];
+        if (!ln.unchecked) continue;
+        ln.unchecked = false;
+        const unsigned long long* set = (const unsigned long long*)(ctx->kconst + (l ? RCV_KC_FR_TICKETS2 : RCV_KC_FR_TICKETS) + 2048 * ((ln.seq - 1u) & 3u));
+        hipLaunchKernelGGL(k_chain_check, dim3(1), dim3(64), 0, ctx->stream, set, ln.prev[0], ln.prev[1], ln.prev[2], ln.prev[3], ln.prev[4], ctx->fr_fault);
+        RCV_TRY(rcv_launch_check(ctx));
+    }
+    return RCV_OK;
 }
 int rcv_chain_poll(rcv_ctx* ctx)
 {
@@ -1264,8 +1270,10 @@ int rcv_chain_poll(rcv_ctx* ctx)
     // some queue of a chained launch was left short: what that launch (and the chained ones after it) wrote is incomplete.  Reported once;
     // the counters are zeroed again before they are used and this context stays on the one-band-per-wave kernel from here on.
     __atomic_store_n(ctx->fr_fault, 0u, __ATOMIC_RELEASE);
-    ctx->fr_tickets_ready = false;
-    ctx->fr_unchecked = false;
+    for (rcv_ctx::ChainLane& l : ctx->fr_lane) {
+        l.tickets_ready = false;
+        l.unchecked = false;
+    }
     ctx->fr_chain_off = true;
     return RCV_ERR_DEVICE;
 }
@@ -1283,6 +1291,90 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     t.chain = g.fr_chain;
     t.chain_rows = g.fr_chain_rows;
     return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy, t);
+}
+
+// ---- one call, two halves, two streams (rcv_internal.h: rcv_ctx::half has the contract) -------------------------------------------------
+static inline bool hull_hit(const rcv_ctx::Hull& a, const rcv_ctx::Hull& b) { return a.lo < a.hi && b.lo < b.hi && a.lo < b.hi && b.lo < a.hi; }
+static inline void hull_add(rcv_ctx::Hull& h, const rcv_ctx::Hull& x)
+{
+    if (h.lo >= h.hi) h = x;
+    else {
+        h.lo = x.lo < h.lo ? x.lo : h.lo;
+        h.hi = x.hi > h.hi ? x.hi : h.hi;
+    }
+}
+static inline rcv_ctx::Hull view_hull(const View& v, int f0, int f1)   // frames [f0, f1)
+{
+    const uintptr_t base = (uintptr_t)v.p;
+    return rcv_ctx::Hull{base + (uintptr_t)f0 * v.fstride, base + (uintptr_t)(f1 - 1) * v.fstride + (uintptr_t)v.rows * v.step};
+}
+
+// The chained filter2D of a batch of 16+ BGR frames as two launches: frames [0, h) on the context's stream, [h, n) on its half stream.
+// RCV_ERR_UNSUPPORTED = not taken, NOTHING was enqueued and no state changed (the caller goes through rcv_bind and the ordinary path).
+// Called INSTEAD of rcv_bind: `stream` does not wait for `half` here; the hazards between this call's halves and what the other stream still
+// holds are checked on address ranges, and only a hit (or work of other entry points on `stream`) makes one stream wait for the other.
+int rcv_filter_i8_split(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
+{
+    const RcvKnobs& g = rcv_knobs();
+    if (!ctx || ctx->zombie) return RCV_ERR_UNSUPPORTED;
+    if (g.fr_split == 0 || g.fr_chain == 0 || g.f7_rows == 0 || g.fr_chain_drop_xcd >= 0 || ctx->fr_chain_off || ctx->stream_exported) return RCV_ERR_UNSUPPORTED;
+    if (s.n < 16 || s.ch != 3 || d.ch != 3 || s.rows < 64 || ctx->cu_count != 256 || (ksize != 3 && ksize != 5 && ksize != 7)) return RCV_ERR_UNSUPPORTED;
+    if (s.p == d.p) return RCV_ERR_UNSUPPORTED;   // (in-place is the generic path's business)
+    RCV_TRY(rcv_bind_raw(ctx));
+    if (rcv_other_context_busy(ctx)) return RCV_ERR_UNSUPPORTED;   // someone else keeps the GPU's tail busy already: two batches in flight
+    const int h = s.n / 2;
+    const View sa = [&] { View v = s; v.n = h; return v; }(), da = [&] { View v = d; v.n = h; return v; }();
+    View sb = s, db = d;
+    sb.p = s.p + (size_t)h * s.fstride; sb.n = s.n - h;
+    db.p = d.p + (size_t)h * d.fstride; db.n = d.n - h;
+    const rcv_ctx::Hull ra = view_hull(s, 0, h), wa = view_hull(d, 0, h), rb = view_hull(s, h, s.n), wb = view_hull(d, h, d.n);
+    if (hull_hit(wa, rb) || hull_hit(wb, ra) || hull_hit(wa, wb)) return RCV_ERR_UNSUPPORTED;   // the halves of THIS call depend on each other (overlapping frames)
+    int16_t k16[49];
+    for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
+    RowsTune t;
+    t.f7_rows = g.f7_rows;
+    t.chain = g.fr_chain;
+    t.chain_rows = g.fr_chain_rows;
+    t.must_chain = true;
+    // half A on `stream`: must not touch what `half` still holds (reads or writes of its pending launches)
+    const bool join = ctx->half_busy && (hull_hit(wa, ctx->half_r) || hull_hit(wa, ctx->half_w) || hull_hit(ra, ctx->half_w));
+    if (join) RCV_TRY(rcv_join_half(ctx));
+    const unsigned up0 = ctx->fr_uploads;
+    int rc = rows_launch(ctx, sa, da, k16, ksize, shift, 0, true, nullptr, nullptr, t);
+    if (rc == RCV_ERR_UNSUPPORTED) {   // (not a chained shape after all: nothing was enqueued -- unless the join above, which is harmless)
+        return RCV_ERR_UNSUPPORTED;
+    }
+    RCV_TRY(rc);
+    hull_add(ctx->main_r, ra);
+    hull_add(ctx->main_w, wa);
+    // half B on `half`: behind everything on `stream` that it could depend on -- work of other entry points (main_unknown), a weight table
+    // uploaded a moment ago, a pending split launch whose ranges it touches
+    const bool fork = ctx->main_unknown || ctx->fr_uploads != up0 || hull_hit(wb, ctx->main_r) || hull_hit(wb, ctx->main_w) || hull_hit(rb, ctx->main_w);
+    // (main_r / main_w now include half A of this very call: ra / wa were checked against rb / wb above, but the hulls may have grown over them)
+    if (fork) {
+        hipError_t e = hipEventRecord(ctx->ev_main, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->half, ctx->ev_main, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return RCV_ERR_DEVICE;
+        }
+        ctx->main_unknown = false;
+        ctx->main_r = ra;   // (what `half` has now waited for cannot conflict any more; half A of this call was launched before the event, too)
+        ctx->main_w = wa;
+    }
+    t.lane = 1;
+    rc = rows_launch(ctx, sb, db, k16, ksize, shift, 0, true, nullptr, nullptr, t);
+    if (rc == RCV_ERR_UNSUPPORTED) {   // (cannot happen for a geometry whose first half chained; if it does: the second half on `stream`, the ordinary way)
+        t.lane = 0;
+        t.must_chain = false;
+        ctx->main_unknown = true;
+        return rows_launch(ctx, sb, db, k16, ksize, shift, 0, true, nullptr, nullptr, t);
+    }
+    RCV_TRY(rc);
+    ctx->half_busy = true;
+    hull_add(ctx->half_r, rb);
+    hull_add(ctx->half_w, wb);
+    return RCV_OK;
 }
 #else
 // Measurement entry (librustcv_hip_bench.so): the BGR -> BGR filter of a device-resident batch with every plan parameter explicit.
@@ -1417,6 +1509,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
         // stream-ordered behind every kernel that still reads this entry's old table; the host copy lives in the context
         RCV_HIP(hipMemcpyAsync(ctx->fr_tabs + (size_t)slot * 16384, t.host, (size_t)(dual ? 4 : 2) * np * 1024, hipMemcpyHostToDevice, ctx->stream));
         RCV_HIP(hipEventRecord(t.uploaded, ctx->stream));
+        ++ctx->fr_uploads;   // (on the context's stream: the half stream must wait for it before it launches with this table)
         memcpy(t.k, k, (size_t)nk * sizeof(int16_t));
         t.ksize = ksize;
         t.split2 = split2;
@@ -1559,11 +1652,14 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                 RCV_HIP(hipHostMalloc((void**)&ctx->fr_fault, 64, hipHostMallocDefault));
                 *ctx->fr_fault = 0u;
             }
-            if (!ctx->fr_tickets_ready) {
-                RCV_TRY(rcv_chain_flush(ctx));   // (the check of the last launch reads the counters this is about to zero)
-                RCV_HIP(hipMemsetAsync(ctx->kconst + RCV_KC_FR_TICKETS, 0, RCV_KC_FR_TICKETS_BYTES, ctx->stream));
-                ctx->fr_seq = 0;
-                ctx->fr_tickets_ready = true;
+            rcv_ctx::ChainLane& ln = ctx->fr_lane[kn.lane ? 1 : 0];
+            uint8_t* const tk0 = ctx->kconst + (kn.lane ? RCV_KC_FR_TICKETS2 : RCV_KC_FR_TICKETS);
+            const hipStream_t st = kn.lane ? ctx->half : ctx->stream;
+            if (!ln.tickets_ready) {
+                ln.unchecked = false;   // (the counters the check would read are about to be zeroed: a fault before this point was reported by the wait that cleared the flag)
+                RCV_HIP(hipMemsetAsync(tk0, 0, RCV_KC_FR_TICKETS_BYTES, st));
+                ln.seq = 0;
+                ln.tickets_ready = true;
             }
             // tapered tail (kn.taper: -1 the product's plan, 0 none, else halved + 256 * quartered bands per XCD)
             {
@@ -1581,13 +1677,13 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
                 a.tp1 = t1;
                 a.tp2 = t2;
             }
-            a.prev_tickets = ctx->fr_unchecked ? (const unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq - 1u) & 3u)) : nullptr;
-            a.prev_cbands = ctx->fr_prev[0]; a.prev_kint = ctx->fr_prev[1]; a.prev_kedge = ctx->fr_prev[2]; a.prev_tp1 = ctx->fr_prev[3]; a.prev_tp2 = ctx->fr_prev[4];
+            a.prev_tickets = ln.unchecked ? (const unsigned long long*)(tk0 + 2048 * ((ln.seq - 1u) & 3u)) : nullptr;
+            a.prev_cbands = ln.prev[0]; a.prev_kint = ln.prev[1]; a.prev_kedge = ln.prev[2]; a.prev_tp1 = ln.prev[3]; a.prev_tp2 = ln.prev[4];
             a.fault = ctx->fr_fault;
             a.drop_xcd = rcv_knobs().fr_chain_drop_xcd;
             static_assert(RCV_KC_FR_TICKETS_BYTES == 4 * 2048, "four sets of 16 counters, 128 bytes apart");
-            a.tickets = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * (ctx->fr_seq & 3u));
-            a.tickets_next = (unsigned long long*)(ctx->kconst + RCV_KC_FR_TICKETS + 2048 * ((ctx->fr_seq + 2u) & 3u));
+            a.tickets = (unsigned long long*)(tk0 + 2048 * (ln.seq & 3u));
+            a.tickets_next = (unsigned long long*)(tk0 + 2048 * ((ln.seq + 2u) & 3u));
             const dim3 grid(8u * waves);
             // EXACTLY 8 waves per CU, all resident from the start: the 7x7 instantiation's registers would let the dispatcher stack 12
             // waves on some CUs and leave others short.  An untouched dynamic-LDS request of an eighth of the CU's 160 KB caps it.
@@ -1599,35 +1695,36 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
 #endif
             if (ksize == 7) {
 #ifdef RCV_ROWS_BENCH
-                if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, ctx->stream, a);
-                else if ((kn.dbg & 255) == 132) RCV_LAUNCH((k_filter_rows_chain<7, 3, 384>), grid, dim3(64), cap, ctx->stream, a);
-                else if ((kn.dbg & 255) == 128) RCV_LAUNCH((k_filter_rows_chain<7, 3, 128>), grid, dim3(64), cap, ctx->stream, a);
-                else if (kn.var == 1000) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 0>), grid, dim3(64), cap, ctx->stream, a);   // (the round-5 form)
-                else if (kn.var == 33) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 33>), grid, dim3(64), cap, ctx->stream, a);   // wave timeline
-                else if (kn.pp == 4) RCV_LAUNCH((k_filter_rows_chain<7, 4, 0>), grid, dim3(64), cap, ctx->stream, a);
-                else if (kn.pp == 2) RCV_LAUNCH((k_filter_rows_chain<7, 2, 0>), grid, dim3(64), cap, ctx->stream, a);
+                if ((kn.dbg & 255) == 4) RCV_LAUNCH((k_filter_rows_chain<7, 3, 256>), grid, dim3(64), cap, st, a);
+                else if ((kn.dbg & 255) == 132) RCV_LAUNCH((k_filter_rows_chain<7, 3, 384>), grid, dim3(64), cap, st, a);
+                else if ((kn.dbg & 255) == 128) RCV_LAUNCH((k_filter_rows_chain<7, 3, 128>), grid, dim3(64), cap, st, a);
+                else if (kn.var == 1000) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 0>), grid, dim3(64), cap, st, a);   // (the round-5 form)
+                else if (kn.var == 33) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, 33>), grid, dim3(64), cap, st, a);   // wave timeline
+                else if (kn.pp == 4) RCV_LAUNCH((k_filter_rows_chain<7, 4, 0>), grid, dim3(64), cap, st, a);
+                else if (kn.pp == 2) RCV_LAUNCH((k_filter_rows_chain<7, 2, 0>), grid, dim3(64), cap, st, a);
                 else
 #endif
 #ifdef RCV_ROWS_BENCH
-                if (dmask != 0 && centre7) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kCentre7>), grid, dim3(64), cap, ctx->stream, a);
-                else if (dmask != 0) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kAll7>), grid, dim3(64), cap, ctx->stream, a);
+                if (dmask != 0 && centre7) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kCentre7>), grid, dim3(64), cap, st, a);
+                else if (dmask != 0) RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, kAll7>), grid, dim3(64), cap, st, a);
                 else
 #endif
-                    RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
+                    RCV_LAUNCH((k_filter_rows_chain<7, 3, 0, 0, kChainVar>), grid, dim3(64), cap, st, a);
             } else if (dmask != 0) return RCV_ERR_UNSUPPORTED;   // (measurement build: two tables chained for 7x7 only)
-            else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
-            else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0, 0, kChainVar>), grid, dim3(64), cap, ctx->stream, a);
+            else if (ksize == 5) RCV_LAUNCH((k_filter_rows_chain<5, 3, 0, 0, kChainVar>), grid, dim3(64), cap, st, a);
+            else RCV_LAUNCH((k_filter_rows_chain<3, 3, 0, 0, kChainVar>), grid, dim3(64), cap, st, a);
             const int rc = rcv_launch_check(ctx);
             if (rc == RCV_OK) {   // (a launch that did not start touched no counter: the same set serves the next one)
-                ++ctx->fr_seq;
-                ctx->fr_prev[0] = a.cbands; ctx->fr_prev[1] = (unsigned)n_int; ctx->fr_prev[2] = (unsigned)n_edge; ctx->fr_prev[3] = a.tp1; ctx->fr_prev[4] = a.tp2;
-                ctx->fr_unchecked = true;
+                ++ln.seq;
+                ln.prev[0] = a.cbands; ln.prev[1] = (unsigned)n_int; ln.prev[2] = (unsigned)n_edge; ln.prev[3] = a.tp1; ln.prev[4] = a.tp2;
+                ln.unchecked = true;
             } else {
-                ctx->fr_tickets_ready = false;
+                ln.tickets_ready = false;
             }
             return rc;
         }
     }
+    if (kn.must_chain) return RCV_ERR_UNSUPPORTED;   // (the split call: its halves are chained launches or the call is not split)
     if ((long long)a.bands_per_xcd * a.nstrips * 8 > 0x3fffffffLL) return RCV_ERR_UNSUPPORTED;
     a.wpb = sob ? 4 : (kn.wpb == 2 || kn.wpb == 4 || kn.wpb == 8 ? kn.wpb : 1);   // (sob: a group's four waves are one workgroup)
     const unsigned ldsw = lds * (unsigned)a.wpb > 163840u ? 163840u : lds * (unsigned)a.wpb;   // (the occupancy cap is per workgroup)

@@ -80,6 +80,7 @@ extern "C" void rcv_import_release(rcv_import* im)
     rcv_ctx* ctx = im->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
+        if (ctx->half) (void)hipStreamSynchronize(ctx->half);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // kernels may still read the mapping
     }
     if (im->ext) (void)hipDestroyExternalMemory(im->ext);

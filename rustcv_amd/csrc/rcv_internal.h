@@ -17,7 +17,8 @@ constexpr size_t RCV_KC_FR_TAB = 32768, RCV_KC_FR_TAB_BYTES = 16384;     // row 
 constexpr size_t RCV_KC_BENCH = 49152, RCV_KC_BENCH_BYTES = 4096;        // rcv__membench read-only dump (256 threads x 16 B)
 constexpr size_t RCV_KC_PROBE = 57344, RCV_KC_PROBE_BYTES = 128;         // rcv__clock_probe: 8 x 2 counters
 constexpr size_t RCV_KC_FR_DUMP = 61440, RCV_KC_FR_DUMP_BYTES = 1024;    // row kernel: 64 lanes x 16 B
-constexpr size_t RCV_KC_BYTES = 65536;
+constexpr size_t RCV_KC_FR_TICKETS2 = 65536;   // the ticket sets of the context's second launch lane (the half stream: see rcv_ctx::half), RCV_KC_FR_TICKETS_BYTES
+constexpr size_t RCV_KC_BYTES = 65536 + 8192;
 static_assert(RCV_KC_F7_TAB + RCV_KC_F7_TAB_BYTES <= RCV_KC_SOBEL_DUMP && RCV_KC_SOBEL_DUMP + RCV_KC_SOBEL_DUMP_BYTES <= RCV_KC_F7_DUMP &&
               RCV_KC_F7_DUMP + RCV_KC_F7_DUMP_BYTES <= RCV_KC_FR_TICKETS && RCV_KC_FR_TICKETS + RCV_KC_FR_TICKETS_BYTES <= RCV_KC_FR_TAB && RCV_KC_FR_TAB + RCV_KC_FR_TAB_BYTES <= RCV_KC_BENCH &&
               RCV_KC_BENCH + RCV_KC_BENCH_BYTES <= RCV_KC_PROBE && RCV_KC_PROBE + RCV_KC_PROBE_BYTES <= RCV_KC_FR_DUMP &&
@@ -57,15 +58,32 @@ struct rcv_ctx {
         hipEvent_t uploaded;      // recorded behind the entry's last upload: its host copy may be rewritten once this has passed
         int8_t host[16384];
     } fr_tab[4];
-    bool fr_tickets_ready;        // the chained row kernel's ticket counters (kconst + RCV_KC_FR_TICKETS) have been zeroed
-    unsigned fr_seq;              // chained launches of this context so far: launch i draws from counter set i % 4 and zeroes set (i + 2) % 4
-    // completion check of the chained kernel (rcv_filter_rows_mfma.hip: fr_check_set): launch i + 1 checks launch i, rcv_chain_flush() the last
-    // one before a host-side wait; a launch that left items undone raises *fr_fault (pinned host memory), rcv_chain_poll() turns that into
-    // RCV_ERR_DEVICE once, re-zeroes the counters and sends the context's later launches to the one-band-per-wave kernel
+    // The chained row kernel's launch state, per LANE: lane 0 = the context's stream, lane 1 = the half stream (below).  Ticket counters of
+    // lane l live at kconst + (l ? RCV_KC_FR_TICKETS2 : RCV_KC_FR_TICKETS); launch i of a lane draws from set i % 4 and zeroes set (i + 2) % 4.
+    // Completion check (rcv_filter_rows_mfma.hip: fr_check_set): launch i + 1 of a lane checks launch i, rcv_chain_flush() the last one before a
+    // host-side wait; a launch that left items undone raises *fr_fault (pinned host memory), rcv_chain_poll() turns that into RCV_ERR_DEVICE
+    // once, re-zeroes the counters and sends the context's later launches to the one-band-per-wave kernel
+    struct ChainLane {
+        bool tickets_ready;       // the lane's counters have been zeroed
+        bool unchecked;           // its last chained launch has not been checked yet
+        unsigned seq;             // its chained launches so far
+        unsigned prev[5];         // plan of its last chained launch: cbands, interior strips, edge strips, tapered bands (half, quarter)
+    } fr_lane[2];
     unsigned* fr_fault;           // hipHostMalloc'ed word, 0 = fine; written by the device on a fault only
-    bool fr_unchecked;            // the last chained launch has not been checked yet
     bool fr_chain_off;            // a fault was seen: no chained launches on this context any more
-    unsigned fr_prev[5];          // plan of the last chained launch: cbands, interior strips, edge strips, tapered bands (half, quarter)
+    unsigned fr_uploads;          // weight-table uploads so far (an upload on the stream must be seen by the half stream before it launches)
+    // Two halves of one call on two streams (round 6, profiles/r06_split_halves.txt: -1.4 ... -1.8 %): a chained filter2D call of 16+ frames
+    // runs its first half on `stream` and its second half on `half`; the halves of consecutive calls hide each other's tail and launch gap.
+    // Nothing is joined per call.  EVERY other entry point joins first (rcv_bind: `stream` waits for `half`), so the contract "everything a
+    // context enqueues is ordered on its stream" holds for all that a caller can observe; data hazards between the halves of consecutive
+    // split calls are checked on address ranges (R / W hulls of what each stream has pending since the two last met).  Off when the stream
+    // has been handed out (rcv_ctx_stream), when another context of the device has work in flight, and with RCV_FR_SPLIT=0.
+    hipStream_t half;
+    hipEvent_t ev_half, ev_main;
+    bool half_busy;               // `half` holds work that `stream` has not waited for
+    bool main_unknown;            // `stream` holds work of other entry points since `half` last waited for it
+    bool stream_exported;         // rcv_ctx_stream was called: the caller may enqueue behind our back -- no split any more
+    struct Hull { uintptr_t lo, hi; } main_r, main_w, half_r, half_w;   // byte ranges read / written by the split launches pending on each stream
     uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
     unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
@@ -92,7 +110,7 @@ struct rcv_ctx {
     int harris_wpc[2];           // cached occupancy (waves per CU) of the fused Harris kernel, mask-only / with response
 };
 
-// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), thirteen in all (one of them a fault injection); nothing
+// Environment knobs: DISPATCH OVERRIDES for the tests (send the same shapes through both kernels of a pair), fourteen in all (one of them a fault injection); nothing
 // needs them in production and no tuning parameter is among them (those are arguments of the measurement entries in
 // librustcv_hip_bench.so).  Read ONCE per process -- a launch-bound call (a single 1080p frame: 6 us) must not pay for getenv -- and
 // again on rcv__debug_reload_knobs() (tests, after setenv).  DESIGN.md 5 names them; DESIGN_HISTORY.md 5 lists each with the test that uses it.
@@ -103,6 +121,7 @@ struct RcvKnobs {
     int f7_dual_full;     // RCV_F7_DUAL_FULL  large-weight kernels use K = 4Q + R even where the centre split applies
     int fr_chain;         // RCV_FR_CHAIN      chained-band kernel: 0 never, 1 every eligible launch, -1 (unset) launches that fill the GPU
     int fr_chain_rows;    // RCV_FR_CHAIN_ROWS rows per chained band (0 = 32): band seams at other rows
+    int fr_split;         // RCV_FR_SPLIT      0: a chained filter call never runs as two halves on two streams (tests: both forms, same bytes)
     int fr_chain_drop_xcd;  // RCV_FR_CHAIN_DROP_XCD  FAULT INJECTION (test of the completion check): the chained kernel's waves on this XCD leave at once
     int gauss_rows;       // RCV_GAUSS_ROWS    register-window integer Gaussian: 1 every eligible shape, 0 never, -1 (unset) small launches
     int gr_seg;           // RCV_GR_SEG        its rows per segment (0 = per-SIMD plan): segment seams at every height
@@ -154,7 +173,10 @@ static inline int rcv_elem_size(int depth) { return depth == RCV_8U ? 1 : (depth
 
 // ---- helpers implemented in rcv_ctx.hip -------------------------------------------------
 void rcv_ctx_child_released(rcv_ctx* ctx);                   // a graph / ring of this context was destroyed
-int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ctx->device)
+int rcv_bind(rcv_ctx* ctx);                                   // hipSetDevice(ctx->device); `stream` joins `half`
+int rcv_bind_raw(rcv_ctx* ctx);                               // hipSetDevice only (the split launch path, which keeps the two streams apart)
+int rcv_join_half(rcv_ctx* ctx);                              // `stream` waits for what `half` holds
+bool rcv_other_context_busy(const rcv_ctx* me);               // another context of the device has work in flight right now (hipStreamQuery)
 int rcv_launch_check(rcv_ctx* ctx);                           // hipGetLastError -> code
 int rcv_wait(rcv_ctx* ctx);                                   // every host-side wait on the context's stream: flush + synchronize + poll (below)
 int rcv_chain_flush(rcv_ctx* ctx);                            // enqueue the completion check of the last chained launch, if it is still unchecked

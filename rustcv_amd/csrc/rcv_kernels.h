@@ -31,3 +31,6 @@ int rcv_gauss_int_stream(rcv_ctx* ctx, const View& s, const View& d, const int* 
 // generic kernels restricted to the byte columns [xb_lo, xb_hi) of every row (edge fix-up of the streaming kernels)
 int rcv_filter_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* k, int ksize, float delta, int xb_lo, int xb_hi);
 int rcv_gauss_f32_generic_range(rcv_ctx* ctx, const View& s, const View& d, const float* taps, int ksize, int xb_lo, int xb_hi);
+// the chained filter2D of 16+ BGR frames as two halves on the context's two streams (rcv_filter_rows_mfma.hip); RCV_ERR_UNSUPPORTED: not taken, nothing enqueued.
+// Called INSTEAD of rcv_bind by the entry point.
+int rcv_filter_i8_split(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift);

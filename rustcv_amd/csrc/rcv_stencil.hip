@@ -182,8 +182,14 @@ extern "C" int rcv_gaussian_blur_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_b
 
 extern "C" int rcv_filter2d_i8_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const int8_t* k, int ksize, int shift)
 {
-    RCV_TRY(rcv_bind(ctx));
     View s, d;
+    {   // large BGR batches on the chained kernel: two halves on the context's two streams, nothing joined per call (rcv_internal.h: rcv_ctx::half)
+        if (ctx && src && dst && k && (ksize == 3 || ksize == 5 || ksize == 7) && shift >= 0 && shift <= 24 && src->n >= 16 && check_pair(src, dst, &s, &d) == RCV_OK) {
+            const int rc = rcv_filter_i8_split(ctx, s, d, k, ksize, shift);
+            if (rc != RCV_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    RCV_TRY(rcv_bind(ctx));
     RCV_TRY(check_pair(src, dst, &s, &d));
     if (!k || !(ksize & 1) || ksize < 1 || ksize > 15 || shift < 0 || shift > 24) return RCV_ERR_ARG;
     if (s.rows == 0 || s.cols == 0 || s.n == 0) return RCV_OK;

@@ -611,6 +611,92 @@ def test_filter_rows_chain_tapered_tail(ctx, oracle, n, rows, cols, taper):
     src.free(); dst.free()
 
 
+def test_filter_split_call_two_halves_two_streams(oracle, knob):
+    """round 6: a chained filter2D call of 16+ BGR frames runs as two launches -- frames [0, n/2) on the context's stream, the rest on its half
+    stream -- and NOTHING is joined per call (the halves of consecutive calls hide each other's tail: profiles/r06_split_halves.txt).  Every other
+    entry point joins first, so what a caller can observe stays ordered on the one stream.  Checked here: (a) the split happens (two chained launches
+    per call) and every frame equals the oracle's, odd frame counts too; (b) a dependent chain of calls without a wait in between (call 2 reads
+    what call 1 wrote, call 3 writes what call 2 still reads) gives the oracle's double filter; (c) a call whose source is the previous
+    destination SHIFTED by a few frames -- its halves depend on the OTHER stream's pending work -- still does; (d) other entry points (Sobel of
+    the result, a download) right behind a split call see its whole result; (e) RCV_FR_SPLIT=0 and a second busy context of the device keep the
+    call in one launch, same bytes."""
+    import rustcv_amd as rcv
+    knob("RCV_FR_CHAIN", 1)
+    knob("RCV_F7_ROWS", 1)
+    c = rcv.Context(0)
+    L = _ffi.lib()
+    r = np.random.default_rng(2024 + _SOAK_SEED)
+    rows, cols = 64, 272
+    k = r.integers(-9, 10, size=(7, 7)).astype(np.int8)
+    k2 = r.integers(-9, 10, size=(5, 5)).astype(np.int8)
+    f1 = lambda fr: oracle.filter2d_i8(fr, k, 5)
+    for n in (16, 48, 57):
+        frames = r.integers(0, 256, size=(n, rows, cols, 3), dtype=np.uint8)
+        src = device.DeviceBatch(c, n, rows, cols, 3)
+        src.upload(frames)
+        a = device.DeviceBatch(c, n, rows, cols, 3)
+        b = device.DeviceBatch(c, n + 6, rows, cols, 3)
+        a.memset(0); b.memset(0)
+        c.sync()
+        # (a)
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, a, k, shift=5)
+        assert L.rcv__debug_kernels().decode().count("k_filter_rows_chain<7") == 2, L.rcv__debug_kernels().decode()
+        got = a.download()
+        want1 = [f1(frames[i]) for i in range(n)]
+        assert all(np.array_equal(got[i], want1[i]) for i in range(n))
+        # (b) src -> a -> b' -> a, no wait in between: RAW and WAR across calls, each half against its own predecessor
+        bv = b.view(0, n)
+        device.filter2d(src, a, k, shift=5)
+        device.filter2d(a, bv, k2, shift=4)
+        device.filter2d(bv, a, k, shift=5)
+        got = a.download()
+        for i in (0, n // 2 - 1, n // 2, n - 1):
+            assert np.array_equal(got[i], f1(oracle.filter2d_i8(want1[i], k2, 4))), ("chain", n, i)
+        # (c) the destination of call 1, read SHIFTED by 6 frames by call 2: frame j of call 2's first half is frame j + 6 of call 1's output,
+        # and the frames around n / 2 - 6 .. n / 2 were written by call 1's OTHER half
+        b.memset(0)
+        device.filter2d(src, b.view(6, n), k, shift=5)            # b[6 + i] = f1(frames[i])
+        device.filter2d(b.view(0, n), a, k2, shift=4)             # a[j] = f2(b[j]) ; b[j] = f1(frames[j - 6]) for j >= 6, zeros below
+        got = a.download()
+        zero = np.zeros((rows, cols, 3), np.uint8)
+        for j in (0, 5, 6, n // 2 - 7, n // 2 - 1, n // 2, n // 2 + 5, n - 1):
+            assert np.array_equal(got[j], oracle.filter2d_i8(want1[j - 6] if j >= 6 else zero, k2, 4)), ("shifted", n, j)
+        # (d) another entry point right behind a split call
+        gray_dx = device.DeviceBatch(c, n, rows, cols, 1, _ffi.RCV_16S)
+        gray_dy = device.DeviceBatch(c, n, rows, cols, 1, _ffi.RCV_16S)
+        device.filter2d(src, a, k, shift=5)
+        device.sobel(a, gray_dx, gray_dy)
+        gx = gray_dx.download()
+        for i in (0, n // 2, n - 1):
+            assert np.array_equal(gx[i].reshape(rows, cols), oracle.sobel(oracle.bgr2gray(want1[i]))[0].reshape(rows, cols)), ("sobel behind", n, i)
+        # (e) one launch when asked / when another context of the device is busy
+        knob("RCV_FR_SPLIT", 0)
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, a, k, shift=5)
+        assert L.rcv__debug_kernels().decode().count("k_filter_rows_chain<7") == 1
+        assert np.array_equal(a.download()[n - 1], want1[n - 1])
+        knob("RCV_FR_SPLIT", -1)
+        c2 = rcv.Context(0)
+        junk = device.DeviceBatch(c2, 1, 64, 64, 3)
+        junk.memset(1)                       # c2 has enqueued and not waited: busy
+        c.sync()
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, a, k, shift=5)
+        assert L.rcv__debug_kernels().decode().count("k_filter_rows_chain<7") == 1, "split although a second context is busy"
+        c2.sync()
+        c.sync()
+        L.rcv__debug_kernels_reset()
+        device.filter2d(src, a, k, shift=5)
+        assert L.rcv__debug_kernels().decode().count("k_filter_rows_chain<7") == 2
+        assert np.array_equal(a.download()[n // 2], want1[n // 2])
+        junk.free()
+        c2.close()
+        for x in (src, a, b, gray_dx, gray_dy):
+            x.free()
+    c.close()
+
+
 def test_filter_rows_chain_ticket_accounting(oracle, knob):
     """the chained-band kernel's ticket counters (round 5: four sets; launch i draws from set i % 4, found zero, and zeroes set (i + 2) % 4;
     no host-side count of what a launch draws).  Sixty launches of four different geometries (different item counts, one / three edge
