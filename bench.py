@@ -369,9 +369,16 @@ def run_rank(a, rank, world, device, fence, torch):
     ns = max(a.sustained, a.steps)
     res["launch_ms"] = timed_group(ns) / (ns * F)        # per 64-frame launch with F in flight (bytes moved / wall time)
     res["launches_sustained"] = ns * F
-    if F > 1:                                            # the same launch alone on one stream (the round-1..3 figure)
+    if F > 1:                                            # the same call alone on ONE context (BASELINE's literal batch): the library's default form ...
         settle(30.0, lane[0].step, lanes.sync)
         res["single_launch_ms"] = timed0(ns) / ns
+        if cfg == 3 and world == 1:                      # ... and with the call forced into one launch (round 6: by default a call of 16+ frames runs as two
+            os.environ["RCV_FR_SPLIT"] = "0"             # halves on the context's two streams while no other context of the device is busy)
+            L.rcv__debug_reload_knobs()
+            settle(30.0, lane[0].step, lanes.sync)
+            res["single_one_launch_ms"] = timed0(ns) / ns
+            os.environ.pop("RCV_FR_SPLIT", None)   # (a process-wide knob: this leg runs at N = 1 only)
+            L.rcv__debug_reload_knobs()
     # the same step after an idle gap, over 20 steps: what a short window sees (clocks coming back up) -- for comparison only
     lanes.sync()
     time.sleep(0.25)
@@ -722,7 +729,13 @@ def report(a, world, results):
         roof["single_stream"] = {"launch_ms": round(s_ms, 4), "achieved": round(s_ach, 1), "frac": round(s_ach / HBM_PEAK_GBS, 4)}
         # the same three as scalars (a parser that drops nested objects keeps them): BASELINE's literal "batch=64", one stream
         roof["single_stream_launch_ms"], roof["single_stream_achieved"], roof["single_stream_frac"] = round(s_ms, 4), round(s_ach, 1), round(s_ach / HBM_PEAK_GBS, 4)
-        roof["single_stream_note"] = "copy_ceiling_gbs and memory_only_gbs are one-stream measurements: compare them with single_stream_achieved"
+        roof["single_stream_note"] = ("one context, 64-frame calls back to back.  Round 6: the library runs such a call as two 32-frame launches on the context's two streams "
+                                      "(nothing joined per call; every other entry point joins first); single_stream_one_launch_* = the same with RCV_FR_SPLIT=0 (one launch per "
+                                      "call: the figure of rounds 1-5).  copy_ceiling_gbs and memory_only_gbs are one-launch measurements: compare them with single_stream_one_launch_achieved")
+        if "single_one_launch_ms" in results[0]:
+            o_ms = max(r["single_one_launch_ms"] for r in results)
+            o_ach = alg_bytes / (o_ms * 1e-3) / 1e9
+            roof["single_stream_one_launch_ms"], roof["single_stream_one_launch_achieved"], roof["single_stream_one_launch_frac"] = round(o_ms, 4), round(o_ach, 1), round(o_ach / HBM_PEAK_GBS, 4)
     if "shader_mhz_under_load" in results[0]:
         roof["shader_mhz_under_load"] = min(r["shader_mhz_under_load"] for r in results)
     if "copy_ceiling_gbs" in results[0]:

@@ -227,8 +227,89 @@ int rcv_join_half(rcv_ctx* ctx)
     RCV_HIP(hipEventRecord(ctx->ev_half, ctx->half));
     RCV_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_half, 0));
     ctx->half_busy = false;
-    ctx->half_r = ctx->half_w = rcv_ctx::Hull{0, 0};
+    ctx->half_r.n = ctx->half_w.n = 0;
     return RCV_OK;
+}
+
+// ---- split calls: range bookkeeping ----
+static bool hit(const rcv_ctx::Hull& a, const rcv_ctx::Hull& b) { return a.lo < a.hi && b.lo < b.hi && a.lo < b.hi && b.lo < a.hi; }
+static bool hit(const rcv_ctx::HullSet& s, const rcv_ctx::Hull& x)
+{
+    for (int i = 0; i < s.n; ++i)
+        if (hit(s.h[i], x)) return true;
+    return false;
+}
+static void add(rcv_ctx::HullSet& s, const rcv_ctx::Hull& x)
+{
+    for (int i = 0; i < s.n; ++i)
+        if (s.h[i].lo <= x.lo && x.hi <= s.h[i].hi) return;            // (the steady state: the same ranges call after call)
+    if (s.n < 6) {
+        s.h[s.n++] = x;
+        return;
+    }
+    rcv_ctx::Hull m = x;                                               // full: everything becomes one hull
+    for (int i = 0; i < s.n; ++i) {
+        m.lo = s.h[i].lo < m.lo ? s.h[i].lo : m.lo;
+        m.hi = s.h[i].hi > m.hi ? s.h[i].hi : m.hi;
+    }
+    s.h[0] = m;
+    s.n = 1;
+}
+// does what `x` wants to do collide with what is pending in (pr, pw)?  write-after-read, write-after-write, read-after-write
+static bool collides(const RcvRanges& x, const rcv_ctx::HullSet& pr, const rcv_ctx::HullSet& pw)
+{
+    for (int i = 0; i < x.nw; ++i)
+        if (hit(pr, x.w[i]) || hit(pw, x.w[i])) return true;
+    for (int i = 0; i < x.nr; ++i)
+        if (hit(pw, x.r[i])) return true;
+    return false;
+}
+
+int rcv_split_begin(rcv_ctx* ctx, int n, const RcvRanges& a, const RcvRanges& b)
+{
+    if (!ctx || ctx->zombie || n < 16 || rcv_knobs().fr_split == 0 || ctx->stream_exported) return RCV_ERR_UNSUPPORTED;
+    // the halves of THIS call must not depend on each other (overlapping frames, in-place)
+    for (int i = 0; i < a.nw; ++i) {
+        for (int j = 0; j < b.nw; ++j)
+            if (hit(a.w[i], b.w[j])) return RCV_ERR_UNSUPPORTED;
+        for (int j = 0; j < b.nr; ++j)
+            if (hit(a.w[i], b.r[j])) return RCV_ERR_UNSUPPORTED;
+    }
+    for (int i = 0; i < b.nw; ++i)
+        for (int j = 0; j < a.nr; ++j)
+            if (hit(b.w[i], a.r[j])) return RCV_ERR_UNSUPPORTED;
+    RCV_TRY(rcv_bind_raw(ctx));
+    if (rcv_other_context_busy(ctx)) return RCV_ERR_UNSUPPORTED;   // someone else keeps the GPU's tail busy already: two batches in flight
+    // half A on `stream` must not touch what `half` still holds
+    if (ctx->half_busy && collides(a, ctx->half_r, ctx->half_w)) RCV_TRY(rcv_join_half(ctx));
+    return RCV_OK;
+}
+
+int rcv_split_half(rcv_ctx* ctx, const RcvRanges& a, const RcvRanges& b, unsigned uploads_before)
+{
+    // half B on `half`: behind everything on `stream` that it could depend on -- work of other entry points (main_unknown), a table uploaded a
+    // moment ago, a pending split launch whose ranges it touches (half A of this very call was checked against B in rcv_split_begin)
+    const bool fork = ctx->main_unknown || ctx->fr_uploads != uploads_before || collides(b, ctx->main_r, ctx->main_w);
+    if (fork) {
+        hipError_t e = hipEventRecord(ctx->ev_main, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->half, ctx->ev_main, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return RCV_ERR_DEVICE;
+        }
+        ctx->main_unknown = false;
+        ctx->main_r.n = ctx->main_w.n = 0;   // (`half` has waited for all of it, half A of this call included)
+    }
+    for (int i = 0; i < a.nr; ++i) add(ctx->main_r, a.r[i]);
+    for (int i = 0; i < a.nw; ++i) add(ctx->main_w, a.w[i]);
+    return RCV_OK;
+}
+
+void rcv_split_done(rcv_ctx* ctx, const RcvRanges& b)
+{
+    ctx->half_busy = true;
+    for (int i = 0; i < b.nr; ++i) add(ctx->half_r, b.r[i]);
+    for (int i = 0; i < b.nw; ++i) add(ctx->half_w, b.w[i]);
 }
 
 // Every entry point but the split launch itself comes through here: whatever it enqueues on `stream` is ordered behind both halves of every
@@ -263,7 +344,7 @@ int rcv_wait(rcv_ctx* ctx)
         }
         return RCV_ERR_DEVICE;
     }
-    ctx->main_r = ctx->main_w = rcv_ctx::Hull{0, 0};
+    ctx->main_r.n = ctx->main_w.n = 0;
     RCV_TRY(frc);
     return rcv_chain_poll(ctx);
 }

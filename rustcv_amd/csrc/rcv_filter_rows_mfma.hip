@@ -69,7 +69,7 @@ struct RowsTune {
     int wpb = 0;          // waves per workgroup (2 / 4 / 8)
     int edge_pct = 0;     // (chain) weight of an edge strip against an interior one, % (0 = 115)
     int var = 0;          // (chain, 7x7) code variant under test, a bit mask: see CV_* below
-    int lane = 0;         // launch lane: 0 the context's stream, 1 its half stream (the second half of a split call)
+    int lane = 0;         // lane of ticket counters: 0, or 1 for the second half of a split call (which runs on the half stream)
     bool must_chain = false;   // RCV_ERR_UNSUPPORTED (nothing enqueued) unless the launch takes the chained kernel
     void* trace = nullptr;   // device buffer of the per-wave timeline
 };
@@ -1293,88 +1293,31 @@ int rcv_filter_i16_rows(rcv_ctx* ctx, const View& s, const View& d, const int16_
     return rows_launch(ctx, s, d, k, ksize, shift, src_yuyv, any_size, gx, gy, t);
 }
 
-// ---- one call, two halves, two streams (rcv_internal.h: rcv_ctx::half has the contract) -------------------------------------------------
-static inline bool hull_hit(const rcv_ctx::Hull& a, const rcv_ctx::Hull& b) { return a.lo < a.hi && b.lo < b.hi && a.lo < b.hi && b.lo < a.hi; }
-static inline void hull_add(rcv_ctx::Hull& h, const rcv_ctx::Hull& x)
-{
-    if (h.lo >= h.hi) h = x;
-    else {
-        h.lo = x.lo < h.lo ? x.lo : h.lo;
-        h.hi = x.hi > h.hi ? x.hi : h.hi;
-    }
-}
-static inline rcv_ctx::Hull view_hull(const View& v, int f0, int f1)   // frames [f0, f1)
-{
-    const uintptr_t base = (uintptr_t)v.p;
-    return rcv_ctx::Hull{base + (uintptr_t)f0 * v.fstride, base + (uintptr_t)(f1 - 1) * v.fstride + (uintptr_t)v.rows * v.step};
-}
-
-// The chained filter2D of a batch of 16+ BGR frames as two launches: frames [0, h) on the context's stream, [h, n) on its half stream.
-// RCV_ERR_UNSUPPORTED = not taken, NOTHING was enqueued and no state changed (the caller goes through rcv_bind and the ordinary path).
-// Called INSTEAD of rcv_bind: `stream` does not wait for `half` here; the hazards between this call's halves and what the other stream still
-// holds are checked on address ranges, and only a hit (or work of other entry points on `stream`) makes one stream wait for the other.
+// ---- one call, two halves, two streams (rcv_internal.h: rcv_ctx::half has the contract, rcv_split_run the mechanism) ---------------------
+// The chained filter2D of a batch of 16+ BGR frames as two launches: frames [0, n / 2) on the context's stream, the rest on its half stream, each
+// with its own lane of ticket counters.  RCV_ERR_UNSUPPORTED = not taken, NOTHING was enqueued (the caller goes through rcv_bind and the ordinary
+// path).  Called INSTEAD of rcv_bind.
 int rcv_filter_i8_split(rcv_ctx* ctx, const View& s, const View& d, const int8_t* k, int ksize, int shift)
 {
     const RcvKnobs& g = rcv_knobs();
-    if (!ctx || ctx->zombie) return RCV_ERR_UNSUPPORTED;
-    if (g.fr_split == 0 || g.fr_chain == 0 || g.f7_rows == 0 || g.fr_chain_drop_xcd >= 0 || ctx->fr_chain_off || ctx->stream_exported) return RCV_ERR_UNSUPPORTED;
-    if (s.n < 16 || s.ch != 3 || d.ch != 3 || s.rows < 64 || ctx->cu_count != 256 || (ksize != 3 && ksize != 5 && ksize != 7)) return RCV_ERR_UNSUPPORTED;
-    if (s.p == d.p) return RCV_ERR_UNSUPPORTED;   // (in-place is the generic path's business)
-    RCV_TRY(rcv_bind_raw(ctx));
-    if (rcv_other_context_busy(ctx)) return RCV_ERR_UNSUPPORTED;   // someone else keeps the GPU's tail busy already: two batches in flight
+    if (!ctx || g.fr_chain == 0 || g.f7_rows == 0 || g.fr_chain_drop_xcd >= 0 || ctx->fr_chain_off) return RCV_ERR_UNSUPPORTED;
+    if (s.ch != 3 || d.ch != 3 || s.rows < 64 || ctx->cu_count != 256 || (ksize != 3 && ksize != 5 && ksize != 7) || s.n < 16) return RCV_ERR_UNSUPPORTED;
     const int h = s.n / 2;
-    const View sa = [&] { View v = s; v.n = h; return v; }(), da = [&] { View v = d; v.n = h; return v; }();
-    View sb = s, db = d;
-    sb.p = s.p + (size_t)h * s.fstride; sb.n = s.n - h;
-    db.p = d.p + (size_t)h * d.fstride; db.n = d.n - h;
-    const rcv_ctx::Hull ra = view_hull(s, 0, h), wa = view_hull(d, 0, h), rb = view_hull(s, h, s.n), wb = view_hull(d, h, d.n);
-    if (hull_hit(wa, rb) || hull_hit(wb, ra) || hull_hit(wa, wb)) return RCV_ERR_UNSUPPORTED;   // the halves of THIS call depend on each other (overlapping frames)
+    RcvRanges ra, rb;
+    ra.read(s, 0, h); ra.write(d, 0, h);
+    rb.read(s, h, s.n); rb.write(d, h, s.n);
     int16_t k16[49];
     for (int i = 0; i < ksize * ksize; ++i) k16[i] = k[i];
-    RowsTune t;
-    t.f7_rows = g.f7_rows;
-    t.chain = g.fr_chain;
-    t.chain_rows = g.fr_chain_rows;
-    t.must_chain = true;
-    // half A on `stream`: must not touch what `half` still holds (reads or writes of its pending launches)
-    const bool join = ctx->half_busy && (hull_hit(wa, ctx->half_r) || hull_hit(wa, ctx->half_w) || hull_hit(ra, ctx->half_w));
-    if (join) RCV_TRY(rcv_join_half(ctx));
-    const unsigned up0 = ctx->fr_uploads;
-    int rc = rows_launch(ctx, sa, da, k16, ksize, shift, 0, true, nullptr, nullptr, t);
-    if (rc == RCV_ERR_UNSUPPORTED) {   // (not a chained shape after all: nothing was enqueued -- unless the join above, which is harmless)
-        return RCV_ERR_UNSUPPORTED;
-    }
-    RCV_TRY(rc);
-    hull_add(ctx->main_r, ra);
-    hull_add(ctx->main_w, wa);
-    // half B on `half`: behind everything on `stream` that it could depend on -- work of other entry points (main_unknown), a weight table
-    // uploaded a moment ago, a pending split launch whose ranges it touches
-    const bool fork = ctx->main_unknown || ctx->fr_uploads != up0 || hull_hit(wb, ctx->main_r) || hull_hit(wb, ctx->main_w) || hull_hit(rb, ctx->main_w);
-    // (main_r / main_w now include half A of this very call: ra / wa were checked against rb / wb above, but the hulls may have grown over them)
-    if (fork) {
-        hipError_t e = hipEventRecord(ctx->ev_main, ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->half, ctx->ev_main, 0);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return RCV_ERR_DEVICE;
-        }
-        ctx->main_unknown = false;
-        ctx->main_r = ra;   // (what `half` has now waited for cannot conflict any more; half A of this call was launched before the event, too)
-        ctx->main_w = wa;
-    }
-    t.lane = 1;
-    rc = rows_launch(ctx, sb, db, k16, ksize, shift, 0, true, nullptr, nullptr, t);
-    if (rc == RCV_ERR_UNSUPPORTED) {   // (cannot happen for a geometry whose first half chained; if it does: the second half on `stream`, the ordinary way)
-        t.lane = 0;
-        t.must_chain = false;
-        ctx->main_unknown = true;
-        return rows_launch(ctx, sb, db, k16, ksize, shift, 0, true, nullptr, nullptr, t);
-    }
-    RCV_TRY(rc);
-    ctx->half_busy = true;
-    hull_add(ctx->half_r, rb);
-    hull_add(ctx->half_w, wb);
-    return RCV_OK;
+    return rcv_split_run(ctx, s.n, ra, rb, [&](int half) {
+        RowsTune t;
+        t.f7_rows = g.f7_rows;
+        t.chain = g.fr_chain;
+        t.chain_rows = g.fr_chain_rows;
+        t.must_chain = true;   // (its halves are chained launches or the call is not split)
+        t.lane = half;
+        const int f0 = half ? h : 0, f1 = half ? s.n : h;
+        return rows_launch(ctx, rcv_view_frames(s, f0, f1), rcv_view_frames(d, f0, f1), k16, ksize, shift, 0, true, nullptr, nullptr, t);
+    });
 }
 #else
 // Measurement entry (librustcv_hip_bench.so): the BGR -> BGR filter of a device-resident batch with every plan parameter explicit.
@@ -1654,7 +1597,7 @@ static int rows_launch(rcv_ctx* ctx, const View& s, const View& d, const int16_t
             }
             rcv_ctx::ChainLane& ln = ctx->fr_lane[kn.lane ? 1 : 0];
             uint8_t* const tk0 = ctx->kconst + (kn.lane ? RCV_KC_FR_TICKETS2 : RCV_KC_FR_TICKETS);
-            const hipStream_t st = kn.lane ? ctx->half : ctx->stream;
+            const hipStream_t st = ctx->stream;   // (the second half of a split call runs with the context's two streams swapped: rcv_split_run)
             if (!ln.tickets_ready) {
                 ln.unchecked = false;   // (the counters the check would read are about to be zeroed: a fault before this point was reported by the wait that cleared the flag)
                 RCV_HIP(hipMemsetAsync(tk0, 0, RCV_KC_FR_TICKETS_BYTES, st));

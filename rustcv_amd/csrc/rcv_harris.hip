@@ -311,6 +311,25 @@ extern "C" int rcv_nms3x3_batch(rcv_ctx* ctx, const rcv_batch* resp, rcv_batch* 
 extern "C" int rcv_harris_pipeline_batch(rcv_ctx* ctx, const rcv_batch* bgr, rcv_batch* mask, rcv_batch* resp,
                                          int block, float k, float thr)
 {
+    {   // large batches on the fused kernel: two halves on the context's two streams (rcv_internal.h: rcv_ctx::half)
+        View s, m, r;
+        if (ctx && bgr && mask && bgr->n >= 16 && block >= 1 && block <= 7 && rcv_knobs().harris_general <= 0 && rcv_view_batch(bgr, RCV_8U, &s) == RCV_OK &&
+            rcv_view_batch(mask, RCV_8U, &m) == RCV_OK && (s.ch == 3 || s.ch == 2 || s.ch == 1) && m.ch == 1 && s.rows == m.rows && s.cols == m.cols && s.n == m.n &&
+            !(s.ch == 2 && (s.cols & 1)) && s.rows > 0 && s.cols > 0 && s.rows <= 65535 && s.n <= 65535 &&
+            (!resp || (rcv_view_batch(resp, RCV_32F, &r) == RCV_OK && r.ch == 1 && r.rows == s.rows && r.cols == s.cols && r.n == s.n))) {
+            const int h = s.n / 2;
+            RcvRanges a, b;
+            a.read(s, 0, h); a.write(m, 0, h);
+            b.read(s, h, s.n); b.write(m, h, s.n);
+            if (resp) { a.write(r, 0, h); b.write(r, h, s.n); }
+            const int rc = rcv_split_run(ctx, s.n, a, b, [&](int half) {
+                const int f0 = half ? h : 0, f1 = half ? s.n : h;
+                const View sv = rcv_view_frames(s, f0, f1), mv = rcv_view_frames(m, f0, f1), rv = resp ? rcv_view_frames(r, f0, f1) : View{};
+                return rcv_harris_fused(ctx, sv, &mv, resp ? &rv : nullptr, block, k, thr);
+            });
+            if (rc != RCV_ERR_UNSUPPORTED) return rc;
+        }
+    }
     RCV_TRY(rcv_bind(ctx));
     if (!bgr || !mask) return RCV_ERR_ARG;
     if (block < 1 || block > 7) return RCV_ERR_ARG;

@@ -83,7 +83,11 @@ struct rcv_ctx {
     bool half_busy;               // `half` holds work that `stream` has not waited for
     bool main_unknown;            // `stream` holds work of other entry points since `half` last waited for it
     bool stream_exported;         // rcv_ctx_stream was called: the caller may enqueue behind our back -- no split any more
-    struct Hull { uintptr_t lo, hi; } main_r, main_w, half_r, half_w;   // byte ranges read / written by the split launches pending on each stream
+    struct Hull { uintptr_t lo, hi; };
+    struct HullSet {              // a few byte ranges; more than it holds are merged into their hull (conservative)
+        Hull h[6];
+        int n;
+    } main_r, main_w, half_r, half_w;   // read / written by the split launches pending on each stream since the two last met
     uint8_t* fr_tabs;             // 4 x 16 KiB of device memory (allocated on first use)
     unsigned long long fr_clock;
     // last plan of the LDS-staged warpAffine kernel (rcv_geom.hip: warp_lds_plan), keyed by the matrix
@@ -170,6 +174,52 @@ struct View {
     } while (0)
 
 static inline int rcv_elem_size(int depth) { return depth == RCV_8U ? 1 : (depth == RCV_16S ? 2 : (depth == RCV_32F ? 4 : 0)); }
+
+// ---- one call as two halves on the context's two streams (rcv_ctx::half; implemented in rcv_ctx.hip) ---------------------------------------
+struct RcvRanges {            // what ONE half of a call reads and writes
+    rcv_ctx::Hull r[3], w[3];
+    int nr = 0, nw = 0;
+    void read(const View& v, int f0, int f1) { r[nr++] = span(v, f0, f1); }
+    void write(const View& v, int f0, int f1) { w[nw++] = span(v, f0, f1); }
+    static rcv_ctx::Hull span(const View& v, int f0, int f1)   // frames [f0, f1)
+    {
+        const uintptr_t base = (uintptr_t)v.p;
+        return rcv_ctx::Hull{base + (uintptr_t)f0 * v.fstride, base + (uintptr_t)(f1 - 1) * v.fstride + (uintptr_t)v.rows * v.step};
+    }
+};
+static inline View rcv_view_frames(const View& v, int f0, int f1)
+{
+    View o = v;
+    o.p = v.p + (size_t)f0 * v.fstride;
+    o.n = f1 - f0;
+    return o;
+}
+int rcv_split_begin(rcv_ctx* ctx, int n, const RcvRanges& a, const RcvRanges& b);   // RCV_OK: go (device bound, `stream` clear of what half A touches); RCV_ERR_UNSUPPORTED: not split
+int rcv_split_half(rcv_ctx* ctx, const RcvRanges& a, const RcvRanges& b, unsigned uploads_before);   // half A is enqueued: `half` made to wait where it must
+void rcv_split_done(rcv_ctx* ctx, const RcvRanges& b);
+// launch(i): enqueue half i (0: frames [0, n / 2), 1: the rest) on ctx->stream -- for half 1 the context's two streams are swapped around the call, so
+// every kernel, table upload and event of the ordinary code path lands on the half stream.  launch(0) == RCV_ERR_UNSUPPORTED: nothing was enqueued, the
+// call is not split (the caller goes through rcv_bind and its ordinary path).
+template <class F>
+int rcv_split_run(rcv_ctx* ctx, int n, const RcvRanges& a, const RcvRanges& b, F&& launch)
+{
+    RCV_TRY(rcv_split_begin(ctx, n, a, b));
+    const unsigned up0 = ctx->fr_uploads;
+    int rc = launch(0);
+    if (rc < 0) return rc;
+    RCV_TRY(rcv_split_half(ctx, a, b, up0));
+    hipStream_t t = ctx->stream;
+    ctx->stream = ctx->half;
+    ctx->half = t;
+    rc = launch(1);
+    t = ctx->stream;
+    ctx->stream = ctx->half;
+    ctx->half = t;
+    if (rc == RCV_ERR_UNSUPPORTED) return RCV_ERR_UNSUPPORTED;   // (half 1 not taken where half 0 was: the caller's ordinary path redoes the whole call on `stream`)
+    RCV_TRY(rc);
+    rcv_split_done(ctx, b);
+    return RCV_OK;
+}
 
 // ---- helpers implemented in rcv_ctx.hip -------------------------------------------------
 void rcv_ctx_child_released(rcv_ctx* ctx);                   // a graph / ring of this context was destroyed

@@ -682,8 +682,12 @@ int wrl_launch(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int 
 #ifndef RCV_WRL_BENCH
 // resize(warp_affine(src -> mid_rows x mid_cols), dst) without materialising `mid` when mid = S * dst, S in {2, 4};
 // any other shape runs the two ordinary kernels through the context workspace (same results either way).
+// the one-launch forms (mid = S * dst, S in {2, 4}, BGR) on views; RCV_ERR_UNSUPPORTED (nothing enqueued) for every other shape
+static int warp_resize_fused(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int mid_rows, int mid_cols);
+
 extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dst, const float* M, int mid_rows, int mid_cols)
 {
+    // (as two halves on the context's two streams -- rcv_split_run -- the 32-frame launch measures +1.0 %: not split; tools/ab_split_ops.py)
     RCV_TRY(rcv_bind(ctx));
     if (!M || mid_rows < 0 || mid_cols < 0) return RCV_ERR_ARG;
     View s, d;
@@ -692,6 +696,27 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
     if (mid_rows == 0 || mid_cols == 0) return RCV_ERR_ARG;
     Affine A;
     for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    {
+        const int rc = warp_resize_fused(ctx, s, d, A, mid_rows, mid_cols);
+        if (rc != RCV_ERR_UNSUPPORTED) return rc;
+    }
+    const size_t tstep = ((size_t)mid_cols * s.ch + 15) & ~(size_t)15, tfs = tstep * mid_rows;
+    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
+    uint8_t* tmp;
+    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
+    rcv_batch tb = *dst;
+    tb.frame0.data = tmp;
+    tb.frame0.cap = tfs;
+    tb.frame0.step = tstep;
+    tb.frame0.rows = mid_rows;
+    tb.frame0.cols = mid_cols;
+    tb.frame_stride = tfs;
+    RCV_TRY(rcv_warp_affine_batch(ctx, src, &tb, M));
+    return rcv_resize_batch(ctx, &tb, dst);
+}
+
+static int warp_resize_fused(rcv_ctx* ctx, const View& s, const View& d, const Affine& A, int mid_rows, int mid_cols)
+{
     for (int S = 2; S <= 4; S += 2) {
         if (s.ch == 3 && s.cols >= 3 && mid_cols == S * d.cols && mid_rows == S * d.rows && d.cols % 4 == 0 && (uintptr_t)d.p % 4 == 0 &&
             d.step % 4 == 0 && d.fstride % 4 == 0 && mid_cols < (1 << 24) && mid_rows < (1 << 24)) {
@@ -715,19 +740,7 @@ extern "C" int rcv_warp_affine_resize_batch(rcv_ctx* ctx, const rcv_batch* src, 
             return rcv_launch_check(ctx);
         }
     }
-    const size_t tstep = ((size_t)mid_cols * s.ch + 15) & ~(size_t)15, tfs = tstep * mid_rows;
-    RCV_TRY(rcv_ws_reserve(ctx, tfs * s.n + 512));
-    uint8_t* tmp;
-    RCV_TRY(rcv_ws_alloc(ctx, tfs * s.n, &tmp));
-    rcv_batch tb = *dst;
-    tb.frame0.data = tmp;
-    tb.frame0.cap = tfs;
-    tb.frame0.step = tstep;
-    tb.frame0.rows = mid_rows;
-    tb.frame0.cols = mid_cols;
-    tb.frame_stride = tfs;
-    RCV_TRY(rcv_warp_affine_batch(ctx, src, &tb, M));
-    return rcv_resize_batch(ctx, &tb, dst);
+    return RCV_ERR_UNSUPPORTED;
 }
 
 extern "C" int rcv_warp_affine_resize(rcv_ctx* ctx, const rcv_mat* src, rcv_mat* dst, const float* M, int mid_rows, int mid_cols)

@@ -53,6 +53,13 @@ def test_report_two_batches_in_flight():
     assert abs(out["value_single_stream"] - px / 0.61e-3 / 1e6) < 1 and out["value_single_stream"] < out["value"]
     assert abs(rf["launch_ms_timed_steps"] - 0.55) < 1e-9 and "overlap" in rf["launch_ms_note"]
     assert out["verified_frames"] == [0, 31, 63, 64, 95, 127]
+    # round 6: a call of 16+ frames runs as two halves on the context's two streams by default; the line carries the one-launch form beside it
+    assert "single_stream_one_launch_frac" not in rf
+    r2 = dict(r, single_one_launch_ms=0.620)
+    out2, _ = bench.report(a, 1, [r2])
+    rf2 = out2["roofline"]
+    assert rf2["single_stream_one_launch_ms"] == 0.62 and abs(rf2["single_stream_one_launch_frac"] - 3185049600 / 0.62e-3 / 1e9 / 8000.0) < 1e-4
+    assert "two 32-frame launches" in rf2["single_stream_note"] and "RCV_FR_SPLIT=0" in rf2["single_stream_note"]
 
 
 def test_report_ranks_sharing_a_device_is_labelled_a_test():

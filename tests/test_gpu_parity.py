@@ -697,6 +697,41 @@ def test_filter_split_call_two_halves_two_streams(oracle, knob):
     c.close()
 
 
+@pytest.mark.parametrize("want_resp", [False, True])
+def test_harris_pipeline_split_call(oracle, knob, want_resp):
+    """round 6: the fused Harris pipeline of 16+ frames runs as two halves on the context's two streams as well (-1.6 %; the Sobel, filter -> Sobel and
+    warp -> resize calls measured slower split and are not: tools/ab_split_ops.py).  Two launches per call, every frame equals the oracle's mask (and
+    response); a call right behind it that reads the masks (NMS input of another op: a download here) sees both halves; RCV_FR_SPLIT=0: one launch."""
+    import rustcv_amd as rcv
+    c = rcv.Context(0)
+    L = _ffi.lib()
+    n, rows, cols = 19, 70, 496
+    frames = np.stack([oracle.synth_frame(rows, cols, 3, 1, 0x5EED0005, i) for i in range(n)])
+    src = device.DeviceBatch(c, n, rows, cols, 3)
+    src.upload(frames)
+    mask = device.DeviceBatch(c, n, rows, cols, 1)
+    resp = device.DeviceBatch(c, n, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+    for split in (-1, 0):
+        knob("RCV_FR_SPLIT", split)
+        mask.memset(7)
+        c.sync()
+        L.rcv__debug_kernels_reset()
+        device.harris_pipeline(src, mask, resp, 2, 0.04, 1e-4)
+        device.harris_pipeline(src, mask, resp, 2, 0.04, 1e-4)     # (back to back: the second call's halves behind the first call's)
+        assert L.rcv__debug_kernels().decode().count("k_harris_fused") == (4 if split else 2), L.rcv__debug_kernels().decode()
+        got = mask.download()
+        gr = resp.download() if want_resp else None
+        for i in range(n):
+            want = oracle.harris_pipeline(frames[i], 2, 0.04, 1e-4, want_resp=want_resp)
+            wm = want[0] if want_resp else want
+            assert np.array_equal(got[i].reshape(rows, cols), wm.reshape(rows, cols)), (split, i)
+            if want_resp:
+                assert np.array_equal(gr[i].reshape(rows, cols).view(np.uint32), want[1].reshape(rows, cols).view(np.uint32)), (split, i)
+    for b in (src, mask) + ((resp,) if want_resp else ()):
+        b.free()
+    c.close()
+
+
 def test_filter_rows_chain_ticket_accounting(oracle, knob):
     """the chained-band kernel's ticket counters (round 5: four sets; launch i draws from set i % 4, found zero, and zeroes set (i + 2) % 4;
     no host-side count of what a launch draws).  Sixty launches of four different geometries (different item counts, one / three edge
