@@ -111,6 +111,11 @@ int         rcv_sync(rcv_ctx* ctx);                       /* block until the ctx
  * the context keeps working (on the kernel that does not depend on wave placement). */
 int         rcv_ctx_device(const rcv_ctx* ctx);
 void*       rcv_ctx_stream(const rcv_ctx* ctx);           /* the hipStream_t, for event timing by the harness */
+/* One context = one stream: everything the library enqueues for a context is ordered on this stream as far as any caller can observe.  Inside, a
+ * rcv_filter2d_i8_batch / rcv_harris_pipeline_batch call of 16+ frames runs its second half on a second stream of the context and is not joined
+ * per call (the halves of consecutive calls hide each other's launch tails); every other entry point makes the stream wait for that half first.
+ * Calling rcv_ctx_stream() does the same and switches this behaviour off for the context for good, because the caller may now enqueue work of its
+ * own on the stream.  (Also off: RCV_FR_SPLIT=0; while another context of the device has work in flight.) */
 
 /* ---- device group: one context per GPU of the node, frame-sharded batches ------
  * SURVEY.md 8(e) / north_star "independent per-GPU HIP streams, no RCCL collective": nothing in the reference to
