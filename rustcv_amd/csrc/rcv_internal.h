@@ -104,7 +104,7 @@ struct rcv_ctx {
         int geom[5];   // source rows / cols, destination rows / cols, S
     } wrs[4];
     int wrs_next;
-    hipStream_t side;            // second stream of the context (the measurement library's clock probe runs beside the main one)
+    hipStream_t side;            // (created on first use) third stream: the measurement library's clock probe runs beside the launches
     // grow-only pinned staging for small per-call host tables that outlive the call (rcv_text_blend.hip)
     uint8_t* pin;
     size_t pin_cap;

@@ -305,6 +305,9 @@ extern "C" int rcv__clock_probe(rcv_ctx* ctx, int us, float* mhz)
     RCV_TRY(rcv_bind(ctx));
     if (!mhz || us < 1 || us > 1000000) return RCV_ERR_ARG;
     unsigned long long* d = (unsigned long long*)(ctx->kconst + RCV_KC_PROBE);
+    // (the side stream exists only for this probe and is created on first use: ROCm multiplexes a process's streams onto four hardware queues, and a
+    //  context's two launch streams must not end up sharing one)
+    if (!ctx->side) RCV_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     hipLaunchKernelGGL(k_clock_probe, dim3(8), dim3(64), 0, ctx->side, d, (unsigned)us * 100u);
     unsigned long long h[16];
     RCV_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->side));
