@@ -8,24 +8,25 @@
            rcv_warp_affine_resize_batch; --unfused: the two launches through an 8K intermediate)
         5: 4K cornerHarris pipeline (BGR -> gray -> Sobel -> response -> 3x3 NMS -> mask), 64 frames per launch
 
-What runs (config 3, the default).  The reference's caller is a frame STREAM (rustcv/src/videoio/mod.rs:168-265 feeding
-examples/camera_demo.rs:50-76), so consecutive batches are independent.  Every GPU keeps `--in-flight` F = 2 batches in flight: F
-contexts (= HIP streams) on the one device (rcv_group_create with a repeated ordinal), each with its OWN 64-frame source and
-destination.  A "step" is one rcv_filter2d_i8_batch of 64 device-resident 3840x2160 BGR frames on EVERY context (integer 7x7
-kernel of SURVEY.md 8(d), >>6, saturate): F launches per GPU and step, enqueued by one host thread; the launches of the F
-streams overlap on the GPU and fill each other's ramp-up and tail.  `value` = all pixels of all launches / wall-clock.  Frames are
-generated ON DEVICE before the timed region (no PCIe in `value`).  Per-GPU work is fixed (weak scaling): rank r owns frames
-[128 r, 128 r + 128), its context j the 64 from 128 r + 64 j; frames are independent, so there is no data-path collective -- only a
-barrier and the max over ranks of the elapsed time (RCCL under torch.distributed.run, a thread barrier in the one-process form).
-`--gpus N` on a node with fewer GPUs fails.  `--in-flight 1` is the round-1..3 measurement (one stream).
+What runs (config 3, the default).  A "step" is one rcv_filter2d_i8_batch of 64 device-resident 3840x2160 BGR frames (integer 7x7 kernel of
+SURVEY.md 8(d), >>6, saturate) on ONE context per GPU: BASELINE's literal batch.  Round 6: the library runs such a call as two 32-frame launches on
+the context's two streams and joins nothing per call (the halves of consecutive calls hide each other's launch tails; every other entry point joins
+first), so one context now gives what rounds 4-5 needed two batches in flight for; `--in-flight 2` is that recipe: F contexts on the one device
+(rcv_group_create with a repeated ordinal), each with its OWN 64-frame source and destination, one launch per context and step -- the reference's
+caller is a frame STREAM (rustcv/src/videoio/mod.rs:168-265 feeding examples/camera_demo.rs:50-76), so consecutive batches are independent.
+`value` = all pixels of all launches / wall-clock.  Frames are generated ON DEVICE before the timed region (no PCIe in `value`).  Per-GPU work is
+fixed (weak scaling): rank r owns frames [64 F r, 64 F (r + 1)), its context j the 64 from 64 (F r + j); frames are independent, so there is no
+data-path collective -- only a barrier and the max over ranks of the elapsed time (RCCL under torch.distributed.run, a thread barrier in the
+one-process form).  `--gpus N` on a node with fewer GPUs fails.
 
 Prints ONE JSON line on rank 0 with the contract keys plus
   "roofline":     the dominant kernel's algorithmic HBM bytes per launch / launch_ms, against the 8 TB/s HBM3E peak.
                   launch_ms = HIP events on the kernels' own streams around >= 400 back-to-back steps, divided by the number of
                   LAUNCHES in the window (F per step): the SUSTAINED time per 64-frame launch with F in flight.  With F > 1 the
                   kernels overlap, so ONE kernel's own duration (what rocprofv3 reports) is about F x launch_ms; the figure is
-                  bytes moved / wall time (profiles/r04_inflight_kernel_trace.txt shows the overlap).  single_stream = the same
-                  launch alone on one stream (the round-1..3 figure).  copy_ceiling_gbs = the best plain device copy of the
+                  bytes moved / wall time (profiles/r04_inflight_kernel_trace.txt shows the overlap).  single_stream_one_launch_* = the
+                  call forced into ONE launch (RCV_FR_SPLIT=0: the figure of rounds 1-5, and what rocprofv3's per-kernel duration compares
+                  with); in_flight2_* = two 64-frame batches in flight on two contexts (the headline of rounds 4-5).  copy_ceiling_gbs = the best plain device copy of the
                   same 2 x 1.59 GB measured in this run; memory_only_gbs = the kernel's own loads and stores with nothing in
                   between; shader_mhz_under_load = the shader clock sampled while launches run (a separate window)
   "verified_frames": frames of the LAST timed launches' outputs (every context) compared bit for bit with the CPU oracle
@@ -35,8 +36,8 @@ Prints ONE JSON line on rank 0 with the contract keys plus
                   rcv_filter2d_i8_sobel_batch), "4" and "5" the two 8-GPU configs at their per-GPU batch:
                   {value, ms_per_step, roofline{frac, kernel, launch_ms, alg_bytes_per_launch, traffic, in_flight2_launch_ms, in_flight2_frac},
                   verified, cpu_baseline}  (in_flight2_*: for information, the same launch with a second batch in flight on a second context)
-  "value_single_stream", roofline.single_stream_{launch_ms, achieved, frac}: one 64-frame launch at a time (BASELINE's literal
-                  "batch=64", the round-1..3 measurement) as top-level / flat scalars
+  roofline.single_stream_{launch_ms, achieved, frac}: flat copies of the headline's own figures (F = 1), or the one-context measurement beside an
+                  --in-flight 2 headline (then also "value_single_stream")
   "cpu_baseline": the C oracle (a port: C restatement, the Rust reference cannot be built here) timed on this box's host
                   cores on a bounded sample of the same workload.
 """
@@ -125,7 +126,7 @@ def parse(argv=None):
     if a.batch <= 0:
         a.batch = CONFIGS[a.config]["batch"]
     if a.in_flight <= 0:
-        a.in_flight = 2 if a.config == 3 else 1
+        a.in_flight = 1   # (round 6: BASELINE's literal batch -- one context; rounds 4-5 ran config 3 with two batches in flight: --in-flight 2)
     a.device_list = [int(d) for d in a.devices.split(",")] if a.devices else None
     return a
 
@@ -325,7 +326,8 @@ def run_rank(a, rank, world, device, fence, torch):
 
     L = _ffi.lib()
     n, cfg, F = a.batch, a.config, a.in_flight
-    lanes = multigpu.NativeGroup.in_flight(device, F)     # F contexts = F streams on this GPU (rcv_group_create, repeated ordinal)
+    lanes = multigpu.NativeGroup.in_flight(device, max(F, 2))   # contexts on this GPU (rcv_group_create, repeated ordinal): F of them carry a lane, the second one
+                                                                # serves the "two batches in flight" legs of the default run
     f0 = rank * F * n                                      # this rank's contiguous frame range [f0, f0 + F n): shard.frame_range(world F n, rank, world)
     lane = [Lane(a, cfg, lanes.ctxs[j], f0 + j * n, unfused=a.unfused) for j in range(F)]
     ctx0 = lanes.ctxs[0]
@@ -369,16 +371,32 @@ def run_rank(a, rank, world, device, fence, torch):
     ns = max(a.sustained, a.steps)
     res["launch_ms"] = timed_group(ns) / (ns * F)        # per 64-frame launch with F in flight (bytes moved / wall time)
     res["launches_sustained"] = ns * F
-    if F > 1:                                            # the same call alone on ONE context (BASELINE's literal batch): the library's default form ...
+    if F > 1:                                            # the same call alone on ONE context (BASELINE's literal batch): the library's default form
         settle(30.0, lane[0].step, lanes.sync)
         res["single_launch_ms"] = timed0(ns) / ns
-        if cfg == 3 and world == 1:                      # ... and with the call forced into one launch (round 6: by default a call of 16+ frames runs as two
-            os.environ["RCV_FR_SPLIT"] = "0"             # halves on the context's two streams while no other context of the device is busy)
-            L.rcv__debug_reload_knobs()
-            settle(30.0, lane[0].step, lanes.sync)
-            res["single_one_launch_ms"] = timed0(ns) / ns
-            os.environ.pop("RCV_FR_SPLIT", None)   # (a process-wide knob: this leg runs at N = 1 only)
-            L.rcv__debug_reload_knobs()
+    if cfg == 3 and world == 1:
+        # ... with the call forced into ONE launch (round 6: by default a filter2D call of 16+ frames runs as two halves on the context's two streams
+        # while no other context of the device is busy; a process-wide knob, so this leg runs at N = 1 only)
+        os.environ["RCV_FR_SPLIT"] = "0"
+        L.rcv__debug_reload_knobs()
+        settle(30.0, lane[0].step, lanes.sync)
+        res["single_one_launch_ms"] = timed0(ns) / ns
+        os.environ.pop("RCV_FR_SPLIT", None)
+        L.rcv__debug_reload_knobs()
+        if F == 1 and not a.no_others:
+            # ... and with a second batch in flight on a second context of the device (the headline of rounds 4-5), for information
+            ln2 = Lane(a, cfg, lanes.ctxs[1], f0 + n, unfused=a.unfused)
+
+            def both():
+                lane[0].step()
+                ln2.step()
+            settle(60.0, both, lanes.sync)
+            lanes.timer_start()
+            for _ in range(ns // 2):
+                both()
+            res["in_flight2_launch_ms"] = lanes.timer_stop() / (2 * (ns // 2))
+            ln2.free()
+            settle(30.0, step, lanes.sync)
     # the same step after an idle gap, over 20 steps: what a short window sees (clocks coming back up) -- for comparison only
     lanes.sync()
     time.sleep(0.25)
@@ -723,6 +741,18 @@ def report(a, world, results):
     if F > 1:
         roof["launch_ms_note"] = (f"{F} launches in flight on {F} streams: launch_ms = sustained window / launches in it (bytes moved / wall time); one kernel's own "
                                   f"duration under rocprofv3 is about {F} x that because the kernels overlap")
+    if "in_flight2_launch_ms" in results[0]:
+        i_ms = max(r["in_flight2_launch_ms"] for r in results)
+        roof["in_flight2_launch_ms"], roof["in_flight2_frac"] = round(i_ms, 4), round(alg_bytes / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["in_flight2_note"] = "for information: two 64-frame batches in flight on two contexts of the device (the headline of rounds 4-5)"
+    if F == 1 and "single_one_launch_ms" in results[0]:
+        # one context IS the headline: the flat single_stream_* scalars of rounds 5-6 repeat it (a parser that reads them keeps working)
+        roof["single_stream_launch_ms"], roof["single_stream_achieved"], roof["single_stream_frac"] = roof["launch_ms"], roof["achieved"], roof["frac"]
+        o_ms = max(r["single_one_launch_ms"] for r in results)
+        o_ach = alg_bytes / (o_ms * 1e-3) / 1e9
+        roof["single_stream_one_launch_ms"], roof["single_stream_one_launch_achieved"], roof["single_stream_one_launch_frac"] = round(o_ms, 4), round(o_ach, 1), round(o_ach / HBM_PEAK_GBS, 4)
+        roof["single_stream_note"] = ("the headline is one context with 64-frame calls back to back; single_stream_one_launch_* = the same with RCV_FR_SPLIT=0 (one launch per call: "
+                                      "the figure of rounds 1-5; copy_ceiling_gbs and memory_only_gbs are one-launch measurements: compare them with it)")
     if "single_launch_ms" in results[0]:
         s_ms = max(r["single_launch_ms"] for r in results)
         s_ach = alg_bytes / (s_ms * 1e-3) / 1e9
@@ -755,6 +785,9 @@ def report(a, world, results):
         par += f"; {F} batches in flight per GPU ({F} contexts = HIP streams per device, own buffers each)"
     config = {"workload": c["workload"], "frames_per_launch": n, "launches_per_step_per_gpu": F, "frames_per_gpu": n * F, "global_batch": total_frames,
               "parallelism": par}
+    if F == 1 and cfg == 3:
+        config["call_form"] = ("a filter2D call of 16+ frames runs as two launches (halves of the batch) on the context's two streams, nothing joined per call: library "
+                               "default while no other context of the device is busy; RCV_FR_SPLIT=0: one launch per call = roofline.single_stream_one_launch_*")
     if n_devices != world:   # (--devices 0,0: ranks time-sharing a device -- a test of the N > 1 code, not a scaling number)
         config["contexts"] = world
         config["note"] = f"{world} ranks on {n_devices} device(s): TEST of the multi-rank path, not a scaling measurement"

@@ -22,7 +22,15 @@ def test_report_single_gpu():
     px = 64 * 2160 * 3840
     assert not bad and out["n_gpus"] == 1 and out["unit"] == "Mpix/s" and out["higher_is_better"] and out["vs_baseline"] is None
     assert abs(out["value"] - px * 50 / 0.0275 / 1e6) < 1 and abs(out["ms_per_step"] - 0.55) < 1e-9
-    assert out["roofline"]["in_flight"] == 1 and "single_stream" not in out["roofline"] and out["config"]["frames_per_gpu"] == 64
+    assert out["roofline"]["in_flight"] == 1 and "single_stream" not in out["roofline"] and out["config"]["frames_per_gpu"] == 64 and out["config"]["global_batch"] == 64
+    assert "two launches" in out["config"]["call_form"] and "RCV_FR_SPLIT=0" in out["config"]["call_form"]
+    # round 6: one context is the headline; the one-launch form and the two-batches-in-flight form ride beside it, the flat single_stream_* repeat the headline
+    r6 = dict(_rank(0.0275, 0.55, 6000.0, [0, 31, 63]), single_one_launch_ms=0.56, in_flight2_launch_ms=0.545)
+    o6, _ = bench.report(a, 1, [r6])
+    rf6 = o6["roofline"]
+    assert rf6["single_stream_frac"] == rf6["frac"] and rf6["single_stream_launch_ms"] == rf6["launch_ms"]
+    assert rf6["single_stream_one_launch_ms"] == 0.56 and abs(rf6["single_stream_one_launch_frac"] - 3185049600 / 0.56e-3 / 1e9 / 8000.0) < 1e-4
+    assert rf6["in_flight2_launch_ms"] == 0.545 and abs(rf6["in_flight2_frac"] - 3185049600 / 0.545e-3 / 1e9 / 8000.0) < 1e-4
     r = out["roofline"]
     assert r["alg_bytes_per_launch"] == px * 6 == 3185049600 and r["peak"] == 8000.0 and r["bound"] == "hbm"
     assert abs(r["achieved"] - 3185049600 / 0.55e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
@@ -124,7 +132,7 @@ def test_default_run_names_every_baseline_config():
 
 def test_parse_defaults():
     a = bench.parse([])
-    assert a.in_flight == 2 and a.batch == 64 and a.gpus == 1 and a.device_list is None
+    assert a.in_flight == 1 and a.batch == 64 and a.gpus == 1 and a.device_list is None   # (round 6: BASELINE's literal batch on one context)
     a = bench.parse(["--config", "5"])
     assert a.in_flight == 1 and a.batch == 64
     a = bench.parse(["--config", "4", "--in-flight", "2", "--gpus", "2", "--devices", "0,0"])

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "4", "--warmup", "2", "--sustained", "12", "--settle-ms", "20", "--batch", "4", "--no-cpu", "--no-probe"]
+SMALL = ["--steps", "4", "--warmup", "2", "--sustained", "12", "--settle-ms", "20", "--batch", "4", "--no-cpu", "--no-probe", "--in-flight", "2"]   # (two contexts per rank: the rounds 4-5 recipe stays covered)
 
 
 def _run(cmd, timeout=600):
@@ -128,6 +128,10 @@ def test_default_run_carries_the_other_configs_small():
     assert 1.0 < c2["floors"]["empty_kernel_us"] <= c2["value"] * 1.05 and c2["floors"]["copy_of_the_frame_us"] > 1.0 and c2["value"] < 50.0
     assert c5["roofline"]["worst_case_launch_ms"] >= 0.9 * c5["roofline"]["launch_ms"] and c5["roofline"]["worst_case_verified"].startswith("bit-exact")
     assert out["other_configs"]["3s"]["roofline"]["alg_bytes_per_launch"] == 64 * 2160 * 3840 * 7
+    # round 6: the default headline is ONE context (BASELINE's literal batch; the library runs a call as two halves on the context's two streams); the
+    # one-launch form and the two-batches-in-flight form ride beside it, the flat single_stream_* scalars repeat the headline
     r = out["roofline"]
-    assert r["single_stream_frac"] == r["single_stream"]["frac"] and out["value_single_stream"] > 0    # (four timed steps: no ordering of the two values is asserted)
+    assert r["in_flight"] == 1 and out["config"]["global_batch"] == 64 and out["config"]["launches_per_step_per_gpu"] == 1 and "call_form" in out["config"]
+    assert r["single_stream_frac"] == r["frac"] and 0.05 < r["single_stream_one_launch_frac"] < 1.0 and 0.05 < r["in_flight2_frac"] < 1.0
+    assert out["verified_frames"] == [0, 31, 63]
     assert out["cpu_baseline"]["value"] > 0
