@@ -377,11 +377,15 @@ def run_rank(a, rank, world, device, fence, torch):
     if cfg == 3 and world == 1:
         # ... with the call forced into ONE launch (round 6: by default a filter2D call of 16+ frames runs as two halves on the context's two streams
         # while no other context of the device is busy; a process-wide knob, so this leg runs at N = 1 only)
+        prev_knob = os.environ.get("RCV_FR_SPLIT")
         os.environ["RCV_FR_SPLIT"] = "0"
         L.rcv__debug_reload_knobs()
         settle(30.0, lane[0].step, lanes.sync)
         res["single_one_launch_ms"] = timed0(ns) / ns
-        os.environ.pop("RCV_FR_SPLIT", None)
+        if prev_knob is None:
+            os.environ.pop("RCV_FR_SPLIT", None)
+        else:
+            os.environ["RCV_FR_SPLIT"] = prev_knob   # (a profiling run may have set it for the whole process)
         L.rcv__debug_reload_knobs()
         if F == 1 and not a.no_others:
             # ... and with a second batch in flight on a second context of the device (the headline of rounds 4-5), for information
