@@ -22,6 +22,7 @@
 #include "rcv_kernels.h"
 #include "rcv_device_utils.h"
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -39,6 +40,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kAhead = RCV_HF_AHEAD;   // source rows in flight per lane (x 6 VGPRs)
 constexpr int kStripPx = 62 * 8;
+#ifndef RCV_HF_WPB
+#define RCV_HF_WPB 4
+#endif
+constexpr int kWPB = RCV_HF_WPB;      // waves per workgroup (the waves of a workgroup share nothing)
 
 struct HArgs {
     const uint8_t* src;
@@ -47,6 +52,9 @@ struct HArgs {
     int rows, cols, nstrips, seg_rows, nsegs, total_waves;
     int blocks_per_xcd;   // > 0: XCD-contiguous block order (as rcv_sobel_rows.hip)
     float s2, k, thr_up;   // thr_up: smallest float > thr (+inf for a NaN threshold: nothing is kept, as `rc > NaN` is never true)
+#ifdef RCV_HF_BENCH
+    unsigned long long* trace;   // (measurement library) per wave {start, end} of the chip-wide 100 MHz counter, {XCD, CU} in a third word
+#endif
 };
 
 __device__ __forceinline__ uint32_t pk(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -82,6 +90,42 @@ __device__ __forceinline__ float vmax3(float a, float b, float c)
     return d;
 }
 
+// Packed-f32 operations that read one operand with its halves SWAPPED (op_sel), for the pairs kept as {pixel j + 4, pixel j}: round 6.  A lane's
+// pairs are {pixel j, pixel j + 4}; the neighbour pair of j = 0 is {pixel -1, pixel 3} = {lane-1's pixel 7, own pixel 3}.  With pair 3 kept
+// SWAPPED, {pixel 7, pixel 3}, that neighbour pair is pair 3 itself after ONE in-place DPP move of its low half -- no copy of pixel 3 into
+// a second register pair (the compiler, given plain vector code, un-swaps the pair and copies).  The swap costs nothing where pair 3 is an
+// ordinary operand: op_sel picks the halves.  Same for pair 0 = {pixel 4, pixel 0} and the neighbour pair {pixel 4, pixel 8} of j = 3.
+__device__ __forceinline__ f2 pk_add_bs(f2 a, f2 b)   // {a.x + b.y, a.y + b.x}
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pk_sub_bs(f2 a, f2 b)   // {a.x - b.y, a.y - b.x}
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pk_sub_as(f2 a, f2 b)   // {a.y - b.x, a.x - b.y}
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pk_fma2_as(f2 a, f2 c)   // {2 a.y + c.x, 2 a.x + c.y}
+{
+    f2 d;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2 pk_mul_ss(f2 a, f2 b)   // {a.y * b.y, a.x * b.x}
+{
+    f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // byte 2 of a dword as f32 in ONE instruction (as C the compiler pulls the conversion through the Sobel's additions and does those in integer)
 __device__ __forceinline__ float cvb2(uint32_t w)
 {
@@ -97,6 +141,7 @@ struct U2 { uint32_t a, b; };
 typedef RCV_GLOBAL uint8_t* gptr;
 typedef const RCV_GLOBAL uint8_t* cgptr;
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 // unaligned views (RAG)
 typedef uint32_t U2m __attribute__((ext_vector_type(2), aligned(1)));
@@ -116,14 +161,18 @@ typedef float F2m __attribute__((ext_vector_type(2), aligned(4)));
 #define RCV_HF_OCC_ATTR
 #endif
 template <bool WANT_RESP, int SRCK, bool WANT_MASK = true, bool RAG = false>
-__global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
+__global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
 {
     const int lane = threadIdx.x & 63;
     // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are
     // then SALU work (as VALU work the 64-bit row multiplies alone were ~100 quarter-rate slots per four rows)
     const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+    int wid = __builtin_amdgcn_readfirstlane(blk * kWPB + (int)(threadIdx.x >> 6));
     if (wid >= a.total_waves) return;
+#ifdef RCV_HF_BENCH
+    const int wid0 = wid;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int strip = wid % a.nstrips;
     wid /= a.nstrips;
     const int seg = wid % a.nsegs;
@@ -133,7 +182,11 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
     const int xc = min(max(x, 0), a.cols - 8);
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
-    const bool has_edge = strip == 0 || (strip + 1) * kStripPx + 8 > a.cols;   // (wave-uniform) the strip holds the lane left of x = 0 / the lane at x = cols
+    // (wave-uniform) the strip holds the lane left of x = 0 / the lane at x = cols.  Kept as a scalar INTEGER the compiler cannot see through: as a
+    // bool it lived as a lane mask and one of its three uses per row rebuilt it with a v_cndmask + v_cmp pair (round 6, from the ISA)
+    int has_edge_i = __builtin_amdgcn_readfirstlane((strip == 0 || (strip + 1) * kStripPx + 8 > a.cols) ? 1 : 0);
+    asm volatile("" : "+s"(has_edge_i));
+#define has_edge (has_edge_i != 0)
     // RAG: the lane's 8 logical pixels x .. x+7 (right of the image: their mirror images) as byte selectors into the gray run it
     // gets from the clamped position xc; identity wherever the run lies inside the image (and for the left halo lane, which
     // keeps its own fix-up below)
@@ -155,6 +208,15 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
     uint8_t* const mf = a.mask + (size_t)frame * a.mfs;
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
     constexpr bool YUYV = SRCK == 1, GRAY = SRCK == 2;
+    // Round 6, aligned shapes: BUFFER loads / stores -- the frame base in the resource, the row's byte offset in the instruction's SCALAR offset,
+    // the lane's column offset in its 32-bit vector offset: no vector address arithmetic at all (the global form added the 64-bit row base
+    // to a 64-bit lane offset with one v_lshl_add_u64 per row and per store), and one s_mul_i32 per row where the 64-bit row base took six
+    // scalar instructions.  The host sends frames of 4 GB and more (rows * step) to the RAG instantiation, which keeps 64-bit pointers.
+    constexpr int kRsrc = 0x00020000;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)sf, 0, 0xffffffff, kRsrc);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)mf, 0, 0xffffffff, kRsrc);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)rf, 0, 0xffffffff, kRsrc);
+    const uint32_t sstep32 = (uint32_t)a.sstep, mstep32 = (uint32_t)a.mstep, rstep32 = (uint32_t)a.rstep;
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
     // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD); same box,
     // same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel
@@ -166,9 +228,9 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
     auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
         v = min(v, ye + 1);
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
-        cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
-        asm("" : "+s"(p));   // the row base stays in SGPRs: loads take the saddr + 32-bit voffset form, no VALU address math
         if constexpr (RAG) {
+            cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
+            asm("" : "+s"(p));   // the row base stays in SGPRs
             const U2m q0 = *(const RCV_GLOBAL U2m*)(p + sx);
             if constexpr (GRAY) return Row6{{q0.x, q0.y, 0u, 0u, 0u, 0u}};
             const U2m q1 = *(const RCV_GLOBAL U2m*)(p + sx + 8);
@@ -176,15 +238,16 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
             const U2m q2 = *(const RCV_GLOBAL U2m*)(p + sx + 16);
             return Row6{{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y}};
         }
+        const uint32_t so = (uint32_t)r * sstep32;
         if constexpr (GRAY) {
-            const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx);
+            const u2v q0 = __builtin_amdgcn_raw_buffer_load_b64(srs, sx, so, 0);
             return Row6{{q0.x, q0.y, 0u, 0u, 0u, 0u}};
         }
-        const u2v q0 = *(const RCV_GLOBAL u2v*)(p + sx), q1 = *(const RCV_GLOBAL u2v*)(p + sx + 8);
-        if constexpr (YUYV) return Row6{{q0.x, q0.y, q1.x, q1.y, 0u, 0u}};
+        const u4v q0 = __builtin_amdgcn_raw_buffer_load_b128(srs, sx, so, 0);
+        if constexpr (YUYV) return Row6{{q0.x, q0.y, q0.z, q0.w, 0u, 0u}};
         else {
-            const u2v q2 = *(const RCV_GLOBAL u2v*)(p + sx + 16);
-            return Row6{{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y}};
+            const u2v q2 = __builtin_amdgcn_raw_buffer_load_b64(srs, sx + 16, so, 0);
+            return Row6{{q0.x, q0.y, q0.z, q0.w, q2.x, q2.y}};
         }
     };
 
@@ -200,13 +263,10 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
     // group's loads at the head of the loop counts every vector-memory operation issued before it, stores included (one in-order vmcnt): a
     // store issued a third of a row earlier has long left, the one the feed just issued had not
     uint32_t pm0 = 0, pm1 = 0;
+    bool pdirty = false;                          // (wave-uniform) pm0 / pm1 hold a row's mask
     int pw = -1;
     auto flush_mask = [&]() {
-        if (live && pw >= ys && pw < ye) {
-            gptr mrow = (gptr)(mf + (size_t)pw * a.mstep);
-            asm("" : "+s"(mrow));
-            *(RCV_GLOBAL u2v*)(mrow + mx) = u2v{pm0, pm1};
-        }
+        if (live && pw >= ys && pw < ye) __builtin_amdgcn_raw_buffer_store_b64(u2v{pm0, pm1}, mrs, mx, (uint32_t)pw * mstep32, 0);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -272,30 +332,42 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
                 if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
                 if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
             }
-            const uint32_t lf = shr1(g[7]), rt = shl1(g[0]);
             if constexpr (FSOB) {
                 // Round 4: the Sobel in PACKED F32 on the pairs {pixel j, pixel j + 4} the later stages use anyway.  v_cvt_f32_ubyte2 takes
-                // the gray value straight out of byte 2 of its dword (one instruction per value, twelve per row with the two neighbour
-                // pairs), every intermediate is a small integer, so the f32 arithmetic is exact and Ix, Iy come out as the SAME f32 values
-                // the integer path converts to -- without its nine byte permutes and sixteen i16 -> f32 conversions (-13 per row of 8 px).
-                f2 P[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) P[j] = f2{cvb2(g[j]), cvb2(g[j + 4])};
-                const f2 Pm = f2{cvb2(lf), cvb2(g[3])};   // pixels {-1, 3}
-                const f2 Pp = f2{cvb2(g[4]), cvb2(rt)};   // pixels {4, 8}
+                // the gray value straight out of byte 2 of its dword (one instruction per value), every intermediate is a small integer, so
+                // the f32 arithmetic is exact and Ix, Iy come out as the SAME f32 values the integer path converts to -- without its nine
+                // byte permutes and sixteen i16 -> f32 conversions.
+                // Round 6: pairs 0 and 3 are kept SWAPPED ({4, 0} and {7, 3}); the neighbour pairs {-1, 3} and {4, 8} are then those two
+                // registers after one in-place DPP move each (of the f32 values: the neighbours' conversions are not repeated here) -- eight
+                // conversions and two DPP moves per row where there were ten, two DPP moves and two copies.  The sums of j = 0 / j = 3 are
+                // split so that everything that reads the lane's own pixel 7 / pixel 0 comes before the move that replaces it (exact integers:
+                // the order of the additions does not matter).
+                const f2 P1 = f2{cvb2(g[1]), cvb2(g[5])}, P2 = f2{cvb2(g[2]), cvb2(g[6])};
+                const f2 S0 = f2{cvb2(g[4]), cvb2(g[0])};   // pair 0 swapped
+                const f2 S3 = f2{cvb2(g[7]), cvb2(g[3])};   // pair 3 swapped
+                f2 h1[4], h2[4];
+                h1[1] = pk_sub_bs(P2, S0);                                                        // P2 - P0
+                h2[1] = __builtin_elementwise_fma(P1, f2{2.0f, 2.0f}, pk_add_bs(P2, S0));         // 2 P1 + P0 + P2
+                h1[2] = pk_sub_as(S3, P1);                                                        // P3 - P1
+                h2[2] = __builtin_elementwise_fma(P2, f2{2.0f, 2.0f}, pk_add_bs(P1, S3));         // 2 P2 + P1 + P3
+                const f2 a0 = pk_fma2_as(S0, P1), b3 = pk_fma2_as(S3, P2);                        // 2 P0 + P1, 2 P3 + P2
+                const f2 Pm = f2{shr1f(S3.x), S3.y};   // pixels {-1, 3}
+                const f2 Pp = f2{S0.x, shl1f(S0.y)};   // pixels {4, 8}
+                h1[0] = P1 - Pm;
+                h2[0] = a0 + Pm;
+                h1[3] = Pp - P2;
+                h2[3] = b3 + Pp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f2 lft = j ? P[j - 1] : Pm, rgt = j < 3 ? P[j + 1] : Pp;
-                    const f2 h1 = rgt - lft;
-                    const f2 h2 = __builtin_elementwise_fma(P[j], f2{2.0f, 2.0f}, lft + rgt);
-                    fix[j] = __builtin_elementwise_fma(f1b[j], f2{2.0f, 2.0f}, f1a[j] + h1);
-                    fiy[j] = h2 - f2a[j];
+                    fix[j] = __builtin_elementwise_fma(f1b[j], f2{2.0f, 2.0f}, f1a[j] + h1[j]);
+                    fiy[j] = h2[j] - f2a[j];
                     f1a[j] = f1b[j];
-                    f1b[j] = h1;
+                    f1b[j] = h1[j];
                     f2a[j] = f2b[j];
-                    f2b[j] = h2;
+                    f2b[j] = h2[j];
                 }
             } else {
+            const uint32_t lf = shr1(g[7]), rt = shl1(g[0]);
             constexpr uint32_t kPair = 0x0c060c02u;   // (byte 2 of the low source, byte 2 of the high source) as two u16
             L[0] = pk(g[0], lf, kPair);
             L[1] = pk(g[2], g[1], kPair);
@@ -330,8 +402,6 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         const int u = v - 1;
         const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
         constexpr bool kLimRow = !WANT_RESP && !RAG && RCV_HF_LIMROW;
-        const float limv = mirrored ? -INFINITY : 0.0f;   // (scalar select)
-        f2 lim2 = f2{limv, limv};
         // f32 stages on PACKED pairs {pixel j, pixel j+4} (v_pk_mul/add_f32): with this pairing the horizontal neighbour
         // P(x-1) of a pair is simply the previous pair register (j >= 1) -- pairing adjacent pixels {2j, 2j+1} instead leaves
         // every neighbour pair {2j-1, 2j} straddling two registers, and the compiler rebuilds it with ~3 v_mov per pixel
@@ -366,16 +436,22 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         }
         }
         // ---- products and 2x2 box sums: S(u) = Hs(u-1) + Hs(u), Hs(x) = P(x-1) + P(x) -------------------------------
-        f2 pxx[4], pxy[4], pyy[4];
+        // Round 6: the products of pair 3 are formed SWAPPED, {pixel 7, pixel 3}: the neighbour pair of j = 0, {P(-1), P(3)}, is then that register
+        // after one in-place DPP move of its low half (lane-1's pixel 7) -- the copy of P(3) into a second pair is gone (three per row), and the
+        // select that makes P(-1) := P(1) at the image's left edge runs on the strips that hold that edge only (three more on the others).
+        f2 pxx[4], pxy[4], pyy[4];   // ([3]: swapped)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 3; ++j) {
             pxx[j] = ix2[j] * ix2[j];
             pyy[j] = iy2[j] * iy2[j];          // (-iy)^2 == iy^2 exactly
         }
+        pxx[3] = pk_mul_ss(ix2[3], ix2[3]);
+        pyy[3] = pk_mul_ss(iy2[3], iy2[3]);
         // `mirrored` is a scalar condition (rows outside the image only): a uniform branch between the product and its exact
         // negation (a free source modifier) instead of one v_cndmask per pixel
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pxy[j] = ix2[j] * iy2[j];
+        for (int j = 0; j < 3; ++j) pxy[j] = ix2[j] * iy2[j];
+        pxy[3] = pk_mul_ss(ix2[3], iy2[3]);
         if (mirrored) {
             // (the volatile asm keeps this a BRANCH: if-converted, the two arms met in register copies -- four v_mov_b64 on every row of
             //  the image for the sake of the two rows outside it; round 4, from the ISA)
@@ -383,15 +459,26 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) pxy[j] = -pxy[j];   // exact
         }
-        // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1)
-        const float exx = edgeL ? pxx[1].x : pxx[3].y, exy = edgeL ? pxy[1].x : pxy[3].y, eyy = edgeL ? pyy[1].x : pyy[3].y;
-        const float lxx = shr1f(exx), lxy = shr1f(exy), lyy = shr1f(eyy);
+        // Hs of pixels {3, 7} first: the last readers of the lane's own P(7)
+        const f2 n3xx = pk_add_bs(pxx[2], pxx[3]), n3xy = pk_add_bs(pxy[2], pxy[3]), n3yy = pk_add_bs(pyy[2], pyy[3]);
+        // P(x-1) of the lane's first pixel comes from lane-1's last pixel; at the image's left edge P(-1) := P(1): the lane left of x = 0
+        // (it holds the pixels 0 .. 7 of the row) hands P(1) on
+        if (has_edge) {
+            asm volatile("; strip with the image's left edge: P(-1) := P(1)");
+            if (edgeL) {
+                pxx[3].x = pxx[1].x;
+                pxy[3].x = pxy[1].x;
+                pyy[3].x = pyy[1].x;
+            }
+        }
+        const f2 q0xx = f2{shr1f(pxx[3].x), pxx[3].y}, q0xy = f2{shr1f(pxy[3].x), pxy[3].y}, q0yy = f2{shr1f(pyy[3].x), pyy[3].y};   // pixels {-1, 3}
         float r[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // neighbours of pixels {j, j+4}: pixels {j-1, j+3}
-            const f2 qxx = j ? pxx[j - 1] : f2{lxx, pxx[3].x}, qxy = j ? pxy[j - 1] : f2{lxy, pxy[3].x}, qyy = j ? pyy[j - 1] : f2{lyy, pyy[3].x};
-            const f2 nxx = qxx + pxx[j], nxy = qxy + pxy[j], nyy = qyy + pyy[j];
+            const f2 nxx = j == 3 ? n3xx : (j ? pxx[j - 1] : q0xx) + pxx[j];
+            const f2 nxy = j == 3 ? n3xy : (j ? pxy[j - 1] : q0xy) + pxy[j];
+            const f2 nyy = j == 3 ? n3yy : (j ? pyy[j - 1] : q0yy) + pyy[j];
             const f2 sxx = hsxx[j] + nxx, sxy = hsxy[j] + nxy, syy = hsyy[j] + nyy;   // == (float)(exact integer sum)
             hsxx[j] = nxx;
             hsxy[j] = nxy;
@@ -401,20 +488,22 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
             const f2 t4 = a.k * t3;
             const f2 t5 = t4 * t3;
             f2 rr2 = (t1 - t2) - t5;
-            if constexpr (kLimRow) {
-                // (round 5) a row outside the image: every response -inf -- as a packed ADD of a row-uniform term (+0 on the rows of the
-                // image: exact, only -0 becomes +0, which no comparison below can tell apart; -inf outside: finite + -inf = -inf) on the pairs
-                // themselves (gfx950 has no packed f32 minimum).  The branch that overwrote r[] on those two rows per frame made every r[j] a
-                // merge of two definitions: six to seven register copies on EVERY row to bring the packed results into the merged registers.
-                rr2 = rr2 + lim2;
-            }
+            // (kLimRow, rounds 5 / 6) a row outside the image: its responses stay what the arithmetic gives and the NMS below leaves that row out.
+            // Overwriting r[] with -inf in a branch made every r[j] a merge of two definitions: six to seven register copies on EVERY row;
+            // round 5 added a row-uniform 0 / -inf to the packed results instead: four packed adds per row.
             r[j] = rr2.x;
             r[j + 4] = rr2.y;
         }
         if (WANT_RESP) {
             // (a branch around a store makes the compiler wait for every outstanding load first; harmless here -- the next
             //  rows' loads were issued a whole row of arithmetic earlier)
-            if (live && u >= ys && u < ye) {
+            if constexpr (!RAG) {
+                if (live && u >= ys && u < ye) {
+                    const uint32_t ro = (uint32_t)u * rstep32;
+                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1]), __builtin_bit_cast(uint32_t, r[2]), __builtin_bit_cast(uint32_t, r[3])}, rrs, 4 * mx, ro, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[4]), __builtin_bit_cast(uint32_t, r[5]), __builtin_bit_cast(uint32_t, r[6]), __builtin_bit_cast(uint32_t, r[7])}, rrs, 4 * mx + 16, ro, 0);
+                }
+            } else if (live && u >= ys && u < ye) {
                 gptr orow = (gptr)(rf + (size_t)u * a.rstep);
                 asm("" : "+s"(orow));
                 gptr o = orow + 4 * mx;
@@ -434,9 +523,6 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
                         }
                         if (nvalid & 1) *(RCV_GLOBAL float*)(o + 4 * j) = j == 0 ? r[0] : (j == 2 ? r[2] : (j == 4 ? r[4] : r[6]));
                     }
-                } else {
-                    *(RCV_GLOBAL f4v*)o = f4v{r[0], r[1], r[2], r[3]};
-                    *(RCV_GLOBAL f4v*)(o + 16) = f4v{r[4], r[5], r[6], r[7]};
                 }
             }
         }
@@ -473,16 +559,59 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         uint32_t mbits[2] = {0, 0};
         if (cand_b) {   // (uniform) row w holds a candidate
             asm volatile("; row with a candidate: 3x3 maxima");
-            const float al = shr1f(ra[7]), ar = shl1f(ra[0]), bl = shr1f(rb[7]), br = shl1f(rb[0]), cl = shr1f(r[7]), cr = shl1f(r[0]);
+            const float bl = shr1f(rb[7]), br = shl1f(rb[0]);
+            // USE_A / USE_C: the rows above / below row w = u - 1 take part.  kLimRow launches leave the responses of the two rows outside the image
+            // as they come out of the arithmetic (finite values of mirrored pixels) and skip those rows here, where they would be read: the first /
+            // last row of the image runs a variant of this block without them -- the same maxima as with -inf in their place
+            auto maxima = [&](auto use_a, auto use_c) {
+                constexpr bool USE_A = decltype(use_a)::value, USE_C = decltype(use_c)::value;
+                float al = 0.0f, ar = 0.0f, cl = 0.0f, cr = 0.0f;
+                if constexpr (USE_A) {
+                    al = shr1f(ra[7]);
+                    ar = shl1f(ra[0]);
+                }
+                if constexpr (USE_C) {
+                    cl = shr1f(r[7]);
+                    cr = shl1f(r[0]);
+                }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ma = vmax3(j ? ra[j - 1] : al, ra[j], j < 7 ? ra[j + 1] : ar);
-                const float mc = vmax3(j ? r[j - 1] : cl, r[j], j < 7 ? r[j + 1] : cr);
-                const float mb = vmax3(j ? rb[j - 1] : bl, j < 7 ? rb[j + 1] : br, thr_v);
-                const bool keep = rb[j] >= vmax3(ma, mc, mb);
-                mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                for (int j = 0; j < 8; ++j) {
+                    const float mb = vmax3(j ? rb[j - 1] : bl, j < 7 ? rb[j + 1] : br, thr_v);
+                    float m = mb;
+                    if constexpr (USE_A && USE_C) {
+                        const float ma = vmax3(j ? ra[j - 1] : al, ra[j], j < 7 ? ra[j + 1] : ar);
+                        const float mc = vmax3(j ? r[j - 1] : cl, r[j], j < 7 ? r[j + 1] : cr);
+                        m = vmax3(ma, mc, mb);
+                    } else if constexpr (USE_A) {
+                        m = vmax2(vmax3(j ? ra[j - 1] : al, ra[j], j < 7 ? ra[j + 1] : ar), mb);
+                    } else if constexpr (USE_C) {
+                        m = vmax2(vmax3(j ? r[j - 1] : cl, r[j], j < 7 ? r[j + 1] : cr), mb);
+                    }
+                    const bool keep = rb[j] >= m;
+                    mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                }
+            };
+            if (kLimRow && u - 2 < 0) {
+                asm volatile("; first row of the image: no row above");
+                maxima(std::false_type{}, std::true_type{});
+            } else if (kLimRow && u >= a.rows) {
+                asm volatile("; last row of the image: no row below");
+                maxima(std::true_type{}, std::false_type{});
+            } else {
+                maxima(std::true_type{}, std::true_type{});
             }
+            if constexpr (!RAG) {
+                pm0 = mbits[0];
+                pm1 = mbits[1];
+            }
+        } else if (!RAG && pdirty) {
+            // (round 6) the pending mask registers are zero unless a row with candidates wrote them: they are cleared on the first row without
+            // candidates after such a row, not on every row (two v_mov per row)
+            asm volatile("; first row without candidates after one with: pending mask back to zeros");
+            pm0 = 0;
+            pm1 = 0;
         }
+        if constexpr (!RAG) pdirty = cand_b;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ra[j] = rb[j];
@@ -491,8 +620,6 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         cand_b = cand_u;
         const int w = u - 1;
         if constexpr (!RAG) {
-            pm0 = mbits[0];
-            pm1 = mbits[1];
             pw = w;
             return;
         }
@@ -536,11 +663,33 @@ __global__ __launch_bounds__(256) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
         for (int i = 0; i < kAhead; ++i) feed(nxt[i], v0 + g0 + kAhead + i);
     }
     if constexpr (WANT_MASK && !RAG) flush_mask();
+#ifdef RCV_HF_BENCH
+    if (a.trace) {
+        __builtin_amdgcn_s_waitcnt(0);   // (the wave's last store has left)
+        if (lane == 0) {
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            a.trace[3 * (size_t)wid0] = t_start;
+            a.trace[3 * (size_t)wid0 + 1] = __builtin_amdgcn_s_memrealtime();
+            a.trace[3 * (size_t)wid0 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+        }
+    }
+#endif
 }
+
+#ifdef RCV_HF_BENCH
+int g_hf_seg = 0;             // rows per segment (0: the product's plan)
+void* g_hf_trace = nullptr;
+#endif
 
 } // namespace
 
+#ifdef RCV_HF_BENCH   // (the measurement library carries its own copy under another name: the product's symbol stays the product's)
+static int hf_launch(rcv_ctx* ctx, const View& s, const View* mask, const View* resp, int block, float k, float thr)
+#else
 int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* resp, int block, float k, float thr)
+#endif
 {
     if (block != 2 || (s.ch != 3 && s.ch != 2 && s.ch != 1)) return RCV_ERR_UNSUPPORTED;
     if (!mask && (!resp || s.ch != 1)) return RCV_ERR_UNSUPPORTED;   // response only: the gray-source cornerHarris
@@ -549,7 +698,10 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     const View& m = mask ? *mask : m0;
     if (s.cols < 8 || s.rows < 4 || (s.ch == 2 && (s.cols & 1))) return RCV_ERR_UNSUPPORTED;
     // widths that are not a multiple of 8 and rows that are not 8 / 16-byte aligned: the RAG instantiations
-    const bool rag = s.cols % 8 != 0 || (uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8) ||
+    // (... and frames of 4 GB and more: the aligned instantiations address a frame's rows with 32-bit scalar offsets)
+    const bool huge = (unsigned long long)s.rows * s.step > 0xffffffffull || (mask && (unsigned long long)m.rows * m.step > 0xffffffffull) ||
+                      (resp && (unsigned long long)resp->rows * resp->step > 0xffffffffull);
+    const bool rag = huge || s.cols % 8 != 0 || (uintptr_t)s.p % 8 || s.step % 8 || (s.n > 1 && s.fstride % 8) ||
                      (mask && ((uintptr_t)m.p % 8 || m.step % 8 || (m.n > 1 && m.fstride % 8))) ||
                      (resp && ((uintptr_t)resp->p % 16 || resp->step % 16 || (resp->n > 1 && resp->fstride % 16)));
     if (rag && resp && ((uintptr_t)resp->p % 4 || resp->step % 4 || resp->fstride % 4)) return RCV_ERR_UNSUPPORTED;
@@ -573,19 +725,23 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
         int& wpc = ctx->harris_wpc[resp ? 1 : 0];   // per context: contexts may be driven from different threads
         if (wpc == 0) {
             int nb = 0;
-            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, 0>, 256, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false, 0>, 256, 0);
-            wpc = (e == hipSuccess && nb > 0) ? 4 * nb : 8;
+            hipError_t e = resp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<true, 0>, 64 * kWPB, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_harris_fused<false, 0>, 64 * kWPB, 0);
+            wpc = (e == hipSuccess && nb > 0) ? kWPB * nb : 8;
             (void)hipGetLastError();
         }
-        const long long slots = (long long)wpc * ctx->cu_count, per_seg = (long long)a.nstrips * s.n;
+        // Round 6 (tools/harris_timeline.py, profiles/r06_harris_timeline.txt): identical waves take 0.65 ... 1.25 of the median time (rows with
+        // corners run the 3x3 maxima, the others do not), so whole "rounds" of the resident waves mean little; what a segment costs is its five
+        // halo / fill rows + ~8 rows of set-up, what long segments cost is the ragged end of the launch: cost = (rows + 13) x (waves / slots +
+        // 0.26).  64 x 4K: 135 rows (was 180: +1 %); a half of a split call plans for the pair of launches that share the chip (32 frames:
+        // 135 rows, was 90: +1.5 %).
+        const long long slots = (long long)wpc * ctx->cu_count, per_seg = (long long)a.nstrips * max(s.n, ctx->split_n);
         double best = 1e30;
         for (int ns = 1; ns <= 64; ++ns) {
             const int sr = (s.rows + ns - 1) / ns;
             if (ns > 1 && sr < 64) break;
             const long long tot = per_seg * ((s.rows + sr - 1) / sr);
-            const long long rounds = (tot + slots - 1) / slots;
-            const double cost = (double)rounds * (sr + 5 + 8) * (rounds < 2 ? 1.5 : 1.0);
+            const double cost = (double)(sr + 13) * ((double)tot / (double)slots + 0.26);
             if (cost < best) { best = cost; seg = sr; }
         }
     }
@@ -595,6 +751,10 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     }
 #ifdef RCV_HF_SEG   // (measurement builds: rows per segment fixed)
     seg = RCV_HF_SEG;
+#endif
+#ifdef RCV_HF_BENCH
+    if (g_hf_seg > 0) seg = g_hf_seg;
+    a.trace = (unsigned long long*)g_hf_trace;
 #endif
     a.seg_rows = seg;
     a.nsegs = (s.rows + seg - 1) / seg;
@@ -606,34 +766,58 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     a.k = k;
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
     // response-only launches (cornerHarris: 4 of 5 bytes per pixel are stores): 3 workgroups per CU measured 0.698 against 0.803 ms
-    constexpr unsigned kRespOnlyLds = 54272;
-    const long long nblocks = (waves + 3) / 4;
+    constexpr unsigned kRespOnlyLds = 54272 * kWPB / 4;
+    const long long nblocks = (waves + kWPB - 1) / kWPB;
     a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
     if (rag) {
         if (s.ch == 1) {
-            if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false, true>), grid, dim3(256), kRespOnlyLds, ctx->stream, a);
-            else if (resp) RCV_LAUNCH((k_harris_fused<true, 2, true, true>), grid, dim3(256), 0, ctx->stream, a);
-            else RCV_LAUNCH((k_harris_fused<false, 2, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false, true>), grid, dim3(64 * kWPB), kRespOnlyLds, ctx->stream, a);
+            else if (resp) RCV_LAUNCH((k_harris_fused<true, 2, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 2, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
         } else if (s.ch == 2) {
-            if (resp) RCV_LAUNCH((k_harris_fused<true, 1, true, true>), grid, dim3(256), 0, ctx->stream, a);
-            else RCV_LAUNCH((k_harris_fused<false, 1, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            if (resp) RCV_LAUNCH((k_harris_fused<true, 1, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 1, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
         } else {
-            if (resp) RCV_LAUNCH((k_harris_fused<true, 0, true, true>), grid, dim3(256), 0, ctx->stream, a);
-            else RCV_LAUNCH((k_harris_fused<false, 0, true, true>), grid, dim3(256), 0, ctx->stream, a);
+            if (resp) RCV_LAUNCH((k_harris_fused<true, 0, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+            else RCV_LAUNCH((k_harris_fused<false, 0, true, true>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
         }
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1) {
-        if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(256), kRespOnlyLds, ctx->stream, a);
-        else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(256), 0, ctx->stream, a);
-        else RCV_LAUNCH((k_harris_fused<false, 2>), grid, dim3(256), 0, ctx->stream, a);
+        if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(64 * kWPB), kRespOnlyLds, ctx->stream, a);
+        else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 2>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     } else if (s.ch == 2) {
-        if (resp) RCV_LAUNCH((k_harris_fused<true, 1>), grid, dim3(256), 0, ctx->stream, a);
-        else RCV_LAUNCH((k_harris_fused<false, 1>), grid, dim3(256), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 1>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 1>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     } else {
-        if (resp) RCV_LAUNCH((k_harris_fused<true, 0>), grid, dim3(256), 0, ctx->stream, a);
-        else RCV_LAUNCH((k_harris_fused<false, 0>), grid, dim3(256), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 0>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        else RCV_LAUNCH((k_harris_fused<false, 0>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     }
     return rcv_launch_check(ctx);
 }
+
+#ifdef RCV_HF_BENCH
+// Measurement entry (librustcv_hip_bench.so): the Harris pipeline BGR -> mask of a device-resident batch with the rows per segment given (0: the
+// product's plan) and, if trace != nullptr, three 64-bit words per wave {start, end (100 MHz counter), XCD << 32 | HW_ID}; *waves = the launch's waves
+extern "C" int rcv__harris_fused_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* mask, float k, float thr, int seg_rows, void* trace, int* waves)
+{
+    RCV_TRY(rcv_bind(ctx));
+    if (!src || !mask) return RCV_ERR_ARG;
+    View s, m;
+    RCV_TRY(rcv_view_batch(src, RCV_8U, &s));
+    RCV_TRY(rcv_view_batch(mask, RCV_8U, &m));
+    if (s.rows != m.rows || s.cols != m.cols || s.n != m.n || m.ch != 1) return RCV_ERR_ARG;
+    g_hf_seg = seg_rows;
+    g_hf_trace = trace;
+    const int rc = hf_launch(ctx, s, &m, nullptr, 2, k, thr);
+    g_hf_seg = 0;
+    g_hf_trace = nullptr;
+    if (waves) {
+        const int nstrips = (s.cols + kStripPx - 1) / kStripPx;
+        *waves = nstrips * s.n;   // (x segments: the caller knows seg_rows)
+    }
+    return rc;
+}
+#endif

@@ -83,6 +83,7 @@ struct rcv_ctx {
     bool half_busy;               // `half` holds work that `stream` has not waited for
     bool main_unknown;            // `stream` holds work of other entry points since `half` last waited for it
     bool stream_exported;         // rcv_ctx_stream was called: the caller may enqueue behind our back -- no split any more
+    int split_n = 0;              // inside rcv_split_run: the frames of the WHOLE call (a half's launch plans its segments for the pair of launches)
     struct Hull { uintptr_t lo, hi; };
     struct HullSet {              // a few byte ranges; more than it holds are merged into their hull (conservative)
         Hull h[6];
@@ -205,9 +206,17 @@ int rcv_split_run(rcv_ctx* ctx, int n, const RcvRanges& a, const RcvRanges& b, F
 {
     RCV_TRY(rcv_split_begin(ctx, n, a, b));
     const unsigned up0 = ctx->fr_uploads;
+    ctx->split_n = n;
     int rc = launch(0);
-    if (rc < 0) return rc;
-    RCV_TRY(rcv_split_half(ctx, a, b, up0));
+    if (rc < 0) {
+        ctx->split_n = 0;
+        return rc;
+    }
+    rc = rcv_split_half(ctx, a, b, up0);
+    if (rc < 0) {
+        ctx->split_n = 0;
+        return rc;
+    }
     hipStream_t t = ctx->stream;
     ctx->stream = ctx->half;
     ctx->half = t;
@@ -215,6 +224,7 @@ int rcv_split_run(rcv_ctx* ctx, int n, const RcvRanges& a, const RcvRanges& b, F
     t = ctx->stream;
     ctx->stream = ctx->half;
     ctx->half = t;
+    ctx->split_n = 0;
     if (rc == RCV_ERR_UNSUPPORTED) return RCV_ERR_UNSUPPORTED;   // (half 1 not taken where half 0 was: the caller's ordinary path redoes the whole call on `stream`)
     RCV_TRY(rc);
     rcv_split_done(ctx, b);
