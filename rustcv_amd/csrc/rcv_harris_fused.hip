@@ -562,33 +562,29 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
             const float bl = shr1f(rb[7]), br = shl1f(rb[0]);
             // USE_A / USE_C: the rows above / below row w = u - 1 take part.  kLimRow launches leave the responses of the two rows outside the image
             // as they come out of the arithmetic (finite values of mirrored pixels) and skip those rows here, where they would be read: the first /
-            // last row of the image runs a variant of this block without them -- the same maxima as with -inf in their place
+            // last row of the image runs a variant of this block without them -- the same maxima as with -inf in their place.
+            // Round 6: COLUMNS first -- v = max(above, below, thr) per pixel, then max(v[x-1], v[x], v[x+1], b[x-1], b[x+1]): 24 maxima and four
+            // DPP moves per row where the row-wise grouping took 32 and six.  The mask bytes come from the SIGN of b - m (set iff b < m; b == m
+            // gives +0; no NaN: b is finite or -inf, m >= thr_up > -inf): v_perm_b32's selectors 9 / 11 replicate bit 31 of either source
+            // through a byte, so two differences become two bytes in one instruction -- 8 subtractions, 6 permutes and 2 complements per row
+            // where compare + select + or took 20, and the four byte-mask registers of the selects are gone.
             auto maxima = [&](auto use_a, auto use_c) {
                 constexpr bool USE_A = decltype(use_a)::value, USE_C = decltype(use_c)::value;
-                float al = 0.0f, ar = 0.0f, cl = 0.0f, cr = 0.0f;
-                if constexpr (USE_A) {
-                    al = shr1f(ra[7]);
-                    ar = shl1f(ra[0]);
-                }
-                if constexpr (USE_C) {
-                    cl = shr1f(r[7]);
-                    cr = shl1f(r[0]);
-                }
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (USE_A && USE_C) ? vmax3(ra[j], r[j], thr_v) : vmax2(USE_A ? ra[j] : r[j], thr_v);
+                const float vl = shr1f(v[7]), vr = shl1f(v[0]);
+                uint32_t t[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float mb = vmax3(j ? rb[j - 1] : bl, j < 7 ? rb[j + 1] : br, thr_v);
-                    float m = mb;
-                    if constexpr (USE_A && USE_C) {
-                        const float ma = vmax3(j ? ra[j - 1] : al, ra[j], j < 7 ? ra[j + 1] : ar);
-                        const float mc = vmax3(j ? r[j - 1] : cl, r[j], j < 7 ? r[j + 1] : cr);
-                        m = vmax3(ma, mc, mb);
-                    } else if constexpr (USE_A) {
-                        m = vmax2(vmax3(j ? ra[j - 1] : al, ra[j], j < 7 ? ra[j + 1] : ar), mb);
-                    } else if constexpr (USE_C) {
-                        m = vmax2(vmax3(j ? r[j - 1] : cl, r[j], j < 7 ? r[j + 1] : cr), mb);
-                    }
-                    const bool keep = rb[j] >= m;
-                    mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                    const float hv = vmax3(j ? v[j - 1] : vl, v[j], j < 7 ? v[j + 1] : vr);
+                    const float m = vmax3(hv, j ? rb[j - 1] : bl, j < 7 ? rb[j + 1] : br);
+                    t[j] = __builtin_bit_cast(uint32_t, rb[j] - m);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t lo = pk(t[4 * h + 1], t[4 * h], 0x0c0c0b09u), hi = pk(t[4 * h + 3], t[4 * h + 2], 0x0b090c0cu);   // 0xff where b < m
+                    mbits[h] = ~(lo | hi);
                 }
             };
             if (kLimRow && u - 2 < 0) {
