@@ -35,6 +35,21 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef RCV_HF_FSOB
 #define RCV_HF_FSOB 1
 #endif
+#ifndef RCV_HF_FSOB_RESP
+#define RCV_HF_FSOB_RESP 1
+#endif
+#ifndef RCV_HF_RESP_LDS
+#define RCV_HF_RESP_LDS 0
+#endif
+#ifndef RCV_HF_MASK_AUX
+#define RCV_HF_MASK_AUX 0
+#endif
+#ifndef RCV_HF_RESP_T
+#define RCV_HF_RESP_T 1
+#endif
+#ifndef RCV_HF_RESP_AUX
+#define RCV_HF_RESP_AUX 2   // (non-temporal)
+#endif
 #ifndef RCV_HF_LIMROW
 #define RCV_HF_LIMROW 1
 #endif
@@ -163,6 +178,7 @@ typedef float F2m __attribute__((ext_vector_type(2), aligned(4)));
 template <bool WANT_RESP, int SRCK, bool WANT_MASK = true, bool RAG = false>
 __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
 {
+    extern __shared__ float hf_lds[];   // (aligned launches with the response: 2 KB per wave, see the response store)
     const int lane = threadIdx.x & 63;
     // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are
     // then SALU work (as VALU work the 64-bit row multiplies alone were ~100 quarter-rate slots per four rows)
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
     // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD); same box,
     // same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel
-    constexpr bool FSOB = TQ && !WANT_RESP && RCV_HF_FSOB;
+    constexpr bool FSOB = TQ && (!WANT_RESP || RCV_HF_FSOB_RESP) && RCV_HF_FSOB;
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
     const float thr_v = a.thr_up;
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
     bool pdirty = false;                          // (wave-uniform) pm0 / pm1 hold a row's mask
     int pw = -1;
     auto flush_mask = [&]() {
-        if (live && pw >= ys && pw < ye) __builtin_amdgcn_raw_buffer_store_b64(u2v{pm0, pm1}, mrs, mx, (uint32_t)pw * mstep32, 0);
+        if (live && pw >= ys && pw < ye) __builtin_amdgcn_raw_buffer_store_b64(u2v{pm0, pm1}, mrs, mx, (uint32_t)pw * mstep32, RCV_HF_MASK_AUX);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -497,11 +513,29 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
         if (WANT_RESP) {
             // (a branch around a store makes the compiler wait for every outstanding load first; harmless here -- the next
             //  rows' loads were issued a whole row of arithmetic earlier)
-            if constexpr (!RAG) {
+            if constexpr (!RAG && RCV_HF_RESP_T) {
+                // Round 6: the response row leaves the wave as WHOLE LINES.  A lane owns 8 pixels = 32 bytes of the f32 row; stored from there, each
+                // of its two 16-byte stores writes every other 16 bytes of the wave's 2 KB -- two half-written visits to every 128-byte line, and a
+                // launch time that depended on where the buffers lay (0.61-0.71 ms for one library on one box, `profiles/r06_harris_resp_stores.txt`;
+                // the lesson of the one-launch config 3).  The row goes through 2 KB of wave-private LDS instead (no barrier: a wave's
+                // LDS instructions execute in order) and comes back as float4 number `lane` and number 64 + `lane` of the strip's row.
+                if (u >= ys && u < ye) {
+                    float* const wl = hf_lds + 512 * (threadIdx.x >> 6);
+                    if (lane >= 1 && lane <= 62) {
+                        *(f4v*)(wl + 8 * (lane - 1)) = f4v{r[0], r[1], r[2], r[3]};
+                        *(f4v*)(wl + 8 * (lane - 1) + 4) = f4v{r[4], r[5], r[6], r[7]};
+                    }
+                    const f4v o0 = *(const f4v*)(wl + 4 * lane), o1 = *(const f4v*)(wl + 256 + 4 * lane);
+                    const int n4 = (min(a.cols, (strip + 1) * kStripPx) - strip * kStripPx) >> 2;   // float4s of the row inside this strip (cols % 8 == 0)
+                    const uint32_t ro = (uint32_t)u * rstep32, vo = (uint32_t)(4 * strip * kStripPx + 16 * lane);
+                    if (lane < n4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o0), rrs, vo, ro, RCV_HF_RESP_AUX);
+                    if (64 + lane < n4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o1), rrs, vo + 1024, ro, RCV_HF_RESP_AUX);
+                }
+            } else if constexpr (!RAG) {
                 if (live && u >= ys && u < ye) {
                     const uint32_t ro = (uint32_t)u * rstep32;
-                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1]), __builtin_bit_cast(uint32_t, r[2]), __builtin_bit_cast(uint32_t, r[3])}, rrs, 4 * mx, ro, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[4]), __builtin_bit_cast(uint32_t, r[5]), __builtin_bit_cast(uint32_t, r[6]), __builtin_bit_cast(uint32_t, r[7])}, rrs, 4 * mx + 16, ro, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1]), __builtin_bit_cast(uint32_t, r[2]), __builtin_bit_cast(uint32_t, r[3])}, rrs, 4 * mx, ro, RCV_HF_RESP_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(u4v{__builtin_bit_cast(uint32_t, r[4]), __builtin_bit_cast(uint32_t, r[5]), __builtin_bit_cast(uint32_t, r[6]), __builtin_bit_cast(uint32_t, r[7])}, rrs, 4 * mx + 16, ro, RCV_HF_RESP_AUX);
                 }
             } else if (live && u >= ys && u < ye) {
                 gptr orow = (gptr)(rf + (size_t)u * a.rstep);
@@ -761,8 +795,12 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
     a.s2 = (float)(sc * sc);
     a.k = k;
     a.thr_up = thr != thr ? INFINITY : nextafterf(thr, INFINITY);
-    // response-only launches (cornerHarris: 4 of 5 bytes per pixel are stores): 3 workgroups per CU measured 0.698 against 0.803 ms
-    constexpr unsigned kRespOnlyLds = 54272 * kWPB / 4;
+    // response-only launches (cornerHarris: 4 of 5 bytes per pixel are stores).  Rounds 2-5: untouched dynamic LDS held them at 3 workgroups per CU (0.698
+    // against 0.803 ms).  Round 6: with whole-line non-temporal response stores the full occupancy is the faster one (0.51-0.56 against 0.55-0.59 ms):
+    // RCV_HF_RESP_LDS = 0, the launch takes the 2 KB per wave of the row buffer only.
+    constexpr unsigned kRespOnlyLds = RCV_HF_RESP_LDS * kWPB / 4;
+    constexpr unsigned kRespLds = 2048 * kWPB;   // (aligned launches with the response: the row's way through LDS)
+    static_assert(kRespOnlyLds == 0 || kRespOnlyLds >= kRespLds, "the response-only launch's LDS is also its row buffer");
     const long long nblocks = (waves + kWPB - 1) / kWPB;
     a.blocks_per_xcd = (int)((nblocks + 7) / 8);
     dim3 grid((unsigned)(a.blocks_per_xcd > 0 ? a.blocks_per_xcd * 8 : nblocks));
@@ -781,14 +819,14 @@ int rcv_harris_fused(rcv_ctx* ctx, const View& s, const View* mask, const View* 
         return rcv_launch_check(ctx);
     }
     if (s.ch == 1) {
-        if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(64 * kWPB), kRespOnlyLds, ctx->stream, a);
-        else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        if (!mask) RCV_LAUNCH((k_harris_fused<true, 2, false>), grid, dim3(64 * kWPB), kRespOnlyLds ? kRespOnlyLds : kRespLds, ctx->stream, a);
+        else if (resp) RCV_LAUNCH((k_harris_fused<true, 2>), grid, dim3(64 * kWPB), kRespLds, ctx->stream, a);
         else RCV_LAUNCH((k_harris_fused<false, 2>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     } else if (s.ch == 2) {
-        if (resp) RCV_LAUNCH((k_harris_fused<true, 1>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 1>), grid, dim3(64 * kWPB), kRespLds, ctx->stream, a);
         else RCV_LAUNCH((k_harris_fused<false, 1>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     } else {
-        if (resp) RCV_LAUNCH((k_harris_fused<true, 0>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
+        if (resp) RCV_LAUNCH((k_harris_fused<true, 0>), grid, dim3(64 * kWPB), kRespLds, ctx->stream, a);
         else RCV_LAUNCH((k_harris_fused<false, 0>), grid, dim3(64 * kWPB), 0, ctx->stream, a);
     }
     return rcv_launch_check(ctx);
