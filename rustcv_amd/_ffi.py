@@ -153,7 +153,7 @@ BENCH_SIGNATURES = {
     "rcv__filter_rows_bench": (_i, [_ctx, _bat, _bat, _P(C.c_int8), _i, _i, _P(C.c_int), C.c_void_p]),
     "rcv__gauss_f32_bench": (_i, [_ctx, _bat, _bat, _i, C.c_double, C.c_uint, _i]),
     "rcv__harris_fused_bench": (_i, [_ctx, _bat, _bat, C.c_float, C.c_float, _i, C.c_void_p, C.POINTER(C.c_int)]),
-    "rcv__filter_rows_sobel_bench": (_i, [_ctx, _bat, _bat, _bat, _P(C.c_int8), _i, _i, _P(C.c_int)]),
+    "rcv__filter_rows_sobel_bench": (_i, [_ctx, _bat, _bat, _bat, _P(C.c_int8), _i, _i, _P(C.c_int), C.c_void_p]),
     # the fused warp -> down-scale launch: (src, dst, M, S, variant 0 box / 1 frame loop, fpg, ww, xcd, strip, lds (-1: the product's))
     "rcv__warp_resize_bench": (_i, [_ctx, _bat, _bat, _P(_f), _i, _i, _i, _i, _i, _i, _i]),
 }

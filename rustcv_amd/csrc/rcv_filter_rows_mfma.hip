@@ -1198,6 +1198,7 @@ void launch_rows(const FRArgs& a, int pp, unsigned lds, int dmask, int src_yuyv,
             case 2048: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 2048, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
             case 2052: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 2052, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
             case 4096: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 4096, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;
+            case 1024: RCV_LAUNCH((k_filter_rows_mfma<KS, kSobPP, 1024, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;   // wave timeline
             case 8192: RCV_LAUNCH((k_filter_rows_mfma<KS, 3, 0, 0, 0, 1>), grid, dim3(64 * a.wpb), lds, st, a); return;   // three row pairs in flight, two waves per SIMD (round 6's first form)
             default: break;
             }
@@ -1341,7 +1342,8 @@ extern "C" int rcv__filter_rows_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_ba
     return rows_launch(ctx, s, d, k16, ksize, shift, 0, true, nullptr, nullptr, t);
 }
 // ... and the fused filter2D -> gray -> Sobel launch of a device-resident batch (dx, dy: i16 planes), same tune array
-extern "C" int rcv__filter_rows_sobel_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy, const int8_t* k, int ksize, int shift, const int* tune)
+extern "C" int rcv__filter_rows_sobel_bench(rcv_ctx* ctx, const rcv_batch* src, rcv_batch* dx, rcv_batch* dy, const int8_t* k, int ksize, int shift, const int* tune,
+                                            void* trace)
 {
     RCV_TRY(rcv_bind(ctx));
     if (!src || !dx || !dy || !k || !tune || (ksize != 3 && ksize != 5 && ksize != 7) || shift < 0 || shift > 24) return RCV_ERR_ARG;
@@ -1355,6 +1357,7 @@ extern "C" int rcv__filter_rows_sobel_bench(rcv_ctx* ctx, const rcv_batch* src, 
     t.f7_rows = tune[0]; t.dual_full = tune[1]; t.chain = tune[2]; t.chain_rows = tune[3]; t.dbg = tune[4]; t.wpc = tune[5]; t.rounds = tune[6];
     t.pp = tune[7]; t.order = tune[8]; t.bpf = tune[9]; t.band_rows = tune[10]; t.taper = tune[11]; t.wpb = tune[12]; t.edge_pct = tune[13];
     t.var = tune[14];
+    t.trace = trace;   // (dbg 1024: two 64-bit words per wave, start / end of the 100 MHz counter)
     return rows_launch(ctx, s, s, k16, ksize, shift, 0, true, &vx, &vy, t);
 }
 #endif

@@ -21,7 +21,7 @@ bs, bx, by = src.as_rcv(), dx.as_rcv(), dy.as_rcv()
 def sob(**tune):
     t = _ffi.rows_tune(**tune)
     def f():
-        rc = BL.rcv__filter_rows_sobel_bench(ctx.handle, C.byref(bs), C.byref(bx), C.byref(by), kp, 7, 6, t)
+        rc = BL.rcv__filter_rows_sobel_bench(ctx.handle, C.byref(bs), C.byref(bx), C.byref(by), kp, 7, 6, t, None)
         assert rc == 0, (rc, tune)
     return f
 def timed(fn, launches=40):
