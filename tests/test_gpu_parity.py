@@ -2189,6 +2189,32 @@ def test_harris_pipeline_block3_threshold_edge_values(ctx, oracle, thr):
     mask.free()
 
 
+@pytest.mark.parametrize("want_resp", [False, True])
+def test_harris_pipeline_frame_of_more_than_4gb(ctx, oracle, want_resp):
+    """round 6: the aligned instantiations of k_harris_fused address a frame's rows with 32-bit scalar offsets (buffer loads / stores); a frame whose
+    rows x step reaches 4 GB goes to the 64-bit-pointer instantiation instead.  A 70 x 64 BGR image with a row step of 64 MiB (4.6 GB of mostly
+    padding): the rows beyond 4 GB would wrap onto the first ones if it did not."""
+    rows, cols, step = 70, 64, 64 << 20
+    img = oracle.synth_frame(rows, cols, 3, 1, 0x5EED0005, 5)
+    src = device.DeviceBatch(ctx, 1, rows, cols, 3, step=step)
+    L = _ffi.lib()
+    for r in range(rows):
+        row = np.ascontiguousarray(img[r].reshape(-1))
+        _ffi.check(L.rcv_upload(ctx.handle, C.c_void_p(src.ptr.value + r * step), row.ctypes.data, row.size), "rcv_upload")
+    mask = device.DeviceBatch(ctx, 1, rows, cols, 1)
+    resp = device.DeviceBatch(ctx, 1, rows, cols, 1, _ffi.RCV_32F) if want_resp else None
+    mask.memset(7)
+    launched = _kernels_launched(ctx, lambda: device.harris_pipeline(src, mask, resp, 2, 0.04, 1e-4))
+    assert "k_harris_fused<" in launched and "true, true>" in launched, launched   # (the RAG = true instantiation: 64-bit row pointers)
+    want = oracle.harris_pipeline(img, 2, 0.04, 1e-4, want_resp=want_resp)
+    wm = want[0] if want_resp else want
+    assert np.array_equal(mask.download()[0].reshape(rows, cols), wm.reshape(rows, cols))
+    if want_resp:
+        assert np.array_equal(resp.download()[0].reshape(rows, cols).view(np.uint32), want[1].reshape(rows, cols).view(np.uint32))
+    for b in (src, mask) + ((resp,) if want_resp else ()):
+        b.free()
+
+
 @pytest.mark.parametrize("rows,cols", [(4, 8), (9, 496), (40, 504), (33, 1000), (130, 3840), (300, 64), (61, 120), (7, 12)])
 def test_corner_harris_and_pipeline_from_gray(ctx, oracle, rows, cols):
     """a one-channel source: cornerHarris (response only) and the pipeline (mask, mask + response) on the fused register-window
