@@ -152,3 +152,36 @@ __global__ void k(const v4i* in, unsigned* out, int sh) {
             assert all(lines[i + j].startswith("v_ashr_pk_u8_i32") and "op_sel" in lines[i + j] for j in (1, 2)), lines[i:i + 3]
             blocks += 1
     assert blocks >= 100, blocks
+
+
+@pytest.fixture(scope="module")
+def harris_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "rcv_harris_fused.s"
+    flags = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math".split()
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), os.path.join(ROOT, "rustcv_amd", "csrc", "rcv_harris_fused.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def test_harris_fused_row_loop_has_no_vector_address_math_and_no_pair_copies(harris_asm):
+    """round 6, read from the compiler's output of the mask-only BGR instantiation k_harris_fused<false, 0, true, false>: the source rows
+    come through BUFFER loads whose row offset is a scalar register (no v_lshl_add_u64 / v_mad_u64_u32 per row), the strip-end neighbour pairs are
+    formed by IN-PLACE DPP moves (v_mov_b32_dpp vN, vN: five per row -- two in the Sobel stage, three in the box stage), the swapped pairs are read
+    through op_sel, three waves per SIMD without scratch.  What this pins is worth 8 % of config 5 (profiles/r06_harris_timeline.txt, boxes D / H)."""
+    body = _body(harris_asm, "14k_harris_fusedILb0ELi0ELb1ELb0E")
+    i0 = next(i for i, l in enumerate(body) if l.startswith("buffer_load_dwordx4"))
+    loop = body[i0:]
+    loads = [l for l in loop if l.startswith("buffer_load_dword")]
+    assert loads and all(re.search(r"s\[\d+:\d+\], s\d+ offen", l) for l in loads), loads[:4]
+    assert not [l for l in loop if l.startswith(("global_load", "global_store", "flat_"))]
+    assert not [l for l in loop if l.startswith(("v_lshl_add_u64", "v_mad_u64_u32", "v_mad_i64_i32"))]
+    inplace = [l for l in loop if re.match(r"v_mov_b32_dpp (v\d+), \1 ", l)]
+    swapped = len([l for l in loop if "v_pk_mul_f32" in l and "op_sel:[1,1] op_sel_hi:[0,0]" in l])   # the three products of pair 3, per row
+    feeds = swapped // 3                                                                              # rows per trip of the unrolled loop (2 x kAhead)
+    assert feeds == 4 and swapped == 3 * feeds, (swapped, feeds)
+    assert len(inplace) == 5 * feeds, (len(inplace), feeds)
+    meta = "\n".join(harris_asm)
+    k = meta[meta.index("14k_harris_fusedILb0ELi0ELb1ELb0E"):]
+    assert int(re.search(r"; NumVgprs: (\d+)", k).group(1)) <= 168 and int(re.search(r"; ScratchSize: (\d+)", k).group(1)) == 0
