@@ -175,7 +175,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_f32_stream(View s, View d, FW
     // The four samples of a thread ride in two packed-f32 pairs (samples 0,1 and 2,3): v_pk_fma_f32 performs two IEEE
     // fmaf per instruction with the weight broadcast to both halves -- the same per-sample chain as the scalar oracle, at
     // half the issue cost.  Sample j of tap kx reads p[j + kx*CH]; the pair {p[m], p[m+1]} is formed by the compiler
-    // (v_pk_mov_b32 when m is odd).
+    // (two v_mov_b32 when m is odd.  Round 6: written as vector shuffles of even-aligned pairs every odd pair is ONE v_pk_mov_b32 -- 960 -> 911
+    //  instructions in the 7-tap BGR instantiation -- and the launches were 1 % (7-tap Gaussian) to 6.5 % (dense 7x7 f32) SLOWER, same box, three
+    //  rotations: the packed move does not issue at the rate of a plain one.  Not kept; tools/ab_fs_variants.sh.)
     f2 acc[KS][NP];
 #pragma unroll
     for (int i = 0; i < KS; ++i)
