@@ -217,7 +217,7 @@ def main():
     device.synth(s, 1, SEED + 5, 0)
     record("Harris pipeline (BGR->mask)", "4K batch=64/GPU", s.n, 3840 * 2160, 4, lambda: device.harris_pipeline(s, m, None, 2, 0.04, 1e-4),
            cpu=lambda: cpu_time(lambda orc: orc.harris_pipeline(np.zeros((2160, 3840, 3), np.uint8), 2, 0.04, 1e-4), 3840 * 2160),
-           valu=28)   # VALU instructions per pixel of the kernel as built (rocprofv3 SQ_INSTS_VALU, profiles/r04_op_harris_4k.txt; round 2: 32)
+           valu=23)   # VALU instructions per pixel of the kernel as built (rocprofv3 SQ_INSTS_VALU 1.9e8 per launch, round 6; round 4: 28, round 2: 32)
     yq = B(64, 2160, 3840, 2)
     device.synth(yq, 2, SEED + 5, 0)
     record("Harris pipeline from a YUYV source (config 5 [or YUYV])", "4K batch=64/GPU", yq.n, 3840 * 2160, 3,

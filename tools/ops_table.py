@@ -10,7 +10,7 @@ d = json.load(open(src))
 # what bounds each op (DESIGN_HISTORY.md 4): ops whose fixed arithmetic exceeds what the vector ALU can issue at HBM rate are VALU-bound by
 # construction; for those the HBM percentage is information, not the target (rocprofv3 issue-slot figures: profiles/r02_op_*.txt)
 BOUND = [("filter2D 7x7 f32", "VALU (49 dependent fmaf per sample)"), ("sigma=1.5", "VALU (14 fmaf per sample)"),
-         ("cornerHarris blockSize 3", "VALU / stores"), ("blockSize 3", "VALU (46 instr/px: 95 % of issue slots)"), ("Harris pipeline", "VALU (28 instr/px)"), ("cornerHarris", "VALU / stores"),
+         ("cornerHarris blockSize 3", "VALU / stores"), ("blockSize 3", "VALU (46 instr/px: 95 % of issue slots)"), ("Harris pipeline", "VALU 70-80 % busy + the launch's ragged end (DESIGN 6.3)"), ("cornerHarris", "stores (whole lines, non-temporal: r06_harris_resp_stores.txt)"),
          ("warpAffine + resize", "HBM read stream: every line of the source holds taps, 3.2 GB of unique lines at ~5.4 TB/s (staging alone 0.58-0.60 ms; DESIGN 6.2)"), ("warpAffine bilinear f32", "HBM (LDS-staged f32 patch, no conversions)"), ("(rot 7deg) on a GRAY", "per-workgroup set-up + stores (four frames per LDS pass; round 4: border tiles staged too, ablation in r04_warp_store_wait_ablation.txt)"), ("warpAffine", "VALU 63-80 % at a 1.95-2.15 GHz clock + 6.8 GB of real traffic at 4.5 TB/s (LDS-staged taps; DESIGN 0.3 item 6)"),
          ("rectangle", "launch latency"), ("text blend", "launch latency"), ("batch=1", "launch latency (L3-resident)"),
          ("640x480", "launch latency"), ("resize 8K -> 1080p", "HBM (line granularity: 56 MB/frame must be fetched for 31 MB used)")]
