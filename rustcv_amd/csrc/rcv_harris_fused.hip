@@ -178,7 +178,7 @@ typedef float F2m __attribute__((ext_vector_type(2), aligned(4)));
 template <bool WANT_RESP, int SRCK, bool WANT_MASK = true, bool RAG = false>
 __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArgs a)
 {
-    extern __shared__ float hf_lds[];   // (aligned launches with the response: 2 KB per wave, see the response store)
+    extern __shared__ __attribute__((aligned(16))) float hf_lds[];   // (aligned launches with the response: 2 KB per wave, see the response store)
     const int lane = threadIdx.x & 63;
     // the wave index as a SCALAR: strip / segment / frame, the reflected row indices and every row base address below are
     // then SALU work (as VALU work the 64-bit row multiplies alone were ~100 quarter-rate slots per four rows)
