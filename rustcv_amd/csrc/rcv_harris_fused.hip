@@ -35,6 +35,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef RCV_HF_FSOB
 #define RCV_HF_FSOB 1
 #endif
+#ifndef RCV_HF_FSOB_GRAY
+#define RCV_HF_FSOB_GRAY 1
+#endif
 #ifndef RCV_HF_FSOB_RESP
 #define RCV_HF_FSOB_RESP 1
 #endif
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
     constexpr bool TQ = !GRAY && !RAG;   // gray values stay one per dword (byte 2), see feed
     // the Sobel stage in packed f32 (mask-only launches: with the response the 16 more registers cost the third wave per SIMD); same box,
     // same run, 64 x 4K: 0.4984-0.5012 ms against 0.5148-0.5189 with the packed-i16 Sobel
-    constexpr bool FSOB = TQ && (!WANT_RESP || RCV_HF_FSOB_RESP) && RCV_HF_FSOB;
+    // (round 6: a one-channel source too -- its eight pixels are the bytes of the two source dwords, v_cvt_f32_ubyte0..3 reads them in place)
+    constexpr bool FSOB = (TQ || (GRAY && !RAG && RCV_HF_FSOB_GRAY)) && (!WANT_RESP || RCV_HF_FSOB_RESP) && RCV_HF_FSOB;
     const uint32_t sx = (uint32_t)((GRAY ? 1 : (YUYV ? 2 : 3)) * xc), mx = (uint32_t)max(x, 0);
     const float NEG_INF = -INFINITY;
     const float thr_v = a.thr_up;
@@ -338,15 +342,17 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
         // ---- Sobel: I(u) for u = v-1 -------------------------------------------------------------------------------
         uint32_t L[5], Cc[4];   // zero-extended gray pairs (g[2j-1], g[2j]) and (g[2j], g[2j+1])
         f2 fix[4], fiy[4];      // (FSOB) Ix, Iy of row u as f32 pairs
-        if constexpr (TQ) {
+        if constexpr (TQ || FSOB) {
             // the gray values sit in byte 2 of their dwords: the pairs are picked straight from there, the eight bytes are
             // never packed into two dwords
             // (the two mirror lanes exist in the first / last strip only: a wave-uniform branch around the selects -- 13 of 15 strips
             //  of a 4K row skip them; the volatile asm keeps the compiler from turning it back into selects)
-            if (has_edge) {
-                asm volatile("; strip with a mirror lane");
-                if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
-                if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
+            if constexpr (TQ) {
+                if (has_edge) {
+                    asm volatile("; strip with a mirror lane");
+                    if (edgeL) g[7] = g[1];   // x = -1 mirrors x = 1
+                    if (edgeR) g[0] = g[6];   // x = cols mirrors cols-2
+                }
             }
             if constexpr (FSOB) {
                 // Round 4: the Sobel in PACKED F32 on the pairs {pixel j, pixel j + 4} the later stages use anyway.  v_cvt_f32_ubyte2 takes
@@ -358,9 +364,20 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
                 // conversions and two DPP moves per row where there were ten, two DPP moves and two copies.  The sums of j = 0 / j = 3 are
                 // split so that everything that reads the lane's own pixel 7 / pixel 0 comes before the move that replaces it (exact integers:
                 // the order of the additions does not matter).
-                const f2 P1 = f2{cvb2(g[1]), cvb2(g[5])}, P2 = f2{cvb2(g[2]), cvb2(g[6])};
-                const f2 S0 = f2{cvb2(g[4]), cvb2(g[0])};   // pair 0 swapped
-                const f2 S3 = f2{cvb2(g[7]), cvb2(g[3])};   // pair 3 swapped
+                auto gf = [&](int k) -> float {   // pixel k of the lane as f32
+                    if constexpr (GRAY) return (float)((q.d[k >> 2] >> (8 * (k & 3))) & 0xffu);   // (v_cvt_f32_ubyteN)
+                    else return cvb2(g[k]);
+                };
+                const f2 P1 = f2{gf(1), gf(5)}, P2 = f2{gf(2), gf(6)};
+                f2 S0 = f2{gf(4), gf(0)};   // pair 0 swapped
+                f2 S3 = f2{gf(7), gf(3)};   // pair 3 swapped
+                if constexpr (GRAY) {
+                    if (has_edge) {
+                        asm volatile("; strip with a mirror lane");
+                        if (edgeL) S3.x = P1.x;   // x = -1 mirrors x = 1
+                        if (edgeR) S0.y = P2.y;   // x = cols mirrors cols-2
+                    }
+                }
                 f2 h1[4], h2[4];
                 h1[1] = pk_sub_bs(P2, S0);                                                        // P2 - P0
                 h2[1] = __builtin_elementwise_fma(P1, f2{2.0f, 2.0f}, pk_add_bs(P2, S0));         // 2 P1 + P0 + P2
