@@ -5,15 +5,19 @@
 // One WAVE owns a strip of 496 px (62 lanes x 8 px; lanes 0 / 63 carry halo only) and walks down a row segment.
 // Per source row a lane loads its 8 BGR pixels (3 x 8 B), converts to gray, and every stage pulls the one neighbour
 // value it needs from the adjacent lane with a DPP wave shift:
-//     gray      needs g[x-1], g[x+1]            (Sobel, packed i16 math as in rcv_sobel_rows.hip)
+//     gray      needs g[x-1], g[x+1]            (Sobel: packed f32 on aligned shapes, packed i16 as in rcv_sobel_rows.hip elsewhere)
 //     box 2x2   needs P[x-1]  (P = Ix^2, IxIy, Iy^2 ; window offsets -1..0, anchor = blockSize/2 = 1)
 //     NMS 3x3   needs r[x-1], r[x+1]
 // Vertical neighbours are earlier rows kept in registers (2 rows of Sobel parts, 1 row of horizontal box sums,
-// 2 rows of NMS maxima).  The stream is fed VIRTUAL row indices v = ys-3 .. ye+1 resolved with BORDER_REFLECT_101,
+// 2 rows of raw responses for the NMS).  The stream is fed VIRTUAL row indices v = ys-3 .. ye+1 resolved with BORDER_REFLECT_101,
 // which reproduces the box filter's reflection of the product image at the top border (P(-1) := P(1)) provided Iy
 // is negated on the mirrored row (a mirrored Sobel flips the sign of dy); the left border P(-1) := P(1) is a lane
 // fix-up; response values outside the image are -inf for the NMS.  f32 ops follow the oracle's order exactly
 // (six separate IEEE ops, -ffp-contract=off).
+// Round 6, from the ISA: 192 -> ~165 vector instructions per row.  The packed-f32 stages work on pairs {pixel j, pixel j + 4};
+// pairs 0 and 3 are kept with their halves swapped (op_sel where they are plain operands) so that the strip-end neighbour pairs are those
+// registers after one in-place DPP move; aligned shapes address their rows through buffer resources (row offset in the instruction's scalar
+// offset: no vector address arithmetic); the NMS takes column maxima first and forms the mask bytes from the sign of centre - maximum.
 // RAG instantiation: any width >= 8 and any alignment (Mat::new gives step = cols * channels: odd widths mean byte-aligned
 // rows): unaligned vector loads / stores, the lane with the row's last, partial run rebuilds its 8 logical gray pixels --
 // the valid ones and their mirror images -- with one byte permute per dword, sets the responses right of the image to -inf
@@ -599,8 +603,8 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
         // on real scenes most rows of a 496-pixel strip hold no such pixel (scene family of bench.py, thr 1e-4: 0.34 % of the pixels,
         // 28 % of the (strip, row) pairs).  The window therefore keeps the RAW responses of rows u - 2 and u - 1 (16 registers; it kept
         // 32 of running maxima) and a wave-uniform flag per row -- 4 maxima, a compare and a scalar branch -- and forms the eight
-        // neighbour maxima of row w only when its flag is set: 57 instructions on those rows, 5 on the others, against 43 on every row.
-        // keep = rc >= max(8 neighbours, thr_up) as before: the same maxima of the same values, grouped by row.
+        // neighbour maxima of row w only when its flag is set: 57 instructions on those rows (round 6: 47), 5 on the others, against 43 on every row.
+        // keep = rc >= max(8 neighbours, thr_up) as before: the same maxima of the same values (round 6: grouped by column first, see `maxima`).
         if (has_edge) {   // (uniform) what the lane left of x = 0 and the lanes right of the image hand to their neighbours
             asm volatile("; strip with an edge lane: responses outside the image are -inf");
             if (edgeL) r[7] = NEG_INF;
