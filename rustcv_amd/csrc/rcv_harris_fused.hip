@@ -250,8 +250,11 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
     const float thr_v = a.thr_up;
 
     auto load_row = [&](int v) -> Row6 {  // virtual row -> reflected source row (clamped past what the segment needs)
+        // (round 6, scalar instruction count: a wave issues one instruction of ANY kind every ~10 cycles, tools/ubench_dpp.hip)  BORDER_REFLECT_101 of
+        // v <= rows + 1 in three instructions: |v|, then the smaller of it and its mirror image at the bottom edge (for 0 <= v < rows the image is >= v)
         v = min(v, ye + 1);
-        const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
+        const int av = abs(v);
+        const int r = min(av, 2 * a.rows - 2 - av);
         if constexpr (RAG) {
             cgptr p = (cgptr)(sf + (size_t)r * a.sstep);
             asm("" : "+s"(p));   // the row base stays in SGPRs
@@ -282,15 +285,15 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
                                                   // (<= 1020^2) and every 2x2 sum (< 2^24) is an exactly representable
                                                   // integer, so f32 adds/muls are exact and can use the packed f32 ALU
     float ra[8], rb[8];                           // NMS: responses of rows u-2, u-1 (outside the image: -inf)
-    bool cand_b = false;                          // ... and whether row u-1 holds a pixel >= thr_up (wave-uniform)
+    int cand_b = 0;                               // ... and whether row u-1 holds a pixel >= thr_up (wave-uniform; an integer: as a bool it lived as a lane mask)
     // aligned shapes: the mask row formed at the end of one feed is stored after the Sobel stage of the NEXT one.  The wait for the next row
     // group's loads at the head of the loop counts every vector-memory operation issued before it, stores included (one in-order vmcnt): a
     // store issued a third of a row earlier has long left, the one the feed just issued had not
     uint32_t pm0 = 0, pm1 = 0;
-    bool pdirty = false;                          // (wave-uniform) pm0 / pm1 hold a row's mask
+    int pdirty = 0;                               // (wave-uniform) pm0 / pm1 hold a row's mask
     int pw = -1;
     auto flush_mask = [&]() {
-        if (live && pw >= ys && pw < ye) __builtin_amdgcn_raw_buffer_store_b64(u2v{pm0, pm1}, mrs, mx, (uint32_t)pw * mstep32, RCV_HF_MASK_AUX);
+        if ((unsigned)(pw - ys) < (unsigned)(ye - ys) && live) __builtin_amdgcn_raw_buffer_store_b64(u2v{pm0, pm1}, mrs, mx, (uint32_t)pw * mstep32, RCV_HF_MASK_AUX);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
         }
         if constexpr (WANT_MASK && !RAG) flush_mask();
         const int u = v - 1;
-        const bool mirrored = u < 0 || u >= a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
+        const bool mirrored = (unsigned)u >= (unsigned)a.rows;  // I(u) was formed from a vertically mirrored window: dy changes sign
         constexpr bool kLimRow = !WANT_RESP && !RAG && RCV_HF_LIMROW;
         // f32 stages on PACKED pairs {pixel j, pixel j+4} (v_pk_mul/add_f32): with this pairing the horizontal neighbour
         // P(x-1) of a pair is simply the previous pair register (j >= 1) -- pairing adjacent pixels {2j, 2j+1} instead leaves
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
                 // launch time that depended on where the buffers lay (0.61-0.71 ms for one library on one box, `profiles/r06_harris_resp_stores.txt`;
                 // the lesson of the one-launch config 3).  The row goes through 2 KB of wave-private LDS instead (no barrier: a wave's
                 // LDS instructions execute in order) and comes back as float4 number `lane` and number 64 + `lane` of the strip's row.
-                if (u >= ys && u < ye) {
+                if ((unsigned)(u - ys) < (unsigned)(ye - ys)) {
                     float* const wl = hf_lds + 512 * (threadIdx.x >> 6);
                     if (lane >= 1 && lane <= 62) {
                         *(f4v*)(wl + 8 * (lane - 1)) = f4v{r[0], r[1], r[2], r[3]};
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
         // A row outside the image (scalar condition, two rows per frame edge): every response is -inf.  Columns outside the
         // image belong to whole lanes (cols % 8 == 0: the lane left of x = 0, lanes right of the last column) that never
         // store; only the values they hand to their neighbours matter, and those are replaced right here.
-        if (!kLimRow && (u < 0 || u >= a.rows)) {
+        if (!kLimRow && (unsigned)u >= (unsigned)a.rows) {
             // (a branch, not eight selects on every row: the compiler had if-converted this into a v_cndmask per pixel AND, no longer
             //  knowing the selected value canonical, a v_max_f32 x, x per pixel in front of the maxima below -- 2 of 29 instructions per
             //  pixel; round 4, from the ISA)
@@ -610,9 +613,9 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
             if (edgeL) r[7] = NEG_INF;
             if (x >= a.cols) r[0] = NEG_INF;
         }
-        const bool cand_u = __builtin_amdgcn_ballot_w64(vmax3(vmax3(r[0], r[1], r[2]), vmax3(r[3], r[4], r[5]), vmax2(r[6], r[7])) >= thr_v) != 0ull;
+        const int cand_u = __builtin_amdgcn_ballot_w64(vmax3(vmax3(r[0], r[1], r[2]), vmax3(r[3], r[4], r[5]), vmax2(r[6], r[7])) >= thr_v) != 0ull ? 1 : 0;
         uint32_t mbits[2] = {0, 0};
-        if (cand_b) {   // (uniform) row w holds a candidate
+        if (cand_b != 0) {   // (uniform) row w holds a candidate
             asm volatile("; row with a candidate: 3x3 maxima");
             const float bl = shr1f(rb[7]), br = shl1f(rb[0]);
             // USE_A / USE_C: the rows above / below row w = u - 1 take part.  kLimRow launches leave the responses of the two rows outside the image
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(64 * kWPB) RCV_HF_OCC_ATTR void k_harris_fused(HArg
                 pm0 = mbits[0];
                 pm1 = mbits[1];
             }
-        } else if (!RAG && pdirty) {
+        } else if (!RAG && pdirty != 0) {
             // (round 6) the pending mask registers are zero unless a row with candidates wrote them: they are cleared on the first row without
             // candidates after such a row, not on every row (two v_mov per row)
             asm volatile("; first row without candidates after one with: pending mask back to zeros");
