@@ -75,3 +75,20 @@ __device__ __forceinline__ int rcv_reflect101(int i, int n)
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
     return i;
 }
+
+// The f32 row of a 496-pixel strip leaves its wave as WHOLE LINES (round 6, profiles/r06_harris_resp_stores.txt).  The register-window kernels give lane
+// l (1 .. 62) the 8 pixels 8 (l - 1) .. + 7 of the strip: stored from there, each of the lane's two 16-byte stores writes every other 16 bytes of the wave's 2 KB
+// -- two half-written visits to every 128-byte line.  Through 2 KB of wave-private LDS (`wl`, 16-byte aligned; no barrier: a wave's LDS instructions
+// execute in order) lane i instead stores float4 number i and number 64 + i of the strip's row, non-temporal.  `row` = the strip's first pixel in the
+// destination row (16-byte aligned), n4 = float4s of the row that lie inside the image (wave-uniform).
+__device__ __forceinline__ void rcv_store_strip_row_f32(float* wl, const float (&r)[8], int lane, uint8_t* row, int n4)
+{
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    if (lane >= 1 && lane <= 62) {
+        *(f4s*)(wl + 8 * (lane - 1)) = f4s{r[0], r[1], r[2], r[3]};
+        *(f4s*)(wl + 8 * (lane - 1) + 4) = f4s{r[4], r[5], r[6], r[7]};
+    }
+    const f4s o0 = *(const f4s*)(wl + 4 * lane), o1 = *(const f4s*)(wl + 256 + 4 * lane);
+    if (lane < n4) __builtin_nontemporal_store(o0, (f4s*)row + lane);
+    if (64 + lane < n4) __builtin_nontemporal_store(o1, (f4s*)row + 64 + lane);
+}

@@ -21,6 +21,7 @@
 // store.
 #include "rcv_internal.h"
 #include "rcv_kernels.h"
+#include "rcv_device_utils.h"
 #include <math.h>
 
 namespace {
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
 {
     constexpr int AN = B / 2, RT = B - 1 - AN;   // window offsets -AN .. +RT
     constexpr bool WANT_RESP = MODE != 1, WANT_MASK = MODE != 0;
+    extern __shared__ __attribute__((aligned(16))) float hr_lds[];   // (aligned launches with the response: 2 KB per wave)
     const int lane = threadIdx.x & 63;
     const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int wid = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
@@ -258,9 +260,10 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
                 r[j] = rr.x;
                 r[j + 4] = rr.y;
             }
-            if (WANT_RESP && live && y >= ys && y < ye) {
+            if (WANT_RESP && y >= ys && y < ye) {
                 uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
-                if constexpr (RAG) {   // response rows that are only 4-byte aligned; the row's last, partial run
+                if constexpr (RAG) {
+                  if (live) {   // response rows that are only 4-byte aligned; the row's last, partial run
                     typedef float f4m __attribute__((ext_vector_type(4), aligned(4)));
                     if (nvalid == 8) {
                         *(f4m*)o = f4m{r[0], r[1], r[2], r[3]};
@@ -268,9 +271,10 @@ __global__ __launch_bounds__(256) void k_harris_resp_rows(HBArgs a)
                     } else {
                         for (int j = 0; j < nvalid; ++j) ((float*)o)[j] = r[j];
                     }
-                } else {
-                    __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
-                    __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+                  }
+                } else {   // (whole lines through wave-private LDS: rcv_store_strip_row_f32)
+                    const int n4 = (min(a.cols, (strip + 1) * kStripPx) - strip * kStripPx) >> 2;
+                    rcv_store_strip_row_f32(hr_lds + 512 * (threadIdx.x >> 6), r, lane, rf + (size_t)y * a.rstep + 4 * (size_t)(strip * kStripPx), n4);
                 }
             }
             if constexpr (WANT_MASK) {
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
 {
     constexpr int AN = B / 2, RT = B - 1 - AN;
     constexpr bool WANT_RESP = MODE != 1, WANT_MASK = MODE != 0, GRAY = SRCK == 2;
+    extern __shared__ __attribute__((aligned(16))) float hb_lds[];   // (launches with the response: 2 KB per wave, see the response store)
     typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int blk = a.blocks_per_xcd > 0 ? (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -580,10 +585,9 @@ __global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
                 r[j] = rr.x;
                 r[j + 4] = rr.y;
             }
-            if (WANT_RESP && live && y >= ys && y < ye) {
-                uint8_t* o = rf + (size_t)y * a.rstep + 4 * (size_t)x;
-                __builtin_nontemporal_store(f4v{r[0], r[1], r[2], r[3]}, (f4v*)o);
-                __builtin_nontemporal_store(f4v{r[4], r[5], r[6], r[7]}, (f4v*)(o + 16));
+            if (WANT_RESP && y >= ys && y < ye) {   // (whole lines through wave-private LDS: rcv_store_strip_row_f32)
+                const int n4 = (min(a.cols, (strip + 1) * kStripPx) - strip * kStripPx) >> 2;
+                rcv_store_strip_row_f32(hb_lds + 512 * (threadIdx.x >> 6), r, lane, rf + (size_t)y * a.rstep + 4 * (size_t)(strip * kStripPx), n4);
             }
             if constexpr (WANT_MASK) {
                 const bool rowout = y < 0 || y >= a.rows;
@@ -619,9 +623,9 @@ template <int B, int SRCK>
 void launch_fused(const HFBArgs& a, dim3 grid, hipStream_t st)
 {
     const int mode = a.mask ? (a.resp ? 2 : 1) : 0;
-    if (mode == 0) RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 0>), grid, dim3(256), 0, st, a);
+    if (mode == 0) RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 0>), grid, dim3(256), 8192, st, a);   // (8 KB: the response rows' way through LDS)
     else if (mode == 1) RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 1>), grid, dim3(256), 0, st, a);
-    else RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 2>), grid, dim3(256), 0, st, a);
+    else RCV_LAUNCH((k_harris_blocks_fused<B, SRCK, 2>), grid, dim3(256), 8192, st, a);
 }
 
 template <int B>
@@ -633,9 +637,9 @@ void launch_resp(const HBArgs& a, dim3 grid, bool rag, hipStream_t st)
         else if (mode == 1) RCV_LAUNCH((k_harris_resp_rows<B, true, 1>), grid, dim3(256), 0, st, a);
         else RCV_LAUNCH((k_harris_resp_rows<B, true, 2>), grid, dim3(256), 0, st, a);
     } else {
-        if (mode == 0) RCV_LAUNCH((k_harris_resp_rows<B, false, 0>), grid, dim3(256), 0, st, a);
+        if (mode == 0) RCV_LAUNCH((k_harris_resp_rows<B, false, 0>), grid, dim3(256), 8192, st, a);
         else if (mode == 1) RCV_LAUNCH((k_harris_resp_rows<B, false, 1>), grid, dim3(256), 0, st, a);
-        else RCV_LAUNCH((k_harris_resp_rows<B, false, 2>), grid, dim3(256), 0, st, a);
+        else RCV_LAUNCH((k_harris_resp_rows<B, false, 2>), grid, dim3(256), 8192, st, a);
     }
 }
 
