@@ -352,8 +352,16 @@ struct HFBArgs {
 };
 
 // SRCK: 0 BGR, 2 gray.  MODE: 0 response only, 1 mask only, 2 both.
+#ifndef RCV_HB_OCC
+#define RCV_HB_OCC 0   // (3: forced to 168 registers the block-3 launches spill and take 0.81 instead of 0.66 ms)
+#endif
+#if RCV_HB_OCC > 0
+#define RCV_HB_OCC_ATTR __attribute__((amdgpu_waves_per_eu(RCV_HB_OCC)))
+#else
+#define RCV_HB_OCC_ATTR
+#endif
 template <int B, int SRCK, int MODE>
-__global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
+__global__ __launch_bounds__(256) RCV_HB_OCC_ATTR void k_harris_blocks_fused(HFBArgs a)
 {
     constexpr int AN = B / 2, RT = B - 1 - AN;
     constexpr bool WANT_RESP = MODE != 1, WANT_MASK = MODE != 0, GRAY = SRCK == 2;
@@ -373,22 +381,29 @@ __global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
     const bool edgeL = x < 0, edgeR = x == a.cols;
     const bool edge_wave = strip == 0 || strip == a.nstrips - 1;   // wave-uniform
     const bool live = lane >= 1 && lane <= 62 && x < a.cols;
-    const uint8_t* const sf = a.src + (size_t)frame * a.sfs + (size_t)((GRAY ? 1 : 3) * xc);
+    // (round 6, as rcv_harris_fused.hip) BUFFER loads / stores: the frame base in the resource, the row's byte offset in the instruction's scalar offset, the
+    // lane's column offset in a 32-bit vector offset -- no 64-bit per-lane pointers and row sums in vector registers.  Frames of 4 GB and more: the host takes
+    // the two-launch path.
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + (size_t)frame * a.sfs), 0, 0xffffffff, 0x00020000);
+    const uint32_t sx = (uint32_t)((GRAY ? 1 : 3) * xc), sstep32 = (uint32_t)a.sstep;
     uint8_t* const rf = WANT_RESP ? a.resp + (size_t)frame * a.rfs : nullptr;
     uint8_t* const mf = WANT_MASK ? a.mask + (size_t)frame * a.mfs : nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)mf, 0, 0xffffffff, 0x00020000);
     const float NEG_INF = -INFINITY;
 
     struct Raw { uint32_t d[GRAY ? 2 : 6]; };
     auto load_row = [&](int v) -> Raw {   // virtual gray row -> reflected source row (host: rows >= 8, one reflection is enough)
         v = min(max(v, -6), a.rows + 5);
         const int r = v < 0 ? -v : (v >= a.rows ? 2 * a.rows - 2 - v : v);
-        const uint8_t* p = sf + (size_t)r * a.sstep;
+        const uint32_t so = (uint32_t)r * sstep32;
         Raw w;
-        const u2v q0 = *(const u2v*)p;
-        w.d[0] = q0.x; w.d[1] = q0.y;
-        if constexpr (!GRAY) {
-            const u2v q1 = *(const u2v*)(p + 8), q2 = *(const u2v*)(p + 16);
-            w.d[2] = q1.x; w.d[3] = q1.y; w.d[4] = q2.x; w.d[5] = q2.y;
+        if constexpr (GRAY) {
+            const u2v q0 = __builtin_amdgcn_raw_buffer_load_b64(srs, sx, so, 0);
+            w.d[0] = q0.x; w.d[1] = q0.y;
+        } else {
+            const u4v q0 = __builtin_amdgcn_raw_buffer_load_b128(srs, sx, so, 0);
+            const u2v q2 = __builtin_amdgcn_raw_buffer_load_b64(srs, sx + 16, so, 0);
+            w.d[0] = q0.x; w.d[1] = q0.y; w.d[2] = q0.z; w.d[3] = q0.w; w.d[4] = q2.x; w.d[5] = q2.y;
         }
         return w;
     };
@@ -594,22 +609,29 @@ __global__ __launch_bounds__(256) void k_harris_blocks_fused(HFBArgs a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = (rowout || x < 0 || x >= a.cols) ? NEG_INF : r[j];   // (cols % 8 == 0: whole lanes)
                 const float rl = shr1f(r[7]), rr = shl1f(r[0]);
-                uint32_t mbits[2] = {0, 0};
+                // (round 6, as rcv_harris_fused.hip) the mask bytes from the SIGN of centre - maximum (set iff the centre is smaller; equal gives +0; no NaN:
+                // the centre is finite or -inf, the maximum >= thr_up > -inf): v_perm_b32's selectors 9 / 11 replicate bit 31 of either source through a
+                // byte -- and the four byte-mask registers of compare + select + or are gone (the mask-only block-3 launch: 174 -> 166 registers = three
+                // waves per SIMD instead of two)
+                uint32_t t[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float left = j ? r[j - 1] : rl, right = j < 7 ? r[j + 1] : rr;
                     const float lrmax = fmaxf(fmaxf(left, right), a.thr_up);
                     const float m3 = fmaxf(lrmax, r[j]);
                     const float m8 = fmaxf(fmaxf(m3a[j], mlr[j]), m3);
-                    const bool keep = rc[j] >= m8;
-                    mbits[j >> 2] |= keep ? (0xffu << ((j & 3) * 8)) : 0u;
+                    t[j] = __builtin_bit_cast(uint32_t, rc[j] - m8);
                     m3a[j] = m3b[j];
                     m3b[j] = m3;
                     rc[j] = r[j];
                     mlr[j] = lrmax;
                 }
+                uint32_t mbits[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    mbits[h] = ~(hpk(t[4 * h + 1], t[4 * h], 0x0c0c0b09u) | hpk(t[4 * h + 3], t[4 * h + 2], 0x0b090c0cu));
                 const int w = y - 1;
-                if (live && w >= ys && w < ye) *(u2v*)(mf + (size_t)w * a.mstep + (size_t)x) = u2v{mbits[0], mbits[1]};
+                if (live && w >= ys && w < ye) __builtin_amdgcn_raw_buffer_store_b64(u2v{mbits[0], mbits[1]}, mrs, (uint32_t)x, (uint32_t)w * (uint32_t)a.mstep, 0);
             }
             account(ring[i], true);
             ring[i] = ent;
