@@ -90,9 +90,7 @@ int main()
     run<7>("v_dot4_u32_u8", out, cyc, nblocks);
     run<8>("v_cvt_f32_ubyte2", out, cyc, nblocks);
     run<9>("v_perm_b32", out, cyc, nblocks);
-    run<10>("s_add_u32", out, cyc, nblocks);
     run<11>("s_nop 0", out, cyc, nblocks);
-    run<12>("pairs: v_pk_add_f32 + s_add_u32", out, cyc, nblocks);
     run<13>("pairs: v_pk_add_f32 + s_nop 0", out, cyc, nblocks);
     run<14>("pairs: v_pk_add_f32 + v_mov_b32", out, cyc, nblocks);
     }
